@@ -1,0 +1,218 @@
+/*
+ * probly_search_amd.h — C ABI of the MI355X-native BM25 / zero-to-one query-scoring engine.
+ *
+ * This is the drop-in boundary for probly-search's `Index::query` -> `ScoreCalculator` hot path
+ * (reference: quantleaf/probly-search 2.0.1; citations are `file:line` relative to its root).
+ * The reference is a pure-Rust library with no FFI of its own, so the entry points below are
+ * what a `probly-search-amd-sys` crate would bind (see INTEGRATION.md for the Rust side):
+ * plain pointers and sizes, no C++ or torch types, never unwinds.
+ *
+ * Ownership: every handle is created and freed by the library.  Result arrays returned through
+ * `ps_result**` / `size_t**` are malloc'd by the library and released with ps_free().
+ * Threading: a `ps_index` needs external exclusion for mutation (it is `&mut self` in the
+ * reference); a `ps_snapshot` is immutable and its query entry points are thread-safe
+ * (`query(&self)`, src/query.rs:21-27).
+ * Errors: every fallible call returns a ps_status; ps_last_error() gives the calling thread's
+ * message.  Where the reference would panic (short `fields_boost`, bm25.rs:85) the call returns
+ * PS_EINVAL instead.  There is NO CPU scoring fallback: without a HIP device the query entry
+ * points return PS_ENODEVICE.
+ */
+#ifndef PROBLY_SEARCH_AMD_H
+#define PROBLY_SEARCH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ps_status {
+  PS_OK = 0,
+  PS_EINVAL = 1,       /* bad argument (incl. n_boost < fields_num) */
+  PS_ENOMEM = 2,
+  PS_EHIP = 3,         /* a HIP runtime call failed */
+  PS_EUNSUPPORTED = 4, /* input exceeds a documented engine limit */
+  PS_ENODEVICE = 5     /* no usable HIP device / snapshot is host-only */
+} ps_status;
+
+typedef struct ps_index ps_index;       /* mutable host index  == Index<u64>  (src/index.rs:19-33) */
+typedef struct ps_snapshot ps_snapshot; /* immutable flattened CSR postings resident in HBM       */
+
+/* &str */
+typedef struct ps_str {
+  const char* ptr;
+  size_t len;
+} ps_str;
+
+/* QueryResult<u64> (src/query.rs:10-15) */
+typedef struct ps_result {
+  uint64_t key;
+  double score;
+} ps_result;
+
+/* Tokenizer = fn(&str) -> Vec<Cow<str>> (src/lib.rs:14).  Writes up to `cap` tokens into
+ * tok_ptr/tok_len and returns the total token count.  Tokens must stay valid until the next call
+ * on the same thread.  NULL selects the whitespace tokenizer every reference test uses,
+ * `s.split(' ')` (src/lib.rs:42-44): empty tokens are produced, skipped, but still counted in
+ * query_terms_len (src/query.rs:32-35). */
+typedef size_t (*ps_tokenizer_fn)(const char* s, size_t len, const char** tok_ptr, size_t* tok_len, size_t cap,
+                                  void* user);
+
+/* The two ScoreCalculator implementations the reference ships (src/score/default/). */
+enum { PS_SCORER_BM25 = 1, PS_SCORER_ZERO_TO_ONE = 2 };
+typedef struct ps_scorer_desc {
+  int32_t kind;   /* PS_SCORER_*                                                        */
+  int32_t _pad;
+  double bm25_k1; /* BM25::bm25k1, default 1.2  (src/score/default/bm25.rs:14-26)       */
+  double bm25_b;  /* BM25::bm25b,  default 0.75                                         */
+} ps_scorer_desc;
+
+const char* ps_last_error(void);
+void ps_free(void* p);
+/* Number of visible HIP devices (0 if none / HIP unusable). */
+int ps_device_count(void);
+
+/* ------------------------------------------------------------------ index build side -------- */
+/* Index::new(fields_num)  (src/index.rs:37-39) */
+ps_status ps_index_new(size_t fields_num, ps_index** out);
+/* Index::new_with_capacity (src/index.rs:42-60); capacities are reservation hints only. */
+ps_status ps_index_new_with_capacity(size_t fields_num, size_t expected_index_size,
+                                     size_t expected_documents_count, ps_index** out);
+void ps_index_free(ps_index* idx);
+
+/* Index::add_document(field_accessors, tokenizer, key, doc) (src/index.rs:77-158).  The accessors
+ * have already been applied by the binding: `values` is the concatenation, field by field, of the
+ * strings accessor i returned, n_values[i] of them (multi-valued fields keep the reference's
+ * "sum accumulates, field_length = last value" rule, src/index.rs:112-114). */
+ps_status ps_index_add_document(ps_index* idx, uint64_t key, const ps_str* values, const size_t* n_values,
+                                ps_tokenizer_fn tokenizer, void* user);
+/* Bulk form for single-valued fields and the default tokenizer: value (d, f) is
+ * text[offsets[d*F+f] .. offsets[d*F+f+1]).  Equivalent to n_docs add_document calls in order. */
+ps_status ps_index_add_documents_flat(ps_index* idx, size_t n_docs, const uint64_t* keys, const char* text,
+                                      const uint64_t* offsets);
+/* Index::remove_document (src/index.rs:161-191) — lazy delete, fixes field sums/averages. */
+ps_status ps_index_remove_document(ps_index* idx, uint64_t key);
+/* Index::vacuum (src/index.rs:194-241) — unlinks removed postings, prunes empty trie subtrees. */
+ps_status ps_index_vacuum(ps_index* idx);
+
+/* Read-side introspection (the pub(crate) state the reference's unit tests look at). */
+size_t ps_index_fields_len(const ps_index* idx);
+size_t ps_index_docs_len(const ps_index* idx);                                   /* docs.len()          */
+ps_status ps_index_field_details(const ps_index* idx, size_t field, uint64_t* sum, double* avg); /* FieldDetails */
+int ps_index_doc_field_length(const ps_index* idx, uint64_t key, uint64_t* out); /* 1 if present        */
+size_t ps_index_count_nodes(const ps_index* idx);          /* trie nodes reachable from root, root incl. */
+size_t ps_index_live_pointers(const ps_index* idx);        /* == live DocumentPointer count              */
+/* children chars (list order, newest first) of the node `term` leads to; -1 if no such path */
+long ps_index_children(const ps_index* idx, const char* term, size_t len, uint32_t* out, size_t cap);
+/* Index::count_documents of the node `term` leads to (src/index.rs:282-297); -1 if no such path */
+long ps_index_count_documents(const ps_index* idx, const char* term, size_t len);
+/* Index::expand_term (src/query.rs:109-147): NUL-separated terms into buf, returns the count. */
+size_t ps_index_expand_term(const ps_index* idx, const char* term, size_t len, char* buf, size_t cap,
+                            size_t* bytes_needed);
+
+/* ------------------------------------------------------------------ snapshot ---------------- */
+/* Flatten the trie/posting lists into CSR planes (doc id u32, per-field tf u32, per-field
+ * field-length u32) plus per-list tile-offset tables, and upload them to `device`.
+ * device = -1 builds a host-only snapshot (no HIP call is made; queries return PS_ENODEVICE);
+ * it exists so the flattener and planner can be inspected on machines without a GPU.
+ * tile_docs = documents per LDS accumulator tile (power of two, 256..4096; 0 = default 2048). */
+ps_status ps_index_snapshot(const ps_index* idx, int device, uint32_t tile_docs, ps_snapshot** out);
+void ps_snapshot_free(ps_snapshot* snap);
+
+typedef struct ps_snapshot_info {
+  uint32_t fields_num;
+  uint32_t tile_docs;
+  uint64_t n_docs;         /* documents.len() as BM25 sees it (src/score/default/bm25.rs:41)   */
+  uint64_t n_terms;        /* indexed terms with >=1 live posting                              */
+  uint64_t n_postings;     /* unique (term, doc[, version]) postings in the CSR planes         */
+  uint64_t n_pointers;     /* sum of df_raw == live DocumentPointer count                      */
+  uint64_t n_table_entries;
+  uint64_t device_bytes;
+  int32_t device;
+  int32_t max_layers;      /* >1 only if some key was re-added without removal                 */
+} ps_snapshot_info;
+ps_status ps_snapshot_get_info(const ps_snapshot* snap, ps_snapshot_info* out);
+
+/* ------------------------------------------------------------------ query ------------------- */
+/* Index::query(query, score_calculator, tokenizer, fields_boost) -> Vec<QueryResult>
+ * (src/query.rs:21-106) on the GPU.  Results are in the canonical order of
+ * test_util::test_score, score desc then key asc (src/lib.rs:54-58; the reference's own tie
+ * order is hashbrown iteration order, i.e. unspecified).  top_k = 0 returns every match like the
+ * reference; top_k > 0 returns the first top_k of that same ordering. */
+ps_status ps_snapshot_query(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* query, size_t query_len,
+                            const double* fields_boost, size_t n_boost, ps_tokenizer_fn tokenizer, void* user,
+                            size_t top_k, ps_result** out, size_t* out_len);
+/* Convenience: snapshots lazily (re-flattening after any mutation) on device 0 and queries. */
+ps_status ps_index_query(ps_index* idx, const ps_scorer_desc* scorer, const char* query, size_t query_len,
+                         const double* fields_boost, size_t n_boost, ps_tokenizer_fn tokenizer, void* user,
+                         size_t top_k, ps_result** out, size_t* out_len);
+
+/* Batched form: B independent queries, one kernel pass.  out[out_offsets[i] .. out_offsets[i+1])
+ * are query i's results (out_offsets has B+1 entries). */
+ps_status ps_snapshot_query_batch(ps_snapshot* snap, const ps_scorer_desc* scorer, const ps_str* queries,
+                                  size_t n_queries, const double* fields_boost, size_t n_boost,
+                                  ps_tokenizer_fn tokenizer, void* user, size_t top_k, ps_result** out,
+                                  size_t** out_offsets);
+
+/* Device-resident batched top-k for multi-GPU plumbing: results stay in HBM so the caller can
+ * all-gather them over RCCL.  d_keys: u64[B*top_k], d_scores: f64[B*top_k], d_counts: u32[B]
+ * (device pointers on the snapshot's device; unused slots are key=~0, score=0).  `hip_stream`
+ * is a hipStream_t (NULL = the snapshot's own stream); the call returns after enqueueing when a
+ * stream is given and all work is ordered on it.  1 <= top_k <= PS_MAX_DEVICE_TOPK. */
+#define PS_MAX_DEVICE_TOPK 64
+ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc* scorer, const ps_str* queries,
+                                         size_t n_queries, const double* fields_boost, size_t n_boost,
+                                         ps_tokenizer_fn tokenizer, void* user, size_t top_k, void* d_keys,
+                                         void* d_scores, void* d_counts, void* hip_stream);
+
+/* Timing / roofline accounting of the most recent batch executed on this snapshot. */
+typedef struct ps_batch_stats {
+  uint64_t n_queries;
+  uint64_t n_plan_entries;     /* expanded (term[, version]) lists streamed                      */
+  uint64_t postings_visited;   /* sum over plan entries of list length == unique postings visited */
+  uint64_t algorithmic_bytes;  /* postings_visited*(4+8F) + emitted results*16   */
+  double plan_ms;              /* host: tokenise + expand + before_each                           */
+  double h2d_ms, kernel_ms, d2h_ms; /* HIP-event timed on the engine stream                       */
+  double score_kernel_ms;      /* the dominant posting-accumulate kernel alone (HIP events)       */
+  double total_ms;             /* host wall clock of the whole call                               */
+} ps_batch_stats;
+ps_status ps_snapshot_last_stats(const ps_snapshot* snap, ps_batch_stats* out);
+/* HIP-event time (ms) summed over every launch of the posting-accumulate kernel on this
+ * snapshot since the last reset, and the number of launches; waits for outstanding launches.
+ * Works for caller-stream (pipelined) batches too: the events are recorded on that stream. */
+ps_status ps_snapshot_kernel_times(ps_snapshot* snap, double* total_ms, uint64_t* launches, int reset);
+
+/* ------------------------------------------------------------------ host-side inspection ---- */
+/* The query plan the host hands to the kernels (tokenise -> expand_term -> before_each), one
+ * entry per expanded list.  Host-only; works on device = -1 snapshots. */
+typedef struct ps_plan_entry {
+  uint64_t post_off;   /* first posting of the list in the CSR planes                            */
+  uint32_t len;        /* postings in the list                                                    */
+  uint32_t tbl_off;    /* first entry of the list's tile-offset table                             */
+  uint32_t shift;      /* bits 0-7: table slot of tile t is t >> shift; bits 8+: version layer    */
+  uint32_t qterm;      /* ordinal of the query term (visited-set scope, src/query.rs:37)          */
+  double idf;          /* BM25TermCalculations::idf | zero_to_one: u64 bitmask of same-node entries */
+  double boost;        /* BM25TermCalculations::expansion_boost | zero_to_one: ScoreByTerm::score */
+  uint32_t node;       /* zero_to_one: ordinal of the distinct trie node within the query         */
+  uint32_t qterm_index;/* TermData::query_term_index (position in the token list)                 */
+} ps_plan_entry;
+ps_status ps_snapshot_plan(const ps_snapshot* snap, const ps_scorer_desc* scorer, const char* query,
+                           size_t query_len, ps_tokenizer_fn tokenizer, void* user, ps_plan_entry** out,
+                           size_t* out_len, size_t* query_terms_len);
+/* Borrowed pointers into the host copy of the CSR planes (valid while the snapshot lives). */
+typedef struct ps_host_csr {
+  const uint32_t* doc;       /* [n_postings_padded]                     */
+  const uint32_t* tf;        /* [F][n_postings_padded]                  */
+  const uint32_t* fl;        /* [F][n_postings_padded]                  */
+  const uint32_t* table;     /* [n_table_entries]                       */
+  const uint64_t* keys;      /* [n_docs] doc id -> key (ascending keys) */
+  const double* avg;         /* [F] FieldDetails::avg                   */
+  uint64_t plane_stride;     /* n_postings_padded                       */
+} ps_host_csr;
+ps_status ps_snapshot_host_csr(const ps_snapshot* snap, ps_host_csr* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROBLY_SEARCH_AMD_H */

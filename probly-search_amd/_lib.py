@@ -1,0 +1,134 @@
+"""ctypes loader for libprobly_search_amd.so (C ABI: include/probly_search_amd.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "csrc", "libprobly_search_amd.so")
+
+
+class LibraryNotBuilt(ImportError):
+    pass
+
+
+class PsError(RuntimeError):
+    def __init__(self, status, msg):
+        RuntimeError.__init__(self, "%s (ps_status %d)" % (msg, status))
+        self.status = status
+
+
+PS_OK, PS_EINVAL, PS_ENOMEM, PS_EHIP, PS_EUNSUPPORTED, PS_ENODEVICE = range(6)
+
+
+class Str(C.Structure):
+    _fields_ = [("ptr", C.c_char_p), ("len", C.c_size_t)]
+
+
+class Result(C.Structure):
+    _fields_ = [("key", C.c_uint64), ("score", C.c_double)]
+
+
+class ScorerDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("bm25_k1", C.c_double), ("bm25_b", C.c_double)]
+
+
+class SnapshotInfo(C.Structure):
+    _fields_ = [("fields_num", C.c_uint32), ("tile_docs", C.c_uint32), ("n_docs", C.c_uint64),
+                ("n_terms", C.c_uint64), ("n_postings", C.c_uint64), ("n_pointers", C.c_uint64),
+                ("n_table_entries", C.c_uint64), ("device_bytes", C.c_uint64), ("device", C.c_int32),
+                ("max_layers", C.c_int32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("n_plan_entries", C.c_uint64), ("postings_visited", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64), ("plan_ms", C.c_double), ("h2d_ms", C.c_double),
+                ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("score_kernel_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
+class PlanEntry(C.Structure):
+    _fields_ = [("post_off", C.c_uint64), ("len", C.c_uint32), ("tbl_off", C.c_uint32), ("shift", C.c_uint32),
+                ("qterm", C.c_uint32), ("idf", C.c_double), ("boost", C.c_double), ("node", C.c_uint32),
+                ("qterm_index", C.c_uint32)]
+
+
+class HostCsr(C.Structure):
+    _fields_ = [("doc", C.POINTER(C.c_uint32)), ("tf", C.POINTER(C.c_uint32)), ("fl", C.POINTER(C.c_uint32)),
+                ("table", C.POINTER(C.c_uint32)), ("keys", C.POINTER(C.c_uint64)), ("avg", C.POINTER(C.c_double)),
+                ("plane_stride", C.c_uint64)]
+
+
+TOKENIZER_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                           C.c_size_t, C.c_void_p)
+
+# every symbol include/probly_search_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "ps_last_error": (C.c_char_p, []),
+    "ps_free": (None, [_P]),
+    "ps_device_count": (C.c_int, []),
+    "ps_index_new": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "ps_index_new_with_capacity": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
+    "ps_index_free": (None, [_P]),
+    "ps_index_add_document": (C.c_int, [_P, C.c_uint64, C.POINTER(Str), C.POINTER(C.c_size_t), _P, _P]),
+    "ps_index_add_documents_flat": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
+    "ps_index_remove_document": (C.c_int, [_P, C.c_uint64]),
+    "ps_index_vacuum": (C.c_int, [_P]),
+    "ps_index_fields_len": (C.c_size_t, [_P]),
+    "ps_index_docs_len": (C.c_size_t, [_P]),
+    "ps_index_field_details": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "ps_index_doc_field_length": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "ps_index_count_nodes": (C.c_size_t, [_P]),
+    "ps_index_live_pointers": (C.c_size_t, [_P]),
+    "ps_index_children": (C.c_long, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t]),
+    "ps_index_count_documents": (C.c_long, [_P, C.c_char_p, C.c_size_t]),
+    "ps_index_expand_term": (C.c_size_t, [_P, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                          C.POINTER(C.c_size_t)]),
+    "ps_index_snapshot": (C.c_int, [_P, C.c_int, C.c_uint32, C.POINTER(_P)]),
+    "ps_snapshot_free": (None, [_P]),
+    "ps_snapshot_get_info": (C.c_int, [_P, C.POINTER(SnapshotInfo)]),
+    "ps_snapshot_query": (C.c_int, [_P, C.POINTER(ScorerDesc), C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
+                                    C.c_size_t, _P, _P, C.c_size_t, C.POINTER(C.POINTER(Result)),
+                                    C.POINTER(C.c_size_t)]),
+    "ps_index_query": (C.c_int, [_P, C.POINTER(ScorerDesc), C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
+                                 C.c_size_t, _P, _P, C.c_size_t, C.POINTER(C.POINTER(Result)),
+                                 C.POINTER(C.c_size_t)]),
+    "ps_snapshot_query_batch": (C.c_int, [_P, C.POINTER(ScorerDesc), C.POINTER(Str), C.c_size_t,
+                                          C.POINTER(C.c_double), C.c_size_t, _P, _P, C.c_size_t,
+                                          C.POINTER(C.POINTER(Result)), C.POINTER(C.POINTER(C.c_size_t))]),
+    "ps_snapshot_query_batch_device": (C.c_int, [_P, C.POINTER(ScorerDesc), C.POINTER(Str), C.c_size_t,
+                                                 C.POINTER(C.c_double), C.c_size_t, _P, _P, C.c_size_t, _P, _P, _P,
+                                                 _P]),
+    "ps_snapshot_last_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
+    "ps_snapshot_kernel_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "ps_snapshot_plan": (C.c_int, [_P, C.POINTER(ScorerDesc), C.c_char_p, C.c_size_t, _P, _P,
+                                   C.POINTER(C.POINTER(PlanEntry)), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ps_snapshot_host_csr": (C.c_int, [_P, C.POINTER(HostCsr)]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _SO
+
+
+def load():
+    """Loads the HIP extension.  Raises LibraryNotBuilt (never falls back to anything)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise LibraryNotBuilt("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % _SO)
+        L = C.CDLL(_SO)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != PS_OK:
+        msg = load().ps_last_error()
+        raise PsError(status, msg.decode("utf-8", "replace") if msg else "error")

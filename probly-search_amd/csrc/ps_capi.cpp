@@ -1,0 +1,378 @@
+// ps_capi.cpp — the extern "C" surface declared in include/probly_search_amd.h.
+// Translates C++ exceptions into ps_status codes (nothing unwinds across the ABI).
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/probly_search_amd.h"
+#include "ps_engine.hpp"
+#include "ps_index.hpp"
+#include "ps_snapshot.hpp"
+
+struct ps_snapshot {
+  std::unique_ptr<ps::Snapshot> snap;
+  std::unique_ptr<ps::Engine> engine;  // null for host-only snapshots
+  int device = -1;
+  std::mutex stats_mu;
+  ps_batch_stats last{};
+};
+
+struct ps_index {
+  ps::Index idx;
+  ps_snapshot* cached = nullptr;  // ps_index_query's lazily rebuilt snapshot
+  explicit ps_index(size_t f, size_t a = 1000, size_t b = 10000) : idx(f, a, b) {}
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+template <typename Fn>
+ps_status guard(Fn&& fn) {
+  try {
+    g_err.clear();
+    return fn();
+  } catch (const std::bad_alloc&) {
+    g_err = "out of memory";
+    return PS_ENOMEM;
+  } catch (const std::invalid_argument& e) {
+    g_err = e.what();
+    return PS_EINVAL;
+  } catch (const std::length_error& e) {
+    g_err = e.what();
+    return PS_EUNSUPPORTED;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return g_err.find("no HIP device") != std::string::npos ? PS_ENODEVICE : PS_EHIP;
+  } catch (...) {
+    g_err = "unknown error";
+    return PS_EHIP;
+  }
+}
+
+ps_status fail(ps_status s, const char* msg) {
+  g_err = msg;
+  return s;
+}
+
+ps_status check_query_args(const ps_snapshot* snap, const ps_scorer_desc* sc, const double* boosts, size_t n_boost) {
+  if (!snap || !sc) return fail(PS_EINVAL, "null snapshot or scorer");
+  if (sc->kind != PS_SCORER_BM25 && sc->kind != PS_SCORER_ZERO_TO_ONE) return fail(PS_EINVAL, "unknown scorer kind");
+  // the reference indexes fields_boost[x] for x < fields_num and panics if it is shorter (bm25.rs:85)
+  if (n_boost < snap->snap->F || (snap->snap->F && !boosts)) return fail(PS_EINVAL, "fields_boost shorter than fields_num");
+  if (!snap->engine) return fail(PS_ENODEVICE, "host-only snapshot: no HIP device attached (no CPU scoring fallback)");
+  return PS_OK;
+}
+
+void set_stats(ps_snapshot* s, const ps_batch_stats& st) {
+  std::lock_guard<std::mutex> l(s->stats_mu);
+  s->last = st;
+}
+
+double wall_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ps_last_error(void) { return g_err.c_str(); }
+void ps_free(void* p) { free(p); }
+int ps_device_count(void) { return ps::device_count(); }
+
+ps_status ps_index_new(size_t fields_num, ps_index** out) {
+  return guard([&]() -> ps_status {
+    if (!out) return fail(PS_EINVAL, "null out");
+    *out = new ps_index(fields_num);
+    return PS_OK;
+  });
+}
+
+ps_status ps_index_new_with_capacity(size_t fields_num, size_t expected_index_size, size_t expected_documents_count,
+                                     ps_index** out) {
+  return guard([&]() -> ps_status {
+    if (!out) return fail(PS_EINVAL, "null out");
+    *out = new ps_index(fields_num, expected_index_size, expected_documents_count);
+    return PS_OK;
+  });
+}
+
+void ps_index_free(ps_index* idx) {
+  if (!idx) return;
+  if (idx->cached) ps_snapshot_free(idx->cached);
+  delete idx;
+}
+
+ps_status ps_index_add_document(ps_index* idx, uint64_t key, const ps_str* values, const size_t* n_values,
+                                ps_tokenizer_fn tokenizer, void* user) {
+  return guard([&]() -> ps_status {
+    if (!idx || !n_values) return fail(PS_EINVAL, "null argument");
+    idx->idx.add_document(key, values, n_values, tokenizer, user);
+    return PS_OK;
+  });
+}
+
+ps_status ps_index_add_documents_flat(ps_index* idx, size_t n_docs, const uint64_t* keys, const char* text,
+                                      const uint64_t* offsets) {
+  return guard([&]() -> ps_status {
+    if (!idx || (n_docs && (!keys || !text || !offsets))) return fail(PS_EINVAL, "null argument");
+    const size_t F = idx->idx.fields_len();
+    std::vector<ps_str> vals(F);
+    std::vector<size_t> ones(F, 1);
+    for (size_t d = 0; d < n_docs; ++d) {
+      for (size_t f = 0; f < F; ++f) {
+        vals[f].ptr = text + offsets[d * F + f];
+        vals[f].len = (size_t)(offsets[d * F + f + 1] - offsets[d * F + f]);
+      }
+      idx->idx.add_document(keys[d], vals.data(), ones.data(), nullptr, nullptr);
+    }
+    return PS_OK;
+  });
+}
+
+ps_status ps_index_remove_document(ps_index* idx, uint64_t key) {
+  return guard([&]() -> ps_status {
+    if (!idx) return fail(PS_EINVAL, "null index");
+    idx->idx.remove_document(key);
+    return PS_OK;
+  });
+}
+
+ps_status ps_index_vacuum(ps_index* idx) {
+  return guard([&]() -> ps_status {
+    if (!idx) return fail(PS_EINVAL, "null index");
+    idx->idx.vacuum();
+    return PS_OK;
+  });
+}
+
+size_t ps_index_fields_len(const ps_index* idx) { return idx ? idx->idx.fields_len() : 0; }
+size_t ps_index_docs_len(const ps_index* idx) { return idx ? idx->idx.docs_len() : 0; }
+
+ps_status ps_index_field_details(const ps_index* idx, size_t field, uint64_t* sum, double* avg) {
+  if (!idx || field >= idx->idx.fields_len()) return fail(PS_EINVAL, "bad field index");
+  if (sum) *sum = idx->idx.field(field).sum;
+  if (avg) *avg = idx->idx.field(field).avg;
+  return PS_OK;
+}
+
+int ps_index_doc_field_length(const ps_index* idx, uint64_t key, uint64_t* out) {
+  if (!idx) return 0;
+  const ps::DocDetails* d = idx->idx.doc(key);
+  if (!d) return 0;
+  if (out)
+    for (size_t i = 0; i < d->field_length.size(); ++i) out[i] = d->field_length[i];
+  return 1;
+}
+
+size_t ps_index_count_nodes(const ps_index* idx) { return idx ? idx->idx.count_nodes() : 0; }
+size_t ps_index_live_pointers(const ps_index* idx) { return idx ? idx->idx.live_pointers() : 0; }
+
+long ps_index_children(const ps_index* idx, const char* term, size_t len, uint32_t* out, size_t cap) {
+  if (!idx) return -1;
+  int32_t n = idx->idx.find_node(std::string_view(term ? term : "", len));
+  if (n == ps::NIL) return -1;
+  std::vector<uint32_t> c = idx->idx.children(n);
+  for (size_t i = 0; i < c.size() && i < cap; ++i) out[i] = c[i];
+  return (long)c.size();
+}
+
+long ps_index_count_documents(const ps_index* idx, const char* term, size_t len) {
+  if (!idx) return -1;
+  int32_t n = idx->idx.find_node(std::string_view(term ? term : "", len));
+  if (n == ps::NIL) return -1;
+  return idx->idx.count_documents(n);
+}
+
+size_t ps_index_expand_term(const ps_index* idx, const char* term, size_t len, char* buf, size_t cap,
+                            size_t* bytes_needed) {
+  if (!idx) return 0;
+  std::vector<std::string> r = idx->idx.expand_term(std::string_view(term ? term : "", len));
+  size_t off = 0;
+  for (const std::string& s : r) {
+    if (buf && off + s.size() + 1 <= cap) {
+      memcpy(buf + off, s.data(), s.size());
+      buf[off + s.size()] = 0;
+    }
+    off += s.size() + 1;
+  }
+  if (bytes_needed) *bytes_needed = off;
+  return r.size();
+}
+
+ps_status ps_index_snapshot(const ps_index* idx, int device, uint32_t tile_docs, ps_snapshot** out) {
+  return guard([&]() -> ps_status {
+    if (!idx || !out) return fail(PS_EINVAL, "null argument");
+    std::unique_ptr<ps_snapshot> s(new ps_snapshot());
+    s->snap.reset(new ps::Snapshot(idx->idx, tile_docs));
+    s->device = device;
+    if (device >= 0) s->engine.reset(new ps::Engine(*s->snap, device));
+    *out = s.release();
+    return PS_OK;
+  });
+}
+
+void ps_snapshot_free(ps_snapshot* snap) { delete snap; }
+
+ps_status ps_snapshot_get_info(const ps_snapshot* snap, ps_snapshot_info* out) {
+  if (!snap || !out) return fail(PS_EINVAL, "null argument");
+  const ps::Snapshot& s = *snap->snap;
+  memset(out, 0, sizeof(*out));
+  out->fields_num = s.F;
+  out->tile_docs = s.T;
+  out->n_docs = s.n_docs;
+  out->n_terms = s.n_live_terms;
+  out->n_postings = s.n_postings;
+  out->n_pointers = s.n_pointers;
+  out->n_table_entries = s.table.size();
+  out->device_bytes = snap->engine ? snap->engine->device_bytes() : 0;
+  out->device = snap->device;
+  out->max_layers = (int32_t)s.max_layers;
+  return PS_OK;
+}
+
+static ps_status run_batch(ps_snapshot* snap, const ps_scorer_desc* scorer, const ps_str* queries, size_t n,
+                           const double* fields_boost, size_t n_boost, ps_tokenizer_fn tokenizer, void* user,
+                           size_t top_k, ps_result** out, size_t** out_offsets) {
+  return guard([&]() -> ps_status {
+    ps_status st = check_query_args(snap, scorer, fields_boost, n_boost);
+    if (st != PS_OK) return st;
+    if (!out || !out_offsets || (n && !queries)) return fail(PS_EINVAL, "null argument");
+    const double t0 = wall_ms();
+    ps::Plan plan;
+    plan.qbeg.push_back(0);
+    for (size_t i = 0; i < n; ++i)
+      snap->snap->plan_query(*scorer, std::string_view(queries[i].ptr ? queries[i].ptr : "", queries[i].len), tokenizer,
+                             user, plan);
+    const double t1 = wall_ms();
+    std::vector<ps_result> res;
+    std::vector<size_t> offs;
+    ps_batch_stats stats;
+    snap->engine->run_host(*scorer, fields_boost, plan, top_k, res, offs, stats);
+    stats.plan_ms = t1 - t0;
+    stats.total_ms = wall_ms() - t0;
+    set_stats(snap, stats);
+    ps_result* r = (ps_result*)malloc(sizeof(ps_result) * (res.size() ? res.size() : 1));
+    size_t* o = (size_t*)malloc(sizeof(size_t) * (n + 1));
+    if (!r || !o) { free(r); free(o); return fail(PS_ENOMEM, "out of memory"); }
+    if (!res.empty()) memcpy(r, res.data(), sizeof(ps_result) * res.size());
+    memcpy(o, offs.data(), sizeof(size_t) * (n + 1));
+    *out = r;
+    *out_offsets = o;
+    return PS_OK;
+  });
+}
+
+ps_status ps_snapshot_query_batch(ps_snapshot* snap, const ps_scorer_desc* scorer, const ps_str* queries,
+                                  size_t n_queries, const double* fields_boost, size_t n_boost,
+                                  ps_tokenizer_fn tokenizer, void* user, size_t top_k, ps_result** out,
+                                  size_t** out_offsets) {
+  return run_batch(snap, scorer, queries, n_queries, fields_boost, n_boost, tokenizer, user, top_k, out, out_offsets);
+}
+
+ps_status ps_snapshot_query(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* query, size_t query_len,
+                            const double* fields_boost, size_t n_boost, ps_tokenizer_fn tokenizer, void* user,
+                            size_t top_k, ps_result** out, size_t* out_len) {
+  if (!out || !out_len) return fail(PS_EINVAL, "null argument");
+  ps_str q{query, query_len};
+  size_t* offs = nullptr;
+  ps_status st = run_batch(snap, scorer, &q, 1, fields_boost, n_boost, tokenizer, user, top_k, out, &offs);
+  if (st != PS_OK) return st;
+  *out_len = offs[1];
+  free(offs);
+  return PS_OK;
+}
+
+ps_status ps_index_query(ps_index* idx, const ps_scorer_desc* scorer, const char* query, size_t query_len,
+                         const double* fields_boost, size_t n_boost, ps_tokenizer_fn tokenizer, void* user,
+                         size_t top_k, ps_result** out, size_t* out_len) {
+  if (!idx) return fail(PS_EINVAL, "null index");
+  if (!idx->cached || idx->cached->snap->src_epoch != idx->idx.epoch()) {
+    if (idx->cached) { ps_snapshot_free(idx->cached); idx->cached = nullptr; }
+    ps_status st = ps_index_snapshot(idx, 0, 0, &idx->cached);
+    if (st != PS_OK) return st;
+  }
+  return ps_snapshot_query(idx->cached, scorer, query, query_len, fields_boost, n_boost, tokenizer, user, top_k, out,
+                           out_len);
+}
+
+ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc* scorer, const ps_str* queries,
+                                         size_t n_queries, const double* fields_boost, size_t n_boost,
+                                         ps_tokenizer_fn tokenizer, void* user, size_t top_k, void* d_keys,
+                                         void* d_scores, void* d_counts, void* hip_stream) {
+  return guard([&]() -> ps_status {
+    ps_status st = check_query_args(snap, scorer, fields_boost, n_boost);
+    if (st != PS_OK) return st;
+    if ((n_queries && !queries) || !d_keys || !d_scores || !d_counts) return fail(PS_EINVAL, "null argument");
+    const double t0 = wall_ms();
+    ps::Plan plan;
+    plan.qbeg.push_back(0);
+    for (size_t i = 0; i < n_queries; ++i)
+      snap->snap->plan_query(*scorer, std::string_view(queries[i].ptr ? queries[i].ptr : "", queries[i].len), tokenizer,
+                             user, plan);
+    const double t1 = wall_ms();
+    ps_batch_stats stats;
+    snap->engine->run_device(*scorer, fields_boost, plan, top_k, d_keys, d_scores, d_counts, hip_stream, stats);
+    stats.plan_ms = t1 - t0;
+    stats.total_ms = wall_ms() - t0;
+    set_stats(snap, stats);
+    return PS_OK;
+  });
+}
+
+ps_status ps_snapshot_last_stats(const ps_snapshot* snap, ps_batch_stats* out) {
+  if (!snap || !out) return fail(PS_EINVAL, "null argument");
+  ps_snapshot* s = const_cast<ps_snapshot*>(snap);
+  std::lock_guard<std::mutex> l(s->stats_mu);
+  *out = s->last;
+  return PS_OK;
+}
+
+ps_status ps_snapshot_kernel_times(ps_snapshot* snap, double* total_ms, uint64_t* launches, int reset) {
+  return guard([&]() -> ps_status {
+    if (!snap) return fail(PS_EINVAL, "null snapshot");
+    if (!snap->engine) return fail(PS_ENODEVICE, "host-only snapshot");
+    snap->engine->kernel_times(total_ms, launches, reset != 0);
+    return PS_OK;
+  });
+}
+
+ps_status ps_snapshot_plan(const ps_snapshot* snap, const ps_scorer_desc* scorer, const char* query, size_t query_len,
+                           ps_tokenizer_fn tokenizer, void* user, ps_plan_entry** out, size_t* out_len,
+                           size_t* query_terms_len) {
+  return guard([&]() -> ps_status {
+    if (!snap || !scorer || !out || !out_len) return fail(PS_EINVAL, "null argument");
+    ps::Plan plan;
+    plan.qbeg.push_back(0);
+    snap->snap->plan_query(*scorer, std::string_view(query ? query : "", query_len), tokenizer, user, plan);
+    ps_plan_entry* r = (ps_plan_entry*)malloc(sizeof(ps_plan_entry) * (plan.entries.size() ? plan.entries.size() : 1));
+    if (!r) return fail(PS_ENOMEM, "out of memory");
+    if (!plan.entries.empty()) memcpy(r, plan.entries.data(), sizeof(ps_plan_entry) * plan.entries.size());
+    *out = r;
+    *out_len = plan.entries.size();
+    if (query_terms_len) *query_terms_len = plan.qterms_len[0];
+    return PS_OK;
+  });
+}
+
+ps_status ps_snapshot_host_csr(const ps_snapshot* snap, ps_host_csr* out) {
+  if (!snap || !out) return fail(PS_EINVAL, "null argument");
+  const ps::Snapshot& s = *snap->snap;
+  out->doc = s.doc.data();
+  out->tf = s.tf.data();
+  out->fl = s.fl.data();
+  out->table = s.table.data();
+  out->keys = s.keys.data();
+  out->avg = s.avg.data();
+  out->plane_stride = s.P;
+  return PS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,898 @@
+// ps_engine.hip — HIP kernels (gfx950 / CDNA4) and batch execution for the query-scoring path.
+//
+// Replaces HOT LOOP #1 + #2 of Index::query (src/query.rs:45, 61-89 of probly-search 2.0.1), the
+// per-posting ScoreCalculator::score of BM25 (src/score/default/bm25.rs:60-93) and zero_to_one
+// (src/score/default/zero_to_one.rs:44-126), max_score_merger (src/query.rs:150-164) and the
+// result materialisation + sort (src/query.rs:97-105) with:
+//
+//   K1  k_bm25      one wavefront (64 lanes) per (query, run of S doc tiles).  The wave owns an
+//                   LDS tile of T f64 accumulators (+ u16 visited tags); for every plan entry, in
+//                   plan order, it streams the tile's slice of the doc-sorted posting list with
+//                   coalesced u32 loads (doc, tf[F], fl[F]), evaluates the BM25 term in f64 in the
+//                   reference's exact association (no FMA contraction) and applies the
+//                   add / max / assign merge to its own LDS slot.  A list holds a document at
+//                   most once, and LDS operations of one wave execute in order, so there are no
+//                   atomics and no barriers, and the result is bit-reproducible.
+//                   Epilogue per tile: scan the T slots, offer present documents to a wave-wide
+//                   top-K kept in registers (lane i = i-th best; ballot + popcount rank insert).
+//   K2  k_z21       same traversal; records per (doc, distinct node) tf vectors in LDS, then one
+//                   lane per document runs zero_to_one's greedy finalize in registers.
+//   K3  k_merge     one wave per query merges the per-run top-K lists, maps doc id -> key.
+//
+// Everything here is memory/VALU-f64 bound sparse gather-reduce: no MFMA on purpose.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "ps_engine.hpp"
+
+namespace ps {
+
+#define PS_HIP(call)                                                                            \
+  do {                                                                                          \
+    hipError_t _e = (call);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #call); \
+  } while (0)
+
+constexpr int MAX_F = 8;
+constexpr int WAVE = 64;
+
+struct KParams {
+  const uint32_t* doc;
+  const uint32_t* tf;
+  const uint32_t* fl;
+  const uint32_t* table;
+  const uint64_t* keys;
+  const ps_plan_entry* plan;
+  const uint32_t* qbeg;
+  const uint32_t* qterms_len;  // zero_to_one
+  const uint32_t* zorder;      // zero_to_one: per query, entry indices sorted by (score desc, plan order)
+  uint64_t P;
+  uint32_t B, n_tiles, T, S, n_super, K, n_docs, F, max_qterms, z_nodes, z_tile;
+  double k1, k1p1, one_minus_b, b;
+  double avg[MAX_F], boost[MAX_F];
+  double* cand_score;  // [B * n_super * K]
+  uint32_t* cand_doc;
+  // full-result mode
+  uint32_t* full_doc;
+  double* full_score;
+  const uint64_t* full_off;  // [B+1]
+  uint32_t* full_cnt;        // [B]
+  // final outputs
+  uint64_t* out_keys;
+  double* out_scores;
+  uint32_t* out_counts;
+};
+
+// ------------------------------------------------------------------------------------------
+// wave-level helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// canonical order of test_util::test_score (src/lib.rs:54-58): score desc, then key asc
+// (doc ids are assigned in ascending key order, so doc asc == key asc).
+__device__ __forceinline__ bool better(double as, uint32_t ad, double bs, uint32_t bd) {
+  return as > bs || (as == bs && ad < bd);
+}
+
+struct TopK {
+  double s;      // lane i: score of the i-th best so far (valid for i < n)
+  uint32_t d;    // its doc id
+  uint32_t n;    // wave-uniform fill
+  double thr_s;  // K-th best (valid when n == K)
+  uint32_t thr_d;
+};
+
+// Offer one candidate per lane (`has`), keep the best K.  All lanes must call.
+__device__ __forceinline__ void topk_offer(TopK& tk, const uint32_t K, const int lane, bool has, double v,
+                                           uint32_t d) {
+  bool cand = has && (tk.n < K || better(v, d, tk.thr_s, tk.thr_d));
+  unsigned long long m = __ballot(cand);
+  while (m) {
+    const int src = __ffsll(m) - 1;
+    m &= m - 1;
+    const double cs = readlane_f64(v, src);
+    const uint32_t cd = readlane_u32(d, src);
+    if (tk.n == K && !better(cs, cd, tk.thr_s, tk.thr_d)) continue;
+    const bool lb = ((uint32_t)lane < tk.n) && better(tk.s, tk.d, cs, cd);
+    const uint32_t pos = (uint32_t)__popcll(__ballot(lb));
+    const double us = __shfl_up(tk.s, 1);
+    const uint32_t ud = __shfl_up(tk.d, 1);
+    if ((uint32_t)lane > pos) { tk.s = us; tk.d = ud; }
+    else if ((uint32_t)lane == pos) { tk.s = cs; tk.d = cd; }
+    if (tk.n < K) tk.n++;
+    if (tk.n == K) {
+      tk.thr_s = readlane_f64(tk.s, (int)K - 1);
+      tk.thr_d = readlane_u32(tk.d, (int)K - 1);
+    }
+  }
+}
+
+// Full-result mode: append this wave's present documents to the query's output run.
+__device__ __forceinline__ void full_emit(const KParams& p, uint32_t q, int lane, bool has, double v, uint32_t d) {
+  unsigned long long m = __ballot(has);
+  if (m == 0) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&p.full_cnt[q], (uint32_t)__popcll(m));
+  base = readlane_u32(base, 0);
+  if (has) {
+    uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    uint64_t o = p.full_off[q] + base + rank;
+    p.full_doc[o] = d;
+    p.full_score[o] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: BM25 posting accumulate + merge + per-run top-K   (bm25.rs:60-93, query.rs:61-89,150-164)
+// ------------------------------------------------------------------------------------------
+template <int F_, bool TAGS, bool FULL>
+__global__ __launch_bounds__(WAVE) void k_bm25(const KParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* acc = reinterpret_cast<double*>(smem);
+  uint16_t* tag = reinterpret_cast<uint16_t*>(smem + (size_t)p.T * 8);
+  const int lane = threadIdx.x;
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+  const uint32_t T = p.T;
+  const uint32_t item = blockIdx.x;
+  const uint32_t q = item % p.B;
+  const uint32_t sup = item / p.B;
+  const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
+
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+
+  if (e0 != e1) {
+    for (uint32_t i = lane; i < T; i += WAVE) {
+      acc[i] = 0.0;
+      if (TAGS) tag[i] = 0xFFFFu;
+    }
+    uint32_t tagbase = 0;
+    const uint32_t t_begin = sup * p.S;
+    const uint32_t t_end = min(p.n_tiles, t_begin + p.S);
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+      const uint32_t tile_base = t * T;
+      for (uint32_t e = e0; e < e1; ++e) {
+        // plan entry fields are wave-uniform (scalar loads)
+        const uint64_t post_off = p.plan[e].post_off;
+        const uint32_t tbl_off = p.plan[e].tbl_off;
+        const uint32_t shift = p.plan[e].shift & 0xFFu;
+        const uint32_t slot = t >> shift;
+        const uint32_t rb = p.table[tbl_off + slot];
+        const uint32_t re = p.table[tbl_off + slot + 1];
+        if (rb == re) continue;
+        const double idf = p.plan[e].idf;
+        const double eb = p.plan[e].boost;
+        const uint16_t mytag = (uint16_t)(tagbase + p.plan[e].qterm);
+        for (uint32_t i = rb + lane; i < re; i += WAVE) {
+          const uint64_t pi = post_off + i;
+          const uint32_t local = p.doc[pi] - tile_base;
+          if (shift != 0 && local >= T) continue;  // coarse table slot spans several tiles
+          double s = 0.0;
+#pragma unroll
+          for (uint32_t x = 0; x < F; ++x) {
+            const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
+            if (tfu > 0) {
+              const double tfd = (double)tfu;
+              const double fld = (double)p.fl[(uint64_t)x * p.P + pi];
+              // bm25.rs:78-86, evaluated left to right, no contraction
+              const double tfn = (p.k1p1 * tfd) / (p.k1 * (p.one_minus_b + p.b * (fld / p.avg[x])) + tfd);
+              s += tfn * idf * p.boost[x] * eb;
+            }
+          }
+          if (TAGS) {
+            const double cur = acc[local];
+            const bool visited = tag[local] == mytag;
+            if (s > 0.0) {  // Some(score) iff score > 0 (bm25.rs:89-92)
+              // max_score_merger (query.rs:150-164); present <=> cur > 0 for BM25
+              acc[local] = (cur > 0.0) ? (visited ? fmax(cur, s) : cur + s) : s;
+            }
+            tag[local] = mytag;  // visited even when the score was None (query.rs:87)
+          } else {
+            if (s > 0.0) acc[local] += s;  // one list per query term: always the `+` / assign arm
+          }
+        }
+      }
+      // tile epilogue: harvest + reset
+      for (uint32_t c = 0; c < T; c += WAVE) {
+        const double v = acc[c + lane];
+        const bool has = v > 0.0;
+        if (has) acc[c + lane] = 0.0;
+        const uint32_t d = tile_base + c + lane;
+        if (FULL) full_emit(p, q, lane, has, v, d);
+        else topk_offer(tk, p.K, lane, has, v, d);
+      }
+      if (TAGS) {
+        tagbase += p.max_qterms;
+        if (tagbase + p.max_qterms >= 0xFFFFu) {
+          for (uint32_t i = lane; i < T; i += WAVE) tag[i] = 0xFFFFu;
+          tagbase = 0;
+        }
+      }
+    }
+  }
+  if (!FULL && (uint32_t)lane < p.K) {
+    const uint64_t o = (uint64_t)item * p.K + lane;
+    const bool ok = (uint32_t)lane < tk.n;
+    p.cand_score[o] = ok ? tk.s : 0.0;
+    p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: zero_to_one   (zero_to_one.rs:44-126)
+//
+// LDS per wave: rec[z_tile][z_nodes][F] u32 = term frequency of distinct node n in field x for
+// the tile's documents (0 = no hit).  ScoreByTerm's other members are per-entry constants in the
+// plan (score, query_term_index, node) or per-query (all_query_terms_len); field_length comes
+// with the posting and is kept in fls[z_tile][F].  Deduplicated postings are equivalent to the
+// reference's per-occurrence records (identical adjacent records: the first is either consumed,
+// after which the rest are skipped via consumed_index, or skipped for a reason that skips the
+// rest as well).  finalize per (doc, field): walk the query's entries in
+// zorder = stable sort by score desc (zero_to_one.rs:98), greedy-consume one record per query
+// term with the per-node pool (:101-120); doc score = max over fields (:122).
+// ------------------------------------------------------------------------------------------
+template <bool FULL>
+__global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t F = p.F, ZN = p.z_nodes, ZT = p.z_tile;
+  const uint32_t stride = ZN * F;
+  uint32_t* rec = reinterpret_cast<uint32_t*>(smem);  // [ZT][ZN][F] term frequencies
+  uint32_t* fls = rec + (size_t)ZT * stride;           // [ZT][F]     field lengths
+  const int lane = threadIdx.x;
+  const uint32_t item = blockIdx.x;
+  const uint32_t q = item % p.B;
+  const uint32_t sup = item / p.B;
+  const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
+
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+
+  if (e0 != e1) {
+    for (uint32_t i = lane; i < ZT * stride; i += WAVE) rec[i] = 0;
+    const uint32_t qtl = p.qterms_len[q];
+    const uint32_t sub_per_tile = p.T / ZT;  // ZT is a power of two <= T
+    const uint32_t t_begin = sup * p.S;
+    const uint32_t t_end = min(p.n_tiles, t_begin + p.S);
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+      for (uint32_t sub = 0; sub < sub_per_tile; ++sub) {
+        const uint32_t tile_base = t * p.T + sub * ZT;
+        if (tile_base >= p.n_docs) break;
+        for (uint32_t e = e0; e < e1; ++e) {
+          const uint64_t post_off = p.plan[e].post_off;
+          const uint32_t tbl_off = p.plan[e].tbl_off;
+          const uint32_t shift = p.plan[e].shift & 0xFFu;
+          const uint32_t layer = p.plan[e].shift >> 8;
+          const uint32_t node = p.plan[e].node;
+          const uint32_t slot = t >> shift;
+          const uint32_t rb = p.table[tbl_off + slot];
+          const uint32_t re = p.table[tbl_off + slot + 1];
+          for (uint32_t i = rb + lane; i < re; i += WAVE) {
+            const uint64_t pi = post_off + i;
+            const uint32_t local = p.doc[pi] - tile_base;
+            if (local >= ZT) continue;  // table slot wider than this sub-tile
+            for (uint32_t x = 0; x < F; ++x) {
+              const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
+              uint32_t* r = &rec[local * stride + node * F + x];
+              // layer 0 = newest version of a re-added key; older versions only fill fields
+              // the newer ones left empty (the first record per (entry, doc, field) decides)
+              if (tfu > 0 && (layer == 0 || *r == 0)) *r = tfu;
+              fls[local * F + x] = p.fl[(uint64_t)x * p.P + pi];
+            }
+          }
+        }
+        // finalize (zero_to_one.rs:84-126): one lane per document of the sub-tile
+        for (uint32_t c = 0; c < ZT; c += WAVE) {
+          const uint32_t local = c + lane;
+          bool has = false;
+          double best = 0.0;  // the merged dummy Some(0.) (zero_to_one.rs:81,122)
+          for (uint32_t x = 0; x < F; ++x) {
+            unsigned long long consumed_q = 0ull;  // consumed_index: bit = query-term ordinal
+            unsigned long long consumed_e = 0ull;  // consumed entries: bit = position in the query
+            double pool = 0.0;                     // score_by_pool
+            bool any = false;
+            for (uint32_t z = e0; z < e1; ++z) {
+              const uint32_t e = p.zorder[z];
+              const uint32_t node = p.plan[e].node;
+              const uint32_t tfu = rec[local * stride + node * F + x];
+              if (tfu == 0) continue;  // no record for this (entry, doc, field)
+              any = true;
+              const uint32_t qt = p.plan[e].qterm;
+              if ((consumed_q >> qt) & 1ull) continue;  // :101-103
+              // df_pool_by_id (:104-113): a node may be consumed term_frequency times in total
+              const unsigned long long same_node = (unsigned long long)__double_as_longlong(p.plan[e].idf);
+              if ((uint32_t)__popcll(consumed_e & same_node) >= tfu) continue;
+              consumed_e |= 1ull << (e - e0);
+              consumed_q |= 1ull << qt;
+              const double sc = p.plan[e].boost;
+              const double df = (double)tfu;
+              const uint32_t fl = fls[local * F + x];
+              const uint32_t den = fl > qtl ? fl : qtl;  // usize::max(field_length, all_query_terms_len)
+              pool += fmin(sc / df, 1.0) * df / (double)den;  // :117-120
+            }
+            if (any) { has = true; best = fmax(pool, best); }  // :122
+          }
+          if (has)
+            for (uint32_t w = 0; w < stride; ++w) rec[local * stride + w] = 0;
+          const uint32_t d = tile_base + local;
+          if (FULL) full_emit(p, q, lane, has, best, d);
+          else topk_offer(tk, p.K, lane, has, best, d);
+        }
+      }
+    }
+  }
+  if (!FULL && (uint32_t)lane < p.K) {
+    const uint64_t o = (uint64_t)item * p.K + lane;
+    const bool ok = (uint32_t)lane < tk.n;
+    p.cand_score[o] = ok ? tk.s : 0.0;
+    p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: merge per-run top-K lists -> final top-K per query, doc id -> key   (query.rs:97-105)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_merge(const KParams p) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+  const uint32_t K = p.K;
+  // candidates of (q, sup) live at item = sup * B + q
+  const uint32_t per_round = WAVE / K;  // runs handled per 64-lane load
+  for (uint32_t s0 = 0; s0 < p.n_super; s0 += per_round) {
+    const uint32_t sup = s0 + lane / K;
+    const uint32_t k = lane % K;
+    bool has = false;
+    double v = 0.0;
+    uint32_t d = 0xFFFFFFFFu;
+    if ((uint32_t)lane < per_round * K && sup < p.n_super) {
+      const uint64_t o = ((uint64_t)sup * p.B + q) * K + k;
+      d = p.cand_doc[o];
+      v = p.cand_score[o];
+      has = d != 0xFFFFFFFFu;
+    }
+    topk_offer(tk, K, lane, has, v, d);
+  }
+  if ((uint32_t)lane < K) {
+    const bool ok = (uint32_t)lane < tk.n;
+    const uint64_t o = (uint64_t)q * K + lane;
+    p.out_keys[o] = ok ? p.keys[tk.d] : ~0ull;
+    p.out_scores[o] = ok ? tk.s : 0.0;
+  }
+  if (lane == 0) p.out_counts[q] = tk.n;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 4 + 64;
+    PS_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// Pinned staging slot; `done` fences reuse so a caller-supplied stream may run ahead of the host.
+struct Stage {
+  unsigned char* p = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+  void ensure(size_t n) {
+    if (pending) { PS_HIP(hipEventSynchronize(done)); pending = false; }
+    if (n <= cap) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 4 + 256;
+    PS_HIP(hipHostMalloc((void**)&p, want, hipHostMallocDefault));
+    cap = want;
+  }
+};
+
+constexpr int N_STAGE = 4;
+constexpr int N_KTIMER = 32;
+
+struct EngineImpl {
+  const Snapshot* snap;
+  int device;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {};
+  uint32_t* d_doc = nullptr;
+  uint32_t* d_tf = nullptr;
+  uint32_t* d_fl = nullptr;
+  uint32_t* d_table = nullptr;
+  uint64_t* d_keys = nullptr;
+  uint64_t bytes = 0;
+  std::mutex mu;
+  // per-batch device buffers (grow-only; reuse is ordered by the stream)
+  DevBuf<ps_plan_entry> d_plan;
+  DevBuf<uint32_t> d_qbeg, d_qtl, d_zorder, d_cand_doc, d_out_counts, d_full_doc, d_full_cnt;
+  DevBuf<double> d_cand_score, d_out_scores, d_full_score;
+  DevBuf<uint64_t> d_out_keys, d_full_off;
+  Stage stage[N_STAGE];
+  int next_stage = 0;
+  Stage result;  // download staging (engine stream only)
+  // HIP-event pairs around every launch of the scoring kernel (K1/K2), harvested lazily so a
+  // caller that pipelines batches on its own stream still gets per-launch durations.
+  struct KTimer { hipEvent_t a = nullptr, b = nullptr; bool pending = false; };
+  KTimer kt[N_KTIMER];
+  int next_kt = 0;
+  double kt_total_ms = 0.0;
+  uint64_t kt_launches = 0;
+  void harvest(KTimer& t, bool wait) {
+    if (!t.pending) return;
+    if (!wait && hipEventQuery(t.b) != hipSuccess) return;
+    if (wait) (void)hipEventSynchronize(t.b);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { kt_total_ms += ms; kt_launches++; }
+    t.pending = false;
+  }
+};
+
+int device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
+  EngineImpl& m = *impl_;
+  m.snap = &snap;
+  m.device = device;
+  try {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+      throw std::runtime_error("no HIP device available (this engine has no CPU scoring fallback)");
+    if (device < 0 || device >= n) throw std::runtime_error("device index out of range");
+    PS_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PS_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+      throw std::runtime_error(std::string("built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+    PS_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+    for (auto& ev : m.ev) PS_HIP(hipEventCreate(&ev));
+    for (auto& sg : m.stage) PS_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&m.result.done, hipEventDisableTiming));
+    for (auto& t : m.kt) { PS_HIP(hipEventCreate(&t.a)); PS_HIP(hipEventCreate(&t.b)); }
+    const size_t P = snap.P, F = snap.F;
+    PS_HIP(hipMalloc((void**)&m.d_doc, P * 4));
+    PS_HIP(hipMalloc((void**)&m.d_tf, P * F * 4));
+    PS_HIP(hipMalloc((void**)&m.d_fl, P * F * 4));
+    PS_HIP(hipMalloc((void**)&m.d_table, snap.table.size() * 4));
+    PS_HIP(hipMalloc((void**)&m.d_keys, std::max<size_t>(1, snap.keys.size()) * 8));
+    PS_HIP(hipMemcpy(m.d_doc, snap.doc.data(), P * 4, hipMemcpyHostToDevice));
+    PS_HIP(hipMemcpy(m.d_tf, snap.tf.data(), P * F * 4, hipMemcpyHostToDevice));
+    PS_HIP(hipMemcpy(m.d_fl, snap.fl.data(), P * F * 4, hipMemcpyHostToDevice));
+    PS_HIP(hipMemcpy(m.d_table, snap.table.data(), snap.table.size() * 4, hipMemcpyHostToDevice));
+    if (!snap.keys.empty())
+      PS_HIP(hipMemcpy(m.d_keys, snap.keys.data(), snap.keys.size() * 8, hipMemcpyHostToDevice));
+    m.bytes = P * 4 + 2 * P * F * 4 + snap.table.size() * 4 + snap.keys.size() * 8;
+  } catch (...) {
+    delete impl_;
+    impl_ = nullptr;
+    throw;
+  }
+}
+
+Engine::~Engine() {
+  if (!impl_) return;
+  EngineImpl& m = *impl_;
+  (void)hipSetDevice(m.device);
+  (void)hipDeviceSynchronize();
+  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_keys})
+    if (p) (void)hipFree(p);
+  m.d_plan.release(); m.d_qbeg.release(); m.d_qtl.release(); m.d_zorder.release(); m.d_cand_doc.release();
+  m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
+  m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
+  for (auto& sg : m.stage) {
+    if (sg.p) (void)hipHostFree(sg.p);
+    if (sg.done) (void)hipEventDestroy(sg.done);
+  }
+  if (m.result.p) (void)hipHostFree(m.result.p);
+  if (m.result.done) (void)hipEventDestroy(m.result.done);
+  for (auto& ev : m.ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& t : m.kt) {
+    if (t.a) (void)hipEventDestroy(t.a);
+    if (t.b) (void)hipEventDestroy(t.b);
+  }
+  if (m.stream) (void)hipStreamDestroy(m.stream);
+  delete impl_;
+}
+
+uint64_t Engine::device_bytes() const { return impl_->bytes; }
+void Engine::kernel_times(double* total_ms, uint64_t* launches, bool reset) {
+  EngineImpl& m = *impl_;
+  std::lock_guard<std::mutex> lock(m.mu);
+  (void)hipSetDevice(m.device);
+  for (auto& t : m.kt) m.harvest(t, true);
+  if (total_ms) *total_ms = m.kt_total_ms;
+  if (launches) *launches = m.kt_launches;
+  if (reset) { m.kt_total_ms = 0.0; m.kt_launches = 0; }
+}
+int Engine::device() const { return impl_->device; }
+
+namespace {
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  return (uint32_t)strtoul(v, nullptr, 10);
+}
+
+void validate(const Snapshot& s, const ps_scorer_desc& sc, const Plan& plan) {
+  if (s.F > (uint32_t)MAX_F) throw std::length_error("the GPU path supports at most 8 fields");
+  if (sc.kind != PS_SCORER_BM25 && sc.kind != PS_SCORER_ZERO_TO_ONE) throw std::invalid_argument("unknown scorer kind");
+  if (plan.max_qterms >= 0x7FFF) throw std::length_error("more than 32766 non-empty terms in one query");
+  if (sc.kind == PS_SCORER_ZERO_TO_ONE) {
+    if (plan.max_qterms > 64 || plan.max_entries > 64)
+      throw std::length_error("zero_to_one on the GPU supports at most 64 expanded lists per query");
+  }
+}
+
+// Uploads the plan + per-query arrays through a pinned staging slot; fills the common KParams.
+void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, hipStream_t st,
+                KParams& kp) {
+  const Snapshot& s = *m.snap;
+  const size_t B = plan.qbeg.size() - 1;
+  const size_t ne = plan.entries.size();
+  const bool z = sc.kind == PS_SCORER_ZERO_TO_ONE;
+  const size_t off_e = 0;
+  const size_t off_q = off_e + ne * sizeof(ps_plan_entry);
+  const size_t off_l = off_q + (B + 1) * 4;
+  const size_t off_z = off_l + B * 4;
+  const size_t total = off_z + ne * 4;
+  Stage& sg = m.stage[m.next_stage];
+  m.next_stage = (m.next_stage + 1) % N_STAGE;
+  sg.ensure(total + 16);
+  unsigned char* h = sg.p;
+  if (ne) memcpy(h + off_e, plan.entries.data(), ne * sizeof(ps_plan_entry));
+  memcpy(h + off_q, plan.qbeg.data(), (B + 1) * 4);
+  if (B) memcpy(h + off_l, plan.qterms_len.data(), B * 4);
+  if (z) {
+    // per query: entry indices stably sorted by ScoreByTerm::score desc (zero_to_one.rs:98);
+    // the records' push order == plan order (query term asc, expansion order, newest version first)
+    uint32_t* zo = reinterpret_cast<uint32_t*>(h + off_z);
+    for (size_t q = 0; q < B; ++q) {
+      uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
+      for (uint32_t i = b; i < e; ++i) zo[i] = i;
+      std::stable_sort(zo + b, zo + e,
+                       [&](uint32_t a, uint32_t c) { return plan.entries[c].boost < plan.entries[a].boost; });
+    }
+  }
+  m.d_plan.ensure(ne + 1);
+  m.d_qbeg.ensure(B + 1);
+  m.d_qtl.ensure(B + 1);
+  m.d_zorder.ensure(ne + 1);
+  if (ne) PS_HIP(hipMemcpyAsync(m.d_plan.p, h + off_e, ne * sizeof(ps_plan_entry), hipMemcpyHostToDevice, st));
+  PS_HIP(hipMemcpyAsync(m.d_qbeg.p, h + off_q, (B + 1) * 4, hipMemcpyHostToDevice, st));
+  if (B) PS_HIP(hipMemcpyAsync(m.d_qtl.p, h + off_l, B * 4, hipMemcpyHostToDevice, st));
+  if (z && ne) PS_HIP(hipMemcpyAsync(m.d_zorder.p, h + off_z, ne * 4, hipMemcpyHostToDevice, st));
+  PS_HIP(hipEventRecord(sg.done, st));
+  sg.pending = true;
+
+  memset(&kp, 0, sizeof(kp));
+  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys;
+  kp.plan = m.d_plan.p; kp.qbeg = m.d_qbeg.p; kp.qterms_len = m.d_qtl.p; kp.zorder = m.d_zorder.p;
+  kp.P = s.P;
+  kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
+  kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
+  kp.k1 = sc.bm25_k1; kp.b = sc.bm25_b;
+  kp.k1p1 = sc.bm25_k1 + 1.0;        // (self.bm25k1 + 1_f64), bm25.rs:78 — same IEEE add on the host
+  kp.one_minus_b = 1.0 - sc.bm25_b;  // (1_f64 - self.bm25b),  bm25.rs:80
+  for (uint32_t x = 0; x < s.F; ++x) { kp.avg[x] = s.avg[x]; kp.boost[x] = boosts[x]; }
+  // work decomposition: one wave per (query, run of S tiles)
+  const uint64_t target = env_u32("PS_TARGET_ITEMS", 65536);
+  uint64_t S = ((uint64_t)s.n_tiles * std::max<size_t>(B, 1) + target - 1) / target;
+  const uint32_t s_env = env_u32("PS_TILES_PER_RUN", 0);
+  if (s_env) S = s_env;
+  if (S < 1) S = 1;
+  if (S > s.n_tiles) S = s.n_tiles;
+  kp.S = (uint32_t)S;
+  kp.n_super = (uint32_t)((s.n_tiles + S - 1) / S);
+}
+
+template <bool FULL>
+void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, hipStream_t st) {
+  const uint32_t n_items = kp.B * kp.n_super;
+  if (n_items == 0) return;
+  if (sc.kind == PS_SCORER_BM25) {
+    const bool tags = plan.multi_expansion;
+    const size_t lds = (size_t)kp.T * 8 + (tags ? (size_t)kp.T * 2 : 0);
+#define PS_LAUNCH_BM25(FV)                                                                           \
+  do {                                                                                               \
+    if (tags) hipLaunchKernelGGL((k_bm25<FV, true, FULL>), dim3(n_items), dim3(WAVE), lds, st, kp);  \
+    else hipLaunchKernelGGL((k_bm25<FV, false, FULL>), dim3(n_items), dim3(WAVE), lds, st, kp);      \
+  } while (0)
+    if (kp.F == 1) PS_LAUNCH_BM25(1);
+    else if (kp.F == 2) PS_LAUNCH_BM25(2);
+    else PS_LAUNCH_BM25(0);
+#undef PS_LAUNCH_BM25
+  } else {
+    // zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
+    kp.z_nodes = std::max<uint32_t>(1, plan.max_nodes);
+    const uint32_t per_doc = (kp.z_nodes * kp.F + kp.F) * 4;
+    uint32_t zt = kp.T;
+    const uint32_t budget = env_u32("PS_Z21_LDS", 20480);
+    while (zt > (uint32_t)WAVE && (size_t)zt * per_doc > budget) zt >>= 1;
+    if ((size_t)zt * per_doc > 65536) throw std::length_error("zero_to_one: fields x expanded terms exceed the LDS tile");
+    kp.z_tile = zt;
+    hipLaunchKernelGGL((k_z21<FULL>), dim3(n_items), dim3(WAVE), (size_t)zt * per_doc, st, kp);
+  }
+  PS_HIP(hipGetLastError());
+}
+
+void fill_stats(ps_batch_stats& st, const Snapshot& s, const Plan& plan, uint64_t emitted) {
+  st.n_queries = plan.qbeg.size() - 1;
+  st.n_plan_entries = plan.entries.size();
+  st.postings_visited = plan.postings;
+  st.algorithmic_bytes = plan.postings * (4 + 8 * (uint64_t)s.F) + emitted * 16;
+}
+
+// Enqueue plan upload + K1/K2 + K3 on `st`, writing the final top-k to the given device buffers.
+void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k,
+                  void* d_keys, void* d_scores, void* d_counts, hipStream_t st) {
+  const size_t B = plan.qbeg.size() - 1;
+  KParams kp;
+  PS_HIP(hipEventRecord(m.ev[0], st));
+  stage_plan(m, sc, boosts, plan, st, kp);
+  kp.K = (uint32_t)top_k;
+  const size_t n_cand = (size_t)B * kp.n_super * top_k;
+  m.d_cand_score.ensure(n_cand + 1);
+  m.d_cand_doc.ensure(n_cand + 1);
+  kp.cand_score = m.d_cand_score.p;
+  kp.cand_doc = m.d_cand_doc.p;
+  kp.out_keys = (uint64_t*)d_keys;
+  kp.out_scores = (double*)d_scores;
+  kp.out_counts = (uint32_t*)d_counts;
+  EngineImpl::KTimer& kt = m.kt[m.next_kt];
+  m.next_kt = (m.next_kt + 1) % N_KTIMER;
+  m.harvest(kt, true);
+  PS_HIP(hipEventRecord(m.ev[1], st));
+  PS_HIP(hipEventRecord(kt.a, st));
+  launch_score<false>(sc, plan, kp, st);
+  PS_HIP(hipEventRecord(kt.b, st));
+  kt.pending = true;
+  PS_HIP(hipEventRecord(m.ev[2], st));
+  if (B) {
+    hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE), 0, st, kp);
+    PS_HIP(hipGetLastError());
+  }
+  PS_HIP(hipEventRecord(m.ev[3], st));
+}
+
+void read_kernel_times(EngineImpl& m, ps_batch_stats& stats) {
+  float a = 0, b = 0, c = 0;
+  PS_HIP(hipEventElapsedTime(&a, m.ev[0], m.ev[1]));
+  PS_HIP(hipEventElapsedTime(&b, m.ev[1], m.ev[2]));
+  PS_HIP(hipEventElapsedTime(&c, m.ev[1], m.ev[3]));
+  stats.h2d_ms = a;
+  stats.score_kernel_ms = b;
+  stats.kernel_ms = c;
+}
+
+Plan sub_plan(const Plan& plan, size_t b, size_t e) {
+  Plan p2;
+  p2.qbeg.push_back(0);
+  for (size_t q = b; q < e; ++q) {
+    for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
+      p2.entries.push_back(plan.entries[i]);
+      p2.postings += plan.entries[i].len;
+    }
+    p2.qbeg.push_back((uint32_t)p2.entries.size());
+    p2.qterms_len.push_back(plan.qterms_len[q]);
+    p2.n_nodes.push_back(plan.n_nodes[q]);
+  }
+  p2.max_entries = plan.max_entries;
+  p2.max_qterms = plan.max_qterms;
+  p2.max_nodes = plan.max_nodes;
+  p2.multi_expansion = plan.multi_expansion;
+  return p2;
+}
+
+}  // namespace
+
+void Engine::run_device(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,
+                        void* d_scores, void* d_counts, void* stream, ps_batch_stats& stats) {
+  EngineImpl& m = *impl_;
+  const Snapshot& s = *m.snap;
+  validate(s, sc, plan);
+  if (top_k < 1 || top_k > PS_MAX_DEVICE_TOPK)
+    throw std::invalid_argument("top_k must be in [1, 64] for the device top-k path");
+  std::lock_guard<std::mutex> lock(m.mu);
+  PS_HIP(hipSetDevice(m.device));
+  const double t0 = now_ms();
+  hipStream_t st = stream ? (hipStream_t)stream : m.stream;
+  enqueue_topk(m, sc, boosts, plan, top_k, d_keys, d_scores, d_counts, st);
+  memset(&stats, 0, sizeof(stats));
+  fill_stats(stats, s, plan, (uint64_t)(plan.qbeg.size() - 1) * top_k);
+  if (!stream) {
+    PS_HIP(hipStreamSynchronize(st));
+    read_kernel_times(m, stats);
+  }
+  stats.total_ms = now_ms() - t0;
+}
+
+void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k,
+                      std::vector<ps_result>& out, std::vector<size_t>& offsets, ps_batch_stats& stats) {
+  EngineImpl& m = *impl_;
+  const Snapshot& s = *m.snap;
+  const size_t B = plan.qbeg.size() - 1;
+  validate(s, sc, plan);
+  out.clear();
+  offsets.assign(B + 1, 0);
+  memset(&stats, 0, sizeof(stats));
+  const double t0 = now_ms();
+
+  if (top_k >= 1 && top_k <= PS_MAX_DEVICE_TOPK) {
+    std::lock_guard<std::mutex> lock(m.mu);
+    PS_HIP(hipSetDevice(m.device));
+    hipStream_t st = m.stream;
+    const size_t nb = B * top_k;
+    m.d_out_keys.ensure(nb + 1);
+    m.d_out_scores.ensure(nb + 1);
+    m.d_out_counts.ensure(B + 1);
+    enqueue_topk(m, sc, boosts, plan, top_k, m.d_out_keys.p, m.d_out_scores.p, m.d_out_counts.p, st);
+    m.result.ensure(nb * 16 + B * 4 + 64);
+    uint64_t* hk = reinterpret_cast<uint64_t*>(m.result.p);
+    double* hs = reinterpret_cast<double*>(m.result.p + nb * 8);
+    uint32_t* hc = reinterpret_cast<uint32_t*>(m.result.p + nb * 16);
+    PS_HIP(hipEventRecord(m.ev[4], st));
+    if (nb) {
+      PS_HIP(hipMemcpyAsync(hk, m.d_out_keys.p, nb * 8, hipMemcpyDeviceToHost, st));
+      PS_HIP(hipMemcpyAsync(hs, m.d_out_scores.p, nb * 8, hipMemcpyDeviceToHost, st));
+    }
+    if (B) PS_HIP(hipMemcpyAsync(hc, m.d_out_counts.p, B * 4, hipMemcpyDeviceToHost, st));
+    PS_HIP(hipEventRecord(m.ev[5], st));
+    PS_HIP(hipStreamSynchronize(st));
+    read_kernel_times(m, stats);
+    float d2h = 0;
+    PS_HIP(hipEventElapsedTime(&d2h, m.ev[4], m.ev[5]));
+    stats.d2h_ms = d2h;
+    size_t total = 0;
+    for (size_t q = 0; q < B; ++q) { offsets[q] = total; total += hc[q]; }
+    offsets[B] = total;
+    out.resize(total);
+    for (size_t q = 0; q < B; ++q)
+      for (uint32_t k = 0; k < hc[q]; ++k) out[offsets[q] + k] = ps_result{hk[q * top_k + k], hs[q * top_k + k]};
+    fill_stats(stats, s, plan, total);
+    stats.total_ms = now_ms() - t0;
+    return;
+  }
+
+  // ---- full-result mode: top_k == 0 (every match, like the reference) or top_k > 64 ----------
+  // upper bound of matches per query: min(N, sum of its list lengths)
+  std::vector<uint64_t> cap(B + 1, 0);
+  for (size_t q = 0; q < B; ++q) {
+    uint64_t sum = 0;
+    for (uint32_t e = plan.qbeg[q]; e < plan.qbeg[q + 1]; ++e) sum += plan.entries[e].len;
+    cap[q + 1] = cap[q] + std::min<uint64_t>(sum, s.n_docs);
+  }
+  const uint64_t total_cap = cap[B];
+  const uint64_t budget = (uint64_t)env_u32("PS_FULL_BUDGET_MB", 4096) << 20;
+  if (total_cap * 12 > budget && B > 1) {
+    // keep the result buffers bounded: run the two halves of the batch one after the other
+    const size_t half = B / 2;
+    std::vector<ps_result> o1, o2;
+    std::vector<size_t> f1, f2;
+    ps_batch_stats s1, s2;
+    run_host(sc, boosts, sub_plan(plan, 0, half), top_k, o1, f1, s1);
+    run_host(sc, boosts, sub_plan(plan, half, B), top_k, o2, f2, s2);
+    out = std::move(o1);
+    out.insert(out.end(), o2.begin(), o2.end());
+    for (size_t q = 0; q <= half; ++q) offsets[q] = f1[q];
+    for (size_t q = half; q <= B; ++q) offsets[q] = f1[half] + f2[q - half];
+    fill_stats(stats, s, plan, out.size());
+    stats.h2d_ms = s1.h2d_ms + s2.h2d_ms;
+    stats.kernel_ms = s1.kernel_ms + s2.kernel_ms;
+    stats.score_kernel_ms = s1.score_kernel_ms + s2.score_kernel_ms;
+    stats.d2h_ms = s1.d2h_ms + s2.d2h_ms;
+    stats.total_ms = now_ms() - t0;
+    return;
+  }
+
+  std::lock_guard<std::mutex> lock(m.mu);
+  PS_HIP(hipSetDevice(m.device));
+  hipStream_t st = m.stream;
+  KParams kp;
+  PS_HIP(hipEventRecord(m.ev[0], st));
+  stage_plan(m, sc, boosts, plan, st, kp);
+  kp.K = 1;
+  m.d_full_doc.ensure(total_cap + 1);
+  m.d_full_score.ensure(total_cap + 1);
+  m.d_full_off.ensure(B + 1);
+  m.d_full_cnt.ensure(B + 1);
+  kp.full_doc = m.d_full_doc.p;
+  kp.full_score = m.d_full_score.p;
+  kp.full_off = m.d_full_off.p;
+  kp.full_cnt = m.d_full_cnt.p;
+  m.result.ensure((B + 1) * 12 + 64);
+  uint64_t* h_off = reinterpret_cast<uint64_t*>(m.result.p);
+  uint32_t* h_cnt = reinterpret_cast<uint32_t*>(m.result.p + (B + 1) * 8);
+  memcpy(h_off, cap.data(), (B + 1) * 8);
+  PS_HIP(hipMemcpyAsync(m.d_full_off.p, h_off, (B + 1) * 8, hipMemcpyHostToDevice, st));
+  PS_HIP(hipMemsetAsync(m.d_full_cnt.p, 0, (B + 1) * 4, st));
+  EngineImpl::KTimer& kt = m.kt[m.next_kt];
+  m.next_kt = (m.next_kt + 1) % N_KTIMER;
+  m.harvest(kt, true);
+  PS_HIP(hipEventRecord(m.ev[1], st));
+  PS_HIP(hipEventRecord(kt.a, st));
+  launch_score<true>(sc, plan, kp, st);
+  PS_HIP(hipEventRecord(kt.b, st));
+  kt.pending = true;
+  PS_HIP(hipEventRecord(m.ev[2], st));
+  PS_HIP(hipEventRecord(m.ev[3], st));
+  PS_HIP(hipMemcpyAsync(h_cnt, m.d_full_cnt.p, (B + 1) * 4, hipMemcpyDeviceToHost, st));
+  PS_HIP(hipStreamSynchronize(st));
+  std::vector<uint32_t> cnt(h_cnt, h_cnt + B);
+  read_kernel_times(m, stats);
+  // download only the filled prefix of every query's run
+  std::vector<uint32_t> hdoc(total_cap + 1);
+  std::vector<double> hsc(total_cap + 1);
+  PS_HIP(hipEventRecord(m.ev[4], st));
+  for (size_t q = 0; q < B; ++q) {
+    if (!cnt[q]) continue;
+    PS_HIP(hipMemcpyAsync(hdoc.data() + cap[q], m.d_full_doc.p + cap[q], (size_t)cnt[q] * 4, hipMemcpyDeviceToHost, st));
+    PS_HIP(hipMemcpyAsync(hsc.data() + cap[q], m.d_full_score.p + cap[q], (size_t)cnt[q] * 8, hipMemcpyDeviceToHost, st));
+  }
+  PS_HIP(hipEventRecord(m.ev[5], st));
+  PS_HIP(hipStreamSynchronize(st));
+  float d2h = 0;
+  PS_HIP(hipEventElapsedTime(&d2h, m.ev[4], m.ev[5]));
+  stats.d2h_ms = d2h;
+  size_t total = 0;
+  for (size_t q = 0; q < B; ++q) {
+    offsets[q] = total;
+    total += (top_k ? std::min<size_t>(top_k, cnt[q]) : cnt[q]);
+  }
+  offsets[B] = total;
+  out.resize(total);
+  std::vector<ps_result> tmp;
+  // Q4 (query.rs:97-105): materialise + sort.  Canonical order: score desc, doc id asc (== key asc).
+  auto cmp = [](const ps_result& x, const ps_result& y) { return x.score != y.score ? x.score > y.score : x.key < y.key; };
+  for (size_t q = 0; q < B; ++q) {
+    tmp.resize(cnt[q]);
+    for (uint32_t i = 0; i < cnt[q]; ++i) tmp[i] = ps_result{(uint64_t)hdoc[cap[q] + i], hsc[cap[q] + i]};
+    const size_t keep = offsets[q + 1] - offsets[q];
+    if (keep < tmp.size()) std::partial_sort(tmp.begin(), tmp.begin() + (long)keep, tmp.end(), cmp);
+    else std::sort(tmp.begin(), tmp.end(), cmp);
+    for (size_t i = 0; i < keep; ++i) out[offsets[q] + i] = ps_result{s.keys[(size_t)tmp[i].key], tmp[i].score};
+  }
+  fill_stats(stats, s, plan, total);
+  stats.total_ms = now_ms() - t0;
+}
+
+}  // namespace ps

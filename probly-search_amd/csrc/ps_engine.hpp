@@ -1,0 +1,43 @@
+// ps_engine.hpp — device side of a snapshot: HBM-resident CSR planes, per-batch plan upload,
+// the scoring kernels and result download.  Implemented in ps_engine.hip (HIP, gfx950 only).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "ps_snapshot.hpp"
+
+namespace ps {
+
+struct EngineImpl;
+
+class Engine {
+ public:
+  // Uploads the snapshot's planes to `device`.  Throws std::runtime_error on HIP failure.
+  Engine(const Snapshot& snap, int device);
+  ~Engine();
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  // Runs one planned batch.  top_k == 0: every match (canonical order) into out/offsets.
+  // top_k  > 0: the first top_k of the canonical order per query.
+  void run_host(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k,
+                std::vector<ps_result>& out, std::vector<size_t>& offsets, ps_batch_stats& stats);
+  // Device-resident top-k (1..PS_MAX_DEVICE_TOPK) into caller buffers, ordered on `stream`
+  // (nullptr = engine stream, synchronous).
+  void run_device(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,
+                  void* d_scores, void* d_counts, void* stream, ps_batch_stats& stats);
+
+  // Sum of HIP-event durations of every scoring-kernel launch since the last reset (waits for
+  // outstanding launches).
+  void kernel_times(double* total_ms, uint64_t* launches, bool reset);
+  uint64_t device_bytes() const;
+  int device() const;
+
+ private:
+  EngineImpl* impl_;
+};
+
+int device_count();
+
+}  // namespace ps

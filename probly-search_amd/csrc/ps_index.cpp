@@ -1,0 +1,312 @@
+// ps_index.cpp — host-side mutable index.  See ps_index.hpp for the design notes and the
+// reference citations (src/index.rs of quantleaf/probly-search 2.0.1).
+#include "ps_index.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace ps {
+
+std::vector<std::string_view> tokenize(std::string_view s, ps_tokenizer_fn fn, void* user,
+                                       std::vector<const char*>& sp, std::vector<size_t>& sl) {
+  std::vector<std::string_view> out;
+  if (fn == nullptr) {
+    // `s.split(' ')` (src/lib.rs:42-44): k separators -> k+1 tokens, empty ones included.
+    size_t start = 0;
+    for (size_t i = 0; i <= s.size(); ++i) {
+      if (i == s.size() || s[i] == ' ') {
+        out.emplace_back(s.data() + start, i - start);
+        start = i + 1;
+      }
+    }
+    return out;
+  }
+  size_t cap = s.size() + 2;
+  if (sp.size() < cap) { sp.resize(cap); sl.resize(cap); }
+  size_t n = fn(s.data(), s.size(), sp.data(), sl.data(), sp.size(), user);
+  if (n > sp.size()) {  // tokenizer produced more tokens than bytes+2: retry with the size it asked for
+    sp.resize(n); sl.resize(n);
+    n = fn(s.data(), s.size(), sp.data(), sl.data(), sp.size(), user);
+    if (n > sp.size()) n = sp.size();
+  }
+  out.reserve(n);
+  for (size_t i = 0; i < n; ++i) out.emplace_back(sp[i], sl[i]);
+  return out;
+}
+
+uint32_t next_char(std::string_view s, size_t& i) {
+  unsigned char c = (unsigned char)s[i++];
+  if (c < 0x80) return c;
+  int extra = (c >> 5) == 0x6 ? 1 : (c >> 4) == 0xE ? 2 : 3;
+  uint32_t cp = extra == 1 ? (c & 0x1Fu) : extra == 2 ? (c & 0x0Fu) : (c & 0x07u);
+  for (int k = 0; k < extra && i < s.size(); ++k) cp = (cp << 6) | ((unsigned char)s[i++] & 0x3Fu);
+  return cp;
+}
+
+void append_utf8(std::string& s, uint32_t cp) {
+  if (cp < 0x80) {
+    s.push_back((char)cp);
+  } else if (cp < 0x800) {
+    s.push_back((char)(0xC0 | (cp >> 6)));
+    s.push_back((char)(0x80 | (cp & 0x3F)));
+  } else if (cp < 0x10000) {
+    s.push_back((char)(0xE0 | (cp >> 12)));
+    s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+    s.push_back((char)(0x80 | (cp & 0x3F)));
+  } else {
+    s.push_back((char)(0xF0 | (cp >> 18)));
+    s.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+    s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+    s.push_back((char)(0x80 | (cp & 0x3F)));
+  }
+}
+
+Index::Index(size_t fields_num, size_t expected_index_size, size_t expected_documents_count) {
+  fields_.assign(fields_num, FieldDetails{});
+  nodes_.reserve(std::max<size_t>(expected_index_size, 16));
+  docs_.reserve(expected_documents_count);
+  new_node(0, NIL);  // root, char 0 (src/index.rs:54)
+}
+
+int32_t Index::new_node(uint32_t ch, int32_t parent) {
+  TrieNode n{ch, NIL, NIL, NIL, parent};
+  if (!free_nodes_.empty()) {
+    int32_t i = free_nodes_.back();
+    free_nodes_.pop_back();
+    nodes_[(size_t)i] = n;
+    return i;
+  }
+  nodes_.push_back(n);
+  return (int32_t)nodes_.size() - 1;
+}
+
+int32_t Index::find_child(int32_t node, uint32_t ch) const {
+  for (int32_t it = nodes_[(size_t)node].first_child; it != NIL; it = nodes_[(size_t)it].next)
+    if (nodes_[(size_t)it].ch == ch) return it;
+  return NIL;
+}
+
+// Walk / extend the trie for one term.  New children are prepended to their parent's child
+// list (src/index.rs:409-419, 437-452), which fixes the expansion order seen by queries.
+int32_t Index::find_or_create(std::string_view term) {
+  auto hit = term_cache_.find(std::string(term));
+  if (hit != term_cache_.end()) return hit->second;
+  int32_t node = 0;
+  size_t i = 0;
+  while (i < term.size()) {
+    size_t j = i;
+    uint32_t ch = next_char(term, j);
+    int32_t c = nodes_[(size_t)node].first_child == NIL ? NIL : find_child(node, ch);
+    if (c == NIL) {
+      while (i < term.size()) {
+        uint32_t cc = next_char(term, i);
+        int32_t nn = new_node(cc, node);
+        nodes_[(size_t)nn].next = nodes_[(size_t)node].first_child;
+        nodes_[(size_t)node].first_child = nn;
+        node = nn;
+      }
+      break;
+    }
+    node = c;
+    i = j;
+  }
+  term_cache_.emplace(std::string(term), node);
+  return node;
+}
+
+void Index::add_document(uint64_t key, const ps_str* values, const size_t* n_values, ps_tokenizer_fn tok,
+                         void* user) {
+  const size_t F = fields_.size();
+  std::vector<uint32_t> field_length(F, 0);
+  doc_nodes_.clear();
+  doc_tf_.clear();
+  std::unordered_map<int32_t, uint32_t> big;  // only used once a document has many distinct terms
+  size_t vi = 0;
+  for (size_t i = 0; i < F; ++i) {
+    for (size_t j = 0; j < n_values[i]; ++j, ++vi) {
+      std::string_view value(values[vi].ptr, values[vi].len);
+      uint32_t count = 0;
+      for (std::string_view term : tokenize(value, tok, user, sp_, sl_)) {
+        if (term.empty()) continue;  // src/index.rs:101
+        ++count;
+        int32_t node = find_or_create(term);
+        size_t slot = doc_nodes_.size();
+        if (doc_nodes_.size() <= 48) {
+          for (size_t k = 0; k < doc_nodes_.size(); ++k)
+            if (doc_nodes_[k] == node) { slot = k; break; }
+        } else {
+          if (big.empty())
+            for (size_t k = 0; k < doc_nodes_.size(); ++k) big.emplace(doc_nodes_[k], (uint32_t)k);
+          auto it = big.find(node);
+          if (it != big.end()) slot = it->second;
+        }
+        if (slot == doc_nodes_.size()) {
+          doc_nodes_.push_back(node);
+          doc_tf_.insert(doc_tf_.end(), F, 0u);
+          if (!big.empty() || doc_nodes_.size() > 49) big.emplace(node, (uint32_t)slot);
+        }
+        doc_tf_[slot * F + i] += 1;
+      }
+      fields_[i].sum += count;
+      fields_[i].avg = (double)fields_[i].sum / ((double)docs_.size() + 1.0);  // len BEFORE insert (:113)
+      field_length[i] = count;                                                // assignment (:114)
+    }
+  }
+  docs_[key] = DocDetails{std::move(field_length)};
+  for (size_t k = 0; k < doc_nodes_.size(); ++k) {
+    TrieNode& n = nodes_[(size_t)doc_nodes_[k]];
+    if (n.list == NIL) {
+      if (!free_lists_.empty()) { n.list = free_lists_.back(); free_lists_.pop_back(); }
+      else { lists_.emplace_back(); n.list = (int32_t)lists_.size() - 1; }
+    }
+    PostingList& pl = lists_[(size_t)n.list];
+    pl.keys.push_back(key);
+    pl.tf.insert(pl.tf.end(), doc_tf_.begin() + (long)(k * F), doc_tf_.begin() + (long)((k + 1) * F));
+  }
+  ++epoch_;
+}
+
+void Index::remove_document(uint64_t key) {
+  has_removed_ = true;
+  auto it = docs_.find(key);
+  if (it != docs_.end()) {
+    removed_.insert(key);
+    double new_len = (double)(docs_.size() - 1);
+    for (size_t i = 0; i < fields_.size(); ++i) {
+      uint32_t fl = it->second.field_length[i];
+      if (fl > 0) {
+        fields_[i].sum -= fl;
+        fields_[i].avg = (double)fields_[i].sum / new_len;  // 0/0 -> NaN when the last doc goes (:643)
+      }
+    }
+    docs_.erase(it);
+  }
+  ++epoch_;
+}
+
+// Returns 1 if the subtree still holds a posting (src/index.rs:203-241).
+size_t Index::vacuum_node(int32_t node) {
+  const size_t F = fields_.size();
+  int32_t li = nodes_[(size_t)node].list;
+  size_t ret = 0;
+  if (li != NIL) {
+    PostingList& pl = lists_[(size_t)li];
+    size_t w = 0;
+    for (size_t r = 0; r < pl.keys.size(); ++r) {
+      if (removed_.count(pl.keys[r])) continue;
+      if (w != r) {
+        pl.keys[w] = pl.keys[r];
+        std::copy(pl.tf.begin() + (long)(r * F), pl.tf.begin() + (long)((r + 1) * F), pl.tf.begin() + (long)(w * F));
+      }
+      ++w;
+    }
+    pl.keys.resize(w);
+    pl.tf.resize(w * F);
+    if (w == 0) {
+      PostingList().keys.swap(pl.keys);
+      std::vector<uint32_t>().swap(pl.tf);
+      free_lists_.push_back(li);
+      nodes_[(size_t)node].list = NIL;
+    } else {
+      ret = 1;
+    }
+  }
+  int32_t prev = NIL;
+  int32_t child = nodes_[(size_t)node].first_child;
+  while (child != NIL) {
+    size_t r = vacuum_node(child);
+    ret |= r;
+    int32_t nx = nodes_[(size_t)child].next;
+    if (r == 0) {
+      if (prev != NIL) nodes_[(size_t)prev].next = nx;
+      else nodes_[(size_t)node].first_child = nx;
+      free_nodes_.push_back(child);
+    } else {
+      prev = child;
+    }
+    child = nx;
+  }
+  return ret;
+}
+
+void Index::vacuum() {
+  vacuum_node(0);
+  removed_.clear();
+  has_removed_ = false;
+  term_cache_.clear();
+  ++epoch_;
+}
+
+const DocDetails* Index::doc(uint64_t key) const {
+  auto it = docs_.find(key);
+  return it == docs_.end() ? nullptr : &it->second;
+}
+
+size_t Index::count_nodes() const {
+  size_t c = 0;
+  std::vector<int32_t> st{0};
+  while (!st.empty()) {
+    int32_t n = st.back();
+    st.pop_back();
+    ++c;
+    for (int32_t it = nodes_[(size_t)n].first_child; it != NIL; it = nodes_[(size_t)it].next) st.push_back(it);
+  }
+  return c;
+}
+
+size_t Index::live_pointers() const {
+  size_t c = 0;
+  for (const PostingList& pl : lists_)
+    for (uint32_t t : pl.tf) c += t;
+  return c;
+}
+
+int32_t Index::find_node(std::string_view term) const {
+  int32_t node = 0;
+  size_t i = 0;
+  while (i < term.size() && node != NIL) node = find_child(node, next_char(term, i));
+  return node;
+}
+
+long Index::count_documents(int32_t node) const {
+  int32_t li = nodes_[(size_t)node].list;
+  if (li == NIL) return 0;
+  const PostingList& pl = lists_[(size_t)li];
+  const size_t F = fields_.size();
+  long df = 0;
+  for (size_t r = 0; r < pl.keys.size(); ++r) {
+    if (is_removed(pl.keys[r])) continue;
+    for (size_t x = 0; x < F; ++x) df += pl.tf[r * F + x];  // one pointer per occurrence (:119-157)
+  }
+  return df;
+}
+
+void Index::expand_from(int32_t node, std::string& term, std::vector<std::string>& out) const {
+  int32_t li = nodes_[(size_t)node].list;
+  if (li != NIL && !lists_[(size_t)li].keys.empty()) out.push_back(term);  // first_doc.is_some()
+  for (int32_t it = nodes_[(size_t)node].first_child; it != NIL; it = nodes_[(size_t)it].next) {
+    size_t len = term.size();
+    append_utf8(term, nodes_[(size_t)it].ch);
+    expand_from(it, term, out);
+    term.resize(len);
+  }
+}
+
+std::vector<std::string> Index::expand_term(std::string_view term) const {
+  std::vector<std::string> out;
+  int32_t node = find_node(term);
+  if (node != NIL) {
+    std::string t(term);
+    expand_from(node, t, out);
+  }
+  return out;
+}
+
+std::vector<uint32_t> Index::children(int32_t node) const {
+  std::vector<uint32_t> out;
+  for (int32_t it = nodes_[(size_t)node].first_child; it != NIL; it = nodes_[(size_t)it].next)
+    out.push_back(nodes_[(size_t)it].ch);
+  return out;
+}
+
+}  // namespace ps

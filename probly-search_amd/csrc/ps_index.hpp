@@ -1,0 +1,108 @@
+// ps_index.hpp — host-side mutable index (the build side of probly-search's Index<T>).
+//
+// Observable semantics follow src/index.rs of the reference (quantleaf/probly-search 2.0.1):
+// field sum/avg update rules (:112-114, :176-186), newest-first child order of the trie
+// (:409-419), per-occurrence document frequency (:119-157, :282-297), lazy removal + vacuum
+// (:161-241).  The data structure is NOT the reference's: postings are stored as one compact
+// record per (add_document call, term) carrying the per-field term frequencies — the reference's
+// c identical per-occurrence DocumentPointers are one record of multiplicity c = sum(tf) — in
+// flat per-term arrays that the flattener (ps_snapshot.cpp) turns into CSR planes for the GPU.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/probly_search_amd.h"
+
+namespace ps {
+
+constexpr int32_t NIL = -1;
+
+struct TrieNode {
+  uint32_t ch;          // Unicode scalar value (Rust `char`)
+  int32_t next;         // next sibling
+  int32_t first_child;  // newest child first
+  int32_t list;         // index into Index::lists, NIL if this node never held a posting
+  int32_t parent;
+};
+
+// All postings of one term, in add order (the reference's list order is the reverse).
+struct PostingList {
+  std::vector<uint64_t> keys;  // one per record
+  std::vector<uint32_t> tf;    // F per record
+};
+
+struct DocDetails {
+  std::vector<uint32_t> field_length;
+};
+
+struct FieldDetails {
+  uint64_t sum = 0;
+  double avg = 0.0;
+};
+
+std::vector<std::string_view> tokenize(std::string_view s, ps_tokenizer_fn fn, void* user,
+                                       std::vector<const char*>& scratch_p, std::vector<size_t>& scratch_l);
+// Decodes one UTF-8 scalar starting at s[i]; advances i.
+uint32_t next_char(std::string_view s, size_t& i);
+void append_utf8(std::string& s, uint32_t cp);
+
+class Index {
+ public:
+  explicit Index(size_t fields_num, size_t expected_index_size = 1000, size_t expected_documents_count = 10000);
+
+  void add_document(uint64_t key, const ps_str* values, const size_t* n_values, ps_tokenizer_fn tok, void* user);
+  void remove_document(uint64_t key);
+  void vacuum();
+
+  // read side
+  size_t fields_len() const { return fields_.size(); }
+  size_t docs_len() const { return docs_.size(); }
+  const FieldDetails& field(size_t i) const { return fields_[i]; }
+  const DocDetails* doc(uint64_t key) const;
+  size_t count_nodes() const;
+  size_t live_pointers() const;
+  int32_t find_node(std::string_view term) const;                // find_inverted_index_node
+  long count_documents(int32_t node) const;                      // Index::count_documents
+  std::vector<std::string> expand_term(std::string_view term) const;
+  std::vector<uint32_t> children(int32_t node) const;
+
+  // flattener access
+  const std::vector<TrieNode>& nodes() const { return nodes_; }
+  const std::vector<PostingList>& lists() const { return lists_; }
+  const std::unordered_map<uint64_t, DocDetails>& docs() const { return docs_; }
+  bool is_removed(uint64_t key) const { return has_removed_ && removed_.count(key) != 0; }
+  bool any_removed() const { return has_removed_ && !removed_.empty(); }
+  int32_t root() const { return 0; }
+  uint64_t epoch() const { return epoch_; }  // bumped by every mutation
+
+ private:
+  int32_t new_node(uint32_t ch, int32_t parent);
+  int32_t find_child(int32_t node, uint32_t ch) const;
+  int32_t find_or_create(std::string_view term);
+  size_t vacuum_node(int32_t node);
+  void expand_from(int32_t node, std::string& term, std::vector<std::string>& out) const;
+
+  std::vector<TrieNode> nodes_;
+  std::vector<int32_t> free_nodes_;
+  std::vector<PostingList> lists_;
+  std::vector<int32_t> free_lists_;
+  std::unordered_map<uint64_t, DocDetails> docs_;
+  std::vector<FieldDetails> fields_;
+  bool has_removed_ = false;
+  std::unordered_set<uint64_t> removed_;
+  // term -> node cache so bulk indexing does one hash probe per token instead of a trie walk
+  // over linked sibling lists; dropped whenever vacuum prunes nodes.
+  std::unordered_map<std::string, int32_t> term_cache_;
+  uint64_t epoch_ = 0;
+  // add_document scratch
+  std::vector<const char*> sp_;
+  std::vector<size_t> sl_;
+  std::vector<int32_t> doc_nodes_;
+  std::vector<uint32_t> doc_tf_;
+};
+
+}  // namespace ps

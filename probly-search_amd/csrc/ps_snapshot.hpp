@@ -1,0 +1,82 @@
+// ps_snapshot.hpp — immutable flattened view of an Index: CSR posting planes + frozen trie +
+// host query planner.  Host-only (no HIP here); ps_engine.hip owns the device side.
+//
+// What is flattened (reference structures: src/index.rs:342-396):
+//   * documents get dense ids in ASCENDING KEY order, so "doc id asc" == the canonical tie-break
+//     "key asc" of test_util::test_score (src/lib.rs:54-58);
+//   * every term's linked posting list becomes one (or, if a key was re-added without removal,
+//     several "version layers" of) doc-id-sorted run(s) in three kinds of u32 planes:
+//       doc[P], tf[F][P] (DocumentPointer::term_frequency), fl[F][P] (DocumentDetails::field_length,
+//       denormalised per posting) — 4 + 8F bytes per posting, the north-star layout;
+//   * removed documents are dropped; the per-occurrence pointer count survives as df_raw
+//     (== Index::count_documents, src/index.rs:282-297) because BM25's idf needs it;
+//   * per list, a table of offsets at LDS-tile granularity (tile t -> slot t >> shift), so a
+//     wavefront finds its doc-range slice of a list with two scalar loads and no search;
+//   * the trie is renumbered in DFS pre-order (children newest-first, src/query.rs:130-147), so
+//     `expand_term(prefix)` is a contiguous range of term ordinals.
+#pragma once
+#include <cstdint>
+#include <string_view>
+#include <vector>
+
+#include "ps_index.hpp"
+
+namespace ps {
+
+struct TermInfo {
+  uint64_t df_raw;       // live DocumentPointer count of the term
+  uint32_t byte_len;     // str::len() of the term (bm25.rs:48-53, zero_to_one.rs:57-58)
+  uint32_t first_layer;  // index into Snapshot::layers
+  uint32_t n_layers;     // 0 if no live posting
+  uint32_t fnode;        // frozen node id (unique per term; zero_to_one's index_node_id)
+};
+
+struct LayerInfo {
+  uint64_t post_off;  // multiple of 4 (16-byte aligned planes)
+  uint32_t len;
+  uint32_t tbl_off;
+  uint32_t shift;
+};
+
+struct FrozenNode {
+  uint32_t child_begin, child_count;  // into fchar/fchild, sorted by char
+  uint32_t term_begin, term_end;      // pre-order term ordinals of the subtree
+};
+
+struct Plan {
+  std::vector<ps_plan_entry> entries;
+  std::vector<uint32_t> qbeg;          // per query: first entry; size B+1
+  std::vector<uint32_t> qterms_len;    // per query: TermData::query_terms_len
+  std::vector<uint32_t> n_nodes;       // per query: distinct nodes (zero_to_one)
+  uint64_t postings = 0;               // sum of entry lens
+  uint32_t max_entries = 0, max_qterms = 0, max_nodes = 0;
+  bool multi_expansion = false;        // some query term owns >1 entry -> visited tags needed
+};
+
+class Snapshot {
+ public:
+  Snapshot(const Index& idx, uint32_t tile_docs);
+
+  // host planner: tokenise -> expand_term -> before_each (src/query.rs:29-60, bm25.rs:35-58)
+  void plan_query(const ps_scorer_desc& sc, std::string_view q, ps_tokenizer_fn tok, void* user, Plan& plan) const;
+
+  uint32_t F, T, n_tiles;
+  uint64_t n_docs;  // docs.len()
+  std::vector<uint64_t> keys;
+  std::vector<double> avg;
+  std::vector<TermInfo> terms;
+  std::vector<LayerInfo> layers;
+  std::vector<FrozenNode> fnodes;  // [0] = root
+  std::vector<uint32_t> fchar, fchild;
+  // CSR planes (host copy)
+  uint64_t P = 0;  // padded plane length
+  std::vector<uint32_t> doc, tf, fl, table;
+  uint64_t n_postings = 0, n_pointers = 0, n_live_terms = 0;
+  uint32_t max_layers = 1;
+  uint64_t src_epoch = 0;
+
+ private:
+  int64_t find_fnode(std::string_view term) const;
+};
+
+}  // namespace ps

@@ -1,0 +1,382 @@
+"""Host-side mirror of `probly_search::Index<T>` (src/index.rs, src/query.rs of probly-search
+2.0.1) over the C ABI.  Same method names, argument order and meaning as the reference:
+
+    index = Index(2)                                                      # Index::<usize>::new(2)
+    index.add_document([title_extract, description_extract], tokenizer, doc.id, doc)
+    result = index.query("abc", bm25.new(), tokenizer, [1., 1.])          # -> [QueryResult]
+    index.remove_document(doc.id); index.vacuum()
+
+Keys are u64 at the ABI (the reference's tests use usize).  Where the reference panics
+(fields_boost shorter than fields_num, src/score/default/bm25.rs:85) an IndexError is raised.
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import PsError
+
+
+def whitespace_tokenizer(s):
+    """test_util::tokenizer — `s.split(' ')` (src/lib.rs:42-44).  Passing this function (or
+    None) selects the identical built-in C++ tokenizer instead of a Python callback."""
+    return s.split(" ")
+
+
+class QueryResult:
+    """QueryResult<T> {key, score} (src/query.rs:10-15); == is exact f64 equality like the
+    derived PartialEq the reference's tests rely on."""
+    __slots__ = ("key", "score")
+
+    def __init__(self, key, score):
+        self.key = key
+        self.score = score
+
+    def __eq__(self, other):
+        return isinstance(other, QueryResult) and self.key == other.key and self.score == other.score
+
+    def __iter__(self):
+        return iter((self.key, self.score))
+
+    def __repr__(self):
+        return "QueryResult { key: %r, score: %r }" % (self.key, self.score)
+
+
+class FieldDetails:
+    """FieldDetails {sum, avg} (src/index.rs:391-396)."""
+    __slots__ = ("sum", "avg")
+
+    def __init__(self, sum, avg):
+        self.sum = sum
+        self.avg = avg
+
+    def __eq__(self, other):
+        return isinstance(other, FieldDetails) and self.sum == other.sum and self.avg == other.avg
+
+    def __repr__(self):
+        return "FieldDetails { sum: %r, avg: %r }" % (self.sum, self.avg)
+
+
+def _scorer_desc(score_calculator):
+    kind = getattr(score_calculator, "kind", None)
+    if kind not in (1, 2):
+        raise TypeError("score_calculator must be score.bm25.new() or score.zero_to_one.new(); custom "
+                        "ScoreCalculator callbacks cannot run on the device")
+    return _lib.ScorerDesc(kind, 0, float(score_calculator.bm25k1), float(score_calculator.bm25b))
+
+
+class _Tok:
+    """Wraps a Python tokenizer (str -> list[str]) as a ps_tokenizer_fn; None / the whitespace
+    tokenizer map to NULL (built-in split(' '))."""
+
+    def __init__(self, tokenizer):
+        self.fn = None
+        self._keep = []
+        if tokenizer is None or tokenizer is whitespace_tokenizer:
+            return
+        keep = self._keep
+
+        def cb(ptr, n, out_ptr, out_len, cap, _user):
+            del keep[:]
+            toks = [t.encode("utf-8") for t in tokenizer(C.string_at(ptr, n).decode("utf-8"))]
+            for i, t in enumerate(toks[:cap]):
+                buf = C.create_string_buffer(t, len(t) + 1)
+                keep.append(buf)
+                out_ptr[i] = C.cast(buf, C.c_void_p).value
+                out_len[i] = len(t)
+            return len(toks)
+
+        self.fn = _lib.TOKENIZER_FN(cb)
+
+    @property
+    def ptr(self):
+        return C.cast(self.fn, C.c_void_p) if self.fn is not None else None
+
+
+def _boosts(fields_boost):
+    arr = (C.c_double * max(1, len(fields_boost)))(*[float(b) for b in fields_boost])
+    return arr, len(fields_boost)
+
+
+def _raise(e):
+    if e.status == _lib.PS_EINVAL and "fields_boost" in str(e):
+        raise IndexError(str(e))
+    raise e
+
+
+def _take_results(L, out, n):
+    res = [QueryResult(out[i].key, out[i].score) for i in range(n)]
+    L.ps_free(out)
+    return res
+
+
+class Snapshot:
+    """Immutable flattened CSR view of an Index, resident in HBM (ps_snapshot)."""
+
+    def __init__(self, handle, owner):
+        self._L = _lib.load()
+        self._h = handle
+        self._owner = owner  # keep the Index alive
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.ps_snapshot_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def info(self):
+        i = _lib.SnapshotInfo()
+        _lib.check(self._L.ps_snapshot_get_info(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in i._fields_}
+
+    def query(self, query, score_calculator, tokenizer, fields_boost, top_k=0):
+        qb = query.encode("utf-8")
+        desc = _scorer_desc(score_calculator)
+        b, nb = _boosts(fields_boost)
+        tok = _Tok(tokenizer)
+        out, n = C.POINTER(_lib.Result)(), C.c_size_t()
+        try:
+            _lib.check(self._L.ps_snapshot_query(self._h, C.byref(desc), qb, len(qb), b, nb, tok.ptr, None, top_k,
+                                                 C.byref(out), C.byref(n)))
+        except PsError as e:
+            _raise(e)
+        return _take_results(self._L, out, n.value)
+
+    @staticmethod
+    def _pack_queries(queries):
+        qb = [q.encode("utf-8") if isinstance(q, str) else bytes(q) for q in queries]
+        arr = (_lib.Str * max(1, len(qb)))()
+        for i, v in enumerate(qb):
+            arr[i].ptr, arr[i].len = v, len(v)
+        return qb, arr
+
+    def query_batch(self, queries, score_calculator, tokenizer, fields_boost, top_k=0):
+        """B independent Index::query calls in one kernel pass -> list[list[QueryResult]]."""
+        qb, arr = self._pack_queries(queries)
+        desc = _scorer_desc(score_calculator)
+        b, nb = _boosts(fields_boost)
+        tok = _Tok(tokenizer)
+        out, offs = C.POINTER(_lib.Result)(), C.POINTER(C.c_size_t)()
+        try:
+            _lib.check(self._L.ps_snapshot_query_batch(self._h, C.byref(desc), arr, len(qb), b, nb, tok.ptr, None,
+                                                       top_k, C.byref(out), C.byref(offs)))
+        except PsError as e:
+            _raise(e)
+        res = [[QueryResult(out[j].key, out[j].score) for j in range(offs[i], offs[i + 1])] for i in range(len(qb))]
+        self._L.ps_free(out)
+        self._L.ps_free(offs)
+        return res
+
+    def query_batch_arrays(self, queries, score_calculator, tokenizer, fields_boost, top_k):
+        """Like query_batch but returns numpy arrays (keys u64[n], scores f64[n], offsets[B+1])."""
+        import numpy as np
+        qb, arr = self._pack_queries(queries)
+        desc = _scorer_desc(score_calculator)
+        b, nb = _boosts(fields_boost)
+        tok = _Tok(tokenizer)
+        out, offs = C.POINTER(_lib.Result)(), C.POINTER(C.c_size_t)()
+        try:
+            _lib.check(self._L.ps_snapshot_query_batch(self._h, C.byref(desc), arr, len(qb), b, nb, tok.ptr, None,
+                                                       top_k, C.byref(out), C.byref(offs)))
+        except PsError as e:
+            _raise(e)
+        o = np.ctypeslib.as_array(offs, shape=(len(qb) + 1,)).copy()
+        n = int(o[-1])
+        rec = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(max(n, 1), 2))[:n].copy()
+        self._L.ps_free(out)
+        self._L.ps_free(offs)
+        return rec[:, 0].copy(), rec[:, 1].copy().view(np.float64), o
+
+    def query_batch_device(self, queries, score_calculator, tokenizer, fields_boost, top_k, d_keys, d_scores,
+                           d_counts, stream=None):
+        """Device-resident top-k: d_* are device pointers (ints) on this snapshot's device, e.g.
+        torch tensors' data_ptr(); `stream` a hipStream_t handle (torch.cuda.Stream.cuda_stream)
+        or None for the engine's own stream (synchronous)."""
+        qb, arr = self._pack_queries(queries)
+        desc = _scorer_desc(score_calculator)
+        b, nb = _boosts(fields_boost)
+        tok = _Tok(tokenizer)
+        try:
+            _lib.check(self._L.ps_snapshot_query_batch_device(self._h, C.byref(desc), arr, len(qb), b, nb, tok.ptr,
+                                                              None, top_k, d_keys, d_scores, d_counts,
+                                                              stream if stream else None))
+        except PsError as e:
+            _raise(e)
+
+    def last_stats(self):
+        s = _lib.BatchStats()
+        _lib.check(self._L.ps_snapshot_last_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def kernel_times(self, reset=False):
+        """(total_ms, launches) of the posting-accumulate kernel since the last reset (HIP events)."""
+        t, n = C.c_double(), C.c_uint64()
+        _lib.check(self._L.ps_snapshot_kernel_times(self._h, C.byref(t), C.byref(n), 1 if reset else 0))
+        return t.value, n.value
+
+    def plan(self, query, score_calculator, tokenizer=None):
+        """Host query plan (tokenise -> expand_term -> before_each): (entries, query_terms_len)."""
+        qb = query.encode("utf-8")
+        desc = _scorer_desc(score_calculator)
+        tok = _Tok(tokenizer)
+        out, n, qtl = C.POINTER(_lib.PlanEntry)(), C.c_size_t(), C.c_size_t()
+        _lib.check(self._L.ps_snapshot_plan(self._h, C.byref(desc), qb, len(qb), tok.ptr, None, C.byref(out),
+                                            C.byref(n), C.byref(qtl)))
+        ents = [{k: getattr(out[i], k) for k, _ in _lib.PlanEntry._fields_} for i in range(n.value)]
+        self._L.ps_free(out)
+        return ents, qtl.value
+
+    def host_csr(self):
+        """numpy views of the host copy of the CSR planes (valid while the snapshot lives)."""
+        import numpy as np
+        c = _lib.HostCsr()
+        _lib.check(self._L.ps_snapshot_host_csr(self._h, C.byref(c)))
+        inf = self.info()
+        P, F = int(c.plane_stride), inf["fields_num"]
+        arr = np.ctypeslib.as_array
+        return {"doc": arr(c.doc, shape=(P,)), "tf": arr(c.tf, shape=(max(F, 1), P))[:F],
+                "fl": arr(c.fl, shape=(max(F, 1), P))[:F],
+                "table": arr(c.table, shape=(max(1, inf["n_table_entries"]),)),
+                "keys": arr(c.keys, shape=(max(1, inf["n_docs"]),))[:inf["n_docs"]],
+                "avg": arr(c.avg, shape=(max(F, 1),))[:F].copy(), "tile_docs": inf["tile_docs"]}
+
+
+class Index:
+    """Index<u64> (src/index.rs:19-33)."""
+
+    def __init__(self, fields_num, expected_index_size=None, expected_documents_count=None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        if expected_index_size is None:
+            _lib.check(self._L.ps_index_new(fields_num, C.byref(h)))            # Index::new
+        else:
+            _lib.check(self._L.ps_index_new_with_capacity(fields_num, expected_index_size,
+                                                          expected_documents_count or 10000, C.byref(h)))
+        self._h = h
+        self.fields_num = fields_num
+
+    @classmethod
+    def new(cls, fields_num):
+        return cls(fields_num)
+
+    @classmethod
+    def new_with_capacity(cls, fields_num, expected_index_size, expected_documents_count):
+        return cls(fields_num, expected_index_size, expected_documents_count)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.ps_index_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- build side ------------------------------------------------------------------------
+    def add_document(self, field_accessors, tokenizer, key, doc):
+        """Index::add_document(&[FieldAccessor<D>], Tokenizer, key, &doc) (src/index.rs:77-83).
+        A field accessor is `fn(&D) -> Vec<&str>`: a callable returning a list of strings."""
+        values = [list(acc(doc)) for acc in field_accessors]
+        self.add_field_values(key, values, tokenizer)
+
+    def add_field_values(self, key, values, tokenizer=None):
+        """add_document with the accessors already applied: values[i] = str or list[str]."""
+        vals, counts = [], []
+        for f in values:
+            vs = [f] if isinstance(f, str) else list(f)
+            counts.append(len(vs))
+            vals.extend(v.encode("utf-8") for v in vs)
+        if len(counts) < self.fields_num:
+            raise IndexError("fewer field accessors than fields_num (reference: index out of bounds, src/index.rs:91)")
+        arr = (_lib.Str * max(1, len(vals)))()
+        for i, v in enumerate(vals):
+            arr[i].ptr, arr[i].len = v, len(v)
+        cnt = (C.c_size_t * len(counts))(*counts)
+        tok = _Tok(tokenizer)
+        _lib.check(self._L.ps_index_add_document(self._h, key, arr, cnt, tok.ptr, None))
+
+    def add_documents_flat(self, keys, text, offsets):
+        """Bulk add (single-valued fields, whitespace tokenizer) from numpy arrays: keys u64[n],
+        text uint8[...], offsets u64[n*F+1]."""
+        import numpy as np
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text)
+        _lib.check(self._L.ps_index_add_documents_flat(self._h, len(keys), keys.ctypes.data, text.ctypes.data,
+                                                       offsets.ctypes.data))
+
+    def remove_document(self, key):
+        _lib.check(self._L.ps_index_remove_document(self._h, key))
+
+    def vacuum(self):
+        _lib.check(self._L.ps_index_vacuum(self._h))
+
+    # ---- query ------------------------------------------------------------------------------
+    def query(self, query, score_calculator, tokenizer, fields_boost, top_k=0):
+        """Index::query(query, &mut score_calculator, tokenizer, fields_boost) (src/query.rs:21-27):
+        every matching document, score desc (ties: key asc).  Runs on the GPU; the flattened
+        snapshot is rebuilt lazily after mutations."""
+        qb = query.encode("utf-8")
+        desc = _scorer_desc(score_calculator)
+        b, nb = _boosts(fields_boost)
+        tok = _Tok(tokenizer)
+        out, n = C.POINTER(_lib.Result)(), C.c_size_t()
+        try:
+            _lib.check(self._L.ps_index_query(self._h, C.byref(desc), qb, len(qb), b, nb, tok.ptr, None, top_k,
+                                              C.byref(out), C.byref(n)))
+        except PsError as e:
+            _raise(e)
+        return _take_results(self._L, out, n.value)
+
+    def snapshot(self, device=0, tile_docs=0):
+        """Flatten to CSR planes and upload to `device` (-1: host-only, for inspection)."""
+        h = C.c_void_p()
+        _lib.check(self._L.ps_index_snapshot(self._h, device, tile_docs, C.byref(h)))
+        return Snapshot(h, self)
+
+    # ---- read-side state the reference's unit tests look at -----------------------------------
+    @property
+    def fields(self):
+        out = []
+        for i in range(self.fields_num):
+            s, a = C.c_uint64(), C.c_double()
+            _lib.check(self._L.ps_index_field_details(self._h, i, C.byref(s), C.byref(a)))
+            out.append(FieldDetails(s.value, a.value))
+        return out
+
+    def docs_len(self):
+        return self._L.ps_index_docs_len(self._h)
+
+    def doc_field_length(self, key):
+        out = (C.c_uint64 * max(1, self.fields_num))()
+        if not self._L.ps_index_doc_field_length(self._h, key, out):
+            return None
+        return list(out)[:self.fields_num]
+
+    def count_nodes(self):
+        return self._L.ps_index_count_nodes(self._h)
+
+    def live_pointers(self):
+        return self._L.ps_index_live_pointers(self._h)
+
+    def children(self, term=""):
+        t = term.encode("utf-8")
+        n = self._L.ps_index_children(self._h, t, len(t), None, 0)
+        if n < 0:
+            return None
+        buf = (C.c_uint32 * max(1, n))()
+        self._L.ps_index_children(self._h, t, len(t), buf, n)
+        return [chr(buf[i]) for i in range(n)]
+
+    def count_documents(self, term):
+        t = term.encode("utf-8")
+        return self._L.ps_index_count_documents(self._h, t, len(t))
+
+    def expand_term(self, term):
+        """Index::expand_term (src/query.rs:109-126)."""
+        t = term.encode("utf-8")
+        need = C.c_size_t()
+        n = self._L.ps_index_expand_term(self._h, t, len(t), None, 0, C.byref(need))
+        buf = C.create_string_buffer(max(1, need.value))
+        self._L.ps_index_expand_term(self._h, t, len(t), buf, need.value, C.byref(need))
+        return [s.decode("utf-8") for s in buf.raw[:need.value].split(b"\0")[:n]]

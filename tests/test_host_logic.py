@@ -1,0 +1,105 @@
+"""CPU-only checks of the product's host half against the oracle:
+index state (field sums/averages, trie order, df), and — through tests/emu.py — the flattened
+CSR planes + tile tables + query plans (what the kernels consume)."""
+import math
+
+import pytest
+
+import probly_search_amd as psa
+from adapters import ProductIndex, oracle_scorer, product_scorer, replay
+from corpus_util import build_script, random_queries
+from emu import bits, emulate
+from kat_runner import load_cases, run_case
+from oracle import oracle as orc
+
+STATE_ONLY = [c for c in load_cases("reference_kats.json") if not any("query" in s for s in c["steps"])]
+
+
+@pytest.mark.parametrize("case", STATE_ONLY, ids=lambda c: c["id"])
+def test_product_index_state_kats(case):
+    run_case(ProductIndex, product_scorer, case, force_exact=True)
+
+
+def same_f64(a, b):
+    return (math.isnan(a) and math.isnan(b)) or bits(a) == bits(b)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("shape", ["plain", "shuffled", "multi"])
+def test_index_state_matches_oracle(seed, shape):
+    F, steps, vocab = build_script(seed, n_docs=50, fields=1 + seed % 3, shuffle_keys=shape == "shuffled",
+                                   multi_valued=shape == "multi")
+    o, p = orc.Index(F), ProductIndex(F)
+    replay(steps, F, o, p)
+    assert o.docs_len() == p.docs_len()
+    for i in range(F):
+        (so, ao), (sp, ap) = o.field_details(i), p.field_details(i)
+        assert so == sp and same_f64(ao, ap)
+    assert o.count_nodes() == p.count_nodes()
+    assert o.arena_doc_live() == p.arena_doc_live()
+    prefixes = {""} | {t[:k] for t in vocab for k in range(1, len(t) + 1)}
+    for pre in sorted(prefixes):
+        assert o.children(pre) == p.children(pre), pre
+        if pre:
+            assert o.expand_term(pre) == p.expand_term(pre), pre
+            assert o.count_documents(pre) == p.count_documents(pre), pre
+
+
+def check_queries(o, p, F, queries, tile_docs, scorers, boosts):
+    snap = p.idx.snapshot(device=-1, tile_docs=tile_docs)
+    info = snap.info()
+    assert info["n_docs"] == o.docs_len()
+    for q in queries:
+        for name, kw in scorers:
+            exp = o.query(q, oracle_scorer(name, **kw), boosts)
+            got = emulate(snap, product_scorer(name, **kw), q, boosts)
+            assert [k for k, _ in got] == [k for k, _ in exp], (q, name, got, exp)
+            for (_, a), (_, b) in zip(got, exp):
+                assert bits(a) == bits(b), (q, name, a.hex(), b.hex())
+    return info
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_plan_and_csr_reproduce_oracle(seed):
+    F, steps, vocab = build_script(100 + seed, n_docs=60, fields=1 + seed % 2, shuffle_keys=seed % 2 == 1)
+    o, p = orc.Index(F), ProductIndex(F)
+    replay(steps, F, o, p)
+    boosts = [1.0, 1.0][:F] if seed % 3 else [2.0, 0.5][:F]
+    scorers = [("bm25", {}), ("zero_to_one", {})]
+    if seed % 4 == 0:
+        scorers.append(("bm25", {"k1": 0.9, "b": 0.4}))
+    info = check_queries(o, p, F, random_queries(seed, vocab), 256, scorers, boosts)
+    assert info["n_pointers"] >= info["n_postings"] > 0
+
+
+def test_readd_without_remove_builds_version_layers():
+    # src/index.rs:739-782 re-add the same key; the reference then holds both versions' pointers.
+    o, p = orc.Index(1), ProductIndex(1)
+    for ix in (o, p):
+        ix.add_document(1, ["a a b"])
+        ix.add_document(2, ["a c"])
+        ix.add_document(1, ["a c c"])  # newer version of key 1: tf(a) 2 -> 1
+        ix.add_document(3, ["ab a"])
+    info = check_queries(o, p, 1, ["a", "a c", "c a", "b", "a a"], 256, [("bm25", {}), ("zero_to_one", {})], [1.0])
+    assert info["max_layers"] == 2
+
+
+def test_larger_corpus_multi_tile_tables():
+    F, steps, vocab = build_script(7, n_docs=900, fields=2, vocab_size=60, mutate=True)
+    o, p = orc.Index(F), ProductIndex(F)
+    replay(steps, F, o, p)
+    check_queries(o, p, F, random_queries(3, vocab, n=12), 256, [("bm25", {}), ("zero_to_one", {})], [1.0, 1.0])
+
+
+def test_plan_matches_before_each_values():
+    # R5: "h" expands to "hello" only; idf / expansion_boost as bm25.rs:35-58 computes them.
+    p = ProductIndex(2)
+    p.add_document(1, ["a b c", "hello world"])
+    p.add_document(2, ["c d e", "lorem ipsum"])
+    snap = p.idx.snapshot(device=-1)
+    ents, qtl = snap.plan("h", psa.bm25.new())
+    assert qtl == 1 and len(ents) == 1 and ents[0]["len"] == 1
+    assert ents[0]["idf"] == math.log(1.0 + (1 + 0.5) / (1 + 0.5))
+    assert ents[0]["boost"] == math.log(1.0 + 1.0 / (1.0 + 5.0 - 1.0))
+    ents, qtl = snap.plan("a  zzz c", psa.bm25.new())
+    assert qtl == 4 and [e["qterm_index"] for e in ents] == [0, 3]
