@@ -112,6 +112,26 @@ def lib_path():
     return _SO
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  The library needs `libamdhip64.so.7`; PyTorch-ROCm bundles
+    its own copy (same SONAME) and loads it by file name, so if ours pulled /opt/rocm's first,
+    a later `import torch` would bring up a second runtime and find no GPUs.  When torch is
+    installed we therefore load ITS libamdhip64 first (without importing torch); the dynamic
+    linker then binds our NEEDED entry to it by SONAME.  PS_HIP_RUNTIME=system opts out."""
+    if os.environ.get("PS_HIP_RUNTIME", "auto") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def load():
     """Loads the HIP extension.  Raises LibraryNotBuilt (never falls back to anything)."""
     global _lib
@@ -119,6 +139,7 @@ def load():
         if not os.path.exists(_SO):
             raise LibraryNotBuilt("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                   "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % _SO)
+        _preload_hip_runtime()
         L = C.CDLL(_SO)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
