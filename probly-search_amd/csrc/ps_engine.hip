@@ -43,6 +43,7 @@ namespace ps {
 
 constexpr int MAX_F = 8;
 constexpr int WAVE = 64;
+constexpr int UNROLL = 4;  // postings per lane per trip of the accumulate loop
 
 struct KParams {
   const uint32_t* doc;
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(WAVE) void k_bm25(const KParams p) {
     const uint32_t t_end = min(p.n_tiles, t_begin + p.S);
     for (uint32_t t = t_begin; t < t_end; ++t) {
       const uint32_t tile_base = t * T;
+      bool dirty = false;
       for (uint32_t e = e0; e < e1; ++e) {
         // plan entry fields are wave-uniform (scalar loads)
         const uint64_t post_off = p.plan[e].post_off;
@@ -177,35 +179,55 @@ __global__ __launch_bounds__(WAVE) void k_bm25(const KParams p) {
         const double idf = p.plan[e].idf;
         const double eb = p.plan[e].boost;
         const uint16_t mytag = (uint16_t)(tagbase + p.plan[e].qterm);
-        for (uint32_t i = rb + lane; i < re; i += WAVE) {
-          const uint64_t pi = post_off + i;
-          const uint32_t local = p.doc[pi] - tile_base;
-          if (shift != 0 && local >= T) continue;  // coarse table slot spans several tiles
-          double s = 0.0;
+        dirty = true;
+        // U postings per lane per trip, every load issued before the first use: the wave keeps
+        // (1+2F)*U independent coalesced 256-byte loads in flight instead of a dependent chain.
+        for (uint32_t i0 = rb; i0 < re; i0 += UNROLL * WAVE) {
+          uint32_t dv[UNROLL], tfv[UNROLL][F_ ? F_ : MAX_F], flv[UNROLL][F_ ? F_ : MAX_F];
 #pragma unroll
-          for (uint32_t x = 0; x < F; ++x) {
-            const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
-            if (tfu > 0) {
-              const double tfd = (double)tfu;
-              const double fld = (double)p.fl[(uint64_t)x * p.P + pi];
-              // bm25.rs:78-86, evaluated left to right, no contraction
-              const double tfn = (p.k1p1 * tfd) / (p.k1 * (p.one_minus_b + p.b * (fld / p.avg[x])) + tfd);
-              s += tfn * idf * p.boost[x] * eb;
+          for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t i = i0 + u * WAVE + lane;
+            const uint64_t pi = post_off + (i < re ? i : rb);  // clamp: always a valid posting
+            dv[u] = p.doc[pi];
+#pragma unroll
+            for (uint32_t x = 0; x < F; ++x) {
+              tfv[u][x] = p.tf[(uint64_t)x * p.P + pi];
+              flv[u][x] = p.fl[(uint64_t)x * p.P + pi];
             }
           }
-          if (TAGS) {
-            const double cur = acc[local];
-            const bool visited = tag[local] == mytag;
-            if (s > 0.0) {  // Some(score) iff score > 0 (bm25.rs:89-92)
-              // max_score_merger (query.rs:150-164); present <=> cur > 0 for BM25
-              acc[local] = (cur > 0.0) ? (visited ? fmax(cur, s) : cur + s) : s;
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t i = i0 + u * WAVE + lane;
+            const uint32_t local = dv[u] - tile_base;
+            // coarse table slots (shift != 0) span several tiles: keep only this tile's documents
+            if (i < re && (shift == 0 || local < T)) {
+              double s = 0.0;
+#pragma unroll
+              for (uint32_t x = 0; x < F; ++x) {
+                if (tfv[u][x] > 0) {
+                  const double tfd = (double)tfv[u][x];
+                  const double fld = (double)flv[u][x];
+                  // bm25.rs:78-86, evaluated left to right, no contraction
+                  const double tfn = (p.k1p1 * tfd) / (p.k1 * (p.one_minus_b + p.b * (fld / p.avg[x])) + tfd);
+                  s += tfn * idf * p.boost[x] * eb;
+                }
+              }
+              if (TAGS) {
+                const double cur = acc[local];
+                const bool visited = tag[local] == mytag;
+                if (s > 0.0) {  // Some(score) iff score > 0 (bm25.rs:89-92)
+                  // max_score_merger (query.rs:150-164); present <=> cur > 0 for BM25
+                  acc[local] = (cur > 0.0) ? (visited ? fmax(cur, s) : cur + s) : s;
+                }
+                tag[local] = mytag;  // visited even when the score was None (query.rs:87)
+              } else {
+                if (s > 0.0) acc[local] += s;  // one list per query term: always the `+` / assign arm
+              }
             }
-            tag[local] = mytag;  // visited even when the score was None (query.rs:87)
-          } else {
-            if (s > 0.0) acc[local] += s;  // one list per query term: always the `+` / assign arm
           }
         }
       }
+      if (!dirty) continue;  // no list of this query touches the tile: nothing to harvest
       // tile epilogue: harvest + reset
       for (uint32_t c = 0; c < T; c += WAVE) {
         const double v = acc[c + lane];
