@@ -44,6 +44,11 @@ namespace ps {
 constexpr int MAX_F = 8;
 constexpr int WAVE = 64;
 constexpr int UNROLL = 4;  // postings per lane per trip of the accumulate loop
+constexpr int WG_WAVES = 4;  // waves per workgroup of K1; each wave owns its own LDS tile
+constexpr int LUT_TF = 16;   // LUT columns: term frequency 0..15
+#ifndef PS_ABLATE_BUILD
+#define PS_ABLATE_BUILD 0  // profiling builds only: honour KParams::ablate in the hot loops
+#endif
 
 struct KParams {
   const uint32_t* doc;
@@ -59,6 +64,12 @@ struct KParams {
   uint32_t B, n_tiles, T, S, n_super, K, n_docs, F, max_qterms, z_nodes, z_tile;
   double k1, k1p1, one_minus_b, b;
   double avg[MAX_F], boost[MAX_F];
+  // saturated-tf LUT (see k_bm25_lut): rows of LUT_TF doubles, row = lut_base[x] + field_length
+  const double* lut;
+  uint32_t lut_rows, lut_stride;  // entry (tf, row) lives at tf * lut_stride + row; stride is odd
+  uint32_t lut_cap[MAX_F], lut_base[MAX_F];
+  uint32_t ablate;  // PS_ABLATE debug bit mask (profiling only): 1 = no top-k offer, 2 = no scoring
+  unsigned long long* gthr;  // [B] bits of the best published local K-th score per query (0 = none)
   double* cand_score;  // [B * n_super * K]
   uint32_t* cand_doc;
   // full-result mode
@@ -98,9 +109,11 @@ struct TopK {
 };
 
 // Offer one candidate per lane (`has`), keep the best K.  All lanes must call.
+// `gt` is a lower bound of the query's final K-th best score published by other waves of the same
+// query (0 = none yet): anything strictly below it cannot be in the final top-K.
 __device__ __forceinline__ void topk_offer(TopK& tk, const uint32_t K, const int lane, bool has, double v,
-                                           uint32_t d) {
-  bool cand = has && (tk.n < K || better(v, d, tk.thr_s, tk.thr_d));
+                                           uint32_t d, const double gt = 0.0) {
+  bool cand = has && v >= gt && (tk.n < K || better(v, d, tk.thr_s, tk.thr_d));
   unsigned long long m = __ballot(cand);
   while (m) {
     const int src = __ffsll(m) - 1;
@@ -140,23 +153,202 @@ __device__ __forceinline__ void full_emit(const KParams& p, uint32_t q, int lane
 // ------------------------------------------------------------------------------------------
 // K1: BM25 posting accumulate + merge + per-run top-K   (bm25.rs:60-93, query.rs:61-89,150-164)
 // ------------------------------------------------------------------------------------------
+// The saturated term frequency bm25.rs:78-82 computes per posting-field,
+//   tfn(tf, fl) = ((k1+1)*tf) / (k1*((1-b) + b*(fl/avg_x)) + tf),
+// depends only on (field, tf, fl).  Each batch, k_bm25_lut evaluates THE SAME f64 expression once
+// per (field, fl < lut_cap[x], tf < 16) and K1 stages the table in LDS, so the common small-integer
+// case costs one LDS read instead of two IEEE f64 divisions; everything else takes the inline
+// expression.  Same operations on the same operands -> bit-identical values.
+__device__ __forceinline__ double bm25_tfn(const KParams& p, uint32_t x, uint32_t tfu, uint32_t flu) {
+  const double tfd = (double)tfu;
+  const double fld = (double)flu;
+  // bm25.rs:78-82, evaluated left to right, no contraction
+  return (p.k1p1 * tfd) / (p.k1 * (p.one_minus_b + p.b * (fld / p.avg[x])) + tfd);
+}
+
+__global__ __launch_bounds__(256) void k_bm25_lut(const KParams p, double* out) {
+  for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < p.lut_stride * LUT_TF; i += blockDim.x * gridDim.x) {
+    const uint32_t tfu = i / p.lut_stride, row = i % p.lut_stride;
+    uint32_t x = 0;
+    while (x + 1 < p.F && row >= p.lut_base[x] + p.lut_cap[x]) ++x;
+    out[i] = row < p.lut_rows ? bm25_tfn(p, x, tfu, row - p.lut_base[x]) : 0.0;
+  }
+}
+
+// Score U postings per lane (bm25.rs:60-93) and merge them into the wave's LDS tile
+// (query.rs:78-87,150-164).  Written branch-free on purpose: all LUT gathers of the trip are
+// issued back to back, then all arithmetic, then all LDS updates, so the wave never sits on one
+// LDS round trip per posting-field.  `+ 0.0` for a field with tf == 0 leaves the f64 sum
+// bit-identical to skipping it.
+template <int F_, bool TAGS, int U>
+__device__ __forceinline__ void bm25_trip(const KParams& p, const double* lut, double* acc, uint16_t* tag,
+                                          const uint32_t F, const int lane, const uint32_t tile_base,
+                                          const uint32_t shift, const uint32_t i0, const uint32_t re,
+                                          const uint32_t (&dv)[U], const uint32_t (&tfv)[U][F_ ? F_ : MAX_F],
+                                          const uint32_t (&flv)[U][F_ ? F_ : MAX_F], const double idf, const double eb,
+                                          const uint16_t mytag) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  if (PS_ABLATE_BUILD && (p.ablate & 2u)) {  // profiling only: loads stay alive, no scoring
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if ((dv[u] ^ tfv[u][0] ^ flv[u][0]) == 0xFFFFFFF1u) acc[0] = 1.0;
+    return;
+  }
+  bool ok[U];
+  uint32_t local[U];
+  double tfn[U][FA];
+  bool slow = false;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t i = i0 + u * WAVE + lane;
+    local[u] = dv[u] - tile_base;
+    // coarse table slots (shift != 0) span several tiles: keep only this tile's documents
+    ok[u] = i < re && (shift == 0 || local[u] < p.T);
+#pragma unroll
+    for (uint32_t x = 0; x < F; ++x) {
+      const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+      const bool in_lut = tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x];
+      // transposed, odd-stride table: lanes with different field lengths hit different LDS banks
+      tfn[u][x] = lut[in_lut ? tfu * p.lut_stride + p.lut_base[x] + flu : 0u];
+      slow |= ok[u] && tfu > 0 && !in_lut;
+    }
+  }
+  if (__any(slow)) {  // wave-uniform; rare once the LUT covers the corpus' field lengths
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (uint32_t x = 0; x < F; ++x) {
+        const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+        if (!(tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x])) tfn[u][x] = bm25_tfn(p, x, tfu, flu);
+      }
+    }
+  }
+  double s[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    s[u] = 0.0;
+#pragma unroll
+    for (uint32_t x = 0; x < F; ++x) {
+      const double term = tfn[u][x] * idf * p.boost[x] * eb;  // bm25.rs:83-86: ((tfn*idf)*boost)*expansion_boost
+      s[u] += (tfv[u][x] > 0) ? term : 0.0;
+    }
+  }
+  if (TAGS) {
+    double cur[U];
+    uint16_t tg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cur[u] = ok[u] ? acc[local[u]] : 0.0;
+      tg[u] = ok[u] ? tag[local[u]] : (uint16_t)0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ok[u]) {
+        if (s[u] > 0.0)  // Some(score) iff score > 0 (bm25.rs:89-92)
+          // max_score_merger (query.rs:150-164); present <=> cur > 0 for BM25
+          acc[local[u]] = (cur[u] > 0.0) ? (tg[u] == mytag ? fmax(cur[u], s[u]) : cur[u] + s[u]) : s[u];
+        tag[local[u]] = mytag;  // visited even when the score was None (query.rs:87)
+      }
+    }
+  } else {
+    // one list per query term: always the `+` / assign arm (absent == +0.0).  A list holds a
+    // document once, so the LDS f64 add is uncontended; issuing it as a no-return DS op keeps
+    // the read-modify-write latency off the wave's critical path.
+    if (PS_ABLATE_BUILD && (p.ablate & 32u)) {  // profiling only: plain batched read-modify-write instead of DS atomics
+      double cur[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = ok[u] ? acc[local[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[u] && s[u] > 0.0) acc[local[u]] = cur[u] + s[u];
+      return;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (ok[u] && s[u] > 0.0)
+        __hip_atomic_fetch_add(&acc[local[u]], s[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+}
+
+template <int F_, int U>
+__device__ __forceinline__ void load_trip(const KParams& p, const uint32_t F, const int lane, const uint64_t post_off,
+                                          const uint32_t i0, const uint32_t re, uint32_t (&dv)[U],
+                                          uint32_t (&tfv)[U][F_ ? F_ : MAX_F], uint32_t (&flv)[U][F_ ? F_ : MAX_F]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t i = i0 + u * WAVE + lane;
+    const uint64_t pi = post_off + (i < re ? i : re - 1);  // clamp: always a valid posting
+    dv[u] = p.doc[pi];
+#pragma unroll
+    for (uint32_t x = 0; x < F; ++x) {
+      tfv[u][x] = p.tf[(uint64_t)x * p.P + pi];
+      flv[u][x] = p.fl[(uint64_t)x * p.P + pi];
+    }
+  }
+}
+
+// Stream postings [rb, re) of one list through the tile, UNROLL*64 per trip; the next trip's
+// loads are in flight while the current one is scored.
+template <int F_, bool TAGS>
+__device__ __forceinline__ void bm25_stream(const KParams& p, const double* lut, double* acc, uint16_t* tag,
+                                            const uint32_t F, const int lane, const uint32_t tile_base,
+                                            const uint64_t post_off, const uint32_t shift, uint32_t rb,
+                                            const uint32_t re, const double idf, const double eb,
+                                            const uint16_t mytag) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  uint32_t dv[UNROLL], tfv[UNROLL][FA], flv[UNROLL][FA];
+  uint32_t dn[UNROLL], tfnx[UNROLL][FA], flnx[UNROLL][FA];
+  load_trip<F_, UNROLL>(p, F, lane, post_off, rb, re, dv, tfv, flv);
+  for (uint32_t i0 = rb; i0 < re; i0 += UNROLL * WAVE) {
+    const uint32_t nx = i0 + UNROLL * WAVE;
+    if (nx < re) load_trip<F_, UNROLL>(p, F, lane, post_off, nx, re, dn, tfnx, flnx);
+    bm25_trip<F_, TAGS, UNROLL>(p, lut, acc, tag, F, lane, tile_base, shift, i0, re, dv, tfv, flv, idf, eb, mytag);
+    if (nx < re) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        dv[u] = dn[u];
+#pragma unroll
+        for (uint32_t x = 0; x < F; ++x) { tfv[u][x] = tfnx[u][x]; flv[u][x] = flnx[u][x]; }
+      }
+    }
+  }
+}
+
+constexpr int G = 4;   // plan entries kept register-resident by the fast path
+constexpr int FU = 2;  // postings per lane in the fast path's prefetched first trip
+
 template <int F_, bool TAGS, bool FULL>
-__global__ __launch_bounds__(WAVE) void k_bm25(const KParams p) {
+__global__ __launch_bounds__(WAVE * WG_WAVES) void k_bm25(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* acc = reinterpret_cast<double*>(smem);
-  uint16_t* tag = reinterpret_cast<uint16_t*>(smem + (size_t)p.T * 8);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  // readfirstlane: tell the compiler the wave index is wave-uniform, so everything derived from
+  // it (item, query, plan entries, table ranges) lives in SGPRs and is fetched with scalar loads
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+  constexpr int FA = F_ ? F_ : MAX_F;
   const uint32_t T = p.T;
-  const uint32_t item = blockIdx.x;
+  // LDS: [LUT, shared by the workgroup][wave 0 tile][wave 1 tile]...
+  const double* lut = reinterpret_cast<const double*>(smem);
+  const uint32_t lut_bytes = p.lut_stride * LUT_TF * 8;
+  const uint32_t tile_bytes = T * 8 + (TAGS ? T * 2 : 0);
+  double* acc = reinterpret_cast<double*>(smem + lut_bytes + (size_t)wave * tile_bytes);
+  uint16_t* tag = reinterpret_cast<uint16_t*>(smem + lut_bytes + (size_t)wave * tile_bytes + (size_t)T * 8);
+  {
+    double* l = reinterpret_cast<double*>(smem);
+    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * WG_WAVES) l[i] = p.lut[i];
+    __syncthreads();  // the only workgroup-level synchronisation: waves are independent from here on
+  }
+  const uint32_t item = blockIdx.x * WG_WAVES + wave;
+  if (item >= p.B * p.n_super) return;
   const uint32_t q = item % p.B;
   const uint32_t sup = item / p.B;
   const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
+  const uint32_t ne = e1 - e0;
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
 
-  if (e0 != e1) {
+  if (ne != 0) {
     for (uint32_t i = lane; i < T; i += WAVE) {
       acc[i] = 0.0;
       if (TAGS) tag[i] = 0xFFFFu;
@@ -164,78 +356,97 @@ __global__ __launch_bounds__(WAVE) void k_bm25(const KParams p) {
     uint32_t tagbase = 0;
     const uint32_t t_begin = sup * p.S;
     const uint32_t t_end = min(p.n_tiles, t_begin + p.S);
+
+    // ---- fast path set-up: the whole plan of this query fits in registers ----------------------
+    // Entry constants go to SGPRs; the tile-offset table slice of the run goes to one VGPR pair per
+    // entry (lane l <-> tile t_begin + l), so the per-tile range lookup is a v_readlane instead
+    // of a dependent scalar-memory round trip.  Requires S <= 63.
+    const bool fast = F_ != 0 && ne <= (uint32_t)G && p.S < (uint32_t)WAVE;  // generic-F build: arrays would spill
+    uint64_t g_post[G];
+    uint32_t g_shift[G], g_rbv[G], g_rev[G], g_qterm[G];
+    double g_idf[G], g_eb[G];
+    if (fast) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        g_rbv[g] = 0; g_rev[g] = 0; g_post[g] = 0; g_shift[g] = 0; g_qterm[g] = 0; g_idf[g] = 0.0; g_eb[g] = 0.0;
+        if ((uint32_t)g < ne) {
+          const ps_plan_entry& en = p.plan[e0 + g];
+          g_post[g] = en.post_off;
+          g_shift[g] = en.shift & 0xFFu;
+          g_qterm[g] = en.qterm;
+          g_idf[g] = en.idf;
+          g_eb[g] = en.boost;
+          const uint32_t tl = min(t_begin + (uint32_t)lane, p.n_tiles - 1);
+          const uint32_t slot = tl >> g_shift[g];
+          g_rbv[g] = p.table[en.tbl_off + slot];
+          g_rev[g] = p.table[en.tbl_off + slot + 1];
+        }
+      }
+    }
+
     for (uint32_t t = t_begin; t < t_end; ++t) {
       const uint32_t tile_base = t * T;
       bool dirty = false;
-      for (uint32_t e = e0; e < e1; ++e) {
-        // plan entry fields are wave-uniform (scalar loads)
-        const uint64_t post_off = p.plan[e].post_off;
-        const uint32_t tbl_off = p.plan[e].tbl_off;
-        const uint32_t shift = p.plan[e].shift & 0xFFu;
-        const uint32_t slot = t >> shift;
-        const uint32_t rb = p.table[tbl_off + slot];
-        const uint32_t re = p.table[tbl_off + slot + 1];
-        if (rb == re) continue;
-        const double idf = p.plan[e].idf;
-        const double eb = p.plan[e].boost;
-        const uint16_t mytag = (uint16_t)(tagbase + p.plan[e].qterm);
-        dirty = true;
-        // U postings per lane per trip, every load issued before the first use: the wave keeps
-        // (1+2F)*U independent coalesced 256-byte loads in flight instead of a dependent chain.
-        for (uint32_t i0 = rb; i0 < re; i0 += UNROLL * WAVE) {
-          uint32_t dv[UNROLL], tfv[UNROLL][F_ ? F_ : MAX_F], flv[UNROLL][F_ ? F_ : MAX_F];
+      if (fast) {
+        const int tl = (int)(t - t_begin);
+        uint32_t rb[G], re[G];
+        uint32_t dv[G][FU], tfv[G][FU][FA], flv[G][FU][FA];
+        // phase 1: first trips of every entry, all loads in flight together
 #pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
-            const uint32_t i = i0 + u * WAVE + lane;
-            const uint64_t pi = post_off + (i < re ? i : rb);  // clamp: always a valid posting
-            dv[u] = p.doc[pi];
+        for (int g = 0; g < G; ++g) {
+          rb[g] = readlane_u32(g_rbv[g], tl);
+          re[g] = readlane_u32(g_rev[g], tl);
+          if (rb[g] < re[g]) load_trip<F_, FU>(p, F, lane, g_post[g], rb[g], re[g], dv[g], tfv[g], flv[g]);  // wave-uniform
+        }
+        // phase 2: consume in plan order
 #pragma unroll
-            for (uint32_t x = 0; x < F; ++x) {
-              tfv[u][x] = p.tf[(uint64_t)x * p.P + pi];
-              flv[u][x] = p.fl[(uint64_t)x * p.P + pi];
-            }
+        for (int g = 0; g < G; ++g) {
+          if (rb[g] < re[g]) {
+            dirty = true;
+            const uint16_t mytag = (uint16_t)(tagbase + g_qterm[g]);
+            bm25_trip<F_, TAGS, FU>(p, lut, acc, tag, F, lane, tile_base, g_shift[g], rb[g], re[g], dv[g], tfv[g], flv[g],
+                                    g_idf[g], g_eb[g], mytag);
+            if (rb[g] + FU * WAVE < re[g])
+              bm25_stream<F_, TAGS>(p, lut, acc, tag, F, lane, tile_base, g_post[g], g_shift[g], rb[g] + FU * WAVE,
+                                    re[g], g_idf[g], g_eb[g], mytag);
           }
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
-            const uint32_t i = i0 + u * WAVE + lane;
-            const uint32_t local = dv[u] - tile_base;
-            // coarse table slots (shift != 0) span several tiles: keep only this tile's documents
-            if (i < re && (shift == 0 || local < T)) {
-              double s = 0.0;
-#pragma unroll
-              for (uint32_t x = 0; x < F; ++x) {
-                if (tfv[u][x] > 0) {
-                  const double tfd = (double)tfv[u][x];
-                  const double fld = (double)flv[u][x];
-                  // bm25.rs:78-86, evaluated left to right, no contraction
-                  const double tfn = (p.k1p1 * tfd) / (p.k1 * (p.one_minus_b + p.b * (fld / p.avg[x])) + tfd);
-                  s += tfn * idf * p.boost[x] * eb;
-                }
-              }
-              if (TAGS) {
-                const double cur = acc[local];
-                const bool visited = tag[local] == mytag;
-                if (s > 0.0) {  // Some(score) iff score > 0 (bm25.rs:89-92)
-                  // max_score_merger (query.rs:150-164); present <=> cur > 0 for BM25
-                  acc[local] = (cur > 0.0) ? (visited ? fmax(cur, s) : cur + s) : s;
-                }
-                tag[local] = mytag;  // visited even when the score was None (query.rs:87)
-              } else {
-                if (s > 0.0) acc[local] += s;  // one list per query term: always the `+` / assign arm
-              }
-            }
-          }
+        }
+      } else {
+        for (uint32_t e = e0; e < e1; ++e) {
+          // plan entry fields are wave-uniform (scalar loads)
+          const uint32_t tbl_off = p.plan[e].tbl_off;
+          const uint32_t shift = p.plan[e].shift & 0xFFu;
+          const uint32_t slot = t >> shift;
+          const uint32_t rb = p.table[tbl_off + slot];
+          const uint32_t re = p.table[tbl_off + slot + 1];
+          if (rb == re) continue;
+          dirty = true;
+          bm25_stream<F_, TAGS>(p, lut, acc, tag, F, lane, tile_base, p.plan[e].post_off, shift, rb, re, p.plan[e].idf,
+                                p.plan[e].boost, (uint16_t)(tagbase + p.plan[e].qterm));
         }
       }
       if (!dirty) continue;  // no list of this query touches the tile: nothing to harvest
-      // tile epilogue: harvest + reset
-      for (uint32_t c = 0; c < T; c += WAVE) {
-        const double v = acc[c + lane];
-        const bool has = v > 0.0;
-        if (has) acc[c + lane] = 0.0;
-        const uint32_t d = tile_base + c + lane;
-        if (FULL) full_emit(p, q, lane, has, v, d);
-        else topk_offer(tk, p.K, lane, has, v, d);
+      if (PS_ABLATE_BUILD && (p.ablate & 4u)) continue;
+      // tile epilogue: harvest + reset, two documents per lane per LDS access (ds_read_b128)
+      double gt = 0.0;
+      if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      for (uint32_t c = 0; c < T; c += 2 * WAVE) {
+        double2* slot = reinterpret_cast<double2*>(&acc[c + 2 * lane]);
+        const double2 v = *slot;
+        const bool h0 = v.x > 0.0, h1 = v.y > 0.0;
+        if (h0 || h1) *slot = make_double2(0.0, 0.0);
+        const uint32_t d = tile_base + c + 2 * lane;
+        if (FULL) {
+          full_emit(p, q, lane, h0, v.x, d);
+          full_emit(p, q, lane, h1, v.y, d + 1);
+        } else if (!(PS_ABLATE_BUILD && (p.ablate & 1u))) {
+          topk_offer(tk, p.K, lane, h0, v.x, d, gt);
+          topk_offer(tk, p.K, lane, h1, v.y, d + 1, gt);
+        }
+      }
+      if (!FULL && tk.n == p.K && tk.thr_s > gt) {
+        // publish this run's K-th best: the final K-th best of the query can only be higher
+        if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
       }
       if (TAGS) {
         tagbase += p.max_qterms;
@@ -452,6 +663,7 @@ struct EngineImpl {
   uint32_t* d_fl = nullptr;
   uint32_t* d_table = nullptr;
   uint64_t* d_keys = nullptr;
+  double* d_lut = nullptr;
   uint64_t bytes = 0;
   std::mutex mu;
   // per-batch device buffers (grow-only; reuse is ordered by the stream)
@@ -459,6 +671,7 @@ struct EngineImpl {
   DevBuf<uint32_t> d_qbeg, d_qtl, d_zorder, d_cand_doc, d_out_counts, d_full_doc, d_full_cnt;
   DevBuf<double> d_cand_score, d_out_scores, d_full_score;
   DevBuf<uint64_t> d_out_keys, d_full_off;
+  DevBuf<unsigned long long> d_gthr;
   Stage stage[N_STAGE];
   int next_stage = 0;
   Stage result;  // download staging (engine stream only)
@@ -511,6 +724,7 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     PS_HIP(hipMalloc((void**)&m.d_fl, P * F * 4));
     PS_HIP(hipMalloc((void**)&m.d_table, snap.table.size() * 4));
     PS_HIP(hipMalloc((void**)&m.d_keys, std::max<size_t>(1, snap.keys.size()) * 8));
+    PS_HIP(hipMalloc((void**)&m.d_lut, ((size_t)snap.lut_rows + 4) * LUT_TF * 8));
     PS_HIP(hipMemcpy(m.d_doc, snap.doc.data(), P * 4, hipMemcpyHostToDevice));
     PS_HIP(hipMemcpy(m.d_tf, snap.tf.data(), P * F * 4, hipMemcpyHostToDevice));
     PS_HIP(hipMemcpy(m.d_fl, snap.fl.data(), P * F * 4, hipMemcpyHostToDevice));
@@ -530,11 +744,12 @@ Engine::~Engine() {
   EngineImpl& m = *impl_;
   (void)hipSetDevice(m.device);
   (void)hipDeviceSynchronize();
-  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_keys})
+  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_keys, (void*)m.d_lut})
     if (p) (void)hipFree(p);
   m.d_plan.release(); m.d_qbeg.release(); m.d_qtl.release(); m.d_zorder.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
+  m.d_gthr.release();
   for (auto& sg : m.stage) {
     if (sg.p) (void)hipHostFree(sg.p);
     if (sg.done) (void)hipEventDestroy(sg.done);
@@ -632,10 +847,17 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.P = s.P;
   kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
   kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
+  kp.ablate = env_u32("PS_ABLATE", 0);
   kp.k1 = sc.bm25_k1; kp.b = sc.bm25_b;
   kp.k1p1 = sc.bm25_k1 + 1.0;        // (self.bm25k1 + 1_f64), bm25.rs:78 — same IEEE add on the host
   kp.one_minus_b = 1.0 - sc.bm25_b;  // (1_f64 - self.bm25b),  bm25.rs:80
   for (uint32_t x = 0; x < s.F; ++x) { kp.avg[x] = s.avg[x]; kp.boost[x] = boosts[x]; }
+  if (sc.kind == PS_SCORER_BM25 && env_u32("PS_LUT", 1)) {
+    kp.lut = m.d_lut;
+    kp.lut_rows = s.lut_rows;
+    kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;  // odd stride; LUT bytes = stride*128, so tiles stay 16-B aligned
+    for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
+  }
   // work decomposition: one wave per (query, run of S tiles)
   const uint64_t target = env_u32("PS_TARGET_ITEMS", 65536);
   uint64_t S = ((uint64_t)s.n_tiles * std::max<size_t>(B, 1) + target - 1) / target;
@@ -653,11 +875,13 @@ void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, hipSt
   if (n_items == 0) return;
   if (sc.kind == PS_SCORER_BM25) {
     const bool tags = plan.multi_expansion;
-    const size_t lds = (size_t)kp.T * 8 + (tags ? (size_t)kp.T * 2 : 0);
-#define PS_LAUNCH_BM25(FV)                                                                           \
-  do {                                                                                               \
-    if (tags) hipLaunchKernelGGL((k_bm25<FV, true, FULL>), dim3(n_items), dim3(WAVE), lds, st, kp);  \
-    else hipLaunchKernelGGL((k_bm25<FV, false, FULL>), dim3(n_items), dim3(WAVE), lds, st, kp);      \
+    const size_t lds = (size_t)kp.lut_stride * LUT_TF * 8 + WG_WAVES * ((size_t)kp.T * 8 + (tags ? (size_t)kp.T * 2 : 0));
+    const uint32_t n_wg = (n_items + WG_WAVES - 1) / WG_WAVES;
+    if (kp.lut_rows) hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
+#define PS_LAUNCH_BM25(FV)                                                                                     \
+  do {                                                                                                         \
+    if (tags) hipLaunchKernelGGL((k_bm25<FV, true, FULL>), dim3(n_wg), dim3(WAVE * WG_WAVES), lds, st, kp);   \
+    else hipLaunchKernelGGL((k_bm25<FV, false, FULL>), dim3(n_wg), dim3(WAVE * WG_WAVES), lds, st, kp);       \
   } while (0)
     if (kp.F == 1) PS_LAUNCH_BM25(1);
     else if (kp.F == 2) PS_LAUNCH_BM25(2);
@@ -697,6 +921,9 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   m.d_cand_doc.ensure(n_cand + 1);
   kp.cand_score = m.d_cand_score.p;
   kp.cand_doc = m.d_cand_doc.p;
+  m.d_gthr.ensure(B + 1);
+  kp.gthr = m.d_gthr.p;
+  PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, (B + 1) * 8, st));
   kp.out_keys = (uint64_t*)d_keys;
   kp.out_scores = (double*)d_scores;
   kp.out_counts = (uint32_t*)d_counts;

@@ -47,6 +47,25 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
     const DocDetails* d = idx.doc(keys[i]);
     for (uint32_t x = 0; x < F; ++x) fl_by_doc[i * F + x] = d->field_length[x];
   }
+  // LUT geometry: cover field lengths 0..max_fl[x] where the row budget (64 rows = 8 KiB of LDS)
+  // allows; longer documents take the inline arithmetic.
+  max_fl.assign(F, 0);
+  for (size_t i = 0; i < (size_t)n_docs; ++i)
+    for (uint32_t x = 0; x < F; ++x) max_fl[x] = std::max(max_fl[x], fl_by_doc[i * F + x]);
+  lut_cap.assign(F, 0);
+  lut_base.assign(F, 0);
+  {
+    uint32_t budget = 64;
+    for (uint32_t x = 0; x < F; ++x) {
+      uint32_t fair = budget / (F - x);
+      uint32_t want = (uint32_t)std::min<uint64_t>((uint64_t)max_fl[x] + 1, fair);
+      // fields are visited in order; what a short field leaves unused goes to the later ones
+      lut_base[x] = lut_rows;
+      lut_cap[x] = n_docs ? want : 0;
+      lut_rows += lut_cap[x];
+      budget -= lut_cap[x];
+    }
+  }
   auto id_of = [&](uint64_t key) -> uint32_t {
     if (direct) return key <= max_key ? direct_id[(size_t)key] : 0xFFFFFFFFu;
     auto it = hashed_id.find(key);
