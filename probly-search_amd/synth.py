@@ -120,6 +120,15 @@ class Corpus:
         return out
 
 
+def pack_queries(queries):
+    """list[str] -> (uint8 text, uint64 offsets[n+1]) for the *_flat batch entry points."""
+    enc = [q.encode("utf-8") for q in queries]
+    offsets = np.zeros(len(enc) + 1, dtype=np.uint64)
+    np.cumsum([len(e) for e in enc], out=offsets[1:])
+    text = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy()
+    return text, offsets
+
+
 def fill(index, corpus, chunk_docs=100_000):
     """index: anything with add_documents_flat(keys, text, offsets) (product Index or the oracle)."""
     for keys, text, offsets in corpus.chunks(chunk_docs):
