@@ -59,6 +59,8 @@ struct KParams {
   const ps_plan_entry* plan;
   const uint32_t* qbeg;
   const uint32_t* qterms_len;  // zero_to_one
+  const uint32_t* qflags;      // zero_to_one: bit 0 = "simple" query (k_score<MODE_Z21S> owns it)
+  uint32_t slice_bytes;        // per-wave LDS for the table slices (0 = look ranges up in global memory)
   const uint32_t* zorder;      // zero_to_one: per query, entry indices sorted by (score desc, plan order)
   uint64_t P;
   uint32_t B, n_tiles, T, S, n_super, K, n_docs, F, max_qterms, z_nodes, z_tile;
@@ -68,6 +70,7 @@ struct KParams {
   const double* lut;
   uint32_t lut_rows, lut_stride;  // entry (tf, row) lives at tf * lut_stride + row; stride is odd
   uint32_t lut_cap[MAX_F], lut_base[MAX_F];
+  uint32_t n_simple, n_general;  // host-side bookkeeping (zero_to_one query classes in this batch)
   uint32_t ablate;  // PS_ABLATE debug bit mask (profiling only): 1 = no top-k offer, 2 = no scoring
   unsigned long long* gthr;  // [B] bits of the best published local K-th score per query (0 = none)
   double* cand_score;  // [B * n_super * K]
@@ -175,19 +178,59 @@ __global__ __launch_bounds__(256) void k_bm25_lut(const KParams p, double* out) 
   }
 }
 
-// Score U postings per lane (bm25.rs:60-93) and merge them into the wave's LDS tile
-// (query.rs:78-87,150-164).  Written branch-free on purpose: all LUT gathers of the trip are
-// issued back to back, then all arithmetic, then all LDS updates, so the wave never sits on one
-// LDS round trip per posting-field.  `+ 0.0` for a field with tf == 0 leaves the f64 sum
-// bit-identical to skipping it.
-template <int F_, bool TAGS, int U>
-__device__ __forceinline__ void bm25_trip(const KParams& p, const double* lut, double* acc, uint16_t* tag,
-                                          const uint32_t F, const int lane, const uint32_t tile_base,
-                                          const uint32_t shift, const uint32_t i0, const uint32_t re,
-                                          const uint32_t (&dv)[U], const uint32_t (&tfv)[U][F_ ? F_ : MAX_F],
-                                          const uint32_t (&flv)[U][F_ ? F_ : MAX_F], const double idf, const double eb,
-                                          const uint16_t mytag) {
+// ------------------------------------------------------------------------------------------
+// K1: posting accumulate + merge + per-run top-K, one kernel skeleton for two scorers
+//   MODE_BM25  bm25.rs:60-93 + max_score_merger (query.rs:61-89,150-164)
+//   MODE_Z21S  zero_to_one (zero_to_one.rs:44-126) for "simple" queries: every entry of the
+//              query has its own trie node and its own query term, so finalize's greedy scan
+//              never skips a record and a (doc, field) pool is just the f64 sum of its records'
+//              contributions in sorted order (score desc, stable) — the host uploads the entries
+//              of such queries already in that order.  Anything else goes to k_z21.
+// ------------------------------------------------------------------------------------------
+enum { MODE_BM25 = 0, MODE_Z21S = 1 };
+
+struct EntryC {      // wave-uniform per-entry constants (SGPRs)
+  uint64_t post_off;
+  uint32_t shift;
+  uint32_t tag;      // BM25: visited tag of the entry's query term for the current tile
+  double w0;         // BM25: idf              | Z21S: ScoreByTerm::score
+  double w1;         // BM25: expansion_boost  | Z21S: unused
+};
+
+template <int F_, int U>
+__device__ __forceinline__ void load_trip(const KParams& p, const int lane, const uint64_t post_off, const uint32_t i0,
+                                          const uint32_t re, uint32_t (&dv)[U], uint32_t (&tfv)[U][F_ ? F_ : MAX_F],
+                                          uint32_t (&flv)[U][F_ ? F_ : MAX_F]) {
   constexpr int FA = F_ ? F_ : MAX_F;
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t i = i0 + u * WAVE + lane;
+    const uint64_t pi = post_off + (i < re ? i : re - 1);  // clamp: always a valid posting
+    dv[u] = p.doc[pi];
+#pragma unroll
+    for (int x = 0; x < FA; ++x) {
+      if ((uint32_t)x < F) {
+        tfv[u][x] = p.tf[(uint64_t)x * p.P + pi];
+        flv[u][x] = p.fl[(uint64_t)x * p.P + pi];
+      }
+    }
+  }
+}
+
+// Score U postings per lane and merge them into the wave's LDS tile.  Written branch-free on
+// purpose: all LUT gathers of the trip are issued back to back, then all arithmetic, then all
+// LDS updates, so the wave never sits on one LDS round trip per posting-field.  `+ 0.0` for a
+// field with tf == 0 leaves the f64 sum bit-identical to skipping it.
+template <int MODE, int F_, bool TAGS, int U>
+__device__ __forceinline__ void score_trip(const KParams& p, const double* lut, double* acc, uint16_t* tag,
+                                           const int lane, const uint32_t tile_base, const uint32_t i0,
+                                           const uint32_t re, const uint32_t (&dv)[U],
+                                           const uint32_t (&tfv)[U][F_ ? F_ : MAX_F],
+                                           const uint32_t (&flv)[U][F_ ? F_ : MAX_F], const EntryC& ec,
+                                           const uint32_t qtl) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
   if (PS_ABLATE_BUILD && (p.ablate & 2u)) {  // profiling only: loads stay alive, no scoring
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -196,144 +239,149 @@ __device__ __forceinline__ void bm25_trip(const KParams& p, const double* lut, d
   }
   bool ok[U];
   uint32_t local[U];
-  double tfn[U][FA];
-  bool slow = false;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t i = i0 + u * WAVE + lane;
     local[u] = dv[u] - tile_base;
     // coarse table slots (shift != 0) span several tiles: keep only this tile's documents
-    ok[u] = i < re && (shift == 0 || local[u] < p.T);
-#pragma unroll
-    for (uint32_t x = 0; x < F; ++x) {
-      const uint32_t tfu = tfv[u][x], flu = flv[u][x];
-      const bool in_lut = tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x];
-      // transposed, odd-stride table: lanes with different field lengths hit different LDS banks
-      tfn[u][x] = lut[in_lut ? tfu * p.lut_stride + p.lut_base[x] + flu : 0u];
-      slow |= ok[u] && tfu > 0 && !in_lut;
-    }
+    ok[u] = i < re && (ec.shift == 0 || local[u] < p.T);
   }
-  if (__any(slow)) {  // wave-uniform; rare once the LUT covers the corpus' field lengths
+  if (MODE == MODE_BM25) {
+    double tfn[U][FA];
+    bool slow = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (uint32_t x = 0; x < F; ++x) {
-        const uint32_t tfu = tfv[u][x], flu = flv[u][x];
-        if (!(tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x])) tfn[u][x] = bm25_tfn(p, x, tfu, flu);
+      for (int x = 0; x < FA; ++x) {
+        if ((uint32_t)x < F) {
+          const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+          const bool in_lut = tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x];
+          // transposed, odd-stride table: lanes with different field lengths hit different LDS banks
+          tfn[u][x] = lut[in_lut ? tfu * p.lut_stride + p.lut_base[x] + flu : 0u];
+          slow |= ok[u] && tfu > 0 && !in_lut;
+        }
       }
     }
-  }
-  double s[U];
+    if (__any(slow)) {  // wave-uniform; rare once the LUT covers the corpus' field lengths
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    s[u] = 0.0;
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
-    for (uint32_t x = 0; x < F; ++x) {
-      const double term = tfn[u][x] * idf * p.boost[x] * eb;  // bm25.rs:83-86: ((tfn*idf)*boost)*expansion_boost
-      s[u] += (tfv[u][x] > 0) ? term : 0.0;
-    }
-  }
-  if (TAGS) {
-    double cur[U];
-    uint16_t tg[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      cur[u] = ok[u] ? acc[local[u]] : 0.0;
-      tg[u] = ok[u] ? tag[local[u]] : (uint16_t)0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (ok[u]) {
-        if (s[u] > 0.0)  // Some(score) iff score > 0 (bm25.rs:89-92)
-          // max_score_merger (query.rs:150-164); present <=> cur > 0 for BM25
-          acc[local[u]] = (cur[u] > 0.0) ? (tg[u] == mytag ? fmax(cur[u], s[u]) : cur[u] + s[u]) : s[u];
-        tag[local[u]] = mytag;  // visited even when the score was None (query.rs:87)
+        for (int x = 0; x < FA; ++x) {
+          if ((uint32_t)x < F) {
+            const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+            if (!(tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x])) tfn[u][x] = bm25_tfn(p, x, tfu, flu);
+          }
+        }
       }
     }
-  } else {
-    // one list per query term: always the `+` / assign arm (absent == +0.0).  A list holds a
-    // document once, so the LDS f64 add is uncontended; issuing it as a no-return DS op keeps
-    // the read-modify-write latency off the wave's critical path.
-    if (PS_ABLATE_BUILD && (p.ablate & 32u)) {  // profiling only: plain batched read-modify-write instead of DS atomics
+    double s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s[u] = 0.0;
+#pragma unroll
+      for (int x = 0; x < FA; ++x) {
+        if ((uint32_t)x < F) {
+          const double term = tfn[u][x] * ec.w0 * p.boost[x] * ec.w1;  // bm25.rs:83-86: ((tfn*idf)*boost)*expansion_boost
+          s[u] += (tfv[u][x] > 0) ? term : 0.0;
+        }
+      }
+    }
+    if (TAGS) {
       double cur[U];
+      uint16_t tg[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) cur[u] = ok[u] ? acc[local[u]] : 0.0;
+      for (int u = 0; u < U; ++u) {
+        cur[u] = ok[u] ? acc[local[u]] : 0.0;
+        tg[u] = ok[u] ? tag[local[u]] : (uint16_t)0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ok[u]) {
+          if (s[u] > 0.0)  // Some(score) iff score > 0 (bm25.rs:89-92)
+            // max_score_merger (query.rs:150-164); present <=> cur > 0 for BM25
+            acc[local[u]] = (cur[u] > 0.0) ? (tg[u] == (uint16_t)ec.tag ? fmax(cur[u], s[u]) : cur[u] + s[u]) : s[u];
+          tag[local[u]] = (uint16_t)ec.tag;  // visited even when the score was None (query.rs:87)
+        }
+      }
+    } else {
+      // one list per query term: always the `+` / assign arm (absent == +0.0).  A list holds a
+      // document once, so the LDS f64 add is uncontended; issuing it as a no-return DS op keeps
+      // the read-modify-write latency off the wave's critical path.
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (ok[u] && s[u] > 0.0) acc[local[u]] = cur[u] + s[u];
-      return;
+        if (ok[u] && s[u] > 0.0)
+          __hip_atomic_fetch_add(&acc[local[u]], s[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
+  } else {
+    // zero_to_one.rs:117-120: (min(score / tf, 1.) * tf) / max(field_length, all_query_terms_len)
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (ok[u] && s[u] > 0.0)
-        __hip_atomic_fetch_add(&acc[local[u]], s[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  }
-}
-
-template <int F_, int U>
-__device__ __forceinline__ void load_trip(const KParams& p, const uint32_t F, const int lane, const uint64_t post_off,
-                                          const uint32_t i0, const uint32_t re, uint32_t (&dv)[U],
-                                          uint32_t (&tfv)[U][F_ ? F_ : MAX_F], uint32_t (&flv)[U][F_ ? F_ : MAX_F]) {
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const uint32_t i = i0 + u * WAVE + lane;
-    const uint64_t pi = post_off + (i < re ? i : re - 1);  // clamp: always a valid posting
-    dv[u] = p.doc[pi];
-#pragma unroll
-    for (uint32_t x = 0; x < F; ++x) {
-      tfv[u][x] = p.tf[(uint64_t)x * p.P + pi];
-      flv[u][x] = p.fl[(uint64_t)x * p.P + pi];
+      for (int x = 0; x < FA; ++x) {
+        if ((uint32_t)x < F) {
+          const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+          const double df = (double)tfu;
+          const uint32_t den = flu > qtl ? flu : qtl;
+          const double c = fmin(ec.w0 / df, 1.0) * df / (double)den;
+          if (ok[u] && tfu > 0)
+            __hip_atomic_fetch_add(&acc[local[u] * F + x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
     }
   }
 }
 
 // Stream postings [rb, re) of one list through the tile, UNROLL*64 per trip; the next trip's
 // loads are in flight while the current one is scored.
-template <int F_, bool TAGS>
-__device__ __forceinline__ void bm25_stream(const KParams& p, const double* lut, double* acc, uint16_t* tag,
-                                            const uint32_t F, const int lane, const uint32_t tile_base,
-                                            const uint64_t post_off, const uint32_t shift, uint32_t rb,
-                                            const uint32_t re, const double idf, const double eb,
-                                            const uint16_t mytag) {
+template <int MODE, int F_, bool TAGS>
+__device__ __forceinline__ void score_stream(const KParams& p, const double* lut, double* acc, uint16_t* tag,
+                                             const int lane, const uint32_t tile_base, const uint32_t rb,
+                                             const uint32_t re, const EntryC& ec, const uint32_t qtl) {
   constexpr int FA = F_ ? F_ : MAX_F;
-  uint32_t dv[UNROLL], tfv[UNROLL][FA], flv[UNROLL][FA];
-  uint32_t dn[UNROLL], tfnx[UNROLL][FA], flnx[UNROLL][FA];
-  load_trip<F_, UNROLL>(p, F, lane, post_off, rb, re, dv, tfv, flv);
-  for (uint32_t i0 = rb; i0 < re; i0 += UNROLL * WAVE) {
-    const uint32_t nx = i0 + UNROLL * WAVE;
-    if (nx < re) load_trip<F_, UNROLL>(p, F, lane, post_off, nx, re, dn, tfnx, flnx);
-    bm25_trip<F_, TAGS, UNROLL>(p, lut, acc, tag, F, lane, tile_base, shift, i0, re, dv, tfv, flv, idf, eb, mytag);
+  constexpr int UN = F_ ? UNROLL : 1;
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+  uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
+  uint32_t dn[UN], tfnx[UN][FA], flnx[UN][FA];
+  load_trip<F_, UN>(p, lane, ec.post_off, rb, re, dv, tfv, flv);
+  for (uint32_t i0 = rb; i0 < re; i0 += UN * WAVE) {
+    const uint32_t nx = i0 + UN * WAVE;
+    if (nx < re) load_trip<F_, UN>(p, lane, ec.post_off, nx, re, dn, tfnx, flnx);
+    score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
     if (nx < re) {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
+      for (int u = 0; u < UN; ++u) {
         dv[u] = dn[u];
 #pragma unroll
-        for (uint32_t x = 0; x < F; ++x) { tfv[u][x] = tfnx[u][x]; flv[u][x] = flnx[u][x]; }
+        for (int x = 0; x < FA; ++x)
+          if ((uint32_t)x < F) { tfv[u][x] = tfnx[u][x]; flv[u][x] = flnx[u][x]; }
       }
     }
   }
 }
 
-constexpr int G = 4;   // plan entries kept register-resident by the fast path
-constexpr int FU = 2;  // postings per lane in the fast path's prefetched first trip
-
-template <int F_, bool TAGS, bool FULL>
-__global__ __launch_bounds__(WAVE * WG_WAVES) void k_bm25(const KParams p) {
+template <int MODE, int F_, bool TAGS, bool FULL>
+__global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int FA = F_ ? F_ : MAX_F;
+  constexpr int G = F_ ? 4 : 1;   // plan entries whose first trips are in flight together
+  constexpr int FU = F_ ? 2 : 1;  // postings per lane in a prefetched first trip
   const int lane = threadIdx.x & (WAVE - 1);
   // readfirstlane: tell the compiler the wave index is wave-uniform, so everything derived from
   // it (item, query, plan entries, table ranges) lives in SGPRs and is fetched with scalar loads
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t F = F_ ? (uint32_t)F_ : p.F;
-  constexpr int FA = F_ ? F_ : MAX_F;
   const uint32_t T = p.T;
-  // LDS: [LUT, shared by the workgroup][wave 0 tile][wave 1 tile]...
+  const uint32_t AW = MODE == MODE_Z21S ? F : 1u;  // f64 accumulators per document
+  // LDS: [LUT, shared by the workgroup][wave 0: tile, tags, table slices][wave 1: ...]...
   const double* lut = reinterpret_cast<const double*>(smem);
-  const uint32_t lut_bytes = p.lut_stride * LUT_TF * 8;
-  const uint32_t tile_bytes = T * 8 + (TAGS ? T * 2 : 0);
-  double* acc = reinterpret_cast<double*>(smem + lut_bytes + (size_t)wave * tile_bytes);
-  uint16_t* tag = reinterpret_cast<uint16_t*>(smem + lut_bytes + (size_t)wave * tile_bytes + (size_t)T * 8);
-  {
+  const uint32_t lut_bytes = MODE == MODE_BM25 ? p.lut_stride * LUT_TF * 8 : 0u;
+  const uint32_t tile_bytes = T * AW * 8 + (TAGS ? T * 2 : 0);
+  const uint32_t wave_bytes = tile_bytes + p.slice_bytes;
+  unsigned char* wbase = smem + lut_bytes + (size_t)wave * wave_bytes;
+  double* acc = reinterpret_cast<double*>(wbase);
+  uint16_t* tag = reinterpret_cast<uint16_t*>(wbase + (size_t)T * AW * 8);
+  uint32_t* slice = reinterpret_cast<uint32_t*>(wbase + tile_bytes);  // [entry][2][S]: rb, re per tile of the run
+  if (MODE == MODE_BM25) {
     double* l = reinterpret_cast<double*>(smem);
     for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * WG_WAVES) l[i] = p.lut[i];
     __syncthreads();  // the only workgroup-level synchronisation: waves are independent from here on
@@ -344,104 +392,118 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_bm25(const KParams p) {
   const uint32_t sup = item / p.B;
   const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
   const uint32_t ne = e1 - e0;
+  const bool mine = MODE == MODE_BM25 || (p.qflags[q] & 1u);  // Z21S: only "simple" queries
+  if (MODE == MODE_Z21S && !mine) return;                     // k_z21 owns this query's candidate slots
+  const uint32_t qtl = MODE == MODE_Z21S ? p.qterms_len[q] : 0u;
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
 
   if (ne != 0) {
-    for (uint32_t i = lane; i < T; i += WAVE) {
-      acc[i] = 0.0;
-      if (TAGS) tag[i] = 0xFFFFu;
-    }
+    for (uint32_t i = lane; i < T * AW; i += WAVE) acc[i] = 0.0;
+    if (TAGS)
+      for (uint32_t i = lane; i < T; i += WAVE) tag[i] = 0xFFFFu;
     uint32_t tagbase = 0;
     const uint32_t t_begin = sup * p.S;
     const uint32_t t_end = min(p.n_tiles, t_begin + p.S);
-
-    // ---- fast path set-up: the whole plan of this query fits in registers ----------------------
-    // Entry constants go to SGPRs; the tile-offset table slice of the run goes to one VGPR pair per
-    // entry (lane l <-> tile t_begin + l), so the per-tile range lookup is a v_readlane instead
-    // of a dependent scalar-memory round trip.  Requires S <= 63.
-    const bool fast = F_ != 0 && ne <= (uint32_t)G && p.S < (uint32_t)WAVE;  // generic-F build: arrays would spill
-    uint64_t g_post[G];
-    uint32_t g_shift[G], g_rbv[G], g_rev[G], g_qterm[G];
-    double g_idf[G], g_eb[G];
-    if (fast) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        g_rbv[g] = 0; g_rev[g] = 0; g_post[g] = 0; g_shift[g] = 0; g_qterm[g] = 0; g_idf[g] = 0.0; g_eb[g] = 0.0;
-        if ((uint32_t)g < ne) {
-          const ps_plan_entry& en = p.plan[e0 + g];
-          g_post[g] = en.post_off;
-          g_shift[g] = en.shift & 0xFFu;
-          g_qterm[g] = en.qterm;
-          g_idf[g] = en.idf;
-          g_eb[g] = en.boost;
-          const uint32_t tl = min(t_begin + (uint32_t)lane, p.n_tiles - 1);
-          const uint32_t slot = tl >> g_shift[g];
-          g_rbv[g] = p.table[en.tbl_off + slot];
-          g_rev[g] = p.table[en.tbl_off + slot + 1];
+    // Table slices: the [rb, re) range of every (entry, tile of this run), fetched once with
+    // coalesced vector loads into LDS, so the per-tile lookup is an LDS broadcast read instead of
+    // a dependent scalar-memory round trip per (entry, tile).
+    const bool sliced = p.slice_bytes != 0;
+    if (sliced) {
+      for (uint32_t e = 0; e < ne; ++e) {
+        const uint32_t tbl_off = p.plan[e0 + e].tbl_off;
+        const uint32_t shift = p.plan[e0 + e].shift & 0xFFu;
+        if ((uint32_t)lane < p.S) {
+          const uint32_t slot = min(t_begin + (uint32_t)lane, p.n_tiles - 1) >> shift;
+          slice[(e * 2 + 0) * p.S + lane] = p.table[tbl_off + slot];
+          slice[(e * 2 + 1) * p.S + lane] = p.table[tbl_off + slot + 1];
         }
       }
     }
 
+    EntryC ec[G];
+    uint32_t ec_qterm[G], ec_tbl[G];
     for (uint32_t t = t_begin; t < t_end; ++t) {
       const uint32_t tile_base = t * T;
+      const uint32_t tl = t - t_begin;
       bool dirty = false;
-      if (fast) {
-        const int tl = (int)(t - t_begin);
+      for (uint32_t eg = 0; eg < ne; eg += G) {
         uint32_t rb[G], re[G];
         uint32_t dv[G][FU], tfv[G][FU][FA], flv[G][FU][FA];
-        // phase 1: first trips of every entry, all loads in flight together
+        // phase 1: ranges + first trips of up to G entries, all loads in flight together
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          rb[g] = readlane_u32(g_rbv[g], tl);
-          re[g] = readlane_u32(g_rev[g], tl);
-          if (rb[g] < re[g]) load_trip<F_, FU>(p, F, lane, g_post[g], rb[g], re[g], dv[g], tfv[g], flv[g]);  // wave-uniform
+          rb[g] = 0; re[g] = 0;
+          if (eg + g < ne) {  // wave-uniform
+            if (ne > (uint32_t)G || t == t_begin) {  // a plan of <= G entries stays in SGPRs for the whole run
+              const ps_plan_entry& en = p.plan[e0 + eg + g];
+              ec[g].post_off = en.post_off;
+              ec[g].shift = en.shift & 0xFFu;
+              ec[g].w0 = MODE == MODE_BM25 ? en.idf : en.boost;
+              ec[g].w1 = en.boost;
+              ec_qterm[g] = en.qterm;
+              ec_tbl[g] = en.tbl_off;
+            }
+            ec[g].tag = tagbase + ec_qterm[g];
+            if (sliced) {
+              rb[g] = __builtin_amdgcn_readfirstlane(slice[((eg + g) * 2 + 0) * p.S + tl]);
+              re[g] = __builtin_amdgcn_readfirstlane(slice[((eg + g) * 2 + 1) * p.S + tl]);
+            } else {
+              const uint32_t slot = t >> ec[g].shift;
+              rb[g] = p.table[ec_tbl[g] + slot];
+              re[g] = p.table[ec_tbl[g] + slot + 1];
+            }
+            if (rb[g] < re[g]) load_trip<F_, FU>(p, lane, ec[g].post_off, rb[g], re[g], dv[g], tfv[g], flv[g]);
+          }
         }
         // phase 2: consume in plan order
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (rb[g] < re[g]) {
             dirty = true;
-            const uint16_t mytag = (uint16_t)(tagbase + g_qterm[g]);
-            bm25_trip<F_, TAGS, FU>(p, lut, acc, tag, F, lane, tile_base, g_shift[g], rb[g], re[g], dv[g], tfv[g], flv[g],
-                                    g_idf[g], g_eb[g], mytag);
+            score_trip<MODE, F_, TAGS, FU>(p, lut, acc, tag, lane, tile_base, rb[g], re[g], dv[g], tfv[g], flv[g], ec[g], qtl);
             if (rb[g] + FU * WAVE < re[g])
-              bm25_stream<F_, TAGS>(p, lut, acc, tag, F, lane, tile_base, g_post[g], g_shift[g], rb[g] + FU * WAVE,
-                                    re[g], g_idf[g], g_eb[g], mytag);
+              score_stream<MODE, F_, TAGS>(p, lut, acc, tag, lane, tile_base, rb[g] + FU * WAVE, re[g], ec[g], qtl);
           }
-        }
-      } else {
-        for (uint32_t e = e0; e < e1; ++e) {
-          // plan entry fields are wave-uniform (scalar loads)
-          const uint32_t tbl_off = p.plan[e].tbl_off;
-          const uint32_t shift = p.plan[e].shift & 0xFFu;
-          const uint32_t slot = t >> shift;
-          const uint32_t rb = p.table[tbl_off + slot];
-          const uint32_t re = p.table[tbl_off + slot + 1];
-          if (rb == re) continue;
-          dirty = true;
-          bm25_stream<F_, TAGS>(p, lut, acc, tag, F, lane, tile_base, p.plan[e].post_off, shift, rb, re, p.plan[e].idf,
-                                p.plan[e].boost, (uint16_t)(tagbase + p.plan[e].qterm));
         }
       }
       if (!dirty) continue;  // no list of this query touches the tile: nothing to harvest
       if (PS_ABLATE_BUILD && (p.ablate & 4u)) continue;
-      // tile epilogue: harvest + reset, two documents per lane per LDS access (ds_read_b128)
+      // tile epilogue: harvest + reset (two f64 per lane per LDS access where the layout allows)
       double gt = 0.0;
       if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      for (uint32_t c = 0; c < T; c += 2 * WAVE) {
-        double2* slot = reinterpret_cast<double2*>(&acc[c + 2 * lane]);
-        const double2 v = *slot;
-        const bool h0 = v.x > 0.0, h1 = v.y > 0.0;
-        if (h0 || h1) *slot = make_double2(0.0, 0.0);
-        const uint32_t d = tile_base + c + 2 * lane;
-        if (FULL) {
-          full_emit(p, q, lane, h0, v.x, d);
-          full_emit(p, q, lane, h1, v.y, d + 1);
-        } else if (!(PS_ABLATE_BUILD && (p.ablate & 1u))) {
-          topk_offer(tk, p.K, lane, h0, v.x, d, gt);
-          topk_offer(tk, p.K, lane, h1, v.y, d + 1, gt);
+      if (MODE == MODE_BM25) {
+        for (uint32_t c = 0; c < T; c += 2 * WAVE) {
+          double2* slot = reinterpret_cast<double2*>(&acc[c + 2 * lane]);
+          const double2 v = *slot;
+          const bool h0 = v.x > 0.0, h1 = v.y > 0.0;
+          if (h0 || h1) *slot = make_double2(0.0, 0.0);
+          const uint32_t d = tile_base + c + 2 * lane;
+          if (FULL) {
+            full_emit(p, q, lane, h0, v.x, d);
+            full_emit(p, q, lane, h1, v.y, d + 1);
+          } else if (!(PS_ABLATE_BUILD && (p.ablate & 1u))) {
+            topk_offer(tk, p.K, lane, h0, v.x, d, gt);
+            topk_offer(tk, p.K, lane, h1, v.y, d + 1, gt);
+          }
+        }
+      } else {
+        for (uint32_t c = 0; c < T; c += WAVE) {
+          // result.score = max(score_by_pool, result.score) over fields, from the dummy 0. (zero_to_one.rs:81,122)
+          double best = 0.0;
+          bool has = false;
+#pragma unroll
+          for (int x = 0; x < FA; ++x) {
+            if ((uint32_t)x < F) {
+              const double v = acc[(c + lane) * F + x];
+              if (v > 0.0) { has = true; acc[(c + lane) * F + x] = 0.0; }
+              best = fmax(v, best);
+            }
+          }
+          const uint32_t d = tile_base + c + lane;
+          if (FULL) full_emit(p, q, lane, has, best, d);
+          else topk_offer(tk, p.K, lane, has, best, d, gt);
         }
       }
       if (!FULL && tk.n == p.K && tk.thr_s > gt) {
@@ -490,6 +552,7 @@ __global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
   const uint32_t q = item % p.B;
   const uint32_t sup = item / p.B;
   const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
+  if (p.qflags[q] & 1u) return;  // simple query: scored by k_score<MODE_Z21S>
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
@@ -668,7 +731,7 @@ struct EngineImpl {
   std::mutex mu;
   // per-batch device buffers (grow-only; reuse is ordered by the stream)
   DevBuf<ps_plan_entry> d_plan;
-  DevBuf<uint32_t> d_qbeg, d_qtl, d_zorder, d_cand_doc, d_out_counts, d_full_doc, d_full_cnt;
+  DevBuf<uint32_t> d_qbeg, d_qtl, d_zorder, d_qflags, d_cand_doc, d_out_counts, d_full_doc, d_full_cnt;
   DevBuf<double> d_cand_score, d_out_scores, d_full_score;
   DevBuf<uint64_t> d_out_keys, d_full_off;
   DevBuf<unsigned long long> d_gthr;
@@ -749,7 +812,7 @@ Engine::~Engine() {
   m.d_plan.release(); m.d_qbeg.release(); m.d_qtl.release(); m.d_zorder.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
-  m.d_gthr.release();
+  m.d_gthr.release(); m.d_qflags.release();
   for (auto& sg : m.stage) {
     if (sg.p) (void)hipHostFree(sg.p);
     if (sg.done) (void)hipEventDestroy(sg.done);
@@ -794,10 +857,6 @@ void validate(const Snapshot& s, const ps_scorer_desc& sc, const Plan& plan) {
   if (s.F > (uint32_t)MAX_F) throw std::length_error("the GPU path supports at most 8 fields");
   if (sc.kind != PS_SCORER_BM25 && sc.kind != PS_SCORER_ZERO_TO_ONE) throw std::invalid_argument("unknown scorer kind");
   if (plan.max_qterms >= 0x7FFF) throw std::length_error("more than 32766 non-empty terms in one query");
-  if (sc.kind == PS_SCORER_ZERO_TO_ONE) {
-    if (plan.max_qterms > 64 || plan.max_entries > 64)
-      throw std::length_error("zero_to_one on the GPU supports at most 64 expanded lists per query");
-  }
 }
 
 // Uploads the plan + per-query arrays through a pinned staging slot; fills the common KParams.
@@ -811,39 +870,69 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const size_t off_q = off_e + ne * sizeof(ps_plan_entry);
   const size_t off_l = off_q + (B + 1) * 4;
   const size_t off_z = off_l + B * 4;
-  const size_t total = off_z + ne * 4;
+  const size_t off_f = off_z + ne * 4;
+  const size_t total = off_f + B * 4;
   Stage& sg = m.stage[m.next_stage];
   m.next_stage = (m.next_stage + 1) % N_STAGE;
   sg.ensure(total + 16);
   unsigned char* h = sg.p;
-  if (ne) memcpy(h + off_e, plan.entries.data(), ne * sizeof(ps_plan_entry));
+  ps_plan_entry* he = reinterpret_cast<ps_plan_entry*>(h + off_e);
+  if (ne) memcpy(he, plan.entries.data(), ne * sizeof(ps_plan_entry));
   memcpy(h + off_q, plan.qbeg.data(), (B + 1) * 4);
   if (B) memcpy(h + off_l, plan.qterms_len.data(), B * 4);
+  uint32_t n_simple = 0, n_general = 0;
   if (z) {
     // per query: entry indices stably sorted by ScoreByTerm::score desc (zero_to_one.rs:98);
-    // the records' push order == plan order (query term asc, expansion order, newest version first)
+    // the records' push order == plan order (query term asc, expansion order, newest version first).
+    // A query whose entries all have their own trie node, their own query term and a single
+    // version layer is "simple": finalize's greedy scan can never skip a record, so k_score sums
+    // the contributions in that sorted order directly; its entries are uploaded pre-sorted.
     uint32_t* zo = reinterpret_cast<uint32_t*>(h + off_z);
+    uint32_t* qf = reinterpret_cast<uint32_t*>(h + off_f);
+    std::vector<ps_plan_entry> tmp;
     for (size_t q = 0; q < B; ++q) {
-      uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
+      const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
       for (uint32_t i = b; i < e; ++i) zo[i] = i;
       std::stable_sort(zo + b, zo + e,
                        [&](uint32_t a, uint32_t c) { return plan.entries[c].boost < plan.entries[a].boost; });
+      bool simple = true;
+      for (uint32_t i = b; i < e && simple; ++i) {
+        if (plan.entries[i].shift >> 8) simple = false;
+        for (uint32_t j = b; j < i && simple; ++j)
+          if (plan.entries[j].node == plan.entries[i].node || plan.entries[j].qterm == plan.entries[i].qterm) simple = false;
+      }
+      // the simple path keeps F f64 accumulators per document of the tile in LDS
+      if ((size_t)WG_WAVES * ((size_t)s.T * s.F * 8 + 4096) > 160 * 1024) simple = false;
+      if (env_u32("PS_Z21_GENERAL_ONLY", 0)) simple = false;
+      qf[q] = simple ? 1u : 0u;
+      if (simple) {
+        ++n_simple;
+        tmp.assign(plan.entries.begin() + b, plan.entries.begin() + e);
+        for (uint32_t i = b; i < e; ++i) he[i] = tmp[zo[i] - b];
+      } else {
+        if (e != b) ++n_general;
+        if (e - b > 64) throw std::length_error("zero_to_one with repeated terms supports at most 64 expanded lists per query on the GPU");
+      }
     }
   }
   m.d_plan.ensure(ne + 1);
   m.d_qbeg.ensure(B + 1);
   m.d_qtl.ensure(B + 1);
   m.d_zorder.ensure(ne + 1);
+  m.d_qflags.ensure(B + 1);
   if (ne) PS_HIP(hipMemcpyAsync(m.d_plan.p, h + off_e, ne * sizeof(ps_plan_entry), hipMemcpyHostToDevice, st));
   PS_HIP(hipMemcpyAsync(m.d_qbeg.p, h + off_q, (B + 1) * 4, hipMemcpyHostToDevice, st));
   if (B) PS_HIP(hipMemcpyAsync(m.d_qtl.p, h + off_l, B * 4, hipMemcpyHostToDevice, st));
   if (z && ne) PS_HIP(hipMemcpyAsync(m.d_zorder.p, h + off_z, ne * 4, hipMemcpyHostToDevice, st));
+  if (z && B) PS_HIP(hipMemcpyAsync(m.d_qflags.p, h + off_f, B * 4, hipMemcpyHostToDevice, st));
   PS_HIP(hipEventRecord(sg.done, st));
   sg.pending = true;
 
   memset(&kp, 0, sizeof(kp));
   kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys;
   kp.plan = m.d_plan.p; kp.qbeg = m.d_qbeg.p; kp.qterms_len = m.d_qtl.p; kp.zorder = m.d_zorder.p;
+  kp.qflags = m.d_qflags.p;
+  kp.n_simple = n_simple; kp.n_general = n_general;
   kp.P = s.P;
   kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
   kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
@@ -865,8 +954,42 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (s_env) S = s_env;
   if (S < 1) S = 1;
   if (S > s.n_tiles) S = s.n_tiles;
+  if (S > 32) S = 32;  // a run's table slice is fetched by one wave-wide load (lane <-> tile)
   kp.S = (uint32_t)S;
   kp.n_super = (uint32_t)((s.n_tiles + S - 1) / S);
+  // per-wave LDS for the table slices: [entry][rb|re][S] u32; fall back to global lookups if large
+  const size_t slice = (((size_t)plan.max_entries * 2 * S * 4) + 15) & ~(size_t)15;
+  kp.slice_bytes = (slice <= 4096 && env_u32("PS_SLICES", 1)) ? (uint32_t)slice : 0u;
+}
+
+void allow_lds(const void* fn, size_t lds) {
+  if (lds <= 65536) return;
+  if (lds > 160 * 1024) throw std::length_error("LDS tile exceeds 160 KiB: use a smaller tile_docs");
+  PS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+}
+
+template <int MODE, bool FULL>
+void launch_k_score(KParams& kp, bool tags, hipStream_t st) {
+  const uint32_t n_items = kp.B * kp.n_super;
+  const uint32_t n_wg = (n_items + WG_WAVES - 1) / WG_WAVES;
+  const uint32_t aw = MODE == MODE_Z21S ? kp.F : 1u;
+  const size_t lds = (MODE == MODE_BM25 ? (size_t)kp.lut_stride * LUT_TF * 8 : 0) +
+                     WG_WAVES * ((size_t)kp.T * aw * 8 + (tags ? (size_t)kp.T * 2 : 0) + kp.slice_bytes);
+#define PS_LAUNCH(FV, TG)                                                                              \
+  do {                                                                                                 \
+    allow_lds(reinterpret_cast<const void*>(&k_score<MODE, FV, TG, FULL>), lds);                       \
+    hipLaunchKernelGGL((k_score<MODE, FV, TG, FULL>), dim3(n_wg), dim3(WAVE * WG_WAVES), lds, st, kp); \
+  } while (0)
+  if (MODE == MODE_BM25 && tags) {
+    if (kp.F == 1) PS_LAUNCH(1, true);
+    else if (kp.F == 2) PS_LAUNCH(2, true);
+    else PS_LAUNCH(0, true);
+  } else {
+    if (kp.F == 1) PS_LAUNCH(1, false);
+    else if (kp.F == 2) PS_LAUNCH(2, false);
+    else PS_LAUNCH(0, false);
+  }
+#undef PS_LAUNCH
 }
 
 template <bool FULL>
@@ -874,29 +997,21 @@ void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, hipSt
   const uint32_t n_items = kp.B * kp.n_super;
   if (n_items == 0) return;
   if (sc.kind == PS_SCORER_BM25) {
-    const bool tags = plan.multi_expansion;
-    const size_t lds = (size_t)kp.lut_stride * LUT_TF * 8 + WG_WAVES * ((size_t)kp.T * 8 + (tags ? (size_t)kp.T * 2 : 0));
-    const uint32_t n_wg = (n_items + WG_WAVES - 1) / WG_WAVES;
     if (kp.lut_rows) hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
-#define PS_LAUNCH_BM25(FV)                                                                                     \
-  do {                                                                                                         \
-    if (tags) hipLaunchKernelGGL((k_bm25<FV, true, FULL>), dim3(n_wg), dim3(WAVE * WG_WAVES), lds, st, kp);   \
-    else hipLaunchKernelGGL((k_bm25<FV, false, FULL>), dim3(n_wg), dim3(WAVE * WG_WAVES), lds, st, kp);       \
-  } while (0)
-    if (kp.F == 1) PS_LAUNCH_BM25(1);
-    else if (kp.F == 2) PS_LAUNCH_BM25(2);
-    else PS_LAUNCH_BM25(0);
-#undef PS_LAUNCH_BM25
+    launch_k_score<MODE_BM25, FULL>(kp, plan.multi_expansion, st);
   } else {
-    // zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
-    kp.z_nodes = std::max<uint32_t>(1, plan.max_nodes);
-    const uint32_t per_doc = (kp.z_nodes * kp.F + kp.F) * 4;
-    uint32_t zt = kp.T;
-    const uint32_t budget = env_u32("PS_Z21_LDS", 20480);
-    while (zt > (uint32_t)WAVE && (size_t)zt * per_doc > budget) zt >>= 1;
-    if ((size_t)zt * per_doc > 65536) throw std::length_error("zero_to_one: fields x expanded terms exceed the LDS tile");
-    kp.z_tile = zt;
-    hipLaunchKernelGGL((k_z21<FULL>), dim3(n_items), dim3(WAVE), (size_t)zt * per_doc, st, kp);
+    if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(kp, false, st);
+    if (kp.n_general || !kp.n_simple) {
+      // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
+      kp.z_nodes = std::max<uint32_t>(1, plan.max_nodes);
+      const uint32_t per_doc = (kp.z_nodes * kp.F + kp.F) * 4;
+      uint32_t zt = kp.T;
+      const uint32_t budget = env_u32("PS_Z21_LDS", 20480);
+      while (zt > (uint32_t)WAVE && (size_t)zt * per_doc > budget) zt >>= 1;
+      if ((size_t)zt * per_doc > 65536) throw std::length_error("zero_to_one: fields x expanded terms exceed the LDS tile");
+      kp.z_tile = zt;
+      hipLaunchKernelGGL((k_z21<FULL>), dim3(n_items), dim3(WAVE), (size_t)zt * per_doc, st, kp);
+    }
   }
   PS_HIP(hipGetLastError());
 }
