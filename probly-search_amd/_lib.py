@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "csrc", "libprobly_search_amd.so")
+_SO = os.environ.get("PS_SO") or os.path.join(_HERE, "csrc", "libprobly_search_amd.so")  # PS_SO: tuning builds
 
 
 class LibraryNotBuilt(ImportError):

@@ -43,8 +43,20 @@ namespace ps {
 
 constexpr int MAX_F = 8;
 constexpr int WAVE = 64;
-constexpr int UNROLL = 4;  // postings per lane per trip of the accumulate loop
-constexpr int WG_WAVES = 4;  // waves per workgroup of K1; each wave owns its own LDS tile
+#ifndef PS_UNROLL
+#define PS_UNROLL 4
+#endif
+#ifndef PS_WG_WAVES
+#define PS_WG_WAVES 4
+#endif
+#ifndef PS_G
+#define PS_G 4
+#endif
+#ifndef PS_FU
+#define PS_FU 2
+#endif
+constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
+constexpr int WG_WAVES = PS_WG_WAVES;  // waves per workgroup of K1; each wave owns its own LDS tile
 constexpr int LUT_TF = 16;   // LUT columns: term frequency 0..15
 #ifndef PS_ABLATE_BUILD
 #define PS_ABLATE_BUILD 0  // profiling builds only: honour KParams::ablate in the hot loops
@@ -363,8 +375,8 @@ template <int MODE, int F_, bool TAGS, bool FULL>
 __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int FA = F_ ? F_ : MAX_F;
-  constexpr int G = F_ ? 4 : 1;   // plan entries whose first trips are in flight together
-  constexpr int FU = F_ ? 2 : 1;  // postings per lane in a prefetched first trip
+  constexpr int G = F_ ? PS_G : 1;    // plan entries whose first trips are in flight together
+  constexpr int FU = F_ ? PS_FU : 1;  // postings per lane in a prefetched first trip
   const int lane = threadIdx.x & (WAVE - 1);
   // readfirstlane: tell the compiler the wave index is wave-uniform, so everything derived from
   // it (item, query, plan entries, table ranges) lives in SGPRs and is fetched with scalar loads
