@@ -116,7 +116,7 @@ size_t ps_index_expand_term(const ps_index* idx, const char* term, size_t len, c
  * field-length u32) plus per-list tile-offset tables, and upload them to `device`.
  * device = -1 builds a host-only snapshot (no HIP call is made; queries return PS_ENODEVICE);
  * it exists so the flattener and planner can be inspected on machines without a GPU.
- * tile_docs = documents per LDS accumulator tile (power of two, 256..4096; 0 = default 2048). */
+ * tile_docs = documents per LDS accumulator tile (power of two, 256..4096; 0 = default 1024). */
 ps_status ps_index_snapshot(const ps_index* idx, int device, uint32_t tile_docs, ps_snapshot** out);
 void ps_snapshot_free(ps_snapshot* snap);
 

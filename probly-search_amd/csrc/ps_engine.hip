@@ -53,7 +53,7 @@ constexpr int WAVE = 64;
 #define PS_G 4
 #endif
 #ifndef PS_FU
-#define PS_FU 2
+#define PS_FU 1
 #endif
 constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
 constexpr int WG_WAVES = PS_WG_WAVES;  // waves per workgroup of K1; each wave owns its own LDS tile
@@ -84,6 +84,7 @@ struct KParams {
   uint32_t lut_cap[MAX_F], lut_base[MAX_F];
   uint32_t n_simple, n_general;  // host-side bookkeeping (zero_to_one query classes in this batch)
   uint32_t ablate;  // PS_ABLATE debug bit mask (profiling only): 1 = no top-k offer, 2 = no scoring
+  uint32_t* work_counter;    // next (query, run) item for the persistent waves of k_score
   unsigned long long* gthr;  // [B] bits of the best published local K-th score per query (0 = none)
   double* cand_score;  // [B * n_super * K]
   uint32_t* cand_doc;
@@ -179,6 +180,15 @@ __device__ __forceinline__ double bm25_tfn(const KParams& p, uint32_t x, uint32_
   const double fld = (double)flu;
   // bm25.rs:78-82, evaluated left to right, no contraction
   return (p.k1p1 * tfd) / (p.k1 * (p.one_minus_b + p.b * (fld / p.avg[x])) + tfd);
+}
+
+// Out-of-line copy for K1's rare beyond-the-LUT path: keeps ~100 inlined IEEE division
+// sequences out of the hot kernel's instruction stream.
+__device__ __noinline__ double bm25_tfn_cold(double k1, double k1p1, double one_minus_b, double b, double avg,
+                                             uint32_t tfu, uint32_t flu) {
+  const double tfd = (double)tfu;
+  const double fld = (double)flu;
+  return (k1p1 * tfd) / (k1 * (one_minus_b + b * (fld / avg)) + tfd);
 }
 
 __global__ __launch_bounds__(256) void k_bm25_lut(const KParams p, double* out) {
@@ -281,7 +291,8 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
         for (int x = 0; x < FA; ++x) {
           if ((uint32_t)x < F) {
             const uint32_t tfu = tfv[u][x], flu = flv[u][x];
-            if (!(tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x])) tfn[u][x] = bm25_tfn(p, x, tfu, flu);
+            if (!(tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x]))
+              tfn[u][x] = bm25_tfn_cold(p.k1, p.k1p1, p.one_minus_b, p.b, p.avg[x], tfu, flu);
           }
         }
       }
@@ -352,22 +363,34 @@ __device__ __forceinline__ void score_stream(const KParams& p, const double* lut
   constexpr int FA = F_ ? F_ : MAX_F;
   constexpr int UN = F_ ? UNROLL : 1;
   const uint32_t F = F_ ? (uint32_t)F_ : p.F;
-  uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
-  uint32_t dn[UN], tfnx[UN][FA], flnx[UN][FA];
-  load_trip<F_, UN>(p, lane, ec.post_off, rb, re, dv, tfv, flv);
-  for (uint32_t i0 = rb; i0 < re; i0 += UN * WAVE) {
-    const uint32_t nx = i0 + UN * WAVE;
-    if (nx < re) load_trip<F_, UN>(p, lane, ec.post_off, nx, re, dn, tfnx, flnx);
-    score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
-    if (nx < re) {
+  uint32_t i0 = rb;
+  if (re - i0 >= (uint32_t)(UN * WAVE)) {
+    // full trips, double-buffered
+    uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
+    uint32_t dn[UN], tfnx[UN][FA], flnx[UN][FA];
+    load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+    while (re - i0 >= (uint32_t)(UN * WAVE)) {
+      const uint32_t nx = i0 + UN * WAVE;
+      const bool more = re - nx >= (uint32_t)(UN * WAVE);
+      if (more) load_trip<F_, UN>(p, lane, ec.post_off, nx, re, dn, tfnx, flnx);
+      score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+      if (more) {
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        dv[u] = dn[u];
+        for (int u = 0; u < UN; ++u) {
+          dv[u] = dn[u];
 #pragma unroll
-        for (int x = 0; x < FA; ++x)
-          if ((uint32_t)x < F) { tfv[u][x] = tfnx[u][x]; flv[u][x] = flnx[u][x]; }
+          for (int x = 0; x < FA; ++x)
+            if ((uint32_t)x < F) { tfv[u][x] = tfnx[u][x]; flv[u][x] = flnx[u][x]; }
+        }
       }
+      i0 = nx;
     }
+  }
+  // tail (< UN*64 postings): 64 at a time so short ranges do not pay for empty lane slots
+  for (; i0 < re; i0 += WAVE) {
+    uint32_t dv[1], tfv[1][FA], flv[1][FA];
+    load_trip<F_, 1>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+    score_trip<MODE, F_, TAGS, 1>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
   }
 }
 
@@ -398,24 +421,32 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
     for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * WG_WAVES) l[i] = p.lut[i];
     __syncthreads();  // the only workgroup-level synchronisation: waves are independent from here on
   }
-  const uint32_t item = blockIdx.x * WG_WAVES + wave;
-  if (item >= p.B * p.n_super) return;
+  // Persistent waves: the grid only fills the chip; every wave keeps pulling (query, run) items
+  // from one device-scope counter until none are left.  Items are numbered run-major so waves
+  // that are resident together work on the same document range (posting slices stay in L2), and
+  // a heavy head-term item never leaves LDS-holding sibling waves idle.
+  for (uint32_t i = lane; i < T * AW; i += WAVE) acc[i] = 0.0;
+  if (TAGS)
+    for (uint32_t i = lane; i < T; i += WAVE) tag[i] = 0xFFFFu;
+  uint32_t tagbase = 0;
+  const uint32_t n_items = p.B * p.n_super;
+  for (;;) {
+  uint32_t item = 0;
+  if (lane == 0) item = atomicAdd(p.work_counter, 1u);
+  item = __builtin_amdgcn_readfirstlane(item);
+  if (item >= n_items) break;
   const uint32_t q = item % p.B;
   const uint32_t sup = item / p.B;
   const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
   const uint32_t ne = e1 - e0;
   const bool mine = MODE == MODE_BM25 || (p.qflags[q] & 1u);  // Z21S: only "simple" queries
-  if (MODE == MODE_Z21S && !mine) return;                     // k_z21 owns this query's candidate slots
+  if (MODE == MODE_Z21S && !mine) continue;                   // k_z21 owns this query's candidate slots
   const uint32_t qtl = MODE == MODE_Z21S ? p.qterms_len[q] : 0u;
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
 
   if (ne != 0) {
-    for (uint32_t i = lane; i < T * AW; i += WAVE) acc[i] = 0.0;
-    if (TAGS)
-      for (uint32_t i = lane; i < T; i += WAVE) tag[i] = 0xFFFFu;
-    uint32_t tagbase = 0;
     const uint32_t t_begin = sup * p.S;
     const uint32_t t_end = min(p.n_tiles, t_begin + p.S);
     // Table slices: the [rb, re) range of every (entry, tile of this run), fetched once with
@@ -496,8 +527,13 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
             full_emit(p, q, lane, h0, v.x, d);
             full_emit(p, q, lane, h1, v.y, d + 1);
           } else if (!(PS_ABLATE_BUILD && (p.ablate & 1u))) {
-            topk_offer(tk, p.K, lane, h0, v.x, d, gt);
-            topk_offer(tk, p.K, lane, h1, v.y, d + 1, gt);
+            // one wave-wide test against the best known lower bound skips the insert logic for
+            // the (usual) chunks that cannot contribute
+            const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
+            if (__any(fmax(v.x, v.y) >= lo && (h0 || h1))) {
+              topk_offer(tk, p.K, lane, h0, v.x, d, gt);
+              topk_offer(tk, p.K, lane, h1, v.y, d + 1, gt);
+            }
           }
         }
       } else {
@@ -537,6 +573,7 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
     p.cand_score[o] = ok ? tk.s : 0.0;
     p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
   }
+  }  // item loop
 }
 
 // ------------------------------------------------------------------------------------------
@@ -739,6 +776,8 @@ struct EngineImpl {
   uint32_t* d_table = nullptr;
   uint64_t* d_keys = nullptr;
   double* d_lut = nullptr;
+  uint32_t* d_work = nullptr;
+  int n_cu = 256;
   uint64_t bytes = 0;
   std::mutex mu;
   // per-batch device buffers (grow-only; reuse is ordered by the stream)
@@ -788,6 +827,8 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     PS_HIP(hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
       throw std::runtime_error(std::string("built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+    m.n_cu = prop.multiProcessorCount;
+    PS_HIP(hipMalloc((void**)&m.d_work, 64));
     PS_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     for (auto& ev : m.ev) PS_HIP(hipEventCreate(&ev));
     for (auto& sg : m.stage) PS_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
@@ -819,7 +860,7 @@ Engine::~Engine() {
   EngineImpl& m = *impl_;
   (void)hipSetDevice(m.device);
   (void)hipDeviceSynchronize();
-  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_keys, (void*)m.d_lut})
+  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work})
     if (p) (void)hipFree(p);
   m.d_plan.release(); m.d_qbeg.release(); m.d_qtl.release(); m.d_zorder.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
@@ -944,6 +985,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys;
   kp.plan = m.d_plan.p; kp.qbeg = m.d_qbeg.p; kp.qterms_len = m.d_qtl.p; kp.zorder = m.d_zorder.p;
   kp.qflags = m.d_qflags.p;
+  kp.work_counter = m.d_work;
   kp.n_simple = n_simple; kp.n_general = n_general;
   kp.P = s.P;
   kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
@@ -981,15 +1023,21 @@ void allow_lds(const void* fn, size_t lds) {
 }
 
 template <int MODE, bool FULL>
-void launch_k_score(KParams& kp, bool tags, hipStream_t st) {
+void launch_k_score(KParams& kp, bool tags, int n_cu, hipStream_t st) {
+  PS_HIP(hipMemsetAsync(kp.work_counter, 0, 4, st));
   const uint32_t n_items = kp.B * kp.n_super;
-  const uint32_t n_wg = (n_items + WG_WAVES - 1) / WG_WAVES;
+  uint32_t n_wg = (n_items + WG_WAVES - 1) / WG_WAVES;
   const uint32_t aw = MODE == MODE_Z21S ? kp.F : 1u;
   const size_t lds = (MODE == MODE_BM25 ? (size_t)kp.lut_stride * LUT_TF * 8 : 0) +
                      WG_WAVES * ((size_t)kp.T * aw * 8 + (tags ? (size_t)kp.T * 2 : 0) + kp.slice_bytes);
 #define PS_LAUNCH(FV, TG)                                                                              \
   do {                                                                                                 \
-    allow_lds(reinterpret_cast<const void*>(&k_score<MODE, FV, TG, FULL>), lds);                       \
+    const void* fn = reinterpret_cast<const void*>(&k_score<MODE, FV, TG, FULL>);                      \
+    allow_lds(fn, lds);                                                                                \
+    int per_cu = 0;                                                                                    \
+    PS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVE * WG_WAVES, lds));           \
+    const uint32_t resident = (uint32_t)std::max(1, per_cu) * (uint32_t)n_cu;                          \
+    if (n_wg > resident) n_wg = resident;                                                              \
     hipLaunchKernelGGL((k_score<MODE, FV, TG, FULL>), dim3(n_wg), dim3(WAVE * WG_WAVES), lds, st, kp); \
   } while (0)
   if (MODE == MODE_BM25 && tags) {
@@ -1005,14 +1053,14 @@ void launch_k_score(KParams& kp, bool tags, hipStream_t st) {
 }
 
 template <bool FULL>
-void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, hipStream_t st) {
+void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n_cu, hipStream_t st) {
   const uint32_t n_items = kp.B * kp.n_super;
   if (n_items == 0) return;
   if (sc.kind == PS_SCORER_BM25) {
     if (kp.lut_rows) hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
-    launch_k_score<MODE_BM25, FULL>(kp, plan.multi_expansion, st);
+    launch_k_score<MODE_BM25, FULL>(kp, plan.multi_expansion, n_cu, st);
   } else {
-    if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(kp, false, st);
+    if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(kp, false, n_cu, st);
     if (kp.n_general || !kp.n_simple) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
       kp.z_nodes = std::max<uint32_t>(1, plan.max_nodes);
@@ -1072,7 +1120,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   PS_HIP(hipEventRecord(m.ev[1], st));
   PS_HIP(hipEventRecord(kt.a, st));
   TT("ev1");
-  launch_score<false>(sc, plan, kp, st);
+  launch_score<false>(sc, plan, kp, m.n_cu, st);
   TT("launch");
   PS_HIP(hipEventRecord(kt.b, st));
   kt.pending = true;
@@ -1242,7 +1290,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   m.harvest(kt, true);
   PS_HIP(hipEventRecord(m.ev[1], st));
   PS_HIP(hipEventRecord(kt.a, st));
-  launch_score<true>(sc, plan, kp, st);
+  launch_score<true>(sc, plan, kp, m.n_cu, st);
   PS_HIP(hipEventRecord(kt.b, st));
   kt.pending = true;
   PS_HIP(hipEventRecord(m.ev[2], st));

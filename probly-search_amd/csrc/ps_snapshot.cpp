@@ -20,7 +20,7 @@ inline uint32_t utf8_len(uint32_t cp) { return cp < 0x80 ? 1 : cp < 0x800 ? 2 : 
 
 Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   F = (uint32_t)idx.fields_len();
-  T = tile_docs ? tile_docs : 2048;
+  T = tile_docs ? tile_docs : 1024;
   if (T < 256 || T > 4096 || (T & (T - 1))) throw std::invalid_argument("tile_docs must be a power of two in [256, 4096]");
   src_epoch = idx.epoch();
   n_docs = idx.docs_len();
