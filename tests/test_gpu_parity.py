@@ -180,3 +180,16 @@ def test_full_size_properties_c2_slice():
     for r in both:
         exp = (s1[r.key] + s2[r.key]) if (r.key in s1 and r.key in s2) else s1.get(r.key, s2.get(r.key))
         assert bits(r.score) == bits(exp)
+
+
+def test_sharded_entry_point_single_rank():
+    """probly_search_amd.dist.query_batch_sharded at world_size 1 (no collective) == query_batch."""
+    from probly_search_amd import dist as psd
+    cfg = dict(synth.CONFIGS["C2"], n_docs=20_000, vocab=1_500)
+    corpus = synth.Corpus(**cfg)
+    p = synth.fill(psa.Index(2), corpus)
+    snap = p.snapshot(device=0)
+    queries = corpus.queries(33, 3)
+    a = snap.query_batch(queries, psa.bm25.new(), None, [1.0, 1.0], top_k=7)
+    b = psd.query_batch_sharded(snap, queries, psa.bm25.new(), [1.0, 1.0], 7, device=0)
+    assert [[tuple(r) for r in x] for x in a] == b
