@@ -150,6 +150,13 @@ def main():
             ts = time.perf_counter()
             snap.query(q, scorer, None, boosts, top_k=K)
             single.append(time.perf_counter() - ts)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        if os.path.exists(tpath):  # PMC pass of this same command, committed under profiles/
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         result = {
             "metric": "queries/sec, %s over %d-doc/%d-field index (top-%d, %d-query batches)" % (
                 cfg["scorer"], cfg["n_docs"], F, K, B),
@@ -168,14 +175,14 @@ def main():
             "postings_per_step": postings / steps,
             "index_build_s": t_index, "snapshot_s": t_snap, "hbm_resident_bytes": info["device_bytes"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_bm25" if cfg["scorer"] == "bm25" else "k_z21",
                          "kernel_avg_ms": k_avg_ms, "launches": int(k_launches),
                          "algorithmic_bytes_per_launch": alg_bytes_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, corpus, batches[args.warmup], boosts, args.cpu_queries, snap,
-                                                  scorer, K)
+            sample = [q for b in batches[args.warmup:] for q in b][:args.cpu_queries if B > 1 else 1000]
+            result["cpu_baseline"] = cpu_baseline(cfg, corpus, sample, boosts, snap, scorer, K)
     fence()
     if rank == 0:
         print(json.dumps(result))
@@ -183,7 +190,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, corpus, queries, boosts, n_sample, snap, scorer, K):
+def cpu_baseline(cfg, corpus, sample, boosts, snap, scorer, K):
     """Times the oracle (reference-faithful single-threaded C++ restatement) on the first n_sample
     queries of the first timed batch, 1 thread (the reference's execution model) and all cores
     (one query per thread over the shared read-only index); cross-checks the GPU top-k on them."""
@@ -193,7 +200,6 @@ def cpu_baseline(cfg, corpus, queries, boosts, n_sample, snap, scorer, K):
     o = synth.fill(orc.Index(cfg["fields"]), corpus)
     t_build = time.time() - t0
     osc = orc.bm25() if cfg["scorer"] == "bm25" else orc.zero_to_one()
-    sample = queries[:n_sample]
     wall1, secs1, nres, top = o.bench_queries(sample, osc, boosts, threads=1, top_k=K)
     cores = os.cpu_count() or 1
     wallN, secsN, _, _ = o.bench_queries(sample, osc, boosts, threads=cores, top_k=0)
@@ -201,7 +207,7 @@ def cpu_baseline(cfg, corpus, queries, boosts, n_sample, snap, scorer, K):
     mism = sum(1 for g, e in zip(got, top) if [(r.key, r.score) for r in g] != e)
     import numpy as np
     return {"value": len(sample) / wall1, "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": "first %d queries of the first timed batch, full-result Index::query per query, "
+            "sample": "first %d queries of the timed batches, full-result Index::query per query, "
                       "oracle/probly_oracle.cpp (-O2), single thread" % len(sample),
             "p50_query_ms": float(np.median(secs1) * 1e3),
             "all_cores": {"value": len(sample) / wallN, "cores": cores},
