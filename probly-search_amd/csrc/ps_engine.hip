@@ -386,11 +386,18 @@ __device__ __forceinline__ void score_stream(const KParams& p, const double* lut
       i0 = nx;
     }
   }
-  // tail (< UN*64 postings): 64 at a time so short ranges do not pay for empty lane slots
-  for (; i0 < re; i0 += WAVE) {
-    uint32_t dv[1], tfv[1][FA], flv[1][FA];
-    load_trip<F_, 1>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
-    score_trip<MODE, F_, TAGS, 1>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+  // tail (< UN*64 postings): one masked trip when it is long (all loads in flight together), one
+  // 64-wide trip when it is short (no empty lane slots to pay for)
+  if (i0 < re) {
+    if (re - i0 > (uint32_t)WAVE) {
+      uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
+      load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+      score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+    } else {
+      uint32_t dv[1], tfv[1][FA], flv[1][FA];
+      load_trip<F_, 1>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+      score_trip<MODE, F_, TAGS, 1>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+    }
   }
 }
 
