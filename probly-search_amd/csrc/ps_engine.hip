@@ -474,52 +474,60 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
 
     EntryC ec[G];
     uint32_t ec_qterm[G], ec_tbl[G];
-    for (uint32_t t = t_begin; t < t_end; ++t) {
+    uint32_t rb[G], re[G];
+    uint32_t dv[G][FU], tfv[G][FU][FA], flv[G][FU][FA];
+    // phase 1 of a visit (tile VT, entries EG..EG+G): ranges + first trips, all loads in flight together
+#define PS_PHASE1(VT, EG, FIRST)                                                                                \
+  _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                               \
+    rb[g] = 0; re[g] = 0;                                                                                       \
+    if ((EG) + g < ne) { /* wave-uniform */                                                                     \
+      if (ne > (uint32_t)G || (FIRST)) { /* a plan of <= G entries stays in SGPRs for the whole run */          \
+        const ps_plan_entry& en = p.plan[e0 + (EG) + g];                                                        \
+        ec[g].post_off = en.post_off;                                                                           \
+        ec[g].shift = en.shift & 0xFFu;                                                                         \
+        ec[g].w0 = MODE == MODE_BM25 ? en.idf : en.boost;                                                       \
+        ec[g].w1 = en.boost;                                                                                    \
+        ec_qterm[g] = en.qterm;                                                                                 \
+        ec_tbl[g] = en.tbl_off;                                                                                 \
+      }                                                                                                         \
+      if (sliced) {                                                                                             \
+        rb[g] = __builtin_amdgcn_readfirstlane(slice[(((EG) + g) * 2 + 0) * p.S + ((VT) - t_begin)]);           \
+        re[g] = __builtin_amdgcn_readfirstlane(slice[(((EG) + g) * 2 + 1) * p.S + ((VT) - t_begin)]);           \
+      } else {                                                                                                  \
+        const uint32_t slot = (VT) >> ec[g].shift;                                                              \
+        rb[g] = p.table[ec_tbl[g] + slot];                                                                      \
+        re[g] = p.table[ec_tbl[g] + slot + 1];                                                                  \
+      }                                                                                                         \
+      if (rb[g] < re[g]) load_trip<F_, FU>(p, lane, ec[g].post_off, rb[g], re[g], dv[g], tfv[g], flv[g]);       \
+    }                                                                                                           \
+  }
+    PS_PHASE1(t_begin, 0u, true)
+    uint32_t t = t_begin, eg = 0;
+    bool dirty = false;
+    for (;;) {
       const uint32_t tile_base = t * T;
-      const uint32_t tl = t - t_begin;
-      bool dirty = false;
-      for (uint32_t eg = 0; eg < ne; eg += G) {
-        uint32_t rb[G], re[G];
-        uint32_t dv[G][FU], tfv[G][FU][FA], flv[G][FU][FA];
-        // phase 1: ranges + first trips of up to G entries, all loads in flight together
+      // phase 2: consume the visit in plan order
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          rb[g] = 0; re[g] = 0;
-          if (eg + g < ne) {  // wave-uniform
-            if (ne > (uint32_t)G || t == t_begin) {  // a plan of <= G entries stays in SGPRs for the whole run
-              const ps_plan_entry& en = p.plan[e0 + eg + g];
-              ec[g].post_off = en.post_off;
-              ec[g].shift = en.shift & 0xFFu;
-              ec[g].w0 = MODE == MODE_BM25 ? en.idf : en.boost;
-              ec[g].w1 = en.boost;
-              ec_qterm[g] = en.qterm;
-              ec_tbl[g] = en.tbl_off;
-            }
-            ec[g].tag = tagbase + ec_qterm[g];
-            if (sliced) {
-              rb[g] = __builtin_amdgcn_readfirstlane(slice[((eg + g) * 2 + 0) * p.S + tl]);
-              re[g] = __builtin_amdgcn_readfirstlane(slice[((eg + g) * 2 + 1) * p.S + tl]);
-            } else {
-              const uint32_t slot = t >> ec[g].shift;
-              rb[g] = p.table[ec_tbl[g] + slot];
-              re[g] = p.table[ec_tbl[g] + slot + 1];
-            }
-            if (rb[g] < re[g]) load_trip<F_, FU>(p, lane, ec[g].post_off, rb[g], re[g], dv[g], tfv[g], flv[g]);
-          }
-        }
-        // phase 2: consume in plan order
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          if (rb[g] < re[g]) {
-            dirty = true;
-            score_trip<MODE, F_, TAGS, FU>(p, lut, acc, tag, lane, tile_base, rb[g], re[g], dv[g], tfv[g], flv[g], ec[g], qtl);
-            if (rb[g] + FU * WAVE < re[g])
-              score_stream<MODE, F_, TAGS>(p, lut, acc, tag, lane, tile_base, rb[g] + FU * WAVE, re[g], ec[g], qtl);
-          }
+      for (int g = 0; g < G; ++g) {
+        if (rb[g] < re[g]) {
+          dirty = true;
+          ec[g].tag = tagbase + ec_qterm[g];
+          score_trip<MODE, F_, TAGS, FU>(p, lut, acc, tag, lane, tile_base, rb[g], re[g], dv[g], tfv[g], flv[g], ec[g], qtl);
+          if (rb[g] + FU * WAVE < re[g])
+            score_stream<MODE, F_, TAGS>(p, lut, acc, tag, lane, tile_base, rb[g] + FU * WAVE, re[g], ec[g], qtl);
         }
       }
-      if (!dirty) continue;  // no list of this query touches the tile: nothing to harvest
-      if (PS_ABLATE_BUILD && (p.ablate & 4u)) continue;
+      // Request the next visit's ranges and first trips now: the registers are free again, and the
+      // loads then fly while this tile is harvested below.
+      uint32_t neg = eg + G, nt = t;
+      bool last = false;
+      if (neg >= ne) { neg = 0; nt = t + 1; last = true; }
+      const bool more = nt < t_end;
+      if (more) { PS_PHASE1(nt, neg, false) }
+      const bool harvest = last && dirty && !(PS_ABLATE_BUILD && (p.ablate & 4u));
+      if (last) dirty = false;
+      t = nt; eg = neg;
+      if (harvest) {
       // tile epilogue: harvest + reset (two f64 per lane per LDS access where the layout allows)
       double gt = 0.0;
       if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -572,7 +580,10 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
           tagbase = 0;
         }
       }
+      }  // harvest
+      if (!more) break;
     }
+#undef PS_PHASE1
   }
   if (!FULL && (uint32_t)lane < p.K) {
     const uint64_t o = (uint64_t)item * p.K + lane;
