@@ -799,8 +799,8 @@ struct EngineImpl {
   uint64_t bytes = 0;
   std::mutex mu;
   // per-batch device buffers (grow-only; reuse is ordered by the stream)
-  DevBuf<ps_plan_entry> d_plan;
-  DevBuf<uint32_t> d_qbeg, d_qtl, d_zorder, d_qflags, d_cand_doc, d_out_counts, d_full_doc, d_full_cnt;
+  DevBuf<unsigned char> d_stage;  // plan entries + per-query arrays, one H2D copy per batch
+  DevBuf<uint32_t> d_cand_doc, d_out_counts, d_full_doc, d_full_cnt;
   DevBuf<double> d_cand_score, d_out_scores, d_full_score;
   DevBuf<uint64_t> d_out_keys, d_full_off;
   DevBuf<unsigned long long> d_gthr;
@@ -811,6 +811,7 @@ struct EngineImpl {
   // caller that pipelines batches on its own stream still gets per-launch durations.
   struct KTimer { hipEvent_t a = nullptr, b = nullptr; bool pending = false; };
   KTimer kt[N_KTIMER];
+  KTimer* last_kt = nullptr;
   int next_kt = 0;
   double kt_total_ms = 0.0;
   uint64_t kt_launches = 0;
@@ -880,10 +881,10 @@ Engine::~Engine() {
   (void)hipDeviceSynchronize();
   for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work})
     if (p) (void)hipFree(p);
-  m.d_plan.release(); m.d_qbeg.release(); m.d_qtl.release(); m.d_zorder.release(); m.d_cand_doc.release();
+  m.d_stage.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
-  m.d_gthr.release(); m.d_qflags.release();
+  m.d_gthr.release();
   for (auto& sg : m.stage) {
     if (sg.p) (void)hipHostFree(sg.p);
     if (sg.done) (void)hipEventDestroy(sg.done);
@@ -986,24 +987,24 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       }
     }
   }
-  m.d_plan.ensure(ne + 1);
-  m.d_qbeg.ensure(B + 1);
-  m.d_qtl.ensure(B + 1);
-  m.d_zorder.ensure(ne + 1);
-  m.d_qflags.ensure(B + 1);
-  if (ne) PS_HIP(hipMemcpyAsync(m.d_plan.p, h + off_e, ne * sizeof(ps_plan_entry), hipMemcpyHostToDevice, st));
-  PS_HIP(hipMemcpyAsync(m.d_qbeg.p, h + off_q, (B + 1) * 4, hipMemcpyHostToDevice, st));
-  if (B) PS_HIP(hipMemcpyAsync(m.d_qtl.p, h + off_l, B * 4, hipMemcpyHostToDevice, st));
-  if (z && ne) PS_HIP(hipMemcpyAsync(m.d_zorder.p, h + off_z, ne * 4, hipMemcpyHostToDevice, st));
-  if (z && B) PS_HIP(hipMemcpyAsync(m.d_qflags.p, h + off_f, B * 4, hipMemcpyHostToDevice, st));
+  // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | zorder | qflags)
+  m.d_stage.ensure(total + 64);
+  PS_HIP(hipMemcpyAsync(m.d_stage.p, h, z ? total : off_z, hipMemcpyHostToDevice, st));
   PS_HIP(hipEventRecord(sg.done, st));
   sg.pending = true;
 
   memset(&kp, 0, sizeof(kp));
   kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys;
-  kp.plan = m.d_plan.p; kp.qbeg = m.d_qbeg.p; kp.qterms_len = m.d_qtl.p; kp.zorder = m.d_zorder.p;
-  kp.qflags = m.d_qflags.p;
-  kp.work_counter = m.d_work;
+  kp.plan = reinterpret_cast<const ps_plan_entry*>(m.d_stage.p + off_e);
+  kp.qbeg = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_q);
+  kp.qterms_len = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_l);
+  kp.zorder = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_z);
+  kp.qflags = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_f);
+  // control words, zeroed by one memset per batch: gthr[0..B) + the persistent waves' item counter
+  m.d_gthr.ensure(B + 2);
+  kp.gthr = m.d_gthr.p;
+  kp.work_counter = reinterpret_cast<uint32_t*>(m.d_gthr.p + B + 1);
+  PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, (B + 2) * 8, st));
   kp.n_simple = n_simple; kp.n_general = n_general;
   kp.P = s.P;
   kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
@@ -1042,7 +1043,6 @@ void allow_lds(const void* fn, size_t lds) {
 
 template <int MODE, bool FULL>
 void launch_k_score(KParams& kp, bool tags, int n_cu, hipStream_t st) {
-  PS_HIP(hipMemsetAsync(kp.work_counter, 0, 4, st));
   const uint32_t n_items = kp.B * kp.n_super;
   uint32_t n_wg = (n_items + WG_WAVES - 1) / WG_WAVES;
   const uint32_t aw = MODE == MODE_Z21S ? kp.F : 1u;
@@ -1114,8 +1114,6 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     fprintf(stderr, "[ps] %-12s %.3f ms\n", what, n - tt);
     tt = n;
   };
-  PS_HIP(hipEventRecord(m.ev[0], st));
-  TT("ev0");
   stage_plan(m, sc, boosts, plan, st, kp);
   TT("stage_plan");
   kp.K = (uint32_t)top_k;
@@ -1124,10 +1122,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   m.d_cand_doc.ensure(n_cand + 1);
   kp.cand_score = m.d_cand_score.p;
   kp.cand_doc = m.d_cand_doc.p;
-  m.d_gthr.ensure(B + 1);
-  kp.gthr = m.d_gthr.p;
-  PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, (B + 1) * 8, st));
-  TT("memset");
+  TT("ctl");
   kp.out_keys = (uint64_t*)d_keys;
   kp.out_scores = (double*)d_scores;
   kp.out_counts = (uint32_t*)d_counts;
@@ -1135,31 +1130,38 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   m.next_kt = (m.next_kt + 1) % N_KTIMER;
   m.harvest(kt, true);
   TT("harvest");
-  PS_HIP(hipEventRecord(m.ev[1], st));
   PS_HIP(hipEventRecord(kt.a, st));
-  TT("ev1");
   launch_score<false>(sc, plan, kp, m.n_cu, st);
   TT("launch");
   PS_HIP(hipEventRecord(kt.b, st));
   kt.pending = true;
-  PS_HIP(hipEventRecord(m.ev[2], st));
-  TT("ev2");
+  m.last_kt = &kt;
   if (B) {
     hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE), 0, st, kp);
     PS_HIP(hipGetLastError());
   }
-  PS_HIP(hipEventRecord(m.ev[3], st));
-  TT("merge+ev3");
+  TT("merge");
 }
 
+// Latency-oriented stream wait: poll for a short while (a blocking hipStreamSynchronize costs tens
+// of microseconds of wake-up latency, comparable to a whole single-query batch), then block.
+void sync_stream(hipStream_t st) {
+  const double t0 = now_ms();
+  while (now_ms() - t0 < 0.5) {
+    hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) PS_HIP(e);
+  }
+  PS_HIP(hipStreamSynchronize(st));
+}
+
+// After a stream sync: duration of the batch's scoring kernel from its HIP-event pair.
 void read_kernel_times(EngineImpl& m, ps_batch_stats& stats) {
-  float a = 0, b = 0, c = 0;
-  PS_HIP(hipEventElapsedTime(&a, m.ev[0], m.ev[1]));
-  PS_HIP(hipEventElapsedTime(&b, m.ev[1], m.ev[2]));
-  PS_HIP(hipEventElapsedTime(&c, m.ev[1], m.ev[3]));
-  stats.h2d_ms = a;
+  float b = 0;
+  if (m.last_kt && hipEventElapsedTime(&b, m.last_kt->a, m.last_kt->b) != hipSuccess) b = 0;
+  stats.h2d_ms = 0;
   stats.score_kernel_ms = b;
-  stats.kernel_ms = c;
+  stats.kernel_ms = b;
 }
 
 Plan sub_plan(const Plan& plan, size_t b, size_t e) {
@@ -1220,26 +1222,19 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
     PS_HIP(hipSetDevice(m.device));
     hipStream_t st = m.stream;
     const size_t nb = B * top_k;
-    m.d_out_keys.ensure(nb + 1);
-    m.d_out_scores.ensure(nb + 1);
-    m.d_out_counts.ensure(B + 1);
-    enqueue_topk(m, sc, boosts, plan, top_k, m.d_out_keys.p, m.d_out_scores.p, m.d_out_counts.p, st);
-    m.result.ensure(nb * 16 + B * 4 + 64);
+    // keys | scores | counts in one device block -> one D2H copy
+    const size_t res_bytes = nb * 16 + B * 4;
+    m.d_out_keys.ensure(res_bytes / 8 + 2);
+    unsigned char* dres = reinterpret_cast<unsigned char*>(m.d_out_keys.p);
+    enqueue_topk(m, sc, boosts, plan, top_k, dres, dres + nb * 8, dres + nb * 16, st);
+    m.result.ensure(res_bytes + 64);
     uint64_t* hk = reinterpret_cast<uint64_t*>(m.result.p);
     double* hs = reinterpret_cast<double*>(m.result.p + nb * 8);
     uint32_t* hc = reinterpret_cast<uint32_t*>(m.result.p + nb * 16);
-    PS_HIP(hipEventRecord(m.ev[4], st));
-    if (nb) {
-      PS_HIP(hipMemcpyAsync(hk, m.d_out_keys.p, nb * 8, hipMemcpyDeviceToHost, st));
-      PS_HIP(hipMemcpyAsync(hs, m.d_out_scores.p, nb * 8, hipMemcpyDeviceToHost, st));
-    }
-    if (B) PS_HIP(hipMemcpyAsync(hc, m.d_out_counts.p, B * 4, hipMemcpyDeviceToHost, st));
-    PS_HIP(hipEventRecord(m.ev[5], st));
-    PS_HIP(hipStreamSynchronize(st));
+    if (res_bytes) PS_HIP(hipMemcpyAsync(m.result.p, dres, res_bytes, hipMemcpyDeviceToHost, st));
+    sync_stream(st);
     read_kernel_times(m, stats);
-    float d2h = 0;
-    PS_HIP(hipEventElapsedTime(&d2h, m.ev[4], m.ev[5]));
-    stats.d2h_ms = d2h;
+    stats.d2h_ms = 0;
     size_t total = 0;
     for (size_t q = 0; q < B; ++q) { offsets[q] = total; total += hc[q]; }
     offsets[B] = total;
@@ -1286,7 +1281,6 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   PS_HIP(hipSetDevice(m.device));
   hipStream_t st = m.stream;
   KParams kp;
-  PS_HIP(hipEventRecord(m.ev[0], st));
   stage_plan(m, sc, boosts, plan, st, kp);
   kp.K = 1;
   m.d_full_doc.ensure(total_cap + 1);
@@ -1306,13 +1300,11 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   EngineImpl::KTimer& kt = m.kt[m.next_kt];
   m.next_kt = (m.next_kt + 1) % N_KTIMER;
   m.harvest(kt, true);
-  PS_HIP(hipEventRecord(m.ev[1], st));
   PS_HIP(hipEventRecord(kt.a, st));
   launch_score<true>(sc, plan, kp, m.n_cu, st);
   PS_HIP(hipEventRecord(kt.b, st));
   kt.pending = true;
-  PS_HIP(hipEventRecord(m.ev[2], st));
-  PS_HIP(hipEventRecord(m.ev[3], st));
+  m.last_kt = &kt;
   PS_HIP(hipMemcpyAsync(h_cnt, m.d_full_cnt.p, (B + 1) * 4, hipMemcpyDeviceToHost, st));
   PS_HIP(hipStreamSynchronize(st));
   std::vector<uint32_t> cnt(h_cnt, h_cnt + B);
