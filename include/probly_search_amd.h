@@ -184,6 +184,12 @@ typedef struct ps_batch_stats {
   double h2d_ms, kernel_ms, d2h_ms; /* HIP-event timed on the engine stream                       */
   double score_kernel_ms;      /* the dominant posting-accumulate kernel alone (HIP events)       */
   double total_ms;             /* host wall clock of the whole call                               */
+  uint64_t layout_bytes;       /* bytes of the layout the kernels actually streamed this batch:
+                                  20-byte postings for lists read as postings, 8 bytes per document
+                                  for lists served from dense score rows, plus building those rows
+                                  (postings read + row zero-fill + row writes) and emitted results  */
+  uint32_t dense_rows;         /* hot (list, idf, boost) combinations scored once into dense rows  */
+  uint32_t _pad;
 } ps_batch_stats;
 ps_status ps_snapshot_last_stats(const ps_snapshot* snap, ps_batch_stats* out);
 /* HIP-event time (ms) summed over every launch of the posting-accumulate kernel on this

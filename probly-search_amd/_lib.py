@@ -42,7 +42,8 @@ class BatchStats(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("n_plan_entries", C.c_uint64), ("postings_visited", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("plan_ms", C.c_double), ("h2d_ms", C.c_double),
                 ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("score_kernel_ms", C.c_double),
-                ("total_ms", C.c_double)]
+                ("total_ms", C.c_double), ("layout_bytes", C.c_uint64), ("dense_rows", C.c_uint32),
+                ("_pad", C.c_uint32)]
 
 
 class PlanEntry(C.Structure):

@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -62,6 +63,15 @@ constexpr int LUT_TF = 16;   // LUT columns: term frequency 0..15
 #define PS_ABLATE_BUILD 0  // profiling builds only: honour KParams::ablate in the hot loops
 #endif
 
+struct RowDesc {  // one hot (list, idf, expansion_boost) combination of the batch
+  uint64_t post_off;
+  uint32_t len;
+  uint32_t _pad;
+  double idf, eb;
+};
+
+constexpr uint32_t DENSE_FLAG = 0x80000000u;  // ps_plan_entry::shift bit 31: entry reads dense row `node`
+
 struct KParams {
   const uint32_t* doc;
   const uint32_t* tf;
@@ -82,6 +92,12 @@ struct KParams {
   const double* lut;
   uint32_t lut_rows, lut_stride;  // entry (tf, row) lives at tf * lut_stride + row; stride is odd
   uint32_t lut_cap[MAX_F], lut_base[MAX_F];
+  // Dense rows (see k_dense_rows): per-document f64 score of the batch's hot lists, one row each
+  const double* rows;
+  const RowDesc* row_desc;
+  uint64_t row_stride;  // doubles per row = n_tiles * T
+  uint32_t n_rows;
+  uint64_t layout_bytes;         // host-side bookkeeping: bytes of the layout actually streamed
   uint32_t n_simple, n_general;  // host-side bookkeeping (zero_to_one query classes in this batch)
   uint32_t ablate;  // PS_ABLATE debug bit mask (profiling only): 1 = no top-k offer, 2 = no scoring
   uint32_t* work_counter;    // next (query, run) item for the persistent waves of k_score
@@ -209,6 +225,64 @@ __global__ __launch_bounds__(256) void k_bm25_lut(const KParams p, double* out) 
 //              contributions in sorted order (score desc, stable) — the host uploads the entries
 //              of such queries already in that order.  Anything else goes to k_z21.
 // ------------------------------------------------------------------------------------------
+// K0b: batch-level common-subexpression elimination.  A BM25 posting's score
+// s(list, doc) = sum_x ((tfn*idf)*boost_x)*expansion_boost does not depend on the query, and in a
+// Zipf batch a handful of head lists is visited by hundreds of queries (top-12 terms ~ 90 % of all
+// posting visits in C2).  For the (list, idf, eb) combinations the host found hot and dense, this
+// kernel evaluates s ONCE per posting — the very same f64 expression, so the bits are the same —
+// into a dense per-document row (0.0 = no posting).  K1 then adds row values in plan order
+// instead of re-streaming 20-byte postings and re-deriving the score per query.  Runs inside the
+// timed step, once per batch.
+__global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* rows) {
+  const RowDesc rd = p.row_desc[blockIdx.y];
+  double* row = rows + (uint64_t)blockIdx.y * p.row_stride;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rd.len; i += gridDim.x * blockDim.x) {
+    const uint64_t pi = rd.post_off + i;
+    double s = 0.0;
+    for (uint32_t x = 0; x < p.F; ++x) {
+      const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
+      if (tfu > 0) s += bm25_tfn(p, x, tfu, p.fl[(uint64_t)x * p.P + pi]) * rd.idf * p.boost[x] * rd.eb;
+    }
+    row[p.doc[pi]] = s;
+  }
+}
+
+// Merge one dense row's slice for this tile into the wave's LDS tile (same merge rules as
+// score_trip; a row value > 0 <=> the list holds that document).
+template <bool TAGS>
+__device__ __forceinline__ void dense_apply(const KParams& p, double* acc, uint16_t* tag, const int lane,
+                                            const uint32_t row, const uint32_t tile_base, const uint16_t mytag) {
+  const double* r = p.rows + (uint64_t)row * p.row_stride + tile_base;
+  constexpr int CH = 4;  // 4 x 128 documents per batch of 16-byte loads (1 KiB per load instruction)
+  for (uint32_t c0 = 0; c0 < p.T; c0 += CH * 2 * WAVE) {
+    double2 v[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+      if (c0 + k * 2 * WAVE < p.T) v[k] = *reinterpret_cast<const double2*>(r + c0 + k * 2 * WAVE + 2 * lane);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if (c0 + k * 2 * WAVE < p.T) {
+        const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
+        if (TAGS) {
+          const double c0v = acc[i], c1v = acc[i + 1];
+          const uint16_t t0 = tag[i], t1 = tag[i + 1];
+          if (v[k].x > 0.0) {
+            acc[i] = (c0v > 0.0) ? (t0 == mytag ? fmax(c0v, v[k].x) : c0v + v[k].x) : v[k].x;
+            tag[i] = mytag;
+          }
+          if (v[k].y > 0.0) {
+            acc[i + 1] = (c1v > 0.0) ? (t1 == mytag ? fmax(c1v, v[k].y) : c1v + v[k].y) : v[k].y;
+            tag[i + 1] = mytag;
+          }
+        } else {
+          if (v[k].x > 0.0) __hip_atomic_fetch_add(&acc[i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (v[k].y > 0.0) __hip_atomic_fetch_add(&acc[i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+    }
+  }
+}
+
 enum { MODE_BM25 = 0, MODE_Z21S = 1 };
 
 struct EntryC {      // wave-uniform per-entry constants (SGPRs)
@@ -473,7 +547,7 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
     }
 
     EntryC ec[G];
-    uint32_t ec_qterm[G], ec_tbl[G];
+    uint32_t ec_qterm[G], ec_tbl[G], ec_row[G];
     uint32_t rb[G], re[G];
     uint32_t dv[G][FU], tfv[G][FU][FA], flv[G][FU][FA];
     // phase 1 of a visit (tile VT, entries EG..EG+G): ranges + first trips, all loads in flight together
@@ -489,8 +563,10 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
         ec[g].w1 = en.boost;                                                                                    \
         ec_qterm[g] = en.qterm;                                                                                 \
         ec_tbl[g] = en.tbl_off;                                                                                 \
+        ec_row[g] = (MODE == MODE_BM25 && (en.shift & DENSE_FLAG)) ? en.node : 0xFFFFFFFFu;                     \
       }                                                                                                         \
-      if (sliced) {                                                                                             \
+      if (ec_row[g] != 0xFFFFFFFFu) { /* dense row: nothing to fetch up front */                                \
+      } else if (sliced) {                                                                                             \
         rb[g] = __builtin_amdgcn_readfirstlane(slice[(((EG) + g) * 2 + 0) * p.S + ((VT) - t_begin)]);           \
         re[g] = __builtin_amdgcn_readfirstlane(slice[(((EG) + g) * 2 + 1) * p.S + ((VT) - t_begin)]);           \
       } else {                                                                                                  \
@@ -509,7 +585,10 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
       // phase 2: consume the visit in plan order
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        if (rb[g] < re[g]) {
+        if (MODE == MODE_BM25 && eg + g < ne && ec_row[g] != 0xFFFFFFFFu) {
+          dirty = true;
+          dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
+        } else if (rb[g] < re[g]) {
           dirty = true;
           ec[g].tag = tagbase + ec_qterm[g];
           score_trip<MODE, F_, TAGS, FU>(p, lut, acc, tag, lane, tile_base, rb[g], re[g], dv[g], tfv[g], flv[g], ec[g], qtl);
@@ -804,6 +883,7 @@ struct EngineImpl {
   DevBuf<double> d_cand_score, d_out_scores, d_full_score;
   DevBuf<uint64_t> d_out_keys, d_full_off;
   DevBuf<unsigned long long> d_gthr;
+  DevBuf<double> d_rows;  // dense per-document score rows of the batch's hot lists
   Stage stage[N_STAGE];
   int next_stage = 0;
   Stage result;  // download staging (engine stream only)
@@ -812,6 +892,8 @@ struct EngineImpl {
   struct KTimer { hipEvent_t a = nullptr, b = nullptr; bool pending = false; };
   KTimer kt[N_KTIMER];
   KTimer* last_kt = nullptr;
+  uint64_t last_layout_bytes = 0;  // of the most recently staged batch
+  uint32_t last_rows = 0;
   int next_kt = 0;
   double kt_total_ms = 0.0;
   uint64_t kt_launches = 0;
@@ -884,7 +966,7 @@ Engine::~Engine() {
   m.d_stage.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
-  m.d_gthr.release();
+  m.d_gthr.release(); m.d_rows.release();
   for (auto& sg : m.stage) {
     if (sg.p) (void)hipHostFree(sg.p);
     if (sg.done) (void)hipEventDestroy(sg.done);
@@ -943,7 +1025,9 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const size_t off_l = off_q + (B + 1) * 4;
   const size_t off_z = off_l + B * 4;
   const size_t off_f = off_z + ne * 4;
-  const size_t total = off_f + B * 4;
+  const size_t off_r = (off_f + B * 4 + 15) & ~(size_t)15;
+  const size_t max_rows = env_u32("PS_DENSE_MAX_ROWS", 64);
+  const size_t total = off_r + max_rows * sizeof(RowDesc);
   Stage& sg = m.stage[m.next_stage];
   m.next_stage = (m.next_stage + 1) % N_STAGE;
   sg.ensure(total + 16);
@@ -952,6 +1036,63 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (ne) memcpy(he, plan.entries.data(), ne * sizeof(ps_plan_entry));
   memcpy(h + off_q, plan.qbeg.data(), (B + 1) * 4);
   if (B) memcpy(h + off_l, plan.qterms_len.data(), B * 4);
+  // ---- hot dense lists (BM25 only; see k_dense_rows) -------------------------------------------
+  uint32_t n_rows = 0;
+  uint64_t layout_bytes = 0;
+  {
+    bool sane = !z && max_rows > 0 && std::isfinite(sc.bm25_k1) && sc.bm25_k1 >= 0.0 && sc.bm25_b >= 0.0 &&
+                sc.bm25_b <= 1.0 && s.n_docs > 0;
+    for (uint32_t x = 0; x < s.F && sane; ++x)
+      sane = std::isfinite(boosts[x]) && boosts[x] > 0.0 && std::isfinite(s.avg[x]) && s.avg[x] > 0.0;
+    const uint32_t min_uses = env_u32("PS_DENSE_MIN_USES", 4);
+    const double min_density = env_u32("PS_DENSE_MIN_DENSITY_PCT", 25) / 100.0;
+    if (sane && ne) {
+      struct Key { uint64_t post_off, idf, eb; };
+      struct Agg { uint32_t uses, len; };
+      auto kless = [](const Key& a, const Key& b) {
+        return a.post_off != b.post_off ? a.post_off < b.post_off : a.idf != b.idf ? a.idf < b.idf : a.eb < b.eb;
+      };
+      std::map<Key, Agg, decltype(kless)> agg(kless);
+      for (size_t i = 0; i < ne; ++i) {
+        const ps_plan_entry& e = plan.entries[i];
+        if ((double)e.len < min_density * (double)s.n_docs) continue;
+        Key k{e.post_off, 0, 0};
+        memcpy(&k.idf, &e.idf, 8);
+        memcpy(&k.eb, &e.boost, 8);
+        Agg& a = agg[k];
+        a.uses++;
+        a.len = e.len;
+      }
+      std::vector<std::pair<uint64_t, Key>> hot;  // (saved posting visits, key)
+      for (auto& kv : agg)
+        if (kv.second.uses >= min_uses) hot.emplace_back((uint64_t)kv.second.uses * kv.second.len, kv.first);
+      std::sort(hot.begin(), hot.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+      const uint64_t row_bytes = (uint64_t)s.n_tiles * s.T * 8;
+      const uint64_t mem_cap = (uint64_t)env_u32("PS_DENSE_MAX_MB", 4096) << 20;
+      while (hot.size() > max_rows || hot.size() * row_bytes > mem_cap) hot.pop_back();
+      if (!hot.empty()) {
+        RowDesc* rd = reinterpret_cast<RowDesc*>(h + off_r);
+        std::map<Key, uint32_t, decltype(kless)> row_of(kless);
+        for (auto& hk : hot) {
+          RowDesc d;
+          d.post_off = hk.second.post_off;
+          d.len = agg[hk.second].len;
+          d._pad = 0;
+          memcpy(&d.idf, &hk.second.idf, 8);
+          memcpy(&d.eb, &hk.second.eb, 8);
+          row_of[hk.second] = n_rows;
+          rd[n_rows++] = d;
+        }
+        for (size_t i = 0; i < ne; ++i) {
+          Key k{he[i].post_off, 0, 0};
+          memcpy(&k.idf, &he[i].idf, 8);
+          memcpy(&k.eb, &he[i].boost, 8);
+          auto it = row_of.find(k);
+          if (it != row_of.end()) { he[i].shift |= DENSE_FLAG; he[i].node = it->second; }
+        }
+      }
+    }
+  }
   uint32_t n_simple = 0, n_general = 0;
   if (z) {
     // per query: entry indices stably sorted by ScoreByTerm::score desc (zero_to_one.rs:98);
@@ -989,7 +1130,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   }
   // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | zorder | qflags)
   m.d_stage.ensure(total + 64);
-  PS_HIP(hipMemcpyAsync(m.d_stage.p, h, z ? total : off_z, hipMemcpyHostToDevice, st));
+  PS_HIP(hipMemcpyAsync(m.d_stage.p, h, n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z),
+                        hipMemcpyHostToDevice, st));
   PS_HIP(hipEventRecord(sg.done, st));
   sg.pending = true;
 
@@ -1000,12 +1142,31 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.qterms_len = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_l);
   kp.zorder = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_z);
   kp.qflags = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_f);
+  {
+    // bytes of the layout actually used (never claim the wider figure for a narrower stream)
+    const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.n_tiles * s.T * 8;
+    uint64_t lb = 0;
+    for (size_t i = 0; i < ne; ++i) lb += (he[i].shift & DENSE_FLAG) ? row_bytes : (uint64_t)he[i].len * pb;
+    const RowDesc* rd = reinterpret_cast<const RowDesc*>(h + off_r);
+    for (uint32_t r = 0; r < n_rows; ++r) lb += (uint64_t)rd[r].len * (pb + 8) + row_bytes;
+    layout_bytes = lb;
+  }
+  kp.row_desc = reinterpret_cast<const RowDesc*>(m.d_stage.p + off_r);
+  kp.n_rows = n_rows;
+  kp.row_stride = (uint64_t)s.n_tiles * s.T;
+  if (n_rows) {
+    m.d_rows.ensure((size_t)n_rows * kp.row_stride + 16);
+    kp.rows = m.d_rows.p;
+  }
   // control words, zeroed by one memset per batch: gthr[0..B) + the persistent waves' item counter
   m.d_gthr.ensure(B + 2);
   kp.gthr = m.d_gthr.p;
   kp.work_counter = reinterpret_cast<uint32_t*>(m.d_gthr.p + B + 1);
   PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, (B + 2) * 8, st));
   kp.n_simple = n_simple; kp.n_general = n_general;
+  kp.layout_bytes = layout_bytes;
+  m.last_layout_bytes = layout_bytes;
+  m.last_rows = n_rows;
   kp.P = s.P;
   kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
   kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
@@ -1076,6 +1237,10 @@ void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n
   if (n_items == 0) return;
   if (sc.kind == PS_SCORER_BM25) {
     if (kp.lut_rows) hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
+    if (kp.n_rows) {
+      PS_HIP(hipMemsetAsync(const_cast<double*>(kp.rows), 0, (size_t)kp.n_rows * kp.row_stride * 8, st));
+      hipLaunchKernelGGL(k_dense_rows, dim3(256, kp.n_rows), dim3(256), 0, st, kp, const_cast<double*>(kp.rows));
+    }
     launch_k_score<MODE_BM25, FULL>(kp, plan.multi_expansion, n_cu, st);
   } else {
     if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(kp, false, n_cu, st);
@@ -1094,7 +1259,9 @@ void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n
   PS_HIP(hipGetLastError());
 }
 
-void fill_stats(ps_batch_stats& st, const Snapshot& s, const Plan& plan, uint64_t emitted) {
+void fill_stats(const EngineImpl& m, ps_batch_stats& st, const Snapshot& s, const Plan& plan, uint64_t emitted) {
+  st.layout_bytes = m.last_layout_bytes + emitted * 16;
+  st.dense_rows = m.last_rows;
   st.n_queries = plan.qbeg.size() - 1;
   st.n_plan_entries = plan.entries.size();
   st.postings_visited = plan.postings;
@@ -1198,7 +1365,7 @@ void Engine::run_device(const ps_scorer_desc& sc, const double* boosts, const Pl
   hipStream_t st = stream ? (hipStream_t)stream : m.stream;
   enqueue_topk(m, sc, boosts, plan, top_k, d_keys, d_scores, d_counts, st);
   memset(&stats, 0, sizeof(stats));
-  fill_stats(stats, s, plan, (uint64_t)(plan.qbeg.size() - 1) * top_k);
+  fill_stats(m, stats, s, plan, (uint64_t)(plan.qbeg.size() - 1) * top_k);
   if (!stream) {
     PS_HIP(hipStreamSynchronize(st));
     read_kernel_times(m, stats);
@@ -1241,7 +1408,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
     out.resize(total);
     for (size_t q = 0; q < B; ++q)
       for (uint32_t k = 0; k < hc[q]; ++k) out[offsets[q] + k] = ps_result{hk[q * top_k + k], hs[q * top_k + k]};
-    fill_stats(stats, s, plan, total);
+    fill_stats(m, stats, s, plan, total);
     stats.total_ms = now_ms() - t0;
     return;
   }
@@ -1268,7 +1435,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
     out.insert(out.end(), o2.begin(), o2.end());
     for (size_t q = 0; q <= half; ++q) offsets[q] = f1[q];
     for (size_t q = half; q <= B; ++q) offsets[q] = f1[half] + f2[q - half];
-    fill_stats(stats, s, plan, out.size());
+    fill_stats(m, stats, s, plan, out.size());
     stats.h2d_ms = s1.h2d_ms + s2.h2d_ms;
     stats.kernel_ms = s1.kernel_ms + s2.kernel_ms;
     stats.score_kernel_ms = s1.score_kernel_ms + s2.score_kernel_ms;
@@ -1341,7 +1508,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
     else std::sort(tmp.begin(), tmp.end(), cmp);
     for (size_t i = 0; i < keep; ++i) out[offsets[q] + i] = ps_result{s.keys[(size_t)tmp[i].key], tmp[i].score};
   }
-  fill_stats(stats, s, plan, total);
+  fill_stats(m, stats, s, plan, total);
   stats.total_ms = now_ms() - t0;
 }
 

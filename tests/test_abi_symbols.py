@@ -30,7 +30,7 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.PlanEntry) == 48
     assert ctypes.sizeof(_lib.Result) == 16
     assert ctypes.sizeof(_lib.ScorerDesc) == 24
-    assert ctypes.sizeof(_lib.BatchStats) == 80
+    assert ctypes.sizeof(_lib.BatchStats) == 96
 
 
 def test_queries_fail_loudly_without_device_snapshot():

@@ -193,3 +193,25 @@ def test_sharded_entry_point_single_rank():
     a = snap.query_batch(queries, psa.bm25.new(), None, [1.0, 1.0], top_k=7)
     b = psd.query_batch_sharded(snap, queries, psa.bm25.new(), [1.0, 1.0], 7, device=0)
     assert [[tuple(r) for r in x] for x in a] == b
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_dense_rows_path_forced(seed, monkeypatch):
+    """K0b/K1 dense-row path (hot lists scored once per batch) forced on for every list: results
+    must stay bit-identical, single- and multi-expansion (visited tags) queries alike."""
+    monkeypatch.setenv("PS_DENSE_MIN_USES", "1")
+    monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "0")
+    F, steps, vocab = build_script(300 + seed, n_docs=400, fields=1 + seed % 2, vocab_size=25, shuffle_keys=seed % 2 == 1)
+    o, p = orc.Index(F), ProductIndex(F)
+    replay(steps, F, o, p)
+    snap = p.idx.snapshot(device=0, tile_docs=256)
+    boosts = [1.0] * F if seed % 2 else [2.0, 0.5][:F]
+    queries = random_queries(seed, vocab, n=40)
+    for name, kw in (("bm25", {}), ("bm25", {"k1": 0.7, "b": 0.3})):
+        sc = product_scorer(name, **kw)
+        full = snap.query_batch(queries, sc, None, boosts, top_k=0)
+        top = snap.query_batch(queries, sc, None, boosts, top_k=5)
+        for q, f, t in zip(queries, full, top):
+            exp = o.query(q, oracle_scorer(name, **kw), boosts)
+            assert_same([tuple(r) for r in f], exp, (seed, name, q, "dense-full"))
+            assert_same([tuple(r) for r in t], exp[:5], (seed, name, q, "dense-top5"))
