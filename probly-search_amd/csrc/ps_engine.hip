@@ -95,8 +95,10 @@ struct KParams {
   // Dense rows (see k_dense_rows): per-document f64 score of the batch's hot lists, one row each
   const double* rows;
   const RowDesc* row_desc;
-  uint64_t row_stride;  // doubles per row = n_tiles * T
+  uint64_t row_stride;  // doubles per row plane = n_tiles * T
   uint32_t n_rows;
+  uint32_t row_mode;    // MODE_BM25 | MODE_Z21S: what k_dense_rows evaluates
+  uint32_t row_planes;  // 1 (BM25 score) | F (zero_to_one: one contribution plane per field)
   uint64_t layout_bytes;         // host-side bookkeeping: bytes of the layout actually streamed
   uint32_t n_simple, n_general;  // host-side bookkeeping (zero_to_one query classes in this batch)
   uint32_t ablate;  // PS_ABLATE debug bit mask (profiling only): 1 = no top-k offer, 2 = no scoring
@@ -235,7 +237,23 @@ __global__ __launch_bounds__(256) void k_bm25_lut(const KParams p, double* out) 
 // timed step, once per batch.
 __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* rows) {
   const RowDesc rd = p.row_desc[blockIdx.y];
-  double* row = rows + (uint64_t)blockIdx.y * p.row_stride;
+  double* row = rows + (uint64_t)blockIdx.y * p.row_planes * p.row_stride;
+  if (p.row_mode != 0) {
+    // zero_to_one.rs:117-120 per field: (min(score/tf, 1)*tf) / max(field_length, all_query_terms_len)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rd.len; i += gridDim.x * blockDim.x) {
+      const uint64_t pi = rd.post_off + i;
+      const uint32_t d = p.doc[pi];
+      for (uint32_t x = 0; x < p.F; ++x) {
+        const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
+        if (tfu > 0) {
+          const uint32_t flu = p.fl[(uint64_t)x * p.P + pi];
+          const double df = (double)tfu;
+          row[(uint64_t)x * p.row_stride + d] = fmin(rd.idf / df, 1.0) * df / (double)(flu > rd._pad ? flu : rd._pad);
+        }
+      }
+    }
+    return;
+  }
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rd.len; i += gridDim.x * blockDim.x) {
     const uint64_t pi = rd.post_off + i;
     double s = 0.0;
@@ -249,6 +267,29 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
 
 // Merge one dense row's slice for this tile into the wave's LDS tile (same merge rules as
 // score_trip; a row value > 0 <=> the list holds that document).
+// zero_to_one rows: plane x of the row goes to accumulator plane x of the tile ([F][T] in LDS).
+__device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, const int lane, const uint32_t row,
+                                              const uint32_t tile_base) {
+  for (uint32_t x = 0; x < p.F; ++x) {
+    const double* r = p.rows + ((uint64_t)row * p.F + x) * p.row_stride + tile_base;
+    constexpr int CH = 4;
+    for (uint32_t c0 = 0; c0 < p.T; c0 += CH * 2 * WAVE) {
+      double2 v[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+        if (c0 + k * 2 * WAVE < p.T) v[k] = *reinterpret_cast<const double2*>(r + c0 + k * 2 * WAVE + 2 * lane);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        if (c0 + k * 2 * WAVE < p.T) {
+          const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
+          if (v[k].x > 0.0) __hip_atomic_fetch_add(&acc[x * p.T + i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (v[k].y > 0.0) __hip_atomic_fetch_add(&acc[x * p.T + i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+    }
+  }
+}
+
 template <bool TAGS>
 __device__ __forceinline__ void dense_apply(const KParams& p, double* acc, uint16_t* tag, const int lane,
                                             const uint32_t row, const uint32_t tile_base, const uint16_t mytag) {
@@ -421,7 +462,7 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
           const uint32_t den = flu > qtl ? flu : qtl;
           const double c = fmin(ec.w0 / df, 1.0) * df / (double)den;
           if (ok[u] && tfu > 0)
-            __hip_atomic_fetch_add(&acc[local[u] * F + x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(&acc[(uint32_t)x * p.T + local[u]], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
       }
     }
@@ -563,7 +604,7 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
         ec[g].w1 = en.boost;                                                                                    \
         ec_qterm[g] = en.qterm;                                                                                 \
         ec_tbl[g] = en.tbl_off;                                                                                 \
-        ec_row[g] = (MODE == MODE_BM25 && (en.shift & DENSE_FLAG)) ? en.node : 0xFFFFFFFFu;                     \
+        ec_row[g] = (en.shift & DENSE_FLAG) ? en.node : 0xFFFFFFFFu;                     \
       }                                                                                                         \
       if (ec_row[g] != 0xFFFFFFFFu) { /* dense row: nothing to fetch up front */                                \
       } else if (sliced) {                                                                                             \
@@ -585,9 +626,10 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
       // phase 2: consume the visit in plan order
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        if (MODE == MODE_BM25 && eg + g < ne && ec_row[g] != 0xFFFFFFFFu) {
+        if (eg + g < ne && ec_row[g] != 0xFFFFFFFFu) {
           dirty = true;
-          dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
+          if (MODE == MODE_BM25) dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
+          else dense_apply_z(p, acc, lane, ec_row[g], tile_base);
         } else if (rb[g] < re[g]) {
           dirty = true;
           ec[g].tag = tagbase + ec_qterm[g];
@@ -631,21 +673,32 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
           }
         }
       } else {
-        for (uint32_t c = 0; c < T; c += WAVE) {
+        // accumulators are planar ([field][T]); two documents per lane per 16-byte LDS access
+        for (uint32_t c = 0; c < T; c += 2 * WAVE) {
           // result.score = max(score_by_pool, result.score) over fields, from the dummy 0. (zero_to_one.rs:81,122)
-          double best = 0.0;
-          bool has = false;
+          double b0 = 0.0, b1 = 0.0;
+          bool h0 = false, h1 = false;
 #pragma unroll
           for (int x = 0; x < FA; ++x) {
             if ((uint32_t)x < F) {
-              const double v = acc[(c + lane) * F + x];
-              if (v > 0.0) { has = true; acc[(c + lane) * F + x] = 0.0; }
-              best = fmax(v, best);
+              double2* slot = reinterpret_cast<double2*>(&acc[(uint32_t)x * T + c + 2 * lane]);
+              const double2 v = *slot;
+              if (v.x > 0.0 || v.y > 0.0) *slot = make_double2(0.0, 0.0);
+              h0 |= v.x > 0.0; h1 |= v.y > 0.0;
+              b0 = fmax(v.x, b0); b1 = fmax(v.y, b1);
             }
           }
-          const uint32_t d = tile_base + c + lane;
-          if (FULL) full_emit(p, q, lane, has, best, d);
-          else topk_offer(tk, p.K, lane, has, best, d, gt);
+          const uint32_t d = tile_base + c + 2 * lane;
+          if (FULL) {
+            full_emit(p, q, lane, h0, b0, d);
+            full_emit(p, q, lane, h1, b1, d + 1);
+          } else {
+            const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
+            if (__any((h0 && b0 >= lo) || (h1 && b1 >= lo))) {
+              topk_offer(tk, p.K, lane, h0, b0, d, gt);
+              topk_offer(tk, p.K, lane, h1, b1, d + 1, gt);
+            }
+          }
         }
       }
       if (!FULL && tk.n == p.K && tk.thr_s > gt) {
@@ -1036,63 +1089,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (ne) memcpy(he, plan.entries.data(), ne * sizeof(ps_plan_entry));
   memcpy(h + off_q, plan.qbeg.data(), (B + 1) * 4);
   if (B) memcpy(h + off_l, plan.qterms_len.data(), B * 4);
-  // ---- hot dense lists (BM25 only; see k_dense_rows) -------------------------------------------
   uint32_t n_rows = 0;
   uint64_t layout_bytes = 0;
-  {
-    bool sane = !z && max_rows > 0 && std::isfinite(sc.bm25_k1) && sc.bm25_k1 >= 0.0 && sc.bm25_b >= 0.0 &&
-                sc.bm25_b <= 1.0 && s.n_docs > 0;
-    for (uint32_t x = 0; x < s.F && sane; ++x)
-      sane = std::isfinite(boosts[x]) && boosts[x] > 0.0 && std::isfinite(s.avg[x]) && s.avg[x] > 0.0;
-    const uint32_t min_uses = env_u32("PS_DENSE_MIN_USES", 4);
-    const double min_density = env_u32("PS_DENSE_MIN_DENSITY_PCT", 25) / 100.0;
-    if (sane && ne) {
-      struct Key { uint64_t post_off, idf, eb; };
-      struct Agg { uint32_t uses, len; };
-      auto kless = [](const Key& a, const Key& b) {
-        return a.post_off != b.post_off ? a.post_off < b.post_off : a.idf != b.idf ? a.idf < b.idf : a.eb < b.eb;
-      };
-      std::map<Key, Agg, decltype(kless)> agg(kless);
-      for (size_t i = 0; i < ne; ++i) {
-        const ps_plan_entry& e = plan.entries[i];
-        if ((double)e.len < min_density * (double)s.n_docs) continue;
-        Key k{e.post_off, 0, 0};
-        memcpy(&k.idf, &e.idf, 8);
-        memcpy(&k.eb, &e.boost, 8);
-        Agg& a = agg[k];
-        a.uses++;
-        a.len = e.len;
-      }
-      std::vector<std::pair<uint64_t, Key>> hot;  // (saved posting visits, key)
-      for (auto& kv : agg)
-        if (kv.second.uses >= min_uses) hot.emplace_back((uint64_t)kv.second.uses * kv.second.len, kv.first);
-      std::sort(hot.begin(), hot.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-      const uint64_t row_bytes = (uint64_t)s.n_tiles * s.T * 8;
-      const uint64_t mem_cap = (uint64_t)env_u32("PS_DENSE_MAX_MB", 4096) << 20;
-      while (hot.size() > max_rows || hot.size() * row_bytes > mem_cap) hot.pop_back();
-      if (!hot.empty()) {
-        RowDesc* rd = reinterpret_cast<RowDesc*>(h + off_r);
-        std::map<Key, uint32_t, decltype(kless)> row_of(kless);
-        for (auto& hk : hot) {
-          RowDesc d;
-          d.post_off = hk.second.post_off;
-          d.len = agg[hk.second].len;
-          d._pad = 0;
-          memcpy(&d.idf, &hk.second.idf, 8);
-          memcpy(&d.eb, &hk.second.eb, 8);
-          row_of[hk.second] = n_rows;
-          rd[n_rows++] = d;
-        }
-        for (size_t i = 0; i < ne; ++i) {
-          Key k{he[i].post_off, 0, 0};
-          memcpy(&k.idf, &he[i].idf, 8);
-          memcpy(&k.eb, &he[i].boost, 8);
-          auto it = row_of.find(k);
-          if (it != row_of.end()) { he[i].shift |= DENSE_FLAG; he[i].node = it->second; }
-        }
-      }
-    }
-  }
   uint32_t n_simple = 0, n_general = 0;
   if (z) {
     // per query: entry indices stably sorted by ScoreByTerm::score desc (zero_to_one.rs:98);
@@ -1128,6 +1126,72 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       }
     }
   }
+  // ---- hot dense lists (see k_dense_rows) -------------------------------------------------------
+  // BM25: key = (list, idf, expansion_boost).  zero_to_one (simple queries only): key = (list,
+  // ScoreByTerm::score, all_query_terms_len); a row then holds one plane per field.
+  {
+    bool sane = max_rows > 0 && s.n_docs > 0;
+    if (!z) {
+      sane = sane && std::isfinite(sc.bm25_k1) && sc.bm25_k1 >= 0.0 && sc.bm25_b >= 0.0 && sc.bm25_b <= 1.0;
+      for (uint32_t x = 0; x < s.F && sane; ++x)
+        sane = std::isfinite(boosts[x]) && boosts[x] > 0.0 && std::isfinite(s.avg[x]) && s.avg[x] > 0.0;
+    }
+    const uint32_t min_uses = env_u32("PS_DENSE_MIN_USES", 4);
+    const double min_density = env_u32("PS_DENSE_MIN_DENSITY_PCT", 25) / 100.0;
+    const uint32_t planes = z ? s.F : 1u;
+    if (sane && ne) {
+      struct Key { uint64_t post_off, w, k3; };
+      struct Agg { uint32_t uses, len; };
+      auto kless = [](const Key& a, const Key& b) {
+        return a.post_off != b.post_off ? a.post_off < b.post_off : a.w != b.w ? a.w < b.w : a.k3 < b.k3;
+      };
+      const uint32_t* qf = reinterpret_cast<const uint32_t*>(h + off_f);
+      auto key_of = [&](const ps_plan_entry& e, size_t q) {
+        Key k{e.post_off, 0, 0};
+        if (z) { memcpy(&k.w, &e.boost, 8); k.k3 = plan.qterms_len[q]; }
+        else { memcpy(&k.w, &e.idf, 8); memcpy(&k.k3, &e.boost, 8); }
+        return k;
+      };
+      std::map<Key, Agg, decltype(kless)> agg(kless);
+      for (size_t q = 0; q < B; ++q) {
+        if (z && !(qf[q] & 1u)) continue;
+        for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
+          if ((double)he[i].len < min_density * (double)s.n_docs) continue;
+          Agg& a = agg[key_of(he[i], q)];
+          a.uses++;
+          a.len = he[i].len;
+        }
+      }
+      std::vector<std::pair<uint64_t, Key>> hot;  // (saved posting visits, key)
+      for (auto& kv : agg)
+        if (kv.second.uses >= min_uses) hot.emplace_back((uint64_t)kv.second.uses * kv.second.len, kv.first);
+      std::sort(hot.begin(), hot.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+      const uint64_t row_bytes = (uint64_t)s.n_tiles * s.T * 8 * planes;
+      const uint64_t mem_cap = (uint64_t)env_u32("PS_DENSE_MAX_MB", 4096) << 20;
+      while (hot.size() > max_rows || hot.size() * row_bytes > mem_cap) hot.pop_back();
+      if (!hot.empty()) {
+        RowDesc* rd = reinterpret_cast<RowDesc*>(h + off_r);
+        std::map<Key, uint32_t, decltype(kless)> row_of(kless);
+        for (auto& hk : hot) {
+          RowDesc d;
+          d.post_off = hk.second.post_off;
+          d.len = agg[hk.second].len;
+          d._pad = z ? (uint32_t)hk.second.k3 : 0u;  // zero_to_one: all_query_terms_len
+          memcpy(&d.idf, &hk.second.w, 8);           // BM25: idf | zero_to_one: ScoreByTerm::score
+          if (z) d.eb = 0.0; else memcpy(&d.eb, &hk.second.k3, 8);
+          row_of[hk.second] = n_rows;
+          rd[n_rows++] = d;
+        }
+        for (size_t q = 0; q < B; ++q) {
+          if (z && !(qf[q] & 1u)) continue;
+          for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
+            auto it = row_of.find(key_of(he[i], q));
+            if (it != row_of.end()) { he[i].shift |= DENSE_FLAG; he[i].node = it->second; }
+          }
+        }
+      }
+    }
+  }
   // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | zorder | qflags)
   m.d_stage.ensure(total + 64);
   PS_HIP(hipMemcpyAsync(m.d_stage.p, h, n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z),
@@ -1144,18 +1208,20 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.qflags = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_f);
   {
     // bytes of the layout actually used (never claim the wider figure for a narrower stream)
-    const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.n_tiles * s.T * 8;
+    const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.n_tiles * s.T * 8 * (z ? s.F : 1u);
     uint64_t lb = 0;
     for (size_t i = 0; i < ne; ++i) lb += (he[i].shift & DENSE_FLAG) ? row_bytes : (uint64_t)he[i].len * pb;
     const RowDesc* rd = reinterpret_cast<const RowDesc*>(h + off_r);
-    for (uint32_t r = 0; r < n_rows; ++r) lb += (uint64_t)rd[r].len * (pb + 8) + row_bytes;
+    for (uint32_t r = 0; r < n_rows; ++r) lb += (uint64_t)rd[r].len * (pb + 8 * (z ? s.F : 1u)) + row_bytes;
     layout_bytes = lb;
   }
   kp.row_desc = reinterpret_cast<const RowDesc*>(m.d_stage.p + off_r);
   kp.n_rows = n_rows;
+  kp.row_planes = z ? s.F : 1u;
+  kp.row_mode = z ? 1u : 0u;
   kp.row_stride = (uint64_t)s.n_tiles * s.T;
   if (n_rows) {
-    m.d_rows.ensure((size_t)n_rows * kp.row_stride + 16);
+    m.d_rows.ensure((size_t)n_rows * kp.row_planes * kp.row_stride + 16);
     kp.rows = m.d_rows.p;
   }
   // control words, zeroed by one memset per batch: gthr[0..B) + the persistent waves' item counter
@@ -1231,18 +1297,22 @@ void launch_k_score(KParams& kp, bool tags, int n_cu, hipStream_t st) {
 #undef PS_LAUNCH
 }
 
+void launch_rows(const KParams& kp, hipStream_t st) {
+  if (!kp.n_rows) return;
+  PS_HIP(hipMemsetAsync(const_cast<double*>(kp.rows), 0, (size_t)kp.n_rows * kp.row_planes * kp.row_stride * 8, st));
+  hipLaunchKernelGGL(k_dense_rows, dim3(256, kp.n_rows), dim3(256), 0, st, kp, const_cast<double*>(kp.rows));
+}
+
 template <bool FULL>
 void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n_cu, hipStream_t st) {
   const uint32_t n_items = kp.B * kp.n_super;
   if (n_items == 0) return;
   if (sc.kind == PS_SCORER_BM25) {
     if (kp.lut_rows) hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
-    if (kp.n_rows) {
-      PS_HIP(hipMemsetAsync(const_cast<double*>(kp.rows), 0, (size_t)kp.n_rows * kp.row_stride * 8, st));
-      hipLaunchKernelGGL(k_dense_rows, dim3(256, kp.n_rows), dim3(256), 0, st, kp, const_cast<double*>(kp.rows));
-    }
+    launch_rows(kp, st);
     launch_k_score<MODE_BM25, FULL>(kp, plan.multi_expansion, n_cu, st);
   } else {
+    launch_rows(kp, st);
     if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(kp, false, n_cu, st);
     if (kp.n_general || !kp.n_simple) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget

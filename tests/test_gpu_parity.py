@@ -207,10 +207,11 @@ def test_dense_rows_path_forced(seed, monkeypatch):
     snap = p.idx.snapshot(device=0, tile_docs=256)
     boosts = [1.0] * F if seed % 2 else [2.0, 0.5][:F]
     queries = random_queries(seed, vocab, n=40)
-    for name, kw in (("bm25", {}), ("bm25", {"k1": 0.7, "b": 0.3})):
+    for name, kw in (("bm25", {}), ("bm25", {"k1": 0.7, "b": 0.3}), ("zero_to_one", {})):
         sc = product_scorer(name, **kw)
         full = snap.query_batch(queries, sc, None, boosts, top_k=0)
         top = snap.query_batch(queries, sc, None, boosts, top_k=5)
+        assert snap.last_stats()["dense_rows"] > 0
         for q, f, t in zip(queries, full, top):
             exp = o.query(q, oracle_scorer(name, **kw), boosts)
             assert_same([tuple(r) for r in f], exp, (seed, name, q, "dense-full"))
