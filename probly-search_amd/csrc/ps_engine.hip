@@ -32,6 +32,7 @@
 #include <string>
 
 #include "ps_engine.hpp"
+#include "ps_sort.hpp"
 
 namespace ps {
 
@@ -871,6 +872,14 @@ __global__ __launch_bounds__(WAVE) void k_merge(const KParams p) {
   if (lane == 0) p.out_counts[q] = tk.n;
 }
 
+// Full-result mode: the first (out_off[q+1] - out_off[q]) sorted results of run q -> {key, score}.
+__global__ __launch_bounds__(256) void k_pack_results(const uint32_t* doc, const double* score, const uint64_t* run_off,
+                                                      const uint64_t* out_off, const uint64_t* keys, ps_result* out) {
+  const uint32_t q = blockIdx.x;
+  const uint64_t src = run_off[q], dst = out_off[q], n = out_off[q + 1] - out_off[q];
+  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) out[dst + i] = ps_result{keys[doc[src + i]], score[src + i]};
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -937,6 +946,10 @@ struct EngineImpl {
   DevBuf<uint64_t> d_out_keys, d_full_off;
   DevBuf<unsigned long long> d_gthr;
   DevBuf<double> d_rows;  // dense per-document score rows of the batch's hot lists
+  DevBuf<uint32_t> d_sort_doc, d_seg;  // K4 scratch
+  DevBuf<uint64_t> d_sort_score, d_pack_off;
+  DevBuf<unsigned char> d_sort_tmp;
+  DevBuf<ps_result> d_pack;
   Stage stage[N_STAGE];
   int next_stage = 0;
   Stage result;  // download staging (engine stream only)
@@ -1020,6 +1033,8 @@ Engine::~Engine() {
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
   m.d_gthr.release(); m.d_rows.release();
+  m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
+  m.d_sort_tmp.release(); m.d_pack.release();
   for (auto& sg : m.stage) {
     if (sg.p) (void)hipHostFree(sg.p);
     if (sg.done) (void)hipEventDestroy(sg.done);
@@ -1542,24 +1557,36 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   PS_HIP(hipEventRecord(kt.b, st));
   kt.pending = true;
   m.last_kt = &kt;
+  // K4 (query.rs:97-105, "materialise + sort"): canonical order (score desc, doc id asc == key asc)
+  // of every query's run, on the device (ps_sort.hip)
+  if (total_cap >= 0xFFFFFFF0ull) throw std::length_error("full-result batch too large for one pass");
+  m.d_sort_doc.ensure(total_cap + 1);
+  m.d_sort_score.ensure(total_cap + 1);
+  m.d_seg.ensure(2 * (B + 1));
+  SortBuffers sb{m.d_full_doc.p, reinterpret_cast<uint64_t*>(m.d_full_score.p), m.d_sort_doc.p, m.d_sort_score.p,
+                 m.d_seg.p, m.d_seg.p + B + 1};
+  // few or huge runs: device-wide sort per run (needs the counts); many small runs: one segmented sort
+  const bool few_runs = B <= 8 || total_cap / B > 32768;
+  if (total_cap && B && !few_runs) {
+    size_t tb = 0;
+    PS_HIP(sort_results(sb, (unsigned)total_cap, (unsigned)B, m.d_full_off.p, m.d_full_cnt.p, nullptr, tb, st));
+    m.d_sort_tmp.ensure(tb + 256);
+    PS_HIP(sort_results(sb, (unsigned)total_cap, (unsigned)B, m.d_full_off.p, m.d_full_cnt.p, m.d_sort_tmp.p, tb, st));
+  }
   PS_HIP(hipMemcpyAsync(h_cnt, m.d_full_cnt.p, (B + 1) * 4, hipMemcpyDeviceToHost, st));
-  PS_HIP(hipStreamSynchronize(st));
+  sync_stream(st);
   std::vector<uint32_t> cnt(h_cnt, h_cnt + B);
   read_kernel_times(m, stats);
-  // download only the filled prefix of every query's run
-  std::vector<uint32_t> hdoc(total_cap + 1);
-  std::vector<double> hsc(total_cap + 1);
-  PS_HIP(hipEventRecord(m.ev[4], st));
-  for (size_t q = 0; q < B; ++q) {
-    if (!cnt[q]) continue;
-    PS_HIP(hipMemcpyAsync(hdoc.data() + cap[q], m.d_full_doc.p + cap[q], (size_t)cnt[q] * 4, hipMemcpyDeviceToHost, st));
-    PS_HIP(hipMemcpyAsync(hsc.data() + cap[q], m.d_full_score.p + cap[q], (size_t)cnt[q] * 8, hipMemcpyDeviceToHost, st));
+  if (few_runs) {
+    for (size_t q = 0; q < B; ++q) {
+      if (cnt[q] < 2) continue;
+      size_t tb = 0;
+      PS_HIP(sort_run(sb, cap[q], cnt[q], nullptr, tb, st));
+      m.d_sort_tmp.ensure(tb + 256);
+      PS_HIP(sort_run(sb, cap[q], cnt[q], m.d_sort_tmp.p, tb, st));
+    }
   }
-  PS_HIP(hipEventRecord(m.ev[5], st));
-  PS_HIP(hipStreamSynchronize(st));
-  float d2h = 0;
-  PS_HIP(hipEventElapsedTime(&d2h, m.ev[4], m.ev[5]));
-  stats.d2h_ms = d2h;
+  // pack the first `keep` results of every run as {key, score} records, one D2H copy
   size_t total = 0;
   for (size_t q = 0; q < B; ++q) {
     offsets[q] = total;
@@ -1567,16 +1594,20 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   }
   offsets[B] = total;
   out.resize(total);
-  std::vector<ps_result> tmp;
-  // Q4 (query.rs:97-105): materialise + sort.  Canonical order: score desc, doc id asc (== key asc).
-  auto cmp = [](const ps_result& x, const ps_result& y) { return x.score != y.score ? x.score > y.score : x.key < y.key; };
-  for (size_t q = 0; q < B; ++q) {
-    tmp.resize(cnt[q]);
-    for (uint32_t i = 0; i < cnt[q]; ++i) tmp[i] = ps_result{(uint64_t)hdoc[cap[q] + i], hsc[cap[q] + i]};
-    const size_t keep = offsets[q + 1] - offsets[q];
-    if (keep < tmp.size()) std::partial_sort(tmp.begin(), tmp.begin() + (long)keep, tmp.end(), cmp);
-    else std::sort(tmp.begin(), tmp.end(), cmp);
-    for (size_t i = 0; i < keep; ++i) out[offsets[q] + i] = ps_result{s.keys[(size_t)tmp[i].key], tmp[i].score};
+  if (total) {
+    m.d_pack_off.ensure(B + 1);
+    m.d_pack.ensure(total);
+    m.result.ensure(std::max<size_t>((B + 1) * 8, total * sizeof(ps_result)) + 64);
+    uint64_t* h_po = reinterpret_cast<uint64_t*>(m.result.p);
+    for (size_t q = 0; q <= B; ++q) h_po[q] = offsets[q];
+    PS_HIP(hipMemcpyAsync(m.d_pack_off.p, h_po, (B + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pack_results, dim3((uint32_t)B), dim3(256), 0, st, m.d_full_doc.p, m.d_full_score.p,
+                       m.d_full_off.p, m.d_pack_off.p, m.d_keys, m.d_pack.p);
+    PS_HIP(hipGetLastError());
+    sync_stream(st);  // h_po (pinned) is reused as the download target
+    PS_HIP(hipMemcpyAsync(m.result.p, m.d_pack.p, total * sizeof(ps_result), hipMemcpyDeviceToHost, st));
+    sync_stream(st);
+    memcpy(out.data(), m.result.p, total * sizeof(ps_result));
   }
   fill_stats(m, stats, s, plan, total);
   stats.total_ms = now_ms() - t0;
