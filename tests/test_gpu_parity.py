@@ -216,3 +216,37 @@ def test_dense_rows_path_forced(seed, monkeypatch):
             exp = o.query(q, oracle_scorer(name, **kw), boosts)
             assert_same([tuple(r) for r in f], exp, (seed, name, q, "dense-full"))
             assert_same([tuple(r) for r in t], exp[:5], (seed, name, q, "dense-top5"))
+
+
+def test_wide_prefix_expansion_many_entries():
+    """A 1-2 character prefix expanding to hundreds of indexed terms: plans far larger than the
+    register-resident group size, table slices disabled (too many entries for LDS), visited-tag
+    merge across every expansion of the term — BM25 and the general zero_to_one kernel limits."""
+    import random
+    rng = random.Random(5)
+    vocab = sorted({"ab" + "".join(rng.choice("abcdefgh") for _ in range(rng.randint(0, 4))) for _ in range(400)})
+    o, p = orc.Index(1), ProductIndex(1)
+    for k in range(600):
+        text = " ".join(rng.choice(vocab) for _ in range(rng.randint(2, 9)))
+        o.add_document(k, [text])
+        p.add_document(k, [text])
+    snap = p.idx.snapshot(device=0, tile_docs=256)
+    for q in ["a", "ab", "abc x", "abd abe", "ab ab"]:
+        exp = o.query(q, orc.bm25(), [1.0])
+        got = [tuple(r) for r in snap.query(q, psa.bm25.new(), None, [1.0])]
+        assert_same(got, exp, ("wide", q))
+        top = [tuple(r) for r in snap.query(q, psa.bm25.new(), None, [1.0], top_k=10)]
+        assert_same(top, exp[:10], ("wide-top", q))
+    ents, _ = snap.plan("a", psa.bm25.new())
+    assert len(ents) > 200
+    # zero_to_one: a query term with > 64 expansions needs the general kernel, whose limit is 64
+    # lists per query: a documented PS_EUNSUPPORTED, never a wrong answer or a CPU fallback
+    for q in ("a", "ab ab"):
+        with pytest.raises(psa.PsError) as ei:
+            snap.query(q, psa.zero_to_one.new(), None, [1.0])
+        assert ei.value.status == 4  # PS_EUNSUPPORTED
+    # ... while a narrower prefix (<= 64 expansions) goes through it bit-exactly
+    narrow = next(pfx for pfx in ("abcd", "abce", "abda", "abab", "abhh", "abgg") if 1 < len(o.expand_term(pfx)) <= 64)
+    exp = o.query(narrow + " " + narrow, orc.zero_to_one(), [1.0])
+    got = [tuple(r) for r in snap.query(narrow + " " + narrow, psa.zero_to_one.new(), None, [1.0])]
+    assert_same(got, exp, ("wide-z21", narrow))
