@@ -119,6 +119,10 @@ size_t ps_index_expand_term(const ps_index* idx, const char* term, size_t len, c
  * tile_docs = documents per LDS accumulator tile (power of two, 256..4096; 0 = default 1024). */
 ps_status ps_index_snapshot(const ps_index* idx, int device, uint32_t tile_docs, ps_snapshot** out);
 void ps_snapshot_free(ps_snapshot* snap);
+/* On-disk form of a snapshot (the reference has no persistence): a versioned dump of
+ * the flattened arrays.  ps_snapshot_load needs no ps_index; device = -1 loads host-only. */
+ps_status ps_snapshot_save(const ps_snapshot* snap, const char* path);
+ps_status ps_snapshot_load(const char* path, int device, ps_snapshot** out);
 
 typedef struct ps_snapshot_info {
   uint32_t fields_num;

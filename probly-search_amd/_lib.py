@@ -86,6 +86,8 @@ SYMBOLS = {
                                           C.POINTER(C.c_size_t)]),
     "ps_index_snapshot": (C.c_int, [_P, C.c_int, C.c_uint32, C.POINTER(_P)]),
     "ps_snapshot_free": (None, [_P]),
+    "ps_snapshot_save": (C.c_int, [_P, C.c_char_p]),
+    "ps_snapshot_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
     "ps_snapshot_get_info": (C.c_int, [_P, C.POINTER(SnapshotInfo)]),
     "ps_snapshot_query": (C.c_int, [_P, C.POINTER(ScorerDesc), C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
                                     C.c_size_t, _P, _P, C.c_size_t, C.POINTER(C.POINTER(Result)),

@@ -272,6 +272,26 @@ ps_status ps_index_snapshot(const ps_index* idx, int device, uint32_t tile_docs,
 
 void ps_snapshot_free(ps_snapshot* snap) { delete snap; }
 
+ps_status ps_snapshot_save(const ps_snapshot* snap, const char* path) {
+  return guard([&]() -> ps_status {
+    if (!snap || !path) return fail(PS_EINVAL, "null argument");
+    snap->snap->save(path);
+    return PS_OK;
+  });
+}
+
+ps_status ps_snapshot_load(const char* path, int device, ps_snapshot** out) {
+  return guard([&]() -> ps_status {
+    if (!path || !out) return fail(PS_EINVAL, "null argument");
+    std::unique_ptr<ps_snapshot> s(new ps_snapshot());
+    s->snap.reset(new ps::Snapshot(std::string(path)));
+    s->device = device;
+    if (device >= 0) s->engine.reset(new ps::Engine(*s->snap, device));
+    *out = s.release();
+    return PS_OK;
+  });
+}
+
 ps_status ps_snapshot_get_info(const ps_snapshot* snap, ps_snapshot_info* out) {
   if (!snap || !out) return fail(PS_EINVAL, "null argument");
   const ps::Snapshot& s = *snap->snap;

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 
@@ -232,6 +233,62 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
     std::vector<uint32_t>().swap(tfv[x]);
     std::vector<uint32_t>().swap(flv[x]);
   }
+}
+
+// ---- on-disk snapshot ---------------------------------------------------------------------------
+namespace {
+constexpr char MAGIC[8] = {'P', 'S', 'N', 'A', 'P', '0', '0', '1'};
+
+struct File {
+  FILE* f;
+  File(const std::string& path, const char* mode) : f(fopen(path.c_str(), mode)) {
+    if (!f) throw std::invalid_argument("cannot open snapshot file: " + path);
+  }
+  ~File() { if (f) fclose(f); }
+  void put(const void* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) throw std::runtime_error("snapshot write failed"); }
+  void get(void* p, size_t n) { if (n && fread(p, 1, n, f) != n) throw std::invalid_argument("snapshot file truncated"); }
+  template <typename V> void put_vec(const std::vector<V>& v) {
+    uint64_t n = v.size();
+    put(&n, 8);
+    put(v.data(), n * sizeof(V));
+  }
+  template <typename V> void get_vec(std::vector<V>& v) {
+    uint64_t n = 0;
+    get(&n, 8);
+    if (n > (1ull << 40) / sizeof(V)) throw std::invalid_argument("snapshot file corrupt");
+    v.resize((size_t)n);
+    get(v.data(), n * sizeof(V));
+  }
+};
+}  // namespace
+
+void Snapshot::save(const std::string& path) const {
+  File f(path, "wb");
+  f.put(MAGIC, 8);
+  const uint64_t hdr[10] = {F, T, n_tiles, n_docs, P, n_postings, n_pointers, n_live_terms, max_layers, lut_rows};
+  f.put(hdr, sizeof(hdr));
+  f.put_vec(keys); f.put_vec(avg); f.put_vec(terms); f.put_vec(layers); f.put_vec(fnodes);
+  f.put_vec(fchar); f.put_vec(fchild); f.put_vec(doc); f.put_vec(tf); f.put_vec(fl); f.put_vec(table);
+  f.put_vec(max_fl); f.put_vec(lut_cap); f.put_vec(lut_base);
+}
+
+Snapshot::Snapshot(const std::string& path) {
+  File f(path, "rb");
+  char magic[8];
+  f.get(magic, 8);
+  if (memcmp(magic, MAGIC, 8) != 0) throw std::invalid_argument("not a probly-search_amd snapshot (bad magic/version)");
+  uint64_t hdr[10];
+  f.get(hdr, sizeof(hdr));
+  F = (uint32_t)hdr[0]; T = (uint32_t)hdr[1]; n_tiles = (uint32_t)hdr[2]; n_docs = hdr[3]; P = hdr[4];
+  n_postings = hdr[5]; n_pointers = hdr[6]; n_live_terms = hdr[7]; max_layers = (uint32_t)hdr[8];
+  lut_rows = (uint32_t)hdr[9];
+  f.get_vec(keys); f.get_vec(avg); f.get_vec(terms); f.get_vec(layers); f.get_vec(fnodes);
+  f.get_vec(fchar); f.get_vec(fchild); f.get_vec(doc); f.get_vec(tf); f.get_vec(fl); f.get_vec(table);
+  f.get_vec(max_fl); f.get_vec(lut_cap); f.get_vec(lut_base);
+  if (keys.size() != n_docs || avg.size() != F || doc.size() != P || tf.size() != (size_t)P * F ||
+      fl.size() != (size_t)P * F || fnodes.empty() || T < 256 || (T & (T - 1)))
+    throw std::invalid_argument("snapshot file inconsistent");
+  src_epoch = ~0ull;
 }
 
 int64_t Snapshot::find_fnode(std::string_view term) const {

@@ -16,6 +16,7 @@
 //     `expand_term(prefix)` is a contiguous range of term ordinals.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <string_view>
 #include <vector>
 
@@ -56,6 +57,10 @@ struct Plan {
 class Snapshot {
  public:
   Snapshot(const Index& idx, uint32_t tile_docs);
+  // On-disk form of the flattened snapshot (the reference has no persistence at
+  // all): a versioned little-endian dump of the arrays below, loadable without the source Index.
+  explicit Snapshot(const std::string& path);
+  void save(const std::string& path) const;
 
   // host planner: tokenise -> expand_term -> before_each (src/query.rs:29-60, bm25.rs:35-58)
   void plan_query(const ps_scorer_desc& sc, std::string_view q, ps_tokenizer_fn tok, void* user, Plan& plan) const;

@@ -10,6 +10,7 @@ Keys are u64 at the ABI (the reference's tests use usize).  Where the reference 
 (fields_boost shorter than fields_num, src/score/default/bm25.rs:85) an IndexError is raised.
 """
 import ctypes as C
+import os
 
 from . import _lib
 from ._lib import PsError
@@ -123,6 +124,18 @@ class Snapshot:
                 self._h = None
         except Exception:
             pass
+
+    def save(self, path):
+        """Write the flattened snapshot to disk (versioned binary dump)."""
+        _lib.check(self._L.ps_snapshot_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path, device=0):
+        """Load a snapshot written by save(); no Index needed (device=-1: host-only)."""
+        L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(L.ps_snapshot_load(os.fsencode(path), device, C.byref(h)))
+        return cls(h, None)
 
     def info(self):
         i = _lib.SnapshotInfo()

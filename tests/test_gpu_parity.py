@@ -250,3 +250,17 @@ def test_wide_prefix_expansion_many_entries():
     exp = o.query(narrow + " " + narrow, orc.zero_to_one(), [1.0])
     got = [tuple(r) for r in snap.query(narrow + " " + narrow, psa.zero_to_one.new(), None, [1.0])]
     assert_same(got, exp, ("wide-z21", narrow))
+
+
+def test_snapshot_loaded_from_disk_scores_identically(tmp_path):
+    cfg = dict(synth.CONFIGS["C2"], n_docs=20_000, vocab=1_500)
+    corpus = synth.Corpus(**cfg)
+    p = synth.fill(psa.Index(2), corpus)
+    snap = p.snapshot(device=0)
+    path = str(tmp_path / "c2.snap")
+    snap.save(path)
+    back = psa.Snapshot.load(path, device=0)
+    queries = corpus.queries(40, 3)
+    for sc in (psa.bm25.new(), psa.zero_to_one.new()):
+        assert snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=10) == back.query_batch(queries, sc, None, [1.0, 1.0], top_k=10)
+        assert snap.query(queries[0], sc, None, [1.0, 1.0]) == back.query(queries[0], sc, None, [1.0, 1.0])

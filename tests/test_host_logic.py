@@ -103,3 +103,27 @@ def test_plan_matches_before_each_values():
     assert ents[0]["boost"] == math.log(1.0 + 1.0 / (1.0 + 5.0 - 1.0))
     ents, qtl = snap.plan("a  zzz c", psa.bm25.new())
     assert qtl == 4 and [e["qterm_index"] for e in ents] == [0, 3]
+
+
+def test_snapshot_save_load_roundtrip(tmp_path):
+    """On-disk snapshot: the loaded snapshot plans and flattens identically."""
+    import numpy as np
+    F, steps, vocab = build_script(11, n_docs=120, fields=2)
+    o, p = orc.Index(F), ProductIndex(F)
+    replay(steps, F, o, p)
+    snap = p.idx.snapshot(device=-1, tile_docs=256)
+    path = str(tmp_path / "snap.bin")
+    snap.save(path)
+    back = psa.Snapshot.load(path, device=-1)
+    assert back.info() == snap.info()
+    a, b = snap.host_csr(), back.host_csr()
+    for k in ("doc", "tf", "fl", "table", "keys", "avg"):
+        assert np.array_equal(a[k], b[k]), k
+    for q in random_queries(2, vocab, n=10):
+        assert snap.plan(q, psa.bm25.new()) == back.plan(q, psa.bm25.new())
+        exp = o.query(q, orc.zero_to_one(), [1.0, 1.0])
+        assert [k for k, _ in emulate(back, psa.zero_to_one.new(), q, [1.0, 1.0])] == [k for k, _ in exp]
+    with open(path, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(psa.PsError):
+        psa.Snapshot.load(path, device=-1)
