@@ -46,7 +46,7 @@ namespace ps {
 constexpr int MAX_F = 8;
 constexpr int WAVE = 64;
 #ifndef PS_UNROLL
-#define PS_UNROLL 4
+#define PS_UNROLL 2
 #endif
 #ifndef PS_WG_WAVES
 #define PS_WG_WAVES 4
@@ -517,8 +517,8 @@ __device__ __forceinline__ void score_stream(const KParams& p, const double* lut
   }
 }
 
-template <int MODE, int F_, bool TAGS, bool FULL>
-__global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
+template <int MODE, int F_, bool TAGS, bool FULL, int WGW>
+__global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int FA = F_ ? F_ : MAX_F;
   constexpr int G = F_ ? PS_G : 1;    // plan entries whose first trips are in flight together
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
   uint32_t* slice = reinterpret_cast<uint32_t*>(wbase + tile_bytes);  // [entry][2][S]: rb, re per tile of the run
   if (MODE == MODE_BM25) {
     double* l = reinterpret_cast<double*>(smem);
-    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * WG_WAVES) l[i] = p.lut[i];
+    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * WGW) l[i] = p.lut[i];
     __syncthreads();  // the only workgroup-level synchronisation: waves are independent from here on
   }
   // Persistent waves: the grid only fills the chip; every wave keeps pulling (query, run) items
@@ -629,7 +629,8 @@ __global__ __launch_bounds__(WAVE * WG_WAVES) void k_score(const KParams p) {
       for (int g = 0; g < G; ++g) {
         if (eg + g < ne && ec_row[g] != 0xFFFFFFFFu) {
           dirty = true;
-          if (MODE == MODE_BM25) dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
+          if (PS_ABLATE_BUILD && (p.ablate & 8u)) {
+          } else if (MODE == MODE_BM25) dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
           else dense_apply_z(p, acc, lane, ec_row[g], tile_base);
         } else if (rb[g] < re[g]) {
           dirty = true;
@@ -1286,19 +1287,29 @@ void allow_lds(const void* fn, size_t lds) {
 template <int MODE, bool FULL>
 void launch_k_score(KParams& kp, bool tags, int n_cu, hipStream_t st) {
   const uint32_t n_items = kp.B * kp.n_super;
-  uint32_t n_wg = (n_items + WG_WAVES - 1) / WG_WAVES;
   const uint32_t aw = MODE == MODE_Z21S ? kp.F : 1u;
-  const size_t lds = (MODE == MODE_BM25 ? (size_t)kp.lut_stride * LUT_TF * 8 : 0) +
-                     WG_WAVES * ((size_t)kp.T * aw * 8 + (tags ? (size_t)kp.T * 2 : 0) + kp.slice_bytes);
-#define PS_LAUNCH(FV, TG)                                                                              \
+  const size_t lut_b = MODE == MODE_BM25 ? (size_t)kp.lut_stride * LUT_TF * 8 : 0;
+  const size_t wave_b = (size_t)kp.T * aw * 8 + (tags ? (size_t)kp.T * 2 : 0) + kp.slice_bytes;
+  // Workgroups of 8 waves share one LUT copy: two of them (16 waves) fit a CU's 160 KiB when a
+  // wave's tile is small enough; otherwise 4-wave workgroups pack the LDS better.
+  const bool wide = !FULL && lut_b + 8 * wave_b <= 80 * 1024 && env_u32("PS_WG8", 1);
+  const uint32_t wgw = wide ? 8u : (uint32_t)WG_WAVES;
+  uint32_t n_wg = (n_items + wgw - 1) / wgw;
+  const size_t lds = lut_b + wgw * wave_b;
+#define PS_LAUNCH_W(FV, TG, W)                                                                         \
   do {                                                                                                 \
-    const void* fn = reinterpret_cast<const void*>(&k_score<MODE, FV, TG, FULL>);                      \
+    const void* fn = reinterpret_cast<const void*>(&k_score<MODE, FV, TG, FULL, W>);                   \
     allow_lds(fn, lds);                                                                                \
     int per_cu = 0;                                                                                    \
-    PS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVE * WG_WAVES, lds));           \
+    PS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVE * W, lds));                  \
     const uint32_t resident = (uint32_t)std::max(1, per_cu) * (uint32_t)n_cu;                          \
     if (n_wg > resident) n_wg = resident;                                                              \
-    hipLaunchKernelGGL((k_score<MODE, FV, TG, FULL>), dim3(n_wg), dim3(WAVE * WG_WAVES), lds, st, kp); \
+    hipLaunchKernelGGL((k_score<MODE, FV, TG, FULL, W>), dim3(n_wg), dim3(WAVE * W), lds, st, kp);     \
+  } while (0)
+#define PS_LAUNCH(FV, TG)                                                                              \
+  do {                                                                                                 \
+    if (!FULL && wide) PS_LAUNCH_W(FV, TG, (FULL ? WG_WAVES : 8));                                     \
+    else PS_LAUNCH_W(FV, TG, WG_WAVES);                                                                \
   } while (0)
   if (MODE == MODE_BM25 && tags) {
     if (kp.F == 1) PS_LAUNCH(1, true);
@@ -1310,6 +1321,7 @@ void launch_k_score(KParams& kp, bool tags, int n_cu, hipStream_t st) {
     else PS_LAUNCH(0, false);
   }
 #undef PS_LAUNCH
+#undef PS_LAUNCH_W
 }
 
 void launch_rows(const KParams& kp, hipStream_t st) {
