@@ -74,7 +74,7 @@ def main():
     t_index = time.time() - t0
     t0 = time.time()
     # zero_to_one keeps F accumulator planes per tile in LDS: a smaller tile keeps occupancy up
-    tile_docs = args.tile_docs or (256 if cfg["scorer"] == "zero_to_one" else 0)
+    tile_docs = args.tile_docs or (512 if cfg["scorer"] == "zero_to_one" else 0)
     snap = index.snapshot(device=dev, tile_docs=tile_docs)
     t_snap = time.time() - t0
     info = snap.info()

@@ -82,6 +82,7 @@ struct KParams {
   const ps_plan_entry* plan;
   const uint32_t* qbeg;
   const uint32_t* qterms_len;  // zero_to_one
+  const uint32_t* gen_queries; // zero_to_one: the n_general queries k_z21 has to run
   const uint32_t* qflags;      // zero_to_one: bit 0 = "simple" query (k_score<MODE_Z21S> owns it)
   uint32_t slice_bytes;        // per-wave LDS for the table slices (0 = look ranges up in global memory)
   const uint32_t* zorder;      // zero_to_one: per query, entry indices sorted by (score desc, plan order)
@@ -244,12 +245,13 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rd.len; i += gridDim.x * blockDim.x) {
       const uint64_t pi = rd.post_off + i;
       const uint32_t d = p.doc[pi];
+      const uint32_t qtl = rd._pad & 0xFFFFu, need = rd._pad >> 16;
       for (uint32_t x = 0; x < p.F; ++x) {
         const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
-        if (tfu > 0) {
+        if (tfu >= need) {
           const uint32_t flu = p.fl[(uint64_t)x * p.P + pi];
           const double df = (double)tfu;
-          row[(uint64_t)x * p.row_stride + d] = fmin(rd.idf / df, 1.0) * df / (double)(flu > rd._pad ? flu : rd._pad);
+          row[(uint64_t)x * p.row_stride + d] = fmin(rd.idf / df, 1.0) * df / (double)(flu > qtl ? flu : qtl);
         }
       }
     }
@@ -462,7 +464,7 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
           const double df = (double)tfu;
           const uint32_t den = flu > qtl ? flu : qtl;
           const double c = fmin(ec.w0 / df, 1.0) * df / (double)den;
-          if (ok[u] && tfu > 0)
+          if (ok[u] && tfu >= ec.tag)  // ec.tag = occurrence rank of the node (>= 1): the pool rule
             __hip_atomic_fetch_add(&acc[(uint32_t)x * p.T + local[u]], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
       }
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         ec[g].shift = en.shift & 0xFFu;                                                                         \
         ec[g].w0 = MODE == MODE_BM25 ? en.idf : en.boost;                                                       \
         ec[g].w1 = en.boost;                                                                                    \
-        ec_qterm[g] = en.qterm;                                                                                 \
+        ec_qterm[g] = MODE == MODE_Z21S ? en.qterm_index : en.qterm;                                            \
         ec_tbl[g] = en.tbl_off;                                                                                 \
         ec_row[g] = (en.shift & DENSE_FLAG) ? en.node : 0xFFFFFFFFu;                     \
       }                                                                                                         \
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
           else dense_apply_z(p, acc, lane, ec_row[g], tile_base);
         } else if (rb[g] < re[g]) {
           dirty = true;
-          ec[g].tag = tagbase + ec_qterm[g];
+          ec[g].tag = MODE == MODE_Z21S ? ec_qterm[g] : tagbase + ec_qterm[g];
           score_trip<MODE, F_, TAGS, FU>(p, lut, acc, tag, lane, tile_base, rb[g], re[g], dv[g], tfv[g], flv[g], ec[g], qtl);
           if (rb[g] + FU * WAVE < re[g])
             score_stream<MODE, F_, TAGS>(p, lut, acc, tag, lane, tile_base, rb[g] + FU * WAVE, re[g], ec[g], qtl);
@@ -749,11 +751,11 @@ __global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
   uint32_t* rec = reinterpret_cast<uint32_t*>(smem);  // [ZT][ZN][F] term frequencies
   uint32_t* fls = rec + (size_t)ZT * stride;           // [ZT][F]     field lengths
   const int lane = threadIdx.x;
-  const uint32_t item = blockIdx.x;
-  const uint32_t q = item % p.B;
-  const uint32_t sup = item / p.B;
+  // grid = n_general x n_super: only the queries the simple path could not take
+  const uint32_t q = p.gen_queries[blockIdx.x % p.n_general];
+  const uint32_t sup = blockIdx.x / p.n_general;
+  const uint32_t item = sup * p.B + q;  // candidate slot, as k_merge expects it
   const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
-  if (p.qflags[q] & 1u) return;  // simple query: scored by k_score<MODE_Z21S>
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
@@ -1094,7 +1096,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const size_t off_l = off_q + (B + 1) * 4;
   const size_t off_z = off_l + B * 4;
   const size_t off_f = off_z + ne * 4;
-  const size_t off_r = (off_f + B * 4 + 15) & ~(size_t)15;
+  const size_t off_g = off_f + B * 4;
+  const size_t off_r = (off_g + B * 4 + 15) & ~(size_t)15;
   const size_t max_rows = env_u32("PS_DENSE_MAX_ROWS", 64);
   const size_t total = off_r + max_rows * sizeof(RowDesc);
   Stage& sg = m.stage[m.next_stage];
@@ -1116,17 +1119,21 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     // the contributions in that sorted order directly; its entries are uploaded pre-sorted.
     uint32_t* zo = reinterpret_cast<uint32_t*>(h + off_z);
     uint32_t* qf = reinterpret_cast<uint32_t*>(h + off_f);
+    uint32_t* gq = reinterpret_cast<uint32_t*>(h + off_g);  // queries the general kernel has to run
     std::vector<ps_plan_entry> tmp;
     for (size_t q = 0; q < B; ++q) {
       const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
       for (uint32_t i = b; i < e; ++i) zo[i] = i;
       std::stable_sort(zo + b, zo + e,
                        [&](uint32_t a, uint32_t c) { return plan.entries[c].boost < plan.entries[a].boost; });
+      // simple: one entry per query term and a single version layer.  The same trie node may
+      // appear several times ("abc abc"): the k-th record of a node in the sorted order is consumed
+      // iff the node's pool still holds something, i.e. iff term_frequency >= k (zero_to_one.rs:104-113)
       bool simple = true;
       for (uint32_t i = b; i < e && simple; ++i) {
         if (plan.entries[i].shift >> 8) simple = false;
         for (uint32_t j = b; j < i && simple; ++j)
-          if (plan.entries[j].node == plan.entries[i].node || plan.entries[j].qterm == plan.entries[i].qterm) simple = false;
+          if (plan.entries[j].qterm == plan.entries[i].qterm) simple = false;
       }
       // the simple path keeps F f64 accumulators per document of the tile in LDS
       if ((size_t)WG_WAVES * ((size_t)s.T * s.F * 8 + 4096) > 160 * 1024) simple = false;
@@ -1135,9 +1142,15 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       if (simple) {
         ++n_simple;
         tmp.assign(plan.entries.begin() + b, plan.entries.begin() + e);
-        for (uint32_t i = b; i < e; ++i) he[i] = tmp[zo[i] - b];
+        for (uint32_t i = b; i < e; ++i) {
+          he[i] = tmp[zo[i] - b];
+          uint32_t need = 1;  // occurrence rank of the node among the sorted records
+          for (uint32_t j = b; j < i; ++j)
+            if (he[j].node == he[i].node) ++need;
+          he[i].qterm_index = need;
+        }
       } else {
-        if (e != b) ++n_general;
+        gq[n_general++] = (uint32_t)q;  // empty queries too: somebody has to write their (empty) candidate slots
         if (e - b > 64) throw std::length_error("zero_to_one with repeated terms supports at most 64 expanded lists per query on the GPU");
       }
     }
@@ -1164,7 +1177,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       const uint32_t* qf = reinterpret_cast<const uint32_t*>(h + off_f);
       auto key_of = [&](const ps_plan_entry& e, size_t q) {
         Key k{e.post_off, 0, 0};
-        if (z) { memcpy(&k.w, &e.boost, 8); k.k3 = plan.qterms_len[q]; }
+        if (z) { memcpy(&k.w, &e.boost, 8); k.k3 = (uint64_t)plan.qterms_len[q] | ((uint64_t)e.qterm_index << 32); }
         else { memcpy(&k.w, &e.idf, 8); memcpy(&k.k3, &e.boost, 8); }
         return k;
       };
@@ -1192,7 +1205,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
           RowDesc d;
           d.post_off = hk.second.post_off;
           d.len = agg[hk.second].len;
-          d._pad = z ? (uint32_t)hk.second.k3 : 0u;  // zero_to_one: all_query_terms_len
+          // zero_to_one: all_query_terms_len (low 16 bits) | required term frequency (high 16 bits)
+          d._pad = z ? ((uint32_t)(hk.second.k3 & 0xFFFFu) | ((uint32_t)(hk.second.k3 >> 32) << 16)) : 0u;
           memcpy(&d.idf, &hk.second.w, 8);           // BM25: idf | zero_to_one: ScoreByTerm::score
           if (z) d.eb = 0.0; else memcpy(&d.eb, &hk.second.k3, 8);
           row_of[hk.second] = n_rows;
@@ -1222,6 +1236,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.qterms_len = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_l);
   kp.zorder = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_z);
   kp.qflags = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_f);
+  kp.gen_queries = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_g);
   {
     // bytes of the layout actually used (never claim the wider figure for a narrower stream)
     const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.n_tiles * s.T * 8 * (z ? s.F : 1u);
@@ -1341,7 +1356,7 @@ void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n
   } else {
     launch_rows(kp, st);
     if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(kp, false, n_cu, st);
-    if (kp.n_general || !kp.n_simple) {
+    if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
       kp.z_nodes = std::max<uint32_t>(1, plan.max_nodes);
       const uint32_t per_doc = (kp.z_nodes * kp.F + kp.F) * 4;
@@ -1350,7 +1365,7 @@ void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n
       while (zt > (uint32_t)WAVE && (size_t)zt * per_doc > budget) zt >>= 1;
       if ((size_t)zt * per_doc > 65536) throw std::length_error("zero_to_one: fields x expanded terms exceed the LDS tile");
       kp.z_tile = zt;
-      hipLaunchKernelGGL((k_z21<FULL>), dim3(n_items), dim3(WAVE), (size_t)zt * per_doc, st, kp);
+      hipLaunchKernelGGL((k_z21<FULL>), dim3(kp.n_general * kp.n_super), dim3(WAVE), (size_t)zt * per_doc, st, kp);
     }
   }
   PS_HIP(hipGetLastError());
