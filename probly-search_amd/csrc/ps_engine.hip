@@ -102,6 +102,7 @@ struct KParams {
   uint32_t row_mode;    // MODE_BM25 | MODE_Z21S: what k_dense_rows evaluates
   uint32_t row_planes;  // 1 (BM25 score) | F (zero_to_one: one contribution plane per field)
   uint64_t layout_bytes;         // host-side bookkeeping: bytes of the layout actually streamed
+  uint32_t z_masked;             // host-side: some simple query needs the consumed-query-term masks
   uint32_t n_simple, n_general;  // host-side bookkeeping (zero_to_one query classes in this batch)
   uint32_t ablate;  // PS_ABLATE debug bit mask (profiling only): 1 = no top-k offer, 2 = no scoring
   uint32_t* work_counter;    // next (query, run) item for the persistent waves of k_score
@@ -464,7 +465,19 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
           const double df = (double)tfu;
           const uint32_t den = flu > qtl ? flu : qtl;
           const double c = fmin(ec.w0 / df, 1.0) * df / (double)den;
-          if (ok[u] && tfu >= ec.tag)  // ec.tag = occurrence rank of the node (>= 1): the pool rule
+          // ec.tag = occurrence rank of the node (low 16 bits, >= 1: the pool rule) | query-term ordinal
+          bool take = ok[u] && tfu >= (ec.tag & 0xFFFFu);
+          if (TAGS && (ec.tag >> 31)) {  // bit 31: this query has query terms with several expansions
+            // consumed_index (zero_to_one.rs:101-103): the first record of a query term (in sorted
+            // order, which is the order entries are processed in) that hits this (doc, field)
+            // consumes the term; its later expansions are skipped
+            uint32_t* zm = reinterpret_cast<uint32_t*>(tag) + (uint32_t)x * p.T + local[u];
+            const uint32_t bit = 1u << ((ec.tag >> 16) & 31u);
+            const uint32_t mk = take ? *zm : 0u;
+            take = take && !(mk & bit);
+            if (take) *zm = mk | bit;
+          }
+          if (take)
             __hip_atomic_fetch_add(&acc[(uint32_t)x * p.T + local[u]], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
       }
@@ -535,7 +548,8 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
   // LDS: [LUT, shared by the workgroup][wave 0: tile, tags, table slices][wave 1: ...]...
   const double* lut = reinterpret_cast<const double*>(smem);
   const uint32_t lut_bytes = MODE == MODE_BM25 ? p.lut_stride * LUT_TF * 8 : 0u;
-  const uint32_t tile_bytes = T * AW * 8 + (TAGS ? T * 2 : 0);
+  // TAGS: BM25 = u16 visited tag per document; Z21S = u32 consumed-query-term mask per (field, document)
+  const uint32_t tile_bytes = T * AW * 8 + (TAGS ? (MODE == MODE_Z21S ? T * AW * 4 : T * 2) : 0);
   const uint32_t wave_bytes = tile_bytes + p.slice_bytes;
   unsigned char* wbase = smem + lut_bytes + (size_t)wave * wave_bytes;
   double* acc = reinterpret_cast<double*>(wbase);
@@ -551,8 +565,12 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
   // that are resident together work on the same document range (posting slices stay in L2), and
   // a heavy head-term item never leaves LDS-holding sibling waves idle.
   for (uint32_t i = lane; i < T * AW; i += WAVE) acc[i] = 0.0;
-  if (TAGS)
-    for (uint32_t i = lane; i < T; i += WAVE) tag[i] = 0xFFFFu;
+  if (TAGS) {
+    if (MODE == MODE_Z21S)
+      for (uint32_t i = lane; i < T * AW; i += WAVE) reinterpret_cast<uint32_t*>(tag)[i] = 0u;
+    else
+      for (uint32_t i = lane; i < T; i += WAVE) tag[i] = 0xFFFFu;
+  }
   uint32_t tagbase = 0;
   const uint32_t n_items = p.B * p.n_super;
   for (;;) {
@@ -687,7 +705,10 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
             if ((uint32_t)x < F) {
               double2* slot = reinterpret_cast<double2*>(&acc[(uint32_t)x * T + c + 2 * lane]);
               const double2 v = *slot;
-              if (v.x > 0.0 || v.y > 0.0) *slot = make_double2(0.0, 0.0);
+              if (v.x > 0.0 || v.y > 0.0) {
+                *slot = make_double2(0.0, 0.0);
+                if (TAGS) *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(tag) + (uint32_t)x * T + c + 2 * lane) = make_uint2(0u, 0u);
+              }
               h0 |= v.x > 0.0; h1 |= v.y > 0.0;
               b0 = fmax(v.x, b0); b1 = fmax(v.y, b1);
             }
@@ -709,7 +730,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         // publish this run's K-th best: the final K-th best of the query can only be higher
         if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
       }
-      if (TAGS) {
+      if (TAGS && MODE == MODE_BM25) {
         tagbase += p.max_qterms;
         if (tagbase + p.max_qterms >= 0xFFFFu) {
           for (uint32_t i = lane; i < T; i += WAVE) tag[i] = 0xFFFFu;
@@ -1110,7 +1131,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (B) memcpy(h + off_l, plan.qterms_len.data(), B * 4);
   uint32_t n_rows = 0;
   uint64_t layout_bytes = 0;
-  uint32_t n_simple = 0, n_general = 0;
+  uint32_t n_simple = 0, n_general = 0, z_masked = 0;
   if (z) {
     // per query: entry indices stably sorted by ScoreByTerm::score desc (zero_to_one.rs:98);
     // the records' push order == plan order (query term asc, expansion order, newest version first).
@@ -1129,16 +1150,33 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       // simple: one entry per query term and a single version layer.  The same trie node may
       // appear several times ("abc abc"): the k-th record of a node in the sorted order is consumed
       // iff the node's pool still holds something, i.e. iff term_frequency >= k (zero_to_one.rs:104-113)
-      bool simple = true;
+      bool simple = true, masked = false;
       for (uint32_t i = b; i < e && simple; ++i) {
         if (plan.entries[i].shift >> 8) simple = false;
-        for (uint32_t j = b; j < i && simple; ++j)
-          if (plan.entries[j].qterm == plan.entries[i].qterm) simple = false;
+        for (uint32_t j = b; j < i && simple; ++j) {
+          const bool same_q = plan.entries[j].qterm == plan.entries[i].qterm;
+          const bool same_n = plan.entries[j].node == plan.entries[i].node;
+          // several expansions of one query term: fine as long as every record has its own node
+          // (then the pool never blocks and only consumed_index decides) -> mask variant
+          if (same_q) masked = true;
+          if (same_q && same_n) simple = false;
+        }
+      }
+      if (masked) {
+        // masks are u32 per (doc, field); mixing "same node under two query terms" with
+        // expansions needs the full pool bookkeeping of the general kernel
+        for (uint32_t i = b; i < e && simple; ++i) {
+          if (plan.entries[i].qterm >= 32) simple = false;
+          for (uint32_t j = b; j < i && simple; ++j)
+            if (plan.entries[j].node == plan.entries[i].node) simple = false;
+        }
       }
       // the simple path keeps F f64 accumulators per document of the tile in LDS
       if ((size_t)WG_WAVES * ((size_t)s.T * s.F * 8 + 4096) > 160 * 1024) simple = false;
+      if (masked && (size_t)WG_WAVES * ((size_t)s.T * s.F * 12 + 4096) > 160 * 1024) simple = false;
       if (env_u32("PS_Z21_GENERAL_ONLY", 0)) simple = false;
       qf[q] = simple ? 1u : 0u;
+      if (!simple) masked = false;
       if (simple) {
         ++n_simple;
         tmp.assign(plan.entries.begin() + b, plan.entries.begin() + e);
@@ -1147,8 +1185,9 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
           uint32_t need = 1;  // occurrence rank of the node among the sorted records
           for (uint32_t j = b; j < i; ++j)
             if (he[j].node == he[i].node) ++need;
-          he[i].qterm_index = need;
+          he[i].qterm_index = need | ((he[i].qterm & 31u) << 16) | (masked ? 0x80000000u : 0u);
         }
+        if (masked) { z_masked = 1; qf[q] |= 2u; }
       } else {
         gq[n_general++] = (uint32_t)q;  // empty queries too: somebody has to write their (empty) candidate slots
         if (e - b > 64) throw std::length_error("zero_to_one with repeated terms supports at most 64 expanded lists per query on the GPU");
@@ -1177,13 +1216,13 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       const uint32_t* qf = reinterpret_cast<const uint32_t*>(h + off_f);
       auto key_of = [&](const ps_plan_entry& e, size_t q) {
         Key k{e.post_off, 0, 0};
-        if (z) { memcpy(&k.w, &e.boost, 8); k.k3 = (uint64_t)plan.qterms_len[q] | ((uint64_t)e.qterm_index << 32); }
+        if (z) { memcpy(&k.w, &e.boost, 8); k.k3 = (uint64_t)plan.qterms_len[q] | ((uint64_t)(e.qterm_index & 0xFFFFu) << 32); }
         else { memcpy(&k.w, &e.idf, 8); memcpy(&k.k3, &e.boost, 8); }
         return k;
       };
       std::map<Key, Agg, decltype(kless)> agg(kless);
       for (size_t q = 0; q < B; ++q) {
-        if (z && !(qf[q] & 1u)) continue;
+        if (z && (qf[q] & 3u) != 1u) continue;  // zero_to_one: simple, unmasked queries only
         for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
           if ((double)he[i].len < min_density * (double)s.n_docs) continue;
           Agg& a = agg[key_of(he[i], q)];
@@ -1213,7 +1252,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
           rd[n_rows++] = d;
         }
         for (size_t q = 0; q < B; ++q) {
-          if (z && !(qf[q] & 1u)) continue;
+          if (z && (qf[q] & 3u) != 1u) continue;
           for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
             auto it = row_of.find(key_of(he[i], q));
             if (it != row_of.end()) { he[i].shift |= DENSE_FLAG; he[i].node = it->second; }
@@ -1260,7 +1299,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.gthr = m.d_gthr.p;
   kp.work_counter = reinterpret_cast<uint32_t*>(m.d_gthr.p + B + 1);
   PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, (B + 2) * 8, st));
-  kp.n_simple = n_simple; kp.n_general = n_general;
+  kp.n_simple = n_simple; kp.n_general = n_general; kp.z_masked = z_masked;
   kp.layout_bytes = layout_bytes;
   m.last_layout_bytes = layout_bytes;
   m.last_rows = n_rows;
@@ -1304,7 +1343,8 @@ void launch_k_score(KParams& kp, bool tags, int n_cu, hipStream_t st) {
   const uint32_t n_items = kp.B * kp.n_super;
   const uint32_t aw = MODE == MODE_Z21S ? kp.F : 1u;
   const size_t lut_b = MODE == MODE_BM25 ? (size_t)kp.lut_stride * LUT_TF * 8 : 0;
-  const size_t wave_b = (size_t)kp.T * aw * 8 + (tags ? (size_t)kp.T * 2 : 0) + kp.slice_bytes;
+  const size_t wave_b = (size_t)kp.T * aw * 8 + (tags ? (MODE == MODE_Z21S ? (size_t)kp.T * aw * 4 : (size_t)kp.T * 2) : 0) +
+                        kp.slice_bytes;
   // Workgroups of 8 waves share one LUT copy: two of them (16 waves) fit a CU's 160 KiB when a
   // wave's tile is small enough; otherwise 4-wave workgroups pack the LDS better.
   const bool wide = !FULL && lut_b + 8 * wave_b <= 80 * 1024 && env_u32("PS_WG8", 1);
@@ -1326,7 +1366,7 @@ void launch_k_score(KParams& kp, bool tags, int n_cu, hipStream_t st) {
     if (!FULL && wide) PS_LAUNCH_W(FV, TG, (FULL ? WG_WAVES : 8));                                     \
     else PS_LAUNCH_W(FV, TG, WG_WAVES);                                                                \
   } while (0)
-  if (MODE == MODE_BM25 && tags) {
+  if (tags) {
     if (kp.F == 1) PS_LAUNCH(1, true);
     else if (kp.F == 2) PS_LAUNCH(2, true);
     else PS_LAUNCH(0, true);
@@ -1355,7 +1395,7 @@ void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n
     launch_k_score<MODE_BM25, FULL>(kp, plan.multi_expansion, n_cu, st);
   } else {
     launch_rows(kp, st);
-    if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(kp, false, n_cu, st);
+    if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(kp, kp.z_masked != 0, n_cu, st);
     if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
       kp.z_nodes = std::max<uint32_t>(1, plan.max_nodes);

@@ -239,12 +239,16 @@ def test_wide_prefix_expansion_many_entries():
         assert_same(top, exp[:10], ("wide-top", q))
     ents, _ = snap.plan("a", psa.bm25.new())
     assert len(ents) > 200
-    # zero_to_one: a query term with > 64 expansions needs the general kernel, whose limit is 64
-    # lists per query: a documented PS_EUNSUPPORTED, never a wrong answer or a CPU fallback
-    for q in ("a", "ab ab"):
-        with pytest.raises(psa.PsError) as ei:
-            snap.query(q, psa.zero_to_one.new(), None, [1.0])
-        assert ei.value.status == 4  # PS_EUNSUPPORTED
+    # zero_to_one: hundreds of expansions of ONE query term go through the consumed-term-mask path
+    for q in ("a", "ab", "abc x"):
+        exp = o.query(q, orc.zero_to_one(), [1.0])
+        got = [tuple(r) for r in snap.query(q, psa.zero_to_one.new(), None, [1.0])]
+        assert_same(got, exp, ("wide-z21", q))
+    # ... the same nodes under two query terms need the general kernel, whose limit is 64 lists per
+    # query: a documented PS_EUNSUPPORTED, never a wrong answer or a CPU fallback
+    with pytest.raises(psa.PsError) as ei:
+        snap.query("ab ab", psa.zero_to_one.new(), None, [1.0])
+    assert ei.value.status == 4  # PS_EUNSUPPORTED
     # ... while a narrower prefix (<= 64 expansions) goes through it bit-exactly
     narrow = next(pfx for pfx in ("abcd", "abce", "abda", "abab", "abhh", "abgg") if 1 < len(o.expand_term(pfx)) <= 64)
     exp = o.query(narrow + " " + narrow, orc.zero_to_one(), [1.0])
