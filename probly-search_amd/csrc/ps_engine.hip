@@ -269,11 +269,12 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
   }
 }
 
-// Merge one dense row's slice for this tile into the wave's LDS tile (same merge rules as
-// score_trip; a row value > 0 <=> the list holds that document).
 // zero_to_one rows: plane x of the row goes to accumulator plane x of the tile ([F][T] in LDS).
-__device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, const int lane, const uint32_t row,
-                                              const uint32_t tile_base) {
+// mask_bit != 0: the query has several expansions per query term; a (doc, field) takes the row
+// value only if its consumed-query-term mask does not hold the bit yet (zero_to_one.rs:101-103).
+template <bool MASKS>
+__device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, uint32_t* zmask, const int lane,
+                                              const uint32_t row, const uint32_t tile_base, const uint32_t mask_bit) {
   for (uint32_t x = 0; x < p.F; ++x) {
     const double* r = p.rows + ((uint64_t)row * p.F + x) * p.row_stride + tile_base;
     constexpr int CH = 4;
@@ -286,14 +287,24 @@ __device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, con
       for (int k = 0; k < CH; ++k) {
         if (c0 + k * 2 * WAVE < p.T) {
           const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
-          if (v[k].x > 0.0) __hip_atomic_fetch_add(&acc[x * p.T + i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          if (v[k].y > 0.0) __hip_atomic_fetch_add(&acc[x * p.T + i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          bool t0 = v[k].x > 0.0, t1 = v[k].y > 0.0;
+          if (MASKS && mask_bit) {
+            uint2* zm = reinterpret_cast<uint2*>(zmask + x * p.T + i);
+            const uint2 mk = *zm;
+            t0 = t0 && !(mk.x & mask_bit);
+            t1 = t1 && !(mk.y & mask_bit);
+            if (t0 || t1) *zm = make_uint2(mk.x | (t0 ? mask_bit : 0u), mk.y | (t1 ? mask_bit : 0u));
+          }
+          if (t0) __hip_atomic_fetch_add(&acc[x * p.T + i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (t1) __hip_atomic_fetch_add(&acc[x * p.T + i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
       }
     }
   }
 }
 
+// Merge one dense row's slice for this tile into the wave's LDS tile (same merge rules as
+// score_trip; a row value > 0 <=> the list holds that document).
 template <bool TAGS>
 __device__ __forceinline__ void dense_apply(const KParams& p, double* acc, uint16_t* tag, const int lane,
                                             const uint32_t row, const uint32_t tile_base, const uint16_t mytag) {
@@ -651,7 +662,8 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
           dirty = true;
           if (PS_ABLATE_BUILD && (p.ablate & 8u)) {
           } else if (MODE == MODE_BM25) dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
-          else dense_apply_z(p, acc, lane, ec_row[g], tile_base);
+          else dense_apply_z<TAGS>(p, acc, reinterpret_cast<uint32_t*>(tag), lane, ec_row[g], tile_base,
+                                   (ec_qterm[g] >> 31) ? (1u << ((ec_qterm[g] >> 16) & 31u)) : 0u);
         } else if (rb[g] < re[g]) {
           dirty = true;
           ec[g].tag = MODE == MODE_Z21S ? ec_qterm[g] : tagbase + ec_qterm[g];
@@ -1222,7 +1234,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       };
       std::map<Key, Agg, decltype(kless)> agg(kless);
       for (size_t q = 0; q < B; ++q) {
-        if (z && (qf[q] & 3u) != 1u) continue;  // zero_to_one: simple, unmasked queries only
+        if (z && !(qf[q] & 1u)) continue;  // zero_to_one: queries of the fast path only
         for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
           if ((double)he[i].len < min_density * (double)s.n_docs) continue;
           Agg& a = agg[key_of(he[i], q)];
@@ -1252,7 +1264,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
           rd[n_rows++] = d;
         }
         for (size_t q = 0; q < B; ++q) {
-          if (z && (qf[q] & 3u) != 1u) continue;
+          if (z && !(qf[q] & 1u)) continue;
           for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
             auto it = row_of.find(key_of(he[i], q));
             if (it != row_of.end()) { he[i].shift |= DENSE_FLAG; he[i].node = it->second; }
