@@ -1,0 +1,887 @@
+// ps_kernels.hpp — device code of the query-scoring path (gfx950 / CDNA4): kernel parameter
+// block, wave-level top-K, K0 k_bm25_lut, K0b k_dense_rows, K1 k_score, K2 k_z21, K3 k_merge,
+// k_pack_results.  Included by ps_engine.hip only (one translation unit); see that file's header
+// comment for the kernel overview and DESIGN.md section 3 for the design.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/probly_search_amd.h"
+
+namespace ps {
+
+constexpr int MAX_F = 8;
+constexpr int WAVE = 64;
+#ifndef PS_UNROLL
+#define PS_UNROLL 2
+#endif
+#ifndef PS_WG_WAVES
+#define PS_WG_WAVES 4
+#endif
+#ifndef PS_G
+#define PS_G 4
+#endif
+#ifndef PS_FU
+#define PS_FU 1
+#endif
+constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
+constexpr int WG_WAVES = PS_WG_WAVES;  // waves per workgroup of K1; each wave owns its own LDS tile
+constexpr int LUT_TF = 16;   // LUT columns: term frequency 0..15
+#ifndef PS_ABLATE_BUILD
+#define PS_ABLATE_BUILD 0  // profiling builds only: honour KParams::ablate in the hot loops
+#endif
+
+struct RowDesc {  // one hot (list, idf, expansion_boost) combination of the batch
+  uint64_t post_off;
+  uint32_t len;
+  uint32_t _pad;
+  double idf, eb;
+};
+
+constexpr uint32_t DENSE_FLAG = 0x80000000u;  // ps_plan_entry::shift bit 31: entry reads dense row `node`
+
+struct KParams {
+  const uint32_t* doc;
+  const uint32_t* tf;
+  const uint32_t* fl;
+  const uint32_t* table;
+  const uint64_t* keys;
+  const ps_plan_entry* plan;
+  const uint32_t* qbeg;
+  const uint32_t* qterms_len;  // zero_to_one
+  const uint32_t* gen_queries; // zero_to_one: the n_general queries k_z21 has to run
+  const uint32_t* qflags;      // zero_to_one: bit 0 = "simple" query (k_score<MODE_Z21S> owns it)
+  uint32_t slice_bytes;        // per-wave LDS for the table slices (0 = look ranges up in global memory)
+  const uint32_t* zorder;      // zero_to_one: per query, entry indices sorted by (score desc, plan order)
+  uint64_t P;
+  uint32_t B, n_tiles, T, S, n_super, K, n_docs, F, max_qterms, z_nodes, z_tile;
+  double k1, k1p1, one_minus_b, b;
+  double avg[MAX_F], boost[MAX_F];
+  // saturated-tf LUT (see k_bm25_lut): rows of LUT_TF doubles, row = lut_base[x] + field_length
+  const double* lut;
+  uint32_t lut_rows, lut_stride;  // entry (tf, row) lives at tf * lut_stride + row; stride is odd
+  uint32_t lut_cap[MAX_F], lut_base[MAX_F];
+  // Dense rows (see k_dense_rows): per-document f64 score of the batch's hot lists, one row each
+  const double* rows;
+  const RowDesc* row_desc;
+  uint64_t row_stride;  // doubles per row plane = n_tiles * T
+  uint32_t n_rows;
+  uint32_t row_mode;    // MODE_BM25 | MODE_Z21S: what k_dense_rows evaluates
+  uint32_t row_planes;  // 1 (BM25 score) | F (zero_to_one: one contribution plane per field)
+  uint64_t layout_bytes;         // host-side bookkeeping: bytes of the layout actually streamed
+  uint32_t z_masked;             // host-side: some simple query needs the consumed-query-term masks
+  uint32_t n_simple, n_general;  // host-side bookkeeping (zero_to_one query classes in this batch)
+  uint32_t ablate;  // PS_ABLATE debug bit mask (profiling only): 1 = no top-k offer, 2 = no scoring
+  uint32_t* work_counter;    // next (query, run) item for the persistent waves of k_score
+  unsigned long long* gthr;  // [B] bits of the best published local K-th score per query (0 = none)
+  double* cand_score;  // [B * n_super * K]
+  uint32_t* cand_doc;
+  // full-result mode
+  uint32_t* full_doc;
+  double* full_score;
+  const uint64_t* full_off;  // [B+1]
+  uint32_t* full_cnt;        // [B]
+  // final outputs
+  uint64_t* out_keys;
+  double* out_scores;
+  uint32_t* out_counts;
+};
+
+// ------------------------------------------------------------------------------------------
+// wave-level helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// canonical order of test_util::test_score (src/lib.rs:54-58): score desc, then key asc
+// (doc ids are assigned in ascending key order, so doc asc == key asc).
+__device__ __forceinline__ bool better(double as, uint32_t ad, double bs, uint32_t bd) {
+  return as > bs || (as == bs && ad < bd);
+}
+
+struct TopK {
+  double s;      // lane i: score of the i-th best so far (valid for i < n)
+  uint32_t d;    // its doc id
+  uint32_t n;    // wave-uniform fill
+  double thr_s;  // K-th best (valid when n == K)
+  uint32_t thr_d;
+};
+
+// Offer one candidate per lane (`has`), keep the best K.  All lanes must call.
+// `gt` is a lower bound of the query's final K-th best score published by other waves of the same
+// query (0 = none yet): anything strictly below it cannot be in the final top-K.
+__device__ __forceinline__ void topk_offer(TopK& tk, const uint32_t K, const int lane, bool has, double v,
+                                           uint32_t d, const double gt = 0.0) {
+  bool cand = has && v >= gt && (tk.n < K || better(v, d, tk.thr_s, tk.thr_d));
+  unsigned long long m = __ballot(cand);
+  while (m) {
+    const int src = __ffsll(m) - 1;
+    m &= m - 1;
+    const double cs = readlane_f64(v, src);
+    const uint32_t cd = readlane_u32(d, src);
+    if (tk.n == K && !better(cs, cd, tk.thr_s, tk.thr_d)) continue;
+    const bool lb = ((uint32_t)lane < tk.n) && better(tk.s, tk.d, cs, cd);
+    const uint32_t pos = (uint32_t)__popcll(__ballot(lb));
+    const double us = __shfl_up(tk.s, 1);
+    const uint32_t ud = __shfl_up(tk.d, 1);
+    if ((uint32_t)lane > pos) { tk.s = us; tk.d = ud; }
+    else if ((uint32_t)lane == pos) { tk.s = cs; tk.d = cd; }
+    if (tk.n < K) tk.n++;
+    if (tk.n == K) {
+      tk.thr_s = readlane_f64(tk.s, (int)K - 1);
+      tk.thr_d = readlane_u32(tk.d, (int)K - 1);
+    }
+  }
+}
+
+// Full-result mode: append this wave's present documents to the query's output run.
+__device__ __forceinline__ void full_emit(const KParams& p, uint32_t q, int lane, bool has, double v, uint32_t d) {
+  unsigned long long m = __ballot(has);
+  if (m == 0) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&p.full_cnt[q], (uint32_t)__popcll(m));
+  base = readlane_u32(base, 0);
+  if (has) {
+    uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    uint64_t o = p.full_off[q] + base + rank;
+    p.full_doc[o] = d;
+    p.full_score[o] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: BM25 posting accumulate + merge + per-run top-K   (bm25.rs:60-93, query.rs:61-89,150-164)
+// ------------------------------------------------------------------------------------------
+// The saturated term frequency bm25.rs:78-82 computes per posting-field,
+//   tfn(tf, fl) = ((k1+1)*tf) / (k1*((1-b) + b*(fl/avg_x)) + tf),
+// depends only on (field, tf, fl).  Each batch, k_bm25_lut evaluates THE SAME f64 expression once
+// per (field, fl < lut_cap[x], tf < 16) and K1 stages the table in LDS, so the common small-integer
+// case costs one LDS read instead of two IEEE f64 divisions; everything else takes the inline
+// expression.  Same operations on the same operands -> bit-identical values.
+__device__ __forceinline__ double bm25_tfn(const KParams& p, uint32_t x, uint32_t tfu, uint32_t flu) {
+  const double tfd = (double)tfu;
+  const double fld = (double)flu;
+  // bm25.rs:78-82, evaluated left to right, no contraction
+  return (p.k1p1 * tfd) / (p.k1 * (p.one_minus_b + p.b * (fld / p.avg[x])) + tfd);
+}
+
+// Out-of-line copy for K1's rare beyond-the-LUT path: keeps ~100 inlined IEEE division
+// sequences out of the hot kernel's instruction stream.
+__device__ __noinline__ double bm25_tfn_cold(double k1, double k1p1, double one_minus_b, double b, double avg,
+                                             uint32_t tfu, uint32_t flu) {
+  const double tfd = (double)tfu;
+  const double fld = (double)flu;
+  return (k1p1 * tfd) / (k1 * (one_minus_b + b * (fld / avg)) + tfd);
+}
+
+__global__ __launch_bounds__(256) void k_bm25_lut(const KParams p, double* out) {
+  for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < p.lut_stride * LUT_TF; i += blockDim.x * gridDim.x) {
+    const uint32_t tfu = i / p.lut_stride, row = i % p.lut_stride;
+    uint32_t x = 0;
+    while (x + 1 < p.F && row >= p.lut_base[x] + p.lut_cap[x]) ++x;
+    out[i] = row < p.lut_rows ? bm25_tfn(p, x, tfu, row - p.lut_base[x]) : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: posting accumulate + merge + per-run top-K, one kernel skeleton for two scorers
+//   MODE_BM25  bm25.rs:60-93 + max_score_merger (query.rs:61-89,150-164)
+//   MODE_Z21S  zero_to_one (zero_to_one.rs:44-126) for "simple" queries: every entry of the
+//              query has its own trie node and its own query term, so finalize's greedy scan
+//              never skips a record and a (doc, field) pool is just the f64 sum of its records'
+//              contributions in sorted order (score desc, stable) — the host uploads the entries
+//              of such queries already in that order.  Anything else goes to k_z21.
+// ------------------------------------------------------------------------------------------
+// K0b: batch-level common-subexpression elimination.  A BM25 posting's score
+// s(list, doc) = sum_x ((tfn*idf)*boost_x)*expansion_boost does not depend on the query, and in a
+// Zipf batch a handful of head lists is visited by hundreds of queries (top-12 terms ~ 90 % of all
+// posting visits in C2).  For the (list, idf, eb) combinations the host found hot and dense, this
+// kernel evaluates s ONCE per posting — the very same f64 expression, so the bits are the same —
+// into a dense per-document row (0.0 = no posting).  K1 then adds row values in plan order
+// instead of re-streaming 20-byte postings and re-deriving the score per query.  Runs inside the
+// timed step, once per batch.
+__global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* rows) {
+  const RowDesc rd = p.row_desc[blockIdx.y];
+  double* row = rows + (uint64_t)blockIdx.y * p.row_planes * p.row_stride;
+  if (p.row_mode != 0) {
+    // zero_to_one.rs:117-120 per field: (min(score/tf, 1)*tf) / max(field_length, all_query_terms_len)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rd.len; i += gridDim.x * blockDim.x) {
+      const uint64_t pi = rd.post_off + i;
+      const uint32_t d = p.doc[pi];
+      const uint32_t qtl = rd._pad & 0xFFFFu, need = rd._pad >> 16;
+      for (uint32_t x = 0; x < p.F; ++x) {
+        const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
+        if (tfu >= need) {
+          const uint32_t flu = p.fl[(uint64_t)x * p.P + pi];
+          const double df = (double)tfu;
+          row[(uint64_t)x * p.row_stride + d] = fmin(rd.idf / df, 1.0) * df / (double)(flu > qtl ? flu : qtl);
+        }
+      }
+    }
+    return;
+  }
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rd.len; i += gridDim.x * blockDim.x) {
+    const uint64_t pi = rd.post_off + i;
+    double s = 0.0;
+    for (uint32_t x = 0; x < p.F; ++x) {
+      const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
+      if (tfu > 0) s += bm25_tfn(p, x, tfu, p.fl[(uint64_t)x * p.P + pi]) * rd.idf * p.boost[x] * rd.eb;
+    }
+    row[p.doc[pi]] = s;
+  }
+}
+
+// zero_to_one rows: plane x of the row goes to accumulator plane x of the tile ([F][T] in LDS).
+// mask_bit != 0: the query has several expansions per query term; a (doc, field) takes the row
+// value only if its consumed-query-term mask does not hold the bit yet (zero_to_one.rs:101-103).
+template <bool MASKS>
+__device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, uint32_t* zmask, const int lane,
+                                              const uint32_t row, const uint32_t tile_base, const uint32_t mask_bit) {
+  for (uint32_t x = 0; x < p.F; ++x) {
+    const double* r = p.rows + ((uint64_t)row * p.F + x) * p.row_stride + tile_base;
+    constexpr int CH = 4;
+    for (uint32_t c0 = 0; c0 < p.T; c0 += CH * 2 * WAVE) {
+      double2 v[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+        if (c0 + k * 2 * WAVE < p.T) v[k] = *reinterpret_cast<const double2*>(r + c0 + k * 2 * WAVE + 2 * lane);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        if (c0 + k * 2 * WAVE < p.T) {
+          const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
+          bool t0 = v[k].x > 0.0, t1 = v[k].y > 0.0;
+          if (MASKS && mask_bit) {
+            uint2* zm = reinterpret_cast<uint2*>(zmask + x * p.T + i);
+            const uint2 mk = *zm;
+            t0 = t0 && !(mk.x & mask_bit);
+            t1 = t1 && !(mk.y & mask_bit);
+            if (t0 || t1) *zm = make_uint2(mk.x | (t0 ? mask_bit : 0u), mk.y | (t1 ? mask_bit : 0u));
+          }
+          if (t0) __hip_atomic_fetch_add(&acc[x * p.T + i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (t1) __hip_atomic_fetch_add(&acc[x * p.T + i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+    }
+  }
+}
+
+// Merge one dense row's slice for this tile into the wave's LDS tile (same merge rules as
+// score_trip; a row value > 0 <=> the list holds that document).
+template <bool TAGS>
+__device__ __forceinline__ void dense_apply(const KParams& p, double* acc, uint16_t* tag, const int lane,
+                                            const uint32_t row, const uint32_t tile_base, const uint16_t mytag) {
+  const double* r = p.rows + (uint64_t)row * p.row_stride + tile_base;
+  constexpr int CH = 4;  // 4 x 128 documents per batch of 16-byte loads (1 KiB per load instruction)
+  for (uint32_t c0 = 0; c0 < p.T; c0 += CH * 2 * WAVE) {
+    double2 v[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+      if (c0 + k * 2 * WAVE < p.T) v[k] = *reinterpret_cast<const double2*>(r + c0 + k * 2 * WAVE + 2 * lane);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if (c0 + k * 2 * WAVE < p.T) {
+        const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
+        if (TAGS) {
+          const double c0v = acc[i], c1v = acc[i + 1];
+          const uint16_t t0 = tag[i], t1 = tag[i + 1];
+          if (v[k].x > 0.0) {
+            acc[i] = (c0v > 0.0) ? (t0 == mytag ? fmax(c0v, v[k].x) : c0v + v[k].x) : v[k].x;
+            tag[i] = mytag;
+          }
+          if (v[k].y > 0.0) {
+            acc[i + 1] = (c1v > 0.0) ? (t1 == mytag ? fmax(c1v, v[k].y) : c1v + v[k].y) : v[k].y;
+            tag[i + 1] = mytag;
+          }
+        } else {
+          if (v[k].x > 0.0) __hip_atomic_fetch_add(&acc[i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (v[k].y > 0.0) __hip_atomic_fetch_add(&acc[i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+    }
+  }
+}
+
+enum { MODE_BM25 = 0, MODE_Z21S = 1 };
+
+struct EntryC {      // wave-uniform per-entry constants (SGPRs)
+  uint64_t post_off;
+  uint32_t shift;
+  uint32_t tag;      // BM25: visited tag of the entry's query term for the current tile
+  double w0;         // BM25: idf              | Z21S: ScoreByTerm::score
+  double w1;         // BM25: expansion_boost  | Z21S: unused
+};
+
+template <int F_, int U>
+__device__ __forceinline__ void load_trip(const KParams& p, const int lane, const uint64_t post_off, const uint32_t i0,
+                                          const uint32_t re, uint32_t (&dv)[U], uint32_t (&tfv)[U][F_ ? F_ : MAX_F],
+                                          uint32_t (&flv)[U][F_ ? F_ : MAX_F]) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t i = i0 + u * WAVE + lane;
+    const uint64_t pi = post_off + (i < re ? i : re - 1);  // clamp: always a valid posting
+    dv[u] = p.doc[pi];
+#pragma unroll
+    for (int x = 0; x < FA; ++x) {
+      if ((uint32_t)x < F) {
+        tfv[u][x] = p.tf[(uint64_t)x * p.P + pi];
+        flv[u][x] = p.fl[(uint64_t)x * p.P + pi];
+      }
+    }
+  }
+}
+
+// Score U postings per lane and merge them into the wave's LDS tile.  Written branch-free on
+// purpose: all LUT gathers of the trip are issued back to back, then all arithmetic, then all
+// LDS updates, so the wave never sits on one LDS round trip per posting-field.  `+ 0.0` for a
+// field with tf == 0 leaves the f64 sum bit-identical to skipping it.
+template <int MODE, int F_, bool TAGS, int U>
+__device__ __forceinline__ void score_trip(const KParams& p, const double* lut, double* acc, uint16_t* tag,
+                                           const int lane, const uint32_t tile_base, const uint32_t i0,
+                                           const uint32_t re, const uint32_t (&dv)[U],
+                                           const uint32_t (&tfv)[U][F_ ? F_ : MAX_F],
+                                           const uint32_t (&flv)[U][F_ ? F_ : MAX_F], const EntryC& ec,
+                                           const uint32_t qtl) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+  if (PS_ABLATE_BUILD && (p.ablate & 2u)) {  // profiling only: loads stay alive, no scoring
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if ((dv[u] ^ tfv[u][0] ^ flv[u][0]) == 0xFFFFFFF1u) acc[0] = 1.0;
+    return;
+  }
+  bool ok[U];
+  uint32_t local[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t i = i0 + u * WAVE + lane;
+    local[u] = dv[u] - tile_base;
+    // coarse table slots (shift != 0) span several tiles: keep only this tile's documents
+    ok[u] = i < re && (ec.shift == 0 || local[u] < p.T);
+  }
+  if (MODE == MODE_BM25) {
+    double tfn[U][FA];
+    bool slow = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int x = 0; x < FA; ++x) {
+        if ((uint32_t)x < F) {
+          const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+          const bool in_lut = tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x];
+          // transposed, odd-stride table: lanes with different field lengths hit different LDS banks
+          tfn[u][x] = lut[in_lut ? tfu * p.lut_stride + p.lut_base[x] + flu : 0u];
+          slow |= ok[u] && tfu > 0 && !in_lut;
+        }
+      }
+    }
+    if (__any(slow)) {  // wave-uniform; rare once the LUT covers the corpus' field lengths
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int x = 0; x < FA; ++x) {
+          if ((uint32_t)x < F) {
+            const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+            if (!(tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x]))
+              tfn[u][x] = bm25_tfn_cold(p.k1, p.k1p1, p.one_minus_b, p.b, p.avg[x], tfu, flu);
+          }
+        }
+      }
+    }
+    double s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s[u] = 0.0;
+#pragma unroll
+      for (int x = 0; x < FA; ++x) {
+        if ((uint32_t)x < F) {
+          const double term = tfn[u][x] * ec.w0 * p.boost[x] * ec.w1;  // bm25.rs:83-86: ((tfn*idf)*boost)*expansion_boost
+          s[u] += (tfv[u][x] > 0) ? term : 0.0;
+        }
+      }
+    }
+    if (TAGS) {
+      double cur[U];
+      uint16_t tg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        cur[u] = ok[u] ? acc[local[u]] : 0.0;
+        tg[u] = ok[u] ? tag[local[u]] : (uint16_t)0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ok[u]) {
+          if (s[u] > 0.0)  // Some(score) iff score > 0 (bm25.rs:89-92)
+            // max_score_merger (query.rs:150-164); present <=> cur > 0 for BM25
+            acc[local[u]] = (cur[u] > 0.0) ? (tg[u] == (uint16_t)ec.tag ? fmax(cur[u], s[u]) : cur[u] + s[u]) : s[u];
+          tag[local[u]] = (uint16_t)ec.tag;  // visited even when the score was None (query.rs:87)
+        }
+      }
+    } else {
+      // one list per query term: always the `+` / assign arm (absent == +0.0).  A list holds a
+      // document once, so the LDS f64 add is uncontended; issuing it as a no-return DS op keeps
+      // the read-modify-write latency off the wave's critical path.
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[u] && s[u] > 0.0)
+          __hip_atomic_fetch_add(&acc[local[u]], s[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  } else {
+    // zero_to_one.rs:117-120: (min(score / tf, 1.) * tf) / max(field_length, all_query_terms_len)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int x = 0; x < FA; ++x) {
+        if ((uint32_t)x < F) {
+          const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+          const double df = (double)tfu;
+          const uint32_t den = flu > qtl ? flu : qtl;
+          const double c = fmin(ec.w0 / df, 1.0) * df / (double)den;
+          // ec.tag = occurrence rank of the node (low 16 bits, >= 1: the pool rule) | query-term ordinal
+          bool take = ok[u] && tfu >= (ec.tag & 0xFFFFu);
+          if (TAGS && (ec.tag >> 31)) {  // bit 31: this query has query terms with several expansions
+            // consumed_index (zero_to_one.rs:101-103): the first record of a query term (in sorted
+            // order, which is the order entries are processed in) that hits this (doc, field)
+            // consumes the term; its later expansions are skipped
+            uint32_t* zm = reinterpret_cast<uint32_t*>(tag) + (uint32_t)x * p.T + local[u];
+            const uint32_t bit = 1u << ((ec.tag >> 16) & 31u);
+            const uint32_t mk = take ? *zm : 0u;
+            take = take && !(mk & bit);
+            if (take) *zm = mk | bit;
+          }
+          if (take)
+            __hip_atomic_fetch_add(&acc[(uint32_t)x * p.T + local[u]], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+    }
+  }
+}
+
+// Stream postings [rb, re) of one list through the tile, UNROLL*64 per trip; the next trip's
+// loads are in flight while the current one is scored.
+template <int MODE, int F_, bool TAGS>
+__device__ __forceinline__ void score_stream(const KParams& p, const double* lut, double* acc, uint16_t* tag,
+                                             const int lane, const uint32_t tile_base, const uint32_t rb,
+                                             const uint32_t re, const EntryC& ec, const uint32_t qtl) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  constexpr int UN = F_ ? UNROLL : 1;
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+  uint32_t i0 = rb;
+  if (re - i0 >= (uint32_t)(UN * WAVE)) {
+    // full trips, double-buffered
+    uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
+    uint32_t dn[UN], tfnx[UN][FA], flnx[UN][FA];
+    load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+    while (re - i0 >= (uint32_t)(UN * WAVE)) {
+      const uint32_t nx = i0 + UN * WAVE;
+      const bool more = re - nx >= (uint32_t)(UN * WAVE);
+      if (more) load_trip<F_, UN>(p, lane, ec.post_off, nx, re, dn, tfnx, flnx);
+      score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          dv[u] = dn[u];
+#pragma unroll
+          for (int x = 0; x < FA; ++x)
+            if ((uint32_t)x < F) { tfv[u][x] = tfnx[u][x]; flv[u][x] = flnx[u][x]; }
+        }
+      }
+      i0 = nx;
+    }
+  }
+  // tail (< UN*64 postings): one masked trip when it is long (all loads in flight together), one
+  // 64-wide trip when it is short (no empty lane slots to pay for)
+  if (i0 < re) {
+    if (re - i0 > (uint32_t)WAVE) {
+      uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
+      load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+      score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+    } else {
+      uint32_t dv[1], tfv[1][FA], flv[1][FA];
+      load_trip<F_, 1>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+      score_trip<MODE, F_, TAGS, 1>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+    }
+  }
+}
+
+template <int MODE, int F_, bool TAGS, bool FULL, int WGW>
+__global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int FA = F_ ? F_ : MAX_F;
+  constexpr int G = F_ ? PS_G : 1;    // plan entries whose first trips are in flight together
+  constexpr int FU = F_ ? PS_FU : 1;  // postings per lane in a prefetched first trip
+  const int lane = threadIdx.x & (WAVE - 1);
+  // readfirstlane: tell the compiler the wave index is wave-uniform, so everything derived from
+  // it (item, query, plan entries, table ranges) lives in SGPRs and is fetched with scalar loads
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+  const uint32_t T = p.T;
+  const uint32_t AW = MODE == MODE_Z21S ? F : 1u;  // f64 accumulators per document
+  // LDS: [LUT, shared by the workgroup][wave 0: tile, tags, table slices][wave 1: ...]...
+  const double* lut = reinterpret_cast<const double*>(smem);
+  const uint32_t lut_bytes = MODE == MODE_BM25 ? p.lut_stride * LUT_TF * 8 : 0u;
+  // TAGS: BM25 = u16 visited tag per document; Z21S = u32 consumed-query-term mask per (field, document)
+  const uint32_t tile_bytes = T * AW * 8 + (TAGS ? (MODE == MODE_Z21S ? T * AW * 4 : T * 2) : 0);
+  const uint32_t wave_bytes = tile_bytes + p.slice_bytes;
+  unsigned char* wbase = smem + lut_bytes + (size_t)wave * wave_bytes;
+  double* acc = reinterpret_cast<double*>(wbase);
+  uint16_t* tag = reinterpret_cast<uint16_t*>(wbase + (size_t)T * AW * 8);
+  uint32_t* slice = reinterpret_cast<uint32_t*>(wbase + tile_bytes);  // [entry][2][S]: rb, re per tile of the run
+  if (MODE == MODE_BM25) {
+    double* l = reinterpret_cast<double*>(smem);
+    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * WGW) l[i] = p.lut[i];
+    __syncthreads();  // the only workgroup-level synchronisation: waves are independent from here on
+  }
+  // Persistent waves: the grid only fills the chip; every wave keeps pulling (query, run) items
+  // from one device-scope counter until none are left.  Items are numbered run-major so waves
+  // that are resident together work on the same document range (posting slices stay in L2), and
+  // a heavy head-term item never leaves LDS-holding sibling waves idle.
+  for (uint32_t i = lane; i < T * AW; i += WAVE) acc[i] = 0.0;
+  if (TAGS) {
+    if (MODE == MODE_Z21S)
+      for (uint32_t i = lane; i < T * AW; i += WAVE) reinterpret_cast<uint32_t*>(tag)[i] = 0u;
+    else
+      for (uint32_t i = lane; i < T; i += WAVE) tag[i] = 0xFFFFu;
+  }
+  uint32_t tagbase = 0;
+  const uint32_t n_items = p.B * p.n_super;
+  for (;;) {
+  uint32_t item = 0;
+  if (lane == 0) item = atomicAdd(p.work_counter, 1u);
+  item = __builtin_amdgcn_readfirstlane(item);
+  if (item >= n_items) break;
+  const uint32_t q = item % p.B;
+  const uint32_t sup = item / p.B;
+  const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
+  const uint32_t ne = e1 - e0;
+  const bool mine = MODE == MODE_BM25 || (p.qflags[q] & 1u);  // Z21S: only "simple" queries
+  if (MODE == MODE_Z21S && !mine) continue;                   // k_z21 owns this query's candidate slots
+  const uint32_t qtl = MODE == MODE_Z21S ? p.qterms_len[q] : 0u;
+
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+
+  if (ne != 0) {
+    const uint32_t t_begin = sup * p.S;
+    const uint32_t t_end = min(p.n_tiles, t_begin + p.S);
+    // Table slices: the [rb, re) range of every (entry, tile of this run), fetched once with
+    // coalesced vector loads into LDS, so the per-tile lookup is an LDS broadcast read instead of
+    // a dependent scalar-memory round trip per (entry, tile).
+    const bool sliced = p.slice_bytes != 0;
+    if (sliced) {
+      for (uint32_t e = 0; e < ne; ++e) {
+        const uint32_t tbl_off = p.plan[e0 + e].tbl_off;
+        const uint32_t shift = p.plan[e0 + e].shift & 0xFFu;
+        if ((uint32_t)lane < p.S) {
+          const uint32_t slot = min(t_begin + (uint32_t)lane, p.n_tiles - 1) >> shift;
+          slice[(e * 2 + 0) * p.S + lane] = p.table[tbl_off + slot];
+          slice[(e * 2 + 1) * p.S + lane] = p.table[tbl_off + slot + 1];
+        }
+      }
+    }
+
+    EntryC ec[G];
+    uint32_t ec_qterm[G], ec_tbl[G], ec_row[G];
+    uint32_t rb[G], re[G];
+    uint32_t dv[G][FU], tfv[G][FU][FA], flv[G][FU][FA];
+    // phase 1 of a visit (tile VT, entries EG..EG+G): ranges + first trips, all loads in flight together
+#define PS_PHASE1(VT, EG, FIRST)                                                                                \
+  _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                               \
+    rb[g] = 0; re[g] = 0;                                                                                       \
+    if ((EG) + g < ne) { /* wave-uniform */                                                                     \
+      if (ne > (uint32_t)G || (FIRST)) { /* a plan of <= G entries stays in SGPRs for the whole run */          \
+        const ps_plan_entry& en = p.plan[e0 + (EG) + g];                                                        \
+        ec[g].post_off = en.post_off;                                                                           \
+        ec[g].shift = en.shift & 0xFFu;                                                                         \
+        ec[g].w0 = MODE == MODE_BM25 ? en.idf : en.boost;                                                       \
+        ec[g].w1 = en.boost;                                                                                    \
+        ec_qterm[g] = MODE == MODE_Z21S ? en.qterm_index : en.qterm;                                            \
+        ec_tbl[g] = en.tbl_off;                                                                                 \
+        ec_row[g] = (en.shift & DENSE_FLAG) ? en.node : 0xFFFFFFFFu;                     \
+      }                                                                                                         \
+      if (ec_row[g] != 0xFFFFFFFFu) { /* dense row: nothing to fetch up front */                                \
+      } else if (sliced) {                                                                                             \
+        rb[g] = __builtin_amdgcn_readfirstlane(slice[(((EG) + g) * 2 + 0) * p.S + ((VT) - t_begin)]);           \
+        re[g] = __builtin_amdgcn_readfirstlane(slice[(((EG) + g) * 2 + 1) * p.S + ((VT) - t_begin)]);           \
+      } else {                                                                                                  \
+        const uint32_t slot = (VT) >> ec[g].shift;                                                              \
+        rb[g] = p.table[ec_tbl[g] + slot];                                                                      \
+        re[g] = p.table[ec_tbl[g] + slot + 1];                                                                  \
+      }                                                                                                         \
+      if (rb[g] < re[g]) load_trip<F_, FU>(p, lane, ec[g].post_off, rb[g], re[g], dv[g], tfv[g], flv[g]);       \
+    }                                                                                                           \
+  }
+    PS_PHASE1(t_begin, 0u, true)
+    uint32_t t = t_begin, eg = 0;
+    bool dirty = false;
+    for (;;) {
+      const uint32_t tile_base = t * T;
+      // phase 2: consume the visit in plan order
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (eg + g < ne && ec_row[g] != 0xFFFFFFFFu) {
+          dirty = true;
+          if (PS_ABLATE_BUILD && (p.ablate & 8u)) {
+          } else if (MODE == MODE_BM25) dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
+          else dense_apply_z<TAGS>(p, acc, reinterpret_cast<uint32_t*>(tag), lane, ec_row[g], tile_base,
+                                   (ec_qterm[g] >> 31) ? (1u << ((ec_qterm[g] >> 16) & 31u)) : 0u);
+        } else if (rb[g] < re[g]) {
+          dirty = true;
+          ec[g].tag = MODE == MODE_Z21S ? ec_qterm[g] : tagbase + ec_qterm[g];
+          score_trip<MODE, F_, TAGS, FU>(p, lut, acc, tag, lane, tile_base, rb[g], re[g], dv[g], tfv[g], flv[g], ec[g], qtl);
+          if (rb[g] + FU * WAVE < re[g])
+            score_stream<MODE, F_, TAGS>(p, lut, acc, tag, lane, tile_base, rb[g] + FU * WAVE, re[g], ec[g], qtl);
+        }
+      }
+      // Request the next visit's ranges and first trips now: the registers are free again, and the
+      // loads then fly while this tile is harvested below.
+      uint32_t neg = eg + G, nt = t;
+      bool last = false;
+      if (neg >= ne) { neg = 0; nt = t + 1; last = true; }
+      const bool more = nt < t_end;
+      if (more) { PS_PHASE1(nt, neg, false) }
+      const bool harvest = last && dirty && !(PS_ABLATE_BUILD && (p.ablate & 4u));
+      if (last) dirty = false;
+      t = nt; eg = neg;
+      if (harvest) {
+      // tile epilogue: harvest + reset (two f64 per lane per LDS access where the layout allows)
+      double gt = 0.0;
+      if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (MODE == MODE_BM25) {
+        for (uint32_t c = 0; c < T; c += 2 * WAVE) {
+          double2* slot = reinterpret_cast<double2*>(&acc[c + 2 * lane]);
+          const double2 v = *slot;
+          const bool h0 = v.x > 0.0, h1 = v.y > 0.0;
+          if (h0 || h1) *slot = make_double2(0.0, 0.0);
+          const uint32_t d = tile_base + c + 2 * lane;
+          if (FULL) {
+            full_emit(p, q, lane, h0, v.x, d);
+            full_emit(p, q, lane, h1, v.y, d + 1);
+          } else if (!(PS_ABLATE_BUILD && (p.ablate & 1u))) {
+            // one wave-wide test against the best known lower bound skips the insert logic for
+            // the (usual) chunks that cannot contribute
+            const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
+            if (__any(fmax(v.x, v.y) >= lo && (h0 || h1))) {
+              topk_offer(tk, p.K, lane, h0, v.x, d, gt);
+              topk_offer(tk, p.K, lane, h1, v.y, d + 1, gt);
+            }
+          }
+        }
+      } else {
+        // accumulators are planar ([field][T]); two documents per lane per 16-byte LDS access
+        for (uint32_t c = 0; c < T; c += 2 * WAVE) {
+          // result.score = max(score_by_pool, result.score) over fields, from the dummy 0. (zero_to_one.rs:81,122)
+          double b0 = 0.0, b1 = 0.0;
+          bool h0 = false, h1 = false;
+#pragma unroll
+          for (int x = 0; x < FA; ++x) {
+            if ((uint32_t)x < F) {
+              double2* slot = reinterpret_cast<double2*>(&acc[(uint32_t)x * T + c + 2 * lane]);
+              const double2 v = *slot;
+              if (v.x > 0.0 || v.y > 0.0) {
+                *slot = make_double2(0.0, 0.0);
+                if (TAGS) *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(tag) + (uint32_t)x * T + c + 2 * lane) = make_uint2(0u, 0u);
+              }
+              h0 |= v.x > 0.0; h1 |= v.y > 0.0;
+              b0 = fmax(v.x, b0); b1 = fmax(v.y, b1);
+            }
+          }
+          const uint32_t d = tile_base + c + 2 * lane;
+          if (FULL) {
+            full_emit(p, q, lane, h0, b0, d);
+            full_emit(p, q, lane, h1, b1, d + 1);
+          } else {
+            const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
+            if (__any((h0 && b0 >= lo) || (h1 && b1 >= lo))) {
+              topk_offer(tk, p.K, lane, h0, b0, d, gt);
+              topk_offer(tk, p.K, lane, h1, b1, d + 1, gt);
+            }
+          }
+        }
+      }
+      if (!FULL && tk.n == p.K && tk.thr_s > gt) {
+        // publish this run's K-th best: the final K-th best of the query can only be higher
+        if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+      }
+      if (TAGS && MODE == MODE_BM25) {
+        tagbase += p.max_qterms;
+        if (tagbase + p.max_qterms >= 0xFFFFu) {
+          for (uint32_t i = lane; i < T; i += WAVE) tag[i] = 0xFFFFu;
+          tagbase = 0;
+        }
+      }
+      }  // harvest
+      if (!more) break;
+    }
+#undef PS_PHASE1
+  }
+  if (!FULL && (uint32_t)lane < p.K) {
+    const uint64_t o = (uint64_t)item * p.K + lane;
+    const bool ok = (uint32_t)lane < tk.n;
+    p.cand_score[o] = ok ? tk.s : 0.0;
+    p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
+  }
+  }  // item loop
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: zero_to_one   (zero_to_one.rs:44-126)
+//
+// LDS per wave: rec[z_tile][z_nodes][F] u32 = term frequency of distinct node n in field x for
+// the tile's documents (0 = no hit).  ScoreByTerm's other members are per-entry constants in the
+// plan (score, query_term_index, node) or per-query (all_query_terms_len); field_length comes
+// with the posting and is kept in fls[z_tile][F].  Deduplicated postings are equivalent to the
+// reference's per-occurrence records (identical adjacent records: the first is either consumed,
+// after which the rest are skipped via consumed_index, or skipped for a reason that skips the
+// rest as well).  finalize per (doc, field): walk the query's entries in
+// zorder = stable sort by score desc (zero_to_one.rs:98), greedy-consume one record per query
+// term with the per-node pool (:101-120); doc score = max over fields (:122).
+// ------------------------------------------------------------------------------------------
+template <bool FULL>
+__global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t F = p.F, ZN = p.z_nodes, ZT = p.z_tile;
+  const uint32_t stride = ZN * F;
+  uint32_t* rec = reinterpret_cast<uint32_t*>(smem);  // [ZT][ZN][F] term frequencies
+  uint32_t* fls = rec + (size_t)ZT * stride;           // [ZT][F]     field lengths
+  const int lane = threadIdx.x;
+  // grid = n_general x n_super: only the queries the simple path could not take
+  const uint32_t q = p.gen_queries[blockIdx.x % p.n_general];
+  const uint32_t sup = blockIdx.x / p.n_general;
+  const uint32_t item = sup * p.B + q;  // candidate slot, as k_merge expects it
+  const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
+
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+
+  if (e0 != e1) {
+    for (uint32_t i = lane; i < ZT * stride; i += WAVE) rec[i] = 0;
+    const uint32_t qtl = p.qterms_len[q];
+    const uint32_t sub_per_tile = p.T / ZT;  // ZT is a power of two <= T
+    const uint32_t t_begin = sup * p.S;
+    const uint32_t t_end = min(p.n_tiles, t_begin + p.S);
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+      for (uint32_t sub = 0; sub < sub_per_tile; ++sub) {
+        const uint32_t tile_base = t * p.T + sub * ZT;
+        if (tile_base >= p.n_docs) break;
+        for (uint32_t e = e0; e < e1; ++e) {
+          const uint64_t post_off = p.plan[e].post_off;
+          const uint32_t tbl_off = p.plan[e].tbl_off;
+          const uint32_t shift = p.plan[e].shift & 0xFFu;
+          const uint32_t layer = p.plan[e].shift >> 8;
+          const uint32_t node = p.plan[e].node;
+          const uint32_t slot = t >> shift;
+          const uint32_t rb = p.table[tbl_off + slot];
+          const uint32_t re = p.table[tbl_off + slot + 1];
+          for (uint32_t i = rb + lane; i < re; i += WAVE) {
+            const uint64_t pi = post_off + i;
+            const uint32_t local = p.doc[pi] - tile_base;
+            if (local >= ZT) continue;  // table slot wider than this sub-tile
+            for (uint32_t x = 0; x < F; ++x) {
+              const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
+              uint32_t* r = &rec[local * stride + node * F + x];
+              // layer 0 = newest version of a re-added key; older versions only fill fields
+              // the newer ones left empty (the first record per (entry, doc, field) decides)
+              if (tfu > 0 && (layer == 0 || *r == 0)) *r = tfu;
+              fls[local * F + x] = p.fl[(uint64_t)x * p.P + pi];
+            }
+          }
+        }
+        // finalize (zero_to_one.rs:84-126): one lane per document of the sub-tile
+        for (uint32_t c = 0; c < ZT; c += WAVE) {
+          const uint32_t local = c + lane;
+          bool has = false;
+          double best = 0.0;  // the merged dummy Some(0.) (zero_to_one.rs:81,122)
+          for (uint32_t x = 0; x < F; ++x) {
+            unsigned long long consumed_q = 0ull;  // consumed_index: bit = query-term ordinal
+            unsigned long long consumed_e = 0ull;  // consumed entries: bit = position in the query
+            double pool = 0.0;                     // score_by_pool
+            bool any = false;
+            for (uint32_t z = e0; z < e1; ++z) {
+              const uint32_t e = p.zorder[z];
+              const uint32_t node = p.plan[e].node;
+              const uint32_t tfu = rec[local * stride + node * F + x];
+              if (tfu == 0) continue;  // no record for this (entry, doc, field)
+              any = true;
+              const uint32_t qt = p.plan[e].qterm;
+              if ((consumed_q >> qt) & 1ull) continue;  // :101-103
+              // df_pool_by_id (:104-113): a node may be consumed term_frequency times in total
+              const unsigned long long same_node = (unsigned long long)__double_as_longlong(p.plan[e].idf);
+              if ((uint32_t)__popcll(consumed_e & same_node) >= tfu) continue;
+              consumed_e |= 1ull << (e - e0);
+              consumed_q |= 1ull << qt;
+              const double sc = p.plan[e].boost;
+              const double df = (double)tfu;
+              const uint32_t fl = fls[local * F + x];
+              const uint32_t den = fl > qtl ? fl : qtl;  // usize::max(field_length, all_query_terms_len)
+              pool += fmin(sc / df, 1.0) * df / (double)den;  // :117-120
+            }
+            if (any) { has = true; best = fmax(pool, best); }  // :122
+          }
+          if (has)
+            for (uint32_t w = 0; w < stride; ++w) rec[local * stride + w] = 0;
+          const uint32_t d = tile_base + local;
+          if (FULL) full_emit(p, q, lane, has, best, d);
+          else topk_offer(tk, p.K, lane, has, best, d);
+        }
+      }
+    }
+  }
+  if (!FULL && (uint32_t)lane < p.K) {
+    const uint64_t o = (uint64_t)item * p.K + lane;
+    const bool ok = (uint32_t)lane < tk.n;
+    p.cand_score[o] = ok ? tk.s : 0.0;
+    p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: merge per-run top-K lists -> final top-K per query, doc id -> key   (query.rs:97-105)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_merge(const KParams p) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+  const uint32_t K = p.K;
+  // candidates of (q, sup) live at item = sup * B + q
+  const uint32_t per_round = WAVE / K;  // runs handled per 64-lane load
+  for (uint32_t s0 = 0; s0 < p.n_super; s0 += per_round) {
+    const uint32_t sup = s0 + lane / K;
+    const uint32_t k = lane % K;
+    bool has = false;
+    double v = 0.0;
+    uint32_t d = 0xFFFFFFFFu;
+    if ((uint32_t)lane < per_round * K && sup < p.n_super) {
+      const uint64_t o = ((uint64_t)sup * p.B + q) * K + k;
+      d = p.cand_doc[o];
+      v = p.cand_score[o];
+      has = d != 0xFFFFFFFFu;
+    }
+    topk_offer(tk, K, lane, has, v, d);
+  }
+  if ((uint32_t)lane < K) {
+    const bool ok = (uint32_t)lane < tk.n;
+    const uint64_t o = (uint64_t)q * K + lane;
+    p.out_keys[o] = ok ? p.keys[tk.d] : ~0ull;
+    p.out_scores[o] = ok ? tk.s : 0.0;
+  }
+  if (lane == 0) p.out_counts[q] = tk.n;
+}
+
+// Full-result mode: the first (out_off[q+1] - out_off[q]) sorted results of run q -> {key, score}.
+__global__ __launch_bounds__(256) void k_pack_results(const uint32_t* doc, const double* score, const uint64_t* run_off,
+                                                      const uint64_t* out_off, const uint64_t* keys, ps_result* out) {
+  const uint32_t q = blockIdx.x;
+  const uint64_t src = run_off[q], dst = out_off[q], n = out_off[q + 1] - out_off[q];
+  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) out[dst + i] = ps_result{keys[doc[src + i]], score[src + i]};
+}
+
+}  // namespace ps
