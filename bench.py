@@ -47,13 +47,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # debugging aid for 1-GPU boxes: every rank on device 0, collectives over gloo (exercises the
+    # N>1 code path end to end; the numbers it prints are not a multi-GPU measurement)
+    debug_1gpu = os.environ.get("PS_BENCH_DEBUG_ONE_GPU") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if debug_1gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world
-    dev = local_rank if world > 1 else 0
+    dev = local_rank if (world > 1 and not debug_1gpu) else 0
     torch.cuda.set_device(dev)
 
     cfg = dict(synth.CONFIGS[args.config])
@@ -90,13 +96,12 @@ def main():
     # marshalling inside the timed region; a Rust/C caller would hand over exactly this)
     packed = [synth.pack_queries(b) for b in batches]
 
-    d_keys = torch.zeros(B * K, dtype=torch.int64, device="cuda")
-    d_scores = torch.zeros(B * K, dtype=torch.float64, device="cuda")
-    d_counts = torch.zeros(B, dtype=torch.int32, device="cuda")
+    # one device block per rank: [B*K keys u64 | B*K scores f64 | B counts (u32, in 8-byte slots)],
+    # so the multi-GPU exchange is a single all-gather
+    block = torch.zeros(2 * B * K + B, dtype=torch.int64, device="cuda")
+    p_keys, p_scores, p_counts = block.data_ptr(), block.data_ptr() + 8 * B * K, block.data_ptr() + 16 * B * K
     if world > 1:
-        g_keys = torch.zeros(world * B * K, dtype=torch.int64, device="cuda")
-        g_scores = torch.zeros(world * B * K, dtype=torch.float64, device="cuda")
-        g_counts = torch.zeros(world * B, dtype=torch.int32, device="cuda")
+        gathered = torch.zeros(world * block.numel(), dtype=torch.int64, device="cuda")
     # a real (non-null) stream: the library then only enqueues and returns, so the host plans
     # batch s+1 while the GPU scores batch s; torch/RCCL work is ordered on the same stream
     stream = torch.cuda.Stream()
@@ -104,12 +109,10 @@ def main():
 
     def step(batch):
         text, offsets = batch
-        snap.query_batch_device_flat(text, offsets, scorer, boosts, K, d_keys.data_ptr(), d_scores.data_ptr(),
-                                     d_counts.data_ptr(), stream=stream.cuda_stream)
+        snap.query_batch_device_flat(text, offsets, scorer, boosts, K, p_keys, p_scores, p_counts,
+                                     stream=stream.cuda_stream)
         if world > 1:  # top-k all-gather over xGMI only when the batch spans >1 GPU
-            dist.all_gather_into_tensor(g_keys, d_keys)
-            dist.all_gather_into_tensor(g_scores, d_scores)
-            dist.all_gather_into_tensor(g_counts, d_counts)
+            dist.all_gather_into_tensor(gathered, block)
 
     def fence():
         if world > 1:
@@ -172,7 +175,7 @@ def main():
                 cfg["scorer"], cfg["n_docs"], F, K, B),
             "value": qps, "unit": "queries/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" [DEBUG: all ranks on one GPU]" if debug_1gpu else ""),
             "config": {"workload": "%s: %d synthetic docs, %d fields, Zipf(s=%.1f) over %d stems x %d variants, "
                                    "%d-query %s batch per GPU, %d terms/query, top-%d" % (
                                        args.config, cfg["n_docs"], F, cfg["zipf_s"], cfg["vocab"], cfg["variants"], B,
