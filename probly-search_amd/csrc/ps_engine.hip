@@ -53,14 +53,16 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;
-  void ensure(size_t n) {
-    if (n <= cap) return;
+  bool ensure(size_t n, bool zero = false) {  // true: (re)allocated
+    if (n <= cap) return false;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
     size_t want = n + n / 4 + 64;
     PS_HIP(hipMalloc((void**)&p, want * sizeof(T)));
     cap = want;
+    if (zero) PS_HIP(hipMemset(p, 0, want * sizeof(T)));
+    return true;
   }
   void release() {
     if (p) (void)hipFree(p);
@@ -72,6 +74,7 @@ struct DevBuf {
 // Pinned staging slot; `done` fences reuse so a caller-supplied stream may run ahead of the host.
 struct Stage {
   unsigned char* p = nullptr;
+  unsigned char* dp = nullptr;  // the same bytes as the device sees them (zero-copy access for tiny batches)
   size_t cap = 0;
   hipEvent_t done = nullptr;
   bool pending = false;
@@ -80,9 +83,12 @@ struct Stage {
     if (n <= cap) return;
     if (p) (void)hipHostFree(p);
     p = nullptr;
+    dp = nullptr;
     cap = 0;
     size_t want = n + n / 4 + 256;
-    PS_HIP(hipHostMalloc((void**)&p, want, hipHostMallocDefault));
+    // fine-grained (coherent) so that kernels may read / write it in place without a copy
+    PS_HIP(hipHostMalloc((void**)&p, want, hipHostMallocMapped | hipHostMallocCoherent));
+    PS_HIP(hipHostGetDevicePointer((void**)&dp, p, 0));
     cap = want;
   }
 };
@@ -127,6 +133,14 @@ struct EngineImpl {
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0;
   int next_kt = 0;
+  // control words (item counter + per-query thresholds) are left zeroed by k_merge: no memset per batch
+  bool ctl_clean = false;
+  // the saturated-tf table only depends on (k1, b) and the snapshot: built once, not per batch
+  bool lut_valid = false;
+  double lut_k1 = 0.0, lut_b = 0.0;
+  hipStream_t lut_stream = nullptr;
+  Stage* cur_stage = nullptr;   // slot of the batch being enqueued
+  bool cur_zero_copy = false;   // its plan is read in place from pinned host memory
   double kt_total_ms = 0.0;
   uint64_t kt_launches = 0;
   void harvest(KTimer& t, bool wait) {
@@ -161,7 +175,7 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
       throw std::runtime_error(std::string("built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
     m.n_cu = prop.multiProcessorCount;
-    PS_HIP(hipMalloc((void**)&m.d_work, 64));
+    PS_HIP(hipMalloc((void**)&m.d_work, 256));
     PS_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     for (auto& ev : m.ev) PS_HIP(hipEventCreate(&ev));
     for (auto& sg : m.stage) PS_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
@@ -248,8 +262,10 @@ void validate(const Snapshot& s, const ps_scorer_desc& sc, const Plan& plan) {
 }
 
 // Uploads the plan + per-query arrays through a pinned staging slot; fills the common KParams.
+//   topk_path: k_merge follows and leaves the control words zeroed again (no memset next time)
+//   sync_path: the caller waits for the stream before returning, so the slot needs no reuse fence
 void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, hipStream_t st,
-                KParams& kp) {
+                KParams& kp, bool topk_path, bool sync_path) {
   const Snapshot& s = *m.snap;
   const size_t B = plan.qbeg.size() - 1;
   const size_t ne = plan.entries.size();
@@ -403,21 +419,37 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       }
     }
   }
-  // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | zorder | qflags)
-  m.d_stage.ensure(total + 64);
-  PS_HIP(hipMemcpyAsync(m.d_stage.p, h, n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z),
-                        hipMemcpyHostToDevice, st));
-  PS_HIP(hipEventRecord(sg.done, st));
-  sg.pending = true;
+  // A tiny batch whose plans stay in SGPRs for a whole run (<= G entries per query) is read in
+  // place from the pinned slot: a few hundred bytes over PCIe per wave, in parallel, instead of a
+  // copy-engine hand-over in front of the kernel (latency path of a single query).
+  const uint32_t g_regs = (s.F == 1 || s.F == 2) ? (uint32_t)PS_G : 1u;
+  const bool zero_copy = B <= 4 && plan.max_entries <= g_regs && n_rows == 0 && n_general == 0 &&
+                         env_u32("PS_ZERO_COPY", 1);
+  const unsigned char* dbase;
+  m.cur_stage = &sg;
+  m.cur_zero_copy = zero_copy;
+  if (zero_copy) {
+    dbase = sg.dp;
+  } else {
+    // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | zorder | qflags)
+    m.d_stage.ensure(total + 64);
+    PS_HIP(hipMemcpyAsync(m.d_stage.p, h, n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z),
+                          hipMemcpyHostToDevice, st));
+    if (!sync_path) {
+      PS_HIP(hipEventRecord(sg.done, st));
+      sg.pending = true;
+    }
+    dbase = m.d_stage.p;
+  }
 
   memset(&kp, 0, sizeof(kp));
   kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys;
-  kp.plan = reinterpret_cast<const ps_plan_entry*>(m.d_stage.p + off_e);
-  kp.qbeg = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_q);
-  kp.qterms_len = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_l);
-  kp.zorder = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_z);
-  kp.qflags = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_f);
-  kp.gen_queries = reinterpret_cast<const uint32_t*>(m.d_stage.p + off_g);
+  kp.plan = reinterpret_cast<const ps_plan_entry*>(dbase + off_e);
+  kp.qbeg = reinterpret_cast<const uint32_t*>(dbase + off_q);
+  kp.qterms_len = reinterpret_cast<const uint32_t*>(dbase + off_l);
+  kp.zorder = reinterpret_cast<const uint32_t*>(dbase + off_z);
+  kp.qflags = reinterpret_cast<const uint32_t*>(dbase + off_f);
+  kp.gen_queries = reinterpret_cast<const uint32_t*>(dbase + off_g);
   {
     // bytes of the layout actually used (never claim the wider figure for a narrower stream)
     const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.n_tiles * s.T * 8 * (z ? s.F : 1u);
@@ -427,7 +459,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     for (uint32_t r = 0; r < n_rows; ++r) lb += (uint64_t)rd[r].len * (pb + 8 * (z ? s.F : 1u)) + row_bytes;
     layout_bytes = lb;
   }
-  kp.row_desc = reinterpret_cast<const RowDesc*>(m.d_stage.p + off_r);
+  kp.row_desc = reinterpret_cast<const RowDesc*>(dbase + off_r);
   kp.n_rows = n_rows;
   kp.row_planes = z ? s.F : 1u;
   kp.row_mode = z ? 1u : 0u;
@@ -436,11 +468,20 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     m.d_rows.ensure((size_t)n_rows * kp.row_planes * kp.row_stride + 16);
     kp.rows = m.d_rows.p;
   }
-  // control words, zeroed by one memset per batch: gthr[0..B) + the persistent waves' item counter
-  m.d_gthr.ensure(B + 2);
+  // control words: the persistent waves' item counter and the per-query thresholds.  k_merge
+  // zeroes them again behind itself, so a memset is only needed after a (re)allocation, a
+  // full-result batch or an error.  The counter has a cache line of its own: sharing one with
+  // threshold words cost 70 % of K1's speed (L2 atomics on the line stall the epilogues' loads of
+  // the neighbouring thresholds, and the other way round).
+  const size_t n_thr = (B << GTHR_SHIFT) + 2;
+  const bool fresh = m.d_gthr.ensure(n_thr, true);
+  kp.work_counter = m.d_work;
   kp.gthr = m.d_gthr.p;
-  kp.work_counter = reinterpret_cast<uint32_t*>(m.d_gthr.p + B + 1);
-  PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, (B + 2) * 8, st));
+  if (!(m.ctl_clean && topk_path && !fresh)) {
+    PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
+    PS_HIP(hipMemsetAsync(m.d_work, 0, 256, st));
+  }
+  m.ctl_clean = false;  // enqueue_topk sets it once k_merge is in the stream
   kp.n_simple = n_simple; kp.n_general = n_general; kp.z_masked = z_masked;
   kp.layout_bytes = layout_bytes;
   m.last_layout_bytes = layout_bytes;
@@ -528,11 +569,16 @@ void launch_rows(const KParams& kp, hipStream_t st) {
 }
 
 template <bool FULL>
-void launch_score(const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n_cu, hipStream_t st) {
+void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n_cu, hipStream_t st) {
   const uint32_t n_items = kp.B * kp.n_super;
   if (n_items == 0) return;
   if (sc.kind == PS_SCORER_BM25) {
-    if (kp.lut_rows) hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
+    // K0 runs when (k1, b) change (or the stream does: no cross-stream ordering is assumed)
+    if (kp.lut_rows && !(m.lut_valid && m.lut_k1 == sc.bm25_k1 && m.lut_b == sc.bm25_b && m.lut_stream == st &&
+                         env_u32("PS_LUT_CACHE", 1))) {
+      hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
+      m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = st;
+    }
     launch_rows(kp, st);
     launch_k_score<MODE_BM25, FULL>(kp, plan.multi_expansion, n_cu, st);
   } else {
@@ -562,12 +608,16 @@ void fill_stats(const EngineImpl& m, ps_batch_stats& st, const Snapshot& s, cons
   st.algorithmic_bytes = plan.postings * (4 + 8 * (uint64_t)s.F) + emitted * 16;
 }
 
-// Enqueue plan upload + K1/K2 + K3 on `st`, writing the final top-k to the given device buffers.
+// Enqueue plan upload + K1/K2 + K3 on `st`, writing the final top-k to the given buffers (device
+// memory, or device-mapped pinned host memory).  `sync_path`: the caller waits for `st` before it
+// returns — the latency path: no staging-slot fence, and HIP timing events only for batches of
+// >= 8 queries (two extra stream packets are a visible share of a single query's round trip).
 void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k,
-                  void* d_keys, void* d_scores, void* d_counts, hipStream_t st) {
+                  void* d_keys, void* d_scores, void* d_counts, hipStream_t st, bool sync_path) {
   const size_t B = plan.qbeg.size() - 1;
   KParams kp;
   static const bool trace = env_u32("PS_TRACE", 0) != 0;
+  static const bool time_all = env_u32("PS_TIME_ALL", 0) != 0;
   double tt = now_ms();
   auto TT = [&](const char* what) {
     if (!trace) return;
@@ -575,7 +625,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     fprintf(stderr, "[ps] %-12s %.3f ms\n", what, n - tt);
     tt = n;
   };
-  stage_plan(m, sc, boosts, plan, st, kp);
+  stage_plan(m, sc, boosts, plan, st, kp, true, sync_path);
   TT("stage_plan");
   kp.K = (uint32_t)top_k;
   const size_t n_cand = (size_t)B * kp.n_super * top_k;
@@ -587,19 +637,33 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   kp.out_keys = (uint64_t*)d_keys;
   kp.out_scores = (double*)d_scores;
   kp.out_counts = (uint32_t*)d_counts;
-  EngineImpl::KTimer& kt = m.kt[m.next_kt];
-  m.next_kt = (m.next_kt + 1) % N_KTIMER;
-  m.harvest(kt, true);
-  TT("harvest");
-  PS_HIP(hipEventRecord(kt.a, st));
-  launch_score<false>(sc, plan, kp, m.n_cu, st);
+  const bool timed = !sync_path || B >= 8 || time_all;
+  m.last_kt = nullptr;
+  EngineImpl::KTimer* kt = nullptr;
+  if (timed) {
+    kt = &m.kt[m.next_kt];
+    m.next_kt = (m.next_kt + 1) % N_KTIMER;
+    m.harvest(*kt, true);
+    TT("harvest");
+    PS_HIP(hipEventRecord(kt->a, st));
+  }
+  launch_score<false>(m, sc, plan, kp, m.n_cu, st);
   TT("launch");
-  PS_HIP(hipEventRecord(kt.b, st));
-  kt.pending = true;
-  m.last_kt = &kt;
+  if (timed) {
+    PS_HIP(hipEventRecord(kt->b, st));
+    kt->pending = true;
+    m.last_kt = kt;
+  }
   if (B) {
-    hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE), 0, st, kp);
+    // one wave per ~4 wave-wide candidate loads, at most MERGE_WAVES
+    const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));
+    hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
     PS_HIP(hipGetLastError());
+    m.ctl_clean = true;  // k_merge zeroes the control words behind itself
+  }
+  if (m.cur_zero_copy && !sync_path) {  // the kernels read the slot in place: fence it behind them
+    PS_HIP(hipEventRecord(m.cur_stage->done, st));
+    m.cur_stage->pending = true;
   }
   TT("merge");
 }
@@ -657,7 +721,7 @@ void Engine::run_device(const ps_scorer_desc& sc, const double* boosts, const Pl
   PS_HIP(hipSetDevice(m.device));
   const double t0 = now_ms();
   hipStream_t st = stream ? (hipStream_t)stream : m.stream;
-  enqueue_topk(m, sc, boosts, plan, top_k, d_keys, d_scores, d_counts, st);
+  enqueue_topk(m, sc, boosts, plan, top_k, d_keys, d_scores, d_counts, st, false);
   memset(&stats, 0, sizeof(stats));
   fill_stats(m, stats, s, plan, (uint64_t)(plan.qbeg.size() - 1) * top_k);
   if (!stream) {
@@ -683,17 +747,29 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
     PS_HIP(hipSetDevice(m.device));
     hipStream_t st = m.stream;
     const size_t nb = B * top_k;
-    // keys | scores | counts in one device block -> one D2H copy
+    // keys | scores | counts in one block.  Small result sets are written by k_merge straight
+    // into the pinned (device-mapped, coherent) download buffer; larger ones take one D2H copy.
     const size_t res_bytes = nb * 16 + B * 4;
-    m.d_out_keys.ensure(res_bytes / 8 + 2);
-    unsigned char* dres = reinterpret_cast<unsigned char*>(m.d_out_keys.p);
-    enqueue_topk(m, sc, boosts, plan, top_k, dres, dres + nb * 8, dres + nb * 16, st);
     m.result.ensure(res_bytes + 64);
+    const bool direct = res_bytes <= 16384 && env_u32("PS_ZERO_COPY", 1);
+    unsigned char* dres;
+    if (direct) {
+      dres = m.result.dp;
+    } else {
+      m.d_out_keys.ensure(res_bytes / 8 + 2);
+      dres = reinterpret_cast<unsigned char*>(m.d_out_keys.p);
+    }
+    try {
+      enqueue_topk(m, sc, boosts, plan, top_k, dres, dres + nb * 8, dres + nb * 16, st, true);
+      if (!direct && res_bytes) PS_HIP(hipMemcpyAsync(m.result.p, dres, res_bytes, hipMemcpyDeviceToHost, st));
+      sync_stream(st);
+    } catch (...) {
+      (void)hipStreamSynchronize(st);  // nothing may still be reading the staging slot
+      throw;
+    }
     uint64_t* hk = reinterpret_cast<uint64_t*>(m.result.p);
     double* hs = reinterpret_cast<double*>(m.result.p + nb * 8);
     uint32_t* hc = reinterpret_cast<uint32_t*>(m.result.p + nb * 16);
-    if (res_bytes) PS_HIP(hipMemcpyAsync(m.result.p, dres, res_bytes, hipMemcpyDeviceToHost, st));
-    sync_stream(st);
     read_kernel_times(m, stats);
     stats.d2h_ms = 0;
     size_t total = 0;
@@ -742,7 +818,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   PS_HIP(hipSetDevice(m.device));
   hipStream_t st = m.stream;
   KParams kp;
-  stage_plan(m, sc, boosts, plan, st, kp);
+  stage_plan(m, sc, boosts, plan, st, kp, false, false);
   kp.K = 1;
   m.d_full_doc.ensure(total_cap + 1);
   m.d_full_score.ensure(total_cap + 1);
@@ -762,10 +838,14 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   m.next_kt = (m.next_kt + 1) % N_KTIMER;
   m.harvest(kt, true);
   PS_HIP(hipEventRecord(kt.a, st));
-  launch_score<true>(sc, plan, kp, m.n_cu, st);
+  launch_score<true>(m, sc, plan, kp, m.n_cu, st);
   PS_HIP(hipEventRecord(kt.b, st));
   kt.pending = true;
   m.last_kt = &kt;
+  if (m.cur_zero_copy) {  // the kernel reads the staging slot in place: fence it
+    PS_HIP(hipEventRecord(m.cur_stage->done, st));
+    m.cur_stage->pending = true;
+  }
   // K4 (query.rs:97-105, "materialise + sort"): canonical order (score desc, doc id asc == key asc)
   // of every query's run, on the device (ps_sort.hip)
   if (total_cap >= 0xFFFFFFF0ull) throw std::length_error("full-result batch too large for one pass");

@@ -26,6 +26,11 @@ constexpr int WAVE = 64;
 #define PS_FU 1
 #endif
 constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
+#ifndef PS_GTHR_SHIFT
+#define PS_GTHR_SHIFT 0
+#endif
+constexpr int GTHR_SHIFT = PS_GTHR_SHIFT;  // per-query threshold words are 8 << GTHR_SHIFT bytes apart
+constexpr int MERGE_WAVES = 16;         // most waves per workgroup of K3 (the host sizes it to the candidates)
 constexpr int WG_WAVES = PS_WG_WAVES;  // waves per workgroup of K1; each wave owns its own LDS tile
 constexpr int LUT_TF = 16;   // LUT columns: term frequency 0..15
 #ifndef PS_ABLATE_BUILD
@@ -552,10 +557,21 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
   }
   uint32_t tagbase = 0;
   const uint32_t n_items = p.B * p.n_super;
+  // A grid that covers every item with its own wave (a single query: ~1000 waves that would
+  // otherwise all queue on one L2 word before doing anything) assigns them by index; otherwise
+  // items come from the shared counter.
+  const bool by_index = n_items <= gridDim.x * WGW;
+  bool first = true;
   for (;;) {
   uint32_t item = 0;
-  if (lane == 0) item = atomicAdd(p.work_counter, 1u);
-  item = __builtin_amdgcn_readfirstlane(item);
+  if (by_index) {
+    if (!first) break;
+    first = false;
+    item = blockIdx.x * WGW + (uint32_t)wave;
+  } else {
+    if (lane == 0) item = atomicAdd(p.work_counter, 1u);
+    item = __builtin_amdgcn_readfirstlane(item);
+  }
   if (item >= n_items) break;
   const uint32_t q = item % p.B;
   const uint32_t sup = item / p.B;
@@ -653,7 +669,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       if (harvest) {
       // tile epilogue: harvest + reset (two f64 per lane per LDS access where the layout allows)
       double gt = 0.0;
-      if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[(size_t)q << GTHR_SHIFT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if (MODE == MODE_BM25) {
         for (uint32_t c = 0; c < T; c += 2 * WAVE) {
           double2* slot = reinterpret_cast<double2*>(&acc[c + 2 * lane]);
@@ -708,7 +724,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       }
       if (!FULL && tk.n == p.K && tk.thr_s > gt) {
         // publish this run's K-th best: the final K-th best of the query can only be higher
-        if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+        if (lane == 0) atomicMax(&p.gthr[(size_t)q << GTHR_SHIFT], (unsigned long long)__double_as_longlong(tk.thr_s));
       }
       if (TAGS && MODE == MODE_BM25) {
         tagbase += p.max_qterms;
@@ -845,27 +861,53 @@ __global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
 // ------------------------------------------------------------------------------------------
 // K3: merge per-run top-K lists -> final top-K per query, doc id -> key   (query.rs:97-105)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_merge(const KParams p) {
-  const int lane = threadIdx.x;
+// One workgroup of MERGE_WAVES waves per query.  The n_super*K candidates are split over the
+// waves; each keeps several 64-candidate loads in flight and drops everything strictly below the
+// query's published threshold (a lower bound of its final K-th best) before the insert logic.  The
+// waves' lists meet in LDS and wave 0 folds them.  Last, the query's control words are zeroed
+// again, so the next batch needs no memset.
+__global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
+  __shared__ double sh_s[MERGE_WAVES][WAVE];
+  __shared__ uint32_t sh_d[MERGE_WAVES][WAVE];
+  __shared__ uint32_t sh_n[MERGE_WAVES];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t q = blockIdx.x;
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
   const uint32_t K = p.K;
-  // candidates of (q, sup) live at item = sup * B + q
-  const uint32_t per_round = WAVE / K;  // runs handled per 64-lane load
-  for (uint32_t s0 = 0; s0 < p.n_super; s0 += per_round) {
-    const uint32_t sup = s0 + lane / K;
-    const uint32_t k = lane % K;
-    bool has = false;
-    double v = 0.0;
-    uint32_t d = 0xFFFFFFFFu;
-    if ((uint32_t)lane < per_round * K && sup < p.n_super) {
-      const uint64_t o = ((uint64_t)sup * p.B + q) * K + k;
-      d = p.cand_doc[o];
-      v = p.cand_score[o];
-      has = d != 0xFFFFFFFFu;
+  const double gt = __longlong_as_double((long long)p.gthr[(size_t)q << GTHR_SHIFT]);
+  // candidate c of the query = (run c / K, rank c % K); run `sup` lives at item = sup * B + q
+  const uint32_t n_c = p.n_super * K;
+  const uint32_t n_waves = blockDim.x >> 6;
+  constexpr int U = 4;
+  for (uint32_t c0 = (uint32_t)wave * WAVE * U; c0 < n_c; c0 += n_waves * WAVE * U) {
+    double v[U];
+    uint32_t d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t c = c0 + u * WAVE + lane;
+      v[u] = 0.0; d[u] = 0xFFFFFFFFu;
+      if (c < n_c) {
+        const uint64_t o = ((uint64_t)(c / K) * p.B + q) * K + c % K;
+        d[u] = p.cand_doc[o];
+        v[u] = p.cand_score[o];
+      }
     }
-    topk_offer(tk, K, lane, has, v, d);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool has = d[u] != 0xFFFFFFFFu;
+      if (__any(has && v[u] >= gt)) topk_offer(tk, K, lane, has, v[u], d[u], gt);
+    }
+  }
+  sh_s[wave][lane] = tk.s;
+  sh_d[wave][lane] = tk.d;
+  if (lane == 0) sh_n[wave] = tk.n;
+  __syncthreads();
+  if (wave != 0) return;
+  for (uint32_t w = 1; w < n_waves; ++w) {
+    const bool has = (uint32_t)lane < sh_n[w];
+    topk_offer(tk, K, lane, has, sh_s[w][lane], sh_d[w][lane]);
   }
   if ((uint32_t)lane < K) {
     const bool ok = (uint32_t)lane < tk.n;
@@ -873,7 +915,11 @@ __global__ __launch_bounds__(WAVE) void k_merge(const KParams p) {
     p.out_keys[o] = ok ? p.keys[tk.d] : ~0ull;
     p.out_scores[o] = ok ? tk.s : 0.0;
   }
-  if (lane == 0) p.out_counts[q] = tk.n;
+  if (lane == 0) {
+    p.out_counts[q] = tk.n;
+    p.gthr[(size_t)q << GTHR_SHIFT] = 0ull;
+    if (q == 0) *p.work_counter = 0u;
+  }
 }
 
 // Full-result mode: the first (out_off[q+1] - out_off[q]) sorted results of run q -> {key, score}.
