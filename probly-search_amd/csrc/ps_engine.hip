@@ -273,7 +273,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const size_t off_e = 0;
   const size_t off_q = off_e + ne * sizeof(ps_plan_entry);
   const size_t off_l = off_q + (B + 1) * 4;
-  const size_t off_z = off_l + B * 4;
+  const size_t off_o = off_l + B * 4;
+  const size_t off_z = off_o + B * 4;
   const size_t off_f = off_z + ne * 4;
   const size_t off_g = off_f + B * 4;
   const size_t off_r = (off_g + B * 4 + 15) & ~(size_t)15;
@@ -287,6 +288,21 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (ne) memcpy(he, plan.entries.data(), ne * sizeof(ps_plan_entry));
   memcpy(h + off_q, plan.qbeg.data(), (B + 1) * 4);
   if (B) memcpy(h + off_l, plan.qterms_len.data(), B * 4);
+  {
+    // K1 hands out the items of a run heaviest query first (longest-processing-time order): the
+    // last items a launch hands out are then its cheapest ones, which shortens the tail where
+    // most waves have run dry while a few still chew on a head-term query
+    uint32_t* qo = reinterpret_cast<uint32_t*>(h + off_o);
+    std::vector<uint64_t> cost(B, 0);
+    for (size_t q = 0; q < B; ++q) {
+      uint64_t c = 0;
+      for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) c += plan.entries[i].len;
+      cost[q] = c;
+      qo[q] = (uint32_t)q;
+    }
+    if (env_u32("PS_LPT", 1))
+      std::stable_sort(qo, qo + B, [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+  }
   uint32_t n_rows = 0;
   uint64_t layout_bytes = 0;
   uint32_t n_simple = 0, n_general = 0, z_masked = 0;
@@ -431,7 +447,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (zero_copy) {
     dbase = sg.dp;
   } else {
-    // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | zorder | qflags)
+    // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | qorder | zorder | qflags)
     m.d_stage.ensure(total + 64);
     PS_HIP(hipMemcpyAsync(m.d_stage.p, h, n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z),
                           hipMemcpyHostToDevice, st));
@@ -447,6 +463,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.plan = reinterpret_cast<const ps_plan_entry*>(dbase + off_e);
   kp.qbeg = reinterpret_cast<const uint32_t*>(dbase + off_q);
   kp.qterms_len = reinterpret_cast<const uint32_t*>(dbase + off_l);
+  kp.qorder = reinterpret_cast<const uint32_t*>(dbase + off_o);
   kp.zorder = reinterpret_cast<const uint32_t*>(dbase + off_z);
   kp.qflags = reinterpret_cast<const uint32_t*>(dbase + off_f);
   kp.gen_queries = reinterpret_cast<const uint32_t*>(dbase + off_g);

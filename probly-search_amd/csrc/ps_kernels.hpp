@@ -55,6 +55,7 @@ struct KParams {
   const ps_plan_entry* plan;
   const uint32_t* qbeg;
   const uint32_t* qterms_len;  // zero_to_one
+  const uint32_t* qorder;      // [B] queries in the order K1 hands them out within a run (heaviest first)
   const uint32_t* gen_queries; // zero_to_one: the n_general queries k_z21 has to run
   const uint32_t* qflags;      // zero_to_one: bit 0 = "simple" query (k_score<MODE_Z21S> owns it)
   uint32_t slice_bytes;        // per-wave LDS for the table slices (0 = look ranges up in global memory)
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
     item = __builtin_amdgcn_readfirstlane(item);
   }
   if (item >= n_items) break;
-  const uint32_t q = item % p.B;
+  const uint32_t q = p.qorder[item % p.B];
   const uint32_t sup = item / p.B;
   const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
   const uint32_t ne = e1 - e0;
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
 #undef PS_PHASE1
   }
   if (!FULL && (uint32_t)lane < p.K) {
-    const uint64_t o = (uint64_t)item * p.K + lane;
+    const uint64_t o = ((uint64_t)sup * p.B + q) * p.K + lane;  // the slot K2 / K3 expect: (run, query)
     const bool ok = (uint32_t)lane < tk.n;
     p.cand_score[o] = ok ? tk.s : 0.0;
     p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;

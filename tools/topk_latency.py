@@ -22,13 +22,15 @@ for name in sys.argv[1:] or ["C1", "C2"]:
         os.environ["PS_ZERO_COPY"] = zc
         for q in qs[:20]:
             snap.query(q, sc, None, boosts, top_k=10)
-        ts, out = [], []
+        ts, out, eng = [], [], []
         for q in qs:
             t = time.perf_counter()
             r = snap.query(q, sc, None, boosts, top_k=10)
             ts.append((time.perf_counter() - t) * 1e6)
+            eng.append(snap.last_stats()["total_ms"] * 1e3)
             out.append([(x.key, x.score) for x in r])
         if ref is None:
             ref = out
-        print("%s zero_copy=%s: p50 %.1f us  p10 %.1f  p90 %.1f   identical=%s" % (
-            name, zc, np.percentile(ts, 50), np.percentile(ts, 10), np.percentile(ts, 90), out == ref), flush=True)
+        print("%s zero_copy=%s: p50 %.1f us  p10 %.1f  p90 %.1f  (inside ps_snapshot_query, plan + GPU: p50 %.1f us)  identical=%s" % (
+            name, zc, np.percentile(ts, 50), np.percentile(ts, 10), np.percentile(ts, 90), np.percentile(eng, 50),
+            out == ref), flush=True)
