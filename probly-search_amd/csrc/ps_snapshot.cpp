@@ -3,6 +3,12 @@
 #include "ps_snapshot.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -19,7 +25,21 @@ struct Frame {
 inline uint32_t utf8_len(uint32_t cp) { return cp < 0x80 ? 1 : cp < 0x800 ? 2 : cp < 0x10000 ? 3 : 4; }
 }  // namespace
 
+namespace {
+struct PhaseTimer {  // PS_TRACE=1: where the flattener's time goes
+  bool on = getenv("PS_TRACE") && *getenv("PS_TRACE") == '1';
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[ps] flatten %-10s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
+
 Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
+  PhaseTimer pt;
   F = (uint32_t)idx.fields_len();
   T = tile_docs ? tile_docs : 1024;
   if (T < 256 || T > 4096 || (T & (T - 1))) throw std::invalid_argument("tile_docs must be a power of two in [256, 4096]");
@@ -30,6 +50,33 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   if (n_tiles == 0) n_tiles = 1;
   avg.resize(F);
   for (uint32_t x = 0; x < F; ++x) avg[x] = idx.field(x).avg;
+
+  unsigned n_thr = std::thread::hardware_concurrency();
+  if (const char* e = getenv("PS_FLATTEN_THREADS")) n_thr = (unsigned)strtoul(e, nullptr, 10);
+  n_thr = std::max(1u, std::min(n_thr, 32u));
+  // body(i) for i in [0, n), in blocks of 16 handed out to a few threads
+  auto for_range = [&](size_t n, bool serial, const std::function<void(size_t)>& body) {
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex err_mu;
+    auto worker = [&]() {
+      try {
+        for (;;) {
+          const size_t b0 = next.fetch_add(16);
+          if (b0 >= n) break;
+          for (size_t o = b0; o < std::min(n, b0 + 16); ++o) body(o);
+        }
+      } catch (...) {
+        std::lock_guard<std::mutex> l(err_mu);
+        if (!err) err = std::current_exception();
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < (serial ? 1u : n_thr); ++i) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+  };
 
   // ---- dense doc ids in ascending key order ------------------------------------------------
   keys.reserve(n_docs);
@@ -42,12 +89,14 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   std::unordered_map<uint64_t, uint32_t> hashed_id;
   if (direct) direct_id.assign((size_t)max_key + 1, 0xFFFFFFFFu);
   else hashed_id.reserve((size_t)n_docs * 2);
-  for (size_t i = 0; i < keys.size(); ++i) {
+  if (!direct)
+    for (size_t i = 0; i < keys.size(); ++i) hashed_id.emplace(keys[i], (uint32_t)i);
+  for_range(keys.size(), keys.size() < 4096, [&](size_t i) {
     if (direct) direct_id[(size_t)keys[i]] = (uint32_t)i;
-    else hashed_id.emplace(keys[i], (uint32_t)i);
     const DocDetails* d = idx.doc(keys[i]);
     for (uint32_t x = 0; x < F; ++x) fl_by_doc[i * F + x] = d->field_length[x];
-  }
+  });
+  pt.mark("doc ids");
   // LUT geometry: cover field lengths 0..max_fl[x] where the row budget (64 rows = 8 KiB of LDS)
   // allows; longer documents take the inline arithmetic.
   max_fl.assign(F, 0);
@@ -117,122 +166,161 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
     }
   }
 
+  pt.mark("trie");
   // ---- postings: per term, newest-first walk -> doc-sorted layer(s) -------------------------
-  std::vector<std::vector<uint32_t>> tfv(F), flv(F);
-  std::vector<std::pair<uint32_t, uint32_t>> tmp;  // (doc id, record)
+  // Two passes over the terms, both spread over a few threads (terms are independent):
+  //   1. count the live records of every term and notice whether its walk is already doc-sorted;
+  //      the general case (keys added out of order / re-added) builds its version layers here
+  //   2. after one serial prefix sum has fixed every layer's place, write the postings and the
+  //      tile-offset tables straight into the final planes (no staging copy)
   const bool any_removed = idx.any_removed();
-  auto pad4 = [&]() {
-    while (doc.size() & 3) {
-      doc.push_back(0xFFFFFFFFu);
-      for (uint32_t x = 0; x < F; ++x) { tfv[x].push_back(0); flv[x].push_back(0); }
-    }
+  struct TermFlat {
+    uint32_t live = 0;
+    bool sorted_desc = true;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> lay;  // general case: (doc id, record) per layer
   };
-  auto emit_table = [&](LayerInfo& L) {
-    // smallest shift with slots <= max(1, len/2): <= 2 table bytes per posting overall
-    uint32_t shift = 0;
-    uint64_t want = std::max<uint64_t>(1, L.len / 2);
-    while ((((uint64_t)n_tiles - 1) >> shift) + 1 > want) ++shift;
-    uint32_t slots = ((n_tiles - 1) >> shift) + 1;
-    L.shift = shift;
-    if (table.size() + slots + 1 >= 0xFFFFFFFFull) throw std::length_error("tile-offset table exceeds 2^32 entries");
-    L.tbl_off = (uint32_t)table.size();
-    const uint32_t* d = doc.data() + L.post_off;
-    uint32_t pos = 0;
-    for (uint32_t s = 0; s < slots; ++s) {
-      uint64_t first_doc = ((uint64_t)s << shift) * T;
-      while (pos < L.len && d[pos] < first_doc) ++pos;
-      table.push_back(pos);
-    }
-    table.push_back(L.len);
-  };
+  std::vector<TermFlat> flat(terms.size());
+  auto for_terms = [&](const std::function<void(size_t)>& body) { for_range(terms.size(), terms.size() < 256, body); };
 
-  for (size_t o = 0; o < terms.size(); ++o) {
+  for_terms([&](size_t o) {
     const PostingList& pl = lists[(size_t)nodes[(size_t)term_node[o]].list];
     TermInfo& ti = terms[o];
+    TermFlat& tfl = flat[o];
     const size_t nrec = pl.keys.size();
-    tmp.clear();
-    bool sorted_desc = true;  // doc ids strictly descending while walking newest -> oldest
     uint32_t prev = 0xFFFFFFFFu;
-    for (size_t r = nrec; r-- > 0;) {
-      uint64_t key = pl.keys[r];
+    for (size_t r = nrec; r-- > 0;) {  // newest -> oldest
+      const uint64_t key = pl.keys[r];
       if (any_removed && idx.is_removed(key)) continue;  // query.rs:65, index.rs:287-293
-      uint32_t id = id_of(key);
+      const uint32_t id = id_of(key);
       if (id == 0xFFFFFFFFu) continue;
       for (uint32_t x = 0; x < F; ++x) ti.df_raw += pl.tf[r * F + x];
-      if (!tmp.empty() && id >= prev) sorted_desc = false;
+      if (tfl.live && id >= prev) tfl.sorted_desc = false;  // doc ids must strictly descend
       prev = id;
-      tmp.emplace_back(id, (uint32_t)r);
+      ++tfl.live;
     }
-    if (tmp.empty()) continue;
+    if (tfl.live == 0 || tfl.sorted_desc) return;
+    // General case (keys added out of order, or a key re-added without removal).  Per doc the
+    // distinct adjacent tf versions, newest first, become layer 0, 1, ...; the planner emits
+    // the layers as consecutive entries of the same query term, which reproduces the
+    // reference's walk: first version adds (or assigns), later ones take max (query.rs:150-164).
+    std::vector<std::pair<uint32_t, uint32_t>> tmp;
+    tmp.reserve(tfl.live);
+    for (size_t r = nrec; r-- > 0;) {
+      const uint64_t key = pl.keys[r];
+      if (any_removed && idx.is_removed(key)) continue;
+      const uint32_t id = id_of(key);
+      if (id != 0xFFFFFFFFu) tmp.emplace_back(id, (uint32_t)r);
+    }
+    std::sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& b) {
+      return a.first != b.first ? a.first < b.first : a.second > b.second;
+    });
+    for (size_t i = 0; i < tmp.size();) {
+      size_t j = i;
+      uint32_t v = 0;
+      while (j < tmp.size() && tmp[j].first == tmp[i].first) {
+        const bool same = j > i && std::equal(pl.tf.begin() + (long)((size_t)tmp[j].second * F),
+                                              pl.tf.begin() + (long)((size_t)(tmp[j].second + 1) * F),
+                                              pl.tf.begin() + (long)((size_t)tmp[j - 1].second * F));
+        if (!same) {
+          if (tfl.lay.size() <= v) tfl.lay.emplace_back();
+          tfl.lay[v].push_back(tmp[j]);
+          ++v;
+        }
+        ++j;
+      }
+      i = j;
+    }
+  });
+  pt.mark("count");
+
+  // serial: place every layer (4-aligned starts, so 16-byte vector loads never straddle lists)
+  // and its tile-offset table
+  uint64_t cursor = 0, tcursor = 0;
+  for (size_t o = 0; o < terms.size(); ++o) {
+    TermInfo& ti = terms[o];
+    TermFlat& tfl = flat[o];
+    if (tfl.live == 0) continue;
     ++n_live_terms;
     n_pointers += ti.df_raw;
     ti.first_layer = (uint32_t)layers.size();
-    auto push = [&](uint32_t id, uint32_t r) {
-      doc.push_back(id);
-      for (uint32_t x = 0; x < F; ++x) {
-        tfv[x].push_back(pl.tf[(size_t)r * F + x]);
-        flv[x].push_back(fl_by_doc[(size_t)id * F + x]);
-      }
-    };
-    if (sorted_desc) {
-      pad4();
-      LayerInfo L{doc.size(), (uint32_t)tmp.size(), 0, 0};
-      for (size_t i = tmp.size(); i-- > 0;) push(tmp[i].first, tmp[i].second);
+    ti.n_layers = tfl.sorted_desc ? 1u : (uint32_t)tfl.lay.size();
+    max_layers = std::max(max_layers, ti.n_layers);
+    for (uint32_t l = 0; l < ti.n_layers; ++l) {
+      LayerInfo L{0, 0, 0, 0};
+      L.post_off = cursor;
+      L.len = tfl.sorted_desc ? tfl.live : (uint32_t)tfl.lay[l].size();
+      cursor = (cursor + L.len + 3) & ~(uint64_t)3;
+      n_postings += L.len;
+      // smallest shift with slots <= max(1, len/2): <= 2 table bytes per posting overall
+      uint32_t shift = 0;
+      const uint64_t want = std::max<uint64_t>(1, L.len / 2);
+      while ((((uint64_t)n_tiles - 1) >> shift) + 1 > want) ++shift;
+      const uint32_t slots = ((n_tiles - 1) >> shift) + 1;
+      L.shift = shift;
+      if (tcursor + slots + 1 >= 0xFFFFFFFFull) throw std::length_error("tile-offset table exceeds 2^32 entries");
+      L.tbl_off = (uint32_t)tcursor;
+      tcursor += slots + 1;
       layers.push_back(L);
-      ti.n_layers = 1;
-    } else {
-      // General case (keys added out of order, or a key re-added without removal).  Per doc the
-      // distinct adjacent tf versions, newest first, become layer 0, 1, ...; the planner emits
-      // the layers as consecutive entries of the same query term, which reproduces the
-      // reference's walk: first version adds (or assigns), later ones take max (query.rs:150-164).
-      std::sort(tmp.begin(), tmp.end(), [](const auto& a, const auto& b) {
-        return a.first != b.first ? a.first < b.first : a.second > b.second;
-      });
-      std::vector<std::vector<std::pair<uint32_t, uint32_t>>> lay;
-      for (size_t i = 0; i < tmp.size();) {
-        size_t j = i;
-        uint32_t v = 0;
-        while (j < tmp.size() && tmp[j].first == tmp[i].first) {
-          bool same = j > i && std::equal(pl.tf.begin() + (long)((size_t)tmp[j].second * F),
-                                          pl.tf.begin() + (long)((size_t)(tmp[j].second + 1) * F),
-                                          pl.tf.begin() + (long)((size_t)tmp[j - 1].second * F));
-          if (!same) {
-            if (lay.size() <= v) lay.emplace_back();
-            lay[v].push_back(tmp[j]);
-            ++v;
-          }
-          ++j;
-        }
-        i = j;
-      }
-      for (auto& lv : lay) {
-        pad4();
-        LayerInfo L{doc.size(), (uint32_t)lv.size(), 0, 0};
-        for (auto& pr : lv) push(pr.first, pr.second);
-        layers.push_back(L);
-      }
-      ti.n_layers = (uint32_t)lay.size();
-      max_layers = std::max(max_layers, ti.n_layers);
     }
-    for (uint32_t l = 0; l < ti.n_layers; ++l) n_postings += layers[ti.first_layer + l].len;
   }
-  pad4();
-  P = doc.size();
-  if (P == 0) {  // keep planes non-empty so device pointers are always valid
-    P = 4;
-    doc.assign(4, 0xFFFFFFFFu);
-    for (uint32_t x = 0; x < F; ++x) { tfv[x].assign(4, 0); flv[x].assign(4, 0); }
-  }
-  for (LayerInfo& L : layers) emit_table(L);
-  if (table.empty()) table.push_back(0);
+  P = std::max<uint64_t>(cursor, 4);  // keep planes non-empty so device pointers are always valid
+  doc.resize(P);
   tf.resize((size_t)P * F);
   fl.resize((size_t)P * F);
-  for (uint32_t x = 0; x < F; ++x) {
-    memcpy(tf.data() + (size_t)x * P, tfv[x].data(), (size_t)P * 4);
-    memcpy(fl.data() + (size_t)x * P, flv[x].data(), (size_t)P * 4);
-    std::vector<uint32_t>().swap(tfv[x]);
-    std::vector<uint32_t>().swap(flv[x]);
+  table.resize(std::max<uint64_t>(tcursor, 1));
+  if (tcursor == 0) table[0] = 0;
+  if (cursor == 0) {
+    std::fill(doc.begin(), doc.end(), 0xFFFFFFFFu);
+    std::fill(tf.begin(), tf.end(), 0u);
+    std::fill(fl.begin(), fl.end(), 0u);
   }
+  pt.mark("place");
+
+  for_terms([&](size_t o) {
+    const TermInfo& ti = terms[o];
+    const TermFlat& tfl = flat[o];
+    if (tfl.live == 0) return;
+    const PostingList& pl = lists[(size_t)nodes[(size_t)term_node[o]].list];
+    for (uint32_t l = 0; l < ti.n_layers; ++l) {
+      const LayerInfo& L = layers[ti.first_layer + l];
+      uint32_t* d = doc.data() + L.post_off;
+      auto put = [&](uint64_t at, uint32_t id, uint32_t r) {
+        d[at] = id;
+        for (uint32_t x = 0; x < F; ++x) {
+          tf[(size_t)x * P + L.post_off + at] = pl.tf[(size_t)r * F + x];
+          fl[(size_t)x * P + L.post_off + at] = fl_by_doc[(size_t)id * F + x];
+        }
+      };
+      if (tfl.sorted_desc) {
+        // the newest -> oldest walk descends in doc id: fill from the back
+        uint64_t at = L.len;
+        for (size_t r = pl.keys.size(); r-- > 0;) {
+          const uint64_t key = pl.keys[r];
+          if (any_removed && idx.is_removed(key)) continue;
+          const uint32_t id = id_of(key);
+          if (id == 0xFFFFFFFFu) continue;
+          put(--at, id, (uint32_t)r);
+        }
+      } else {
+        for (size_t i = 0; i < tfl.lay[l].size(); ++i) put(i, tfl.lay[l][i].first, tfl.lay[l][i].second);
+      }
+      for (uint64_t at = L.len; at < ((L.len + 3) & ~(uint64_t)3); ++at) {  // pad postings match nothing
+        d[at] = 0xFFFFFFFFu;
+        for (uint32_t x = 0; x < F; ++x) { tf[(size_t)x * P + L.post_off + at] = 0; fl[(size_t)x * P + L.post_off + at] = 0; }
+      }
+      // tile-offset table: first posting of every (group of) tile(s), + the end
+      const uint32_t slots = ((n_tiles - 1) >> L.shift) + 1;
+      uint32_t pos = 0;
+      for (uint32_t sl = 0; sl < slots; ++sl) {
+        const uint64_t first_doc = ((uint64_t)sl << L.shift) * T;
+        while (pos < L.len && d[pos] < first_doc) ++pos;
+        table[L.tbl_off + sl] = pos;
+      }
+      table[L.tbl_off + slots] = L.len;
+    }
+  });
+  { std::vector<TermFlat>().swap(flat); }
+  pt.mark("planes");
 }
 
 // ---- on-disk snapshot ---------------------------------------------------------------------------
@@ -247,17 +335,17 @@ struct File {
   ~File() { if (f) fclose(f); }
   void put(const void* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) throw std::runtime_error("snapshot write failed"); }
   void get(void* p, size_t n) { if (n && fread(p, 1, n, f) != n) throw std::invalid_argument("snapshot file truncated"); }
-  template <typename V> void put_vec(const std::vector<V>& v) {
+  template <typename Vec> void put_vec(const Vec& v) {
     uint64_t n = v.size();
     put(&n, 8);
-    put(v.data(), n * sizeof(V));
+    put(v.data(), n * sizeof(typename Vec::value_type));
   }
-  template <typename V> void get_vec(std::vector<V>& v) {
+  template <typename Vec> void get_vec(Vec& v) {
     uint64_t n = 0;
     get(&n, 8);
-    if (n > (1ull << 40) / sizeof(V)) throw std::invalid_argument("snapshot file corrupt");
+    if (n > (1ull << 40) / sizeof(typename Vec::value_type)) throw std::invalid_argument("snapshot file corrupt");
     v.resize((size_t)n);
-    get(v.data(), n * sizeof(V));
+    get(v.data(), n * sizeof(typename Vec::value_type));
   }
 };
 }  // namespace

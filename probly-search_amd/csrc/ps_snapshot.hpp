@@ -18,6 +18,8 @@
 #include <cstdint>
 #include <string>
 #include <string_view>
+#include <memory>
+#include <utility>
 #include <vector>
 
 #include "ps_index.hpp"
@@ -54,6 +56,18 @@ struct Plan {
   bool multi_expansion = false;        // some query term owns >1 entry -> visited tags needed
 };
 
+// Plane storage: resize() leaves new elements uninitialised, so the flattener's worker threads
+// take the first-touch page faults in parallel instead of one serial zero-fill of ~1 GB.
+template <typename T>
+struct DefaultInitAllocator : std::allocator<T> {
+  template <typename U> struct rebind { using other = DefaultInitAllocator<U>; };
+  DefaultInitAllocator() = default;
+  template <typename U> DefaultInitAllocator(const DefaultInitAllocator<U>&) {}
+  template <typename U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+  template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+using PlaneVec = std::vector<uint32_t, DefaultInitAllocator<uint32_t>>;
+
 class Snapshot {
  public:
   Snapshot(const Index& idx, uint32_t tile_docs);
@@ -75,7 +89,7 @@ class Snapshot {
   std::vector<uint32_t> fchar, fchild;
   // CSR planes (host copy)
   uint64_t P = 0;  // padded plane length
-  std::vector<uint32_t> doc, tf, fl, table;
+  PlaneVec doc, tf, fl, table;
   uint64_t n_postings = 0, n_pointers = 0, n_live_terms = 0;
   uint32_t max_layers = 1;
   uint64_t src_epoch = 0;

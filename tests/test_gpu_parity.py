@@ -218,6 +218,35 @@ def test_dense_rows_path_forced(seed, monkeypatch):
             assert_same([tuple(r) for r in t], exp[:5], (seed, name, q, "dense-top5"))
 
 
+@pytest.mark.parametrize("zero_copy", ["1", "0"])
+def test_latency_path_small_batches(zero_copy, monkeypatch):
+    """The single-query / tiny-batch path: plan read in place from pinned memory, results written
+    straight to pinned memory, no memset between batches (K3 leaves the control words clean),
+    BM25 table reused until (k1, b) change.  Batches of 1..6 queries (the in-place threshold is 4),
+    scorers and parameters alternating from call to call, top-k and full results interleaved."""
+    monkeypatch.setenv("PS_ZERO_COPY", zero_copy)
+    F, steps, vocab = build_script(911, n_docs=2500, fields=2, vocab_size=60)
+    o, p = orc.Index(F), ProductIndex(F)
+    replay(steps, F, o, p)
+    snap = p.idx.snapshot(device=0, tile_docs=256)
+    boosts = [1.5, 0.75]
+    queries = random_queries(5, vocab, n=36) + ["", "zzzz"]
+    variants = [("bm25", {}), ("zero_to_one", {}), ("bm25", {"k1": 2.0, "b": 0.1}), ("bm25", {}),
+                ("bm25", {"k1": 0.5, "b": 1.0})]
+    call = 0
+    for nb in (1, 2, 3, 4, 5, 6, 1, 1):
+        for start in range(0, len(queries) - nb, 7):
+            name, kw = variants[call % len(variants)]
+            call += 1
+            qs = queries[start:start + nb]
+            sc = product_scorer(name, **kw)
+            k = (3, 10, 0)[call % 3]
+            got = snap.query_batch(qs, sc, None, boosts, top_k=k) if nb > 1 else [snap.query(qs[0], sc, None, boosts, top_k=k)]
+            for q, g in zip(qs, got):
+                exp = o.query(q, oracle_scorer(name, **kw), boosts)
+                assert_same([tuple(r) for r in g], exp[:k] if k else exp, (zero_copy, nb, name, kw, q, k))
+
+
 def test_wide_prefix_expansion_many_entries():
     """A 1-2 character prefix expanding to hundreds of indexed terms: plans far larger than the
     register-resident group size, table slices disabled (too many entries for LDS), visited-tag

@@ -127,3 +127,27 @@ def test_snapshot_save_load_roundtrip(tmp_path):
         f.write(b"XXXX")
     with pytest.raises(psa.PsError):
         psa.Snapshot.load(path, device=-1)
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_parallel_flattener_is_deterministic(shuffle, tmp_path, monkeypatch):
+    """The flattener spreads the terms over threads (two passes around one serial prefix sum):
+    1 thread and many threads must produce the same bytes, for doc-sorted lists and for the
+    general layered case (shuffled keys, re-adds), and the result must score like the oracle."""
+    F, steps, vocab = build_script(77, n_docs=700, fields=2, vocab_size=900, shuffle_keys=shuffle)
+    o, p = orc.Index(F), ProductIndex(F)
+    replay(steps, F, o, p)
+    blobs = []
+    for threads in ("1", "7"):
+        monkeypatch.setenv("PS_FLATTEN_THREADS", threads)
+        snap = p.idx.snapshot(device=-1, tile_docs=256)
+        assert snap.info()["n_terms"] >= 256  # large enough for the threaded path
+        path = str(tmp_path / ("snap%s.bin" % threads))
+        snap.save(path)
+        blobs.append(open(path, "rb").read())
+    assert blobs[0] == blobs[1]
+    for q in random_queries(3, vocab, n=12):
+        for name in ("bm25", "zero_to_one"):
+            exp = o.query(q, getattr(orc, name)(), [1.0, 1.0])
+            got = emulate(snap, getattr(psa, name).new(), q, [1.0, 1.0])
+            assert [k for k, _ in got] == [k for k, _ in exp], (q, name)
