@@ -93,6 +93,28 @@ struct Stage {
   }
 };
 
+// Tuning knobs, read from the environment once per engine (a getenv per knob per batch is a
+// measurable share of a single query's round trip).
+struct Tuning {
+  uint32_t dense_max_rows = 64;  // PS_DENSE_MAX_ROWS
+  uint32_t lpt = 1;  // PS_LPT
+  uint32_t z21_general_only = 0;  // PS_Z21_GENERAL_ONLY
+  uint32_t dense_min_uses = 4;  // PS_DENSE_MIN_USES
+  uint32_t dense_min_density_pct = 25;  // PS_DENSE_MIN_DENSITY_PCT
+  uint32_t dense_max_mb = 4096;  // PS_DENSE_MAX_MB
+  uint32_t zero_copy = 1;  // PS_ZERO_COPY
+  uint32_t ablate = 0;  // PS_ABLATE
+  uint32_t lut = 1;  // PS_LUT
+  uint32_t target_items = 65536;  // PS_TARGET_ITEMS
+  uint32_t tiles_per_run = 0;  // PS_TILES_PER_RUN
+  uint32_t slices = 1;  // PS_SLICES
+  uint32_t wg8 = 1;  // PS_WG8
+  uint32_t lut_cache = 1;  // PS_LUT_CACHE
+  uint32_t z21_lds = 20480;  // PS_Z21_LDS
+  uint32_t full_budget_mb = 4096;  // PS_FULL_BUDGET_MB
+  void load();
+};
+
 constexpr int N_STAGE = 4;
 constexpr int N_KTIMER = 32;
 
@@ -109,6 +131,7 @@ struct EngineImpl {
   double* d_lut = nullptr;
   uint32_t* d_work = nullptr;
   int n_cu = 256;
+  Tuning tune;
   uint64_t bytes = 0;
   std::mutex mu;
   // per-batch device buffers (grow-only; reuse is ordered by the stream)
@@ -175,6 +198,7 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
       throw std::runtime_error(std::string("built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
     m.n_cu = prop.multiProcessorCount;
+    m.tune.load();
     PS_HIP(hipMalloc((void**)&m.d_work, 256));
     PS_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     for (auto& ev : m.ev) PS_HIP(hipEventCreate(&ev));
@@ -254,6 +278,28 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
   if (!v || !*v) return dflt;
   return (uint32_t)strtoul(v, nullptr, 10);
 }
+}  // namespace
+
+void Tuning::load() {
+    dense_max_rows = env_u32("PS_DENSE_MAX_ROWS", dense_max_rows);
+    lpt = env_u32("PS_LPT", lpt);
+    z21_general_only = env_u32("PS_Z21_GENERAL_ONLY", z21_general_only);
+    dense_min_uses = env_u32("PS_DENSE_MIN_USES", dense_min_uses);
+    dense_min_density_pct = env_u32("PS_DENSE_MIN_DENSITY_PCT", dense_min_density_pct);
+    dense_max_mb = env_u32("PS_DENSE_MAX_MB", dense_max_mb);
+    zero_copy = env_u32("PS_ZERO_COPY", zero_copy);
+    ablate = env_u32("PS_ABLATE", ablate);
+    lut = env_u32("PS_LUT", lut);
+    target_items = env_u32("PS_TARGET_ITEMS", target_items);
+    tiles_per_run = env_u32("PS_TILES_PER_RUN", tiles_per_run);
+    slices = env_u32("PS_SLICES", slices);
+    wg8 = env_u32("PS_WG8", wg8);
+    lut_cache = env_u32("PS_LUT_CACHE", lut_cache);
+    z21_lds = env_u32("PS_Z21_LDS", z21_lds);
+    full_budget_mb = env_u32("PS_FULL_BUDGET_MB", full_budget_mb);
+}
+
+namespace {
 
 void validate(const Snapshot& s, const ps_scorer_desc& sc, const Plan& plan) {
   if (s.F > (uint32_t)MAX_F) throw std::length_error("the GPU path supports at most 8 fields");
@@ -278,7 +324,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const size_t off_f = off_z + ne * 4;
   const size_t off_g = off_f + B * 4;
   const size_t off_r = (off_g + B * 4 + 15) & ~(size_t)15;
-  const size_t max_rows = env_u32("PS_DENSE_MAX_ROWS", 64);
+  const size_t max_rows = m.tune.dense_max_rows;
   const size_t total = off_r + max_rows * sizeof(RowDesc);
   Stage& sg = m.stage[m.next_stage];
   m.next_stage = (m.next_stage + 1) % N_STAGE;
@@ -300,7 +346,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       cost[q] = c;
       qo[q] = (uint32_t)q;
     }
-    if (env_u32("PS_LPT", 1))
+    if (m.tune.lpt)
       std::stable_sort(qo, qo + B, [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
   }
   uint32_t n_rows = 0;
@@ -348,7 +394,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       // the simple path keeps F f64 accumulators per document of the tile in LDS
       if ((size_t)WG_WAVES * ((size_t)s.T * s.F * 8 + 4096) > 160 * 1024) simple = false;
       if (masked && (size_t)WG_WAVES * ((size_t)s.T * s.F * 12 + 4096) > 160 * 1024) simple = false;
-      if (env_u32("PS_Z21_GENERAL_ONLY", 0)) simple = false;
+      if (m.tune.z21_general_only) simple = false;
       qf[q] = simple ? 1u : 0u;
       if (!simple) masked = false;
       if (simple) {
@@ -378,8 +424,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       for (uint32_t x = 0; x < s.F && sane; ++x)
         sane = std::isfinite(boosts[x]) && boosts[x] > 0.0 && std::isfinite(s.avg[x]) && s.avg[x] > 0.0;
     }
-    const uint32_t min_uses = env_u32("PS_DENSE_MIN_USES", 4);
-    const double min_density = env_u32("PS_DENSE_MIN_DENSITY_PCT", 25) / 100.0;
+    const uint32_t min_uses = m.tune.dense_min_uses;
+    const double min_density = m.tune.dense_min_density_pct / 100.0;
     const uint32_t planes = z ? s.F : 1u;
     if (sane && ne) {
       struct Key { uint64_t post_off, w, k3; };
@@ -409,7 +455,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
         if (kv.second.uses >= min_uses) hot.emplace_back((uint64_t)kv.second.uses * kv.second.len, kv.first);
       std::sort(hot.begin(), hot.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
       const uint64_t row_bytes = (uint64_t)s.n_tiles * s.T * 8 * planes;
-      const uint64_t mem_cap = (uint64_t)env_u32("PS_DENSE_MAX_MB", 4096) << 20;
+      const uint64_t mem_cap = (uint64_t)m.tune.dense_max_mb << 20;
       while (hot.size() > max_rows || hot.size() * row_bytes > mem_cap) hot.pop_back();
       if (!hot.empty()) {
         RowDesc* rd = reinterpret_cast<RowDesc*>(h + off_r);
@@ -440,7 +486,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   // copy-engine hand-over in front of the kernel (latency path of a single query).
   const uint32_t g_regs = (s.F == 1 || s.F == 2) ? (uint32_t)PS_G : 1u;
   const bool zero_copy = B <= 4 && plan.max_entries <= g_regs && n_rows == 0 && n_general == 0 &&
-                         env_u32("PS_ZERO_COPY", 1);
+                         m.tune.zero_copy;
   const unsigned char* dbase;
   m.cur_stage = &sg;
   m.cur_zero_copy = zero_copy;
@@ -506,21 +552,21 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.P = s.P;
   kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
   kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
-  kp.ablate = env_u32("PS_ABLATE", 0);
+  kp.ablate = m.tune.ablate;
   kp.k1 = sc.bm25_k1; kp.b = sc.bm25_b;
   kp.k1p1 = sc.bm25_k1 + 1.0;        // (self.bm25k1 + 1_f64), bm25.rs:78 — same IEEE add on the host
   kp.one_minus_b = 1.0 - sc.bm25_b;  // (1_f64 - self.bm25b),  bm25.rs:80
   for (uint32_t x = 0; x < s.F; ++x) { kp.avg[x] = s.avg[x]; kp.boost[x] = boosts[x]; }
-  if (sc.kind == PS_SCORER_BM25 && env_u32("PS_LUT", 1)) {
+  if (sc.kind == PS_SCORER_BM25 && m.tune.lut) {
     kp.lut = m.d_lut;
     kp.lut_rows = s.lut_rows;
     kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;  // odd stride; LUT bytes = stride*128, so tiles stay 16-B aligned
     for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
   }
   // work decomposition: one wave per (query, run of S tiles)
-  const uint64_t target = env_u32("PS_TARGET_ITEMS", 65536);
+  const uint64_t target = m.tune.target_items;
   uint64_t S = ((uint64_t)s.n_tiles * std::max<size_t>(B, 1) + target - 1) / target;
-  const uint32_t s_env = env_u32("PS_TILES_PER_RUN", 0);
+  const uint32_t s_env = m.tune.tiles_per_run;
   if (s_env) S = s_env;
   if (S < 1) S = 1;
   if (S > s.n_tiles) S = s.n_tiles;
@@ -529,7 +575,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.n_super = (uint32_t)((s.n_tiles + S - 1) / S);
   // per-wave LDS for the table slices: [entry][rb|re][S] u32; fall back to global lookups if large
   const size_t slice = (((size_t)plan.max_entries * 2 * S * 4) + 15) & ~(size_t)15;
-  kp.slice_bytes = (slice <= 4096 && env_u32("PS_SLICES", 1)) ? (uint32_t)slice : 0u;
+  kp.slice_bytes = (slice <= 4096 && m.tune.slices) ? (uint32_t)slice : 0u;
 }
 
 void allow_lds(const void* fn, size_t lds) {
@@ -539,7 +585,7 @@ void allow_lds(const void* fn, size_t lds) {
 }
 
 template <int MODE, bool FULL>
-void launch_k_score(KParams& kp, bool tags, int n_cu, hipStream_t st) {
+void launch_k_score(const Tuning& tune, KParams& kp, bool tags, int n_cu, hipStream_t st) {
   const uint32_t n_items = kp.B * kp.n_super;
   const uint32_t aw = MODE == MODE_Z21S ? kp.F : 1u;
   const size_t lut_b = MODE == MODE_BM25 ? (size_t)kp.lut_stride * LUT_TF * 8 : 0;
@@ -547,7 +593,7 @@ void launch_k_score(KParams& kp, bool tags, int n_cu, hipStream_t st) {
                         kp.slice_bytes;
   // Workgroups of 8 waves share one LUT copy: two of them (16 waves) fit a CU's 160 KiB when a
   // wave's tile is small enough; otherwise 4-wave workgroups pack the LDS better.
-  const bool wide = !FULL && lut_b + 8 * wave_b <= 80 * 1024 && env_u32("PS_WG8", 1);
+  const bool wide = !FULL && lut_b + 8 * wave_b <= 80 * 1024 && tune.wg8;
   const uint32_t wgw = wide ? 8u : (uint32_t)WG_WAVES;
   uint32_t n_wg = (n_items + wgw - 1) / wgw;
   const size_t lds = lut_b + wgw * wave_b;
@@ -592,21 +638,21 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
   if (sc.kind == PS_SCORER_BM25) {
     // K0 runs when (k1, b) change (or the stream does: no cross-stream ordering is assumed)
     if (kp.lut_rows && !(m.lut_valid && m.lut_k1 == sc.bm25_k1 && m.lut_b == sc.bm25_b && m.lut_stream == st &&
-                         env_u32("PS_LUT_CACHE", 1))) {
+                         m.tune.lut_cache)) {
       hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
       m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = st;
     }
     launch_rows(kp, st);
-    launch_k_score<MODE_BM25, FULL>(kp, plan.multi_expansion, n_cu, st);
+    launch_k_score<MODE_BM25, FULL>(m.tune, kp, plan.multi_expansion, n_cu, st);
   } else {
     launch_rows(kp, st);
-    if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(kp, kp.z_masked != 0, n_cu, st);
+    if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(m.tune, kp, kp.z_masked != 0, n_cu, st);
     if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
       kp.z_nodes = std::max<uint32_t>(1, plan.max_nodes);
       const uint32_t per_doc = (kp.z_nodes * kp.F + kp.F) * 4;
       uint32_t zt = kp.T;
-      const uint32_t budget = env_u32("PS_Z21_LDS", 20480);
+      const uint32_t budget = m.tune.z21_lds;
       while (zt > (uint32_t)WAVE && (size_t)zt * per_doc > budget) zt >>= 1;
       if ((size_t)zt * per_doc > 65536) throw std::length_error("zero_to_one: fields x expanded terms exceed the LDS tile");
       kp.z_tile = zt;
@@ -768,7 +814,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
     // into the pinned (device-mapped, coherent) download buffer; larger ones take one D2H copy.
     const size_t res_bytes = nb * 16 + B * 4;
     m.result.ensure(res_bytes + 64);
-    const bool direct = res_bytes <= 16384 && env_u32("PS_ZERO_COPY", 1);
+    const bool direct = res_bytes <= 16384 && m.tune.zero_copy;
     unsigned char* dres;
     if (direct) {
       dres = m.result.dp;
@@ -809,7 +855,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
     cap[q + 1] = cap[q] + std::min<uint64_t>(sum, s.n_docs);
   }
   const uint64_t total_cap = cap[B];
-  const uint64_t budget = (uint64_t)env_u32("PS_FULL_BUDGET_MB", 4096) << 20;
+  const uint64_t budget = (uint64_t)m.tune.full_budget_mb << 20;
   if (total_cap * 12 > budget && B > 1) {
     // keep the result buffers bounded: run the two halves of the batch one after the other
     const size_t half = B / 2;

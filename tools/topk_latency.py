@@ -13,13 +13,13 @@ for name in sys.argv[1:] or ["C1", "C2"]:
     F = cfg["fields"]
     c = synth.Corpus(**cfg)
     idx = synth.fill(psa.Index(F), c)
-    snap = idx.snapshot(device=0)
     qs = c.queries(300, cfg["q_terms"])
     sc = psa.bm25.new()
     boosts = [1.0] * F
     ref = None
     for zc in ("0", "1"):
-        os.environ["PS_ZERO_COPY"] = zc
+        os.environ["PS_ZERO_COPY"] = zc  # knobs are read once per engine: a fresh snapshot per mode
+        snap = idx.snapshot(device=0)
         for q in qs[:20]:
             snap.query(q, sc, None, boosts, top_k=10)
         ts, out, eng = [], [], []
