@@ -163,7 +163,9 @@ ps_status ps_snapshot_query_batch(ps_snapshot* snap, const ps_scorer_desc* score
  * all-gather them over RCCL.  d_keys: u64[B*top_k], d_scores: f64[B*top_k], d_counts: u32[B]
  * (device pointers on the snapshot's device; unused slots are key=~0, score=0).  `hip_stream`
  * is a hipStream_t (NULL = the snapshot's own stream); the call returns after enqueueing when a
- * stream is given and all work is ordered on it.  1 <= top_k <= PS_MAX_DEVICE_TOPK. */
+ * stream is given and all work is ordered on it.  Batches of one snapshot execute one after the
+ * other even when they are enqueued on different streams (they share the snapshot's per-batch
+ * device buffers; the library orders them with an event).  1 <= top_k <= PS_MAX_DEVICE_TOPK. */
 #define PS_MAX_DEVICE_TOPK 64
 ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc* scorer, const ps_str* queries,
                                          size_t n_queries, const double* fields_boost, size_t n_boost,

@@ -162,6 +162,11 @@ struct EngineImpl {
   bool lut_valid = false;
   double lut_k1 = 0.0, lut_b = 0.0;
   hipStream_t lut_stream = nullptr;
+  // Batches share the per-batch device buffers, so they execute one after the other.  On one
+  // stream that is stream order; a batch enqueued on another stream first waits for `tail`, the
+  // event behind the previous asynchronous batch.
+  hipStream_t tail_stream = nullptr;
+  bool tail_pending = false;
   Stage* cur_stage = nullptr;   // slot of the batch being enqueued
   bool cur_zero_copy = false;   // its plan is read in place from pinned host memory
   double kt_total_ms = 0.0;
@@ -688,6 +693,8 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     fprintf(stderr, "[ps] %-12s %.3f ms\n", what, n - tt);
     tt = n;
   };
+  if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
+  m.tail_pending = false;
   stage_plan(m, sc, boosts, plan, st, kp, true, sync_path);
   TT("stage_plan");
   kp.K = (uint32_t)top_k;
@@ -727,6 +734,11 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   if (m.cur_zero_copy && !sync_path) {  // the kernels read the slot in place: fence it behind them
     PS_HIP(hipEventRecord(m.cur_stage->done, st));
     m.cur_stage->pending = true;
+  }
+  if (!sync_path) {  // a synchronous caller leaves nothing in flight
+    PS_HIP(hipEventRecord(m.ev[0], st));
+    m.tail_stream = st;
+    m.tail_pending = true;
   }
   TT("merge");
 }
@@ -881,6 +893,8 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   PS_HIP(hipSetDevice(m.device));
   hipStream_t st = m.stream;
   KParams kp;
+  if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
+  m.tail_pending = false;
   stage_plan(m, sc, boosts, plan, st, kp, false, false);
   kp.K = 1;
   m.d_full_doc.ensure(total_cap + 1);

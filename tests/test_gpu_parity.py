@@ -158,6 +158,41 @@ def test_deterministic_and_device_topk_buffers():
             assert int(hk[i, k]) == r.key and bits(float(hs[i, k])) == bits(r.score)
 
 
+def test_batches_on_different_streams_are_ordered():
+    """Batches share the engine's per-batch device buffers; enqueued back to back on different
+    caller streams (and mixed with synchronous host calls) they must still come out right."""
+    import torch
+    cfg = dict(synth.CONFIGS["C2"], n_docs=120_000, vocab=3_000)
+    corpus = synth.Corpus(**cfg)
+    snap = synth.fill(psa.Index(2), corpus).snapshot(device=0)
+    K, B, rounds = 10, 256, 6
+    batches = [corpus.queries(B, 3, salt=r) for r in range(rounds)]
+    expect = [snap.query_batch(b, psa.bm25.new(), None, [1.0, 1.0], top_k=K) for b in batches]
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(3)]
+    outs = []
+    for r, b in enumerate(batches):
+        dk = torch.zeros(B * K, dtype=torch.int64, device="cuda:0")
+        ds = torch.zeros(B * K, dtype=torch.float64, device="cuda:0")
+        dc = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        outs.append((dk, ds, dc))
+    for r, b in enumerate(batches):  # no host synchronisation between the enqueues
+        dk, ds, dc = outs[r]
+        snap.query_batch_device(b, psa.bm25.new(), None, [1.0, 1.0], K, dk.data_ptr(), ds.data_ptr(), dc.data_ptr(),
+                                stream=streams[r % 3].cuda_stream)
+        if r == 3:  # a synchronous call on the engine's own stream in the middle
+            mid = snap.query_batch(batches[0], psa.bm25.new(), None, [1.0, 1.0], top_k=K)
+            assert mid == expect[0]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        dk, ds, dc = outs[r]
+        hk, hs, hc = dk.cpu().view(B, K), ds.cpu().view(B, K), dc.cpu()
+        for i, res in enumerate(expect[r]):
+            assert int(hc[i]) == len(res), (r, i)
+            for k, x in enumerate(res):
+                assert int(hk[i, k]) == x.key and bits(float(hs[i, k])) == bits(x.score), (r, i, k)
+
+
 def test_full_size_properties_c2_slice():
     """Size-independent properties on a larger index (no oracle): top-k is a prefix of the full
     list, full list is sorted canonically, scores of a 1-term query are invariant to batching."""
