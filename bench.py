@@ -97,30 +97,42 @@ def main():
     packed = [synth.pack_queries(b) for b in batches]
 
     # one device block per rank: [B*K keys u64 | B*K scores f64 | B counts (u32, in 8-byte slots)],
-    # so the multi-GPU exchange is a single all-gather
-    block = torch.zeros(2 * B * K + B, dtype=torch.int64, device="cuda")
-    p_keys, p_scores, p_counts = block.data_ptr(), block.data_ptr() + 8 * B * K, block.data_ptr() + 16 * B * K
+    # so the multi-GPU exchange is a single all-gather.  Two blocks alternate: the all-gather of
+    # step s runs on RCCL's stream while the GPU already scores step s+1 into the other block.
+    n_blk = 2 if world > 1 else 1
+    blocks = [torch.zeros(2 * B * K + B, dtype=torch.int64, device="cuda") for _ in range(n_blk)]
     if world > 1:
-        gathered = torch.zeros(world * block.numel(), dtype=torch.int64, device="cuda")
+        gathered = [torch.zeros(world * blocks[0].numel(), dtype=torch.int64, device="cuda") for _ in range(n_blk)]
+    works = [None] * n_blk
     # a real (non-null) stream: the library then only enqueues and returns, so the host plans
-    # batch s+1 while the GPU scores batch s; torch/RCCL work is ordered on the same stream
+    # batch s+1 while the GPU scores batch s; torch/RCCL work is ordered against the same stream
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
 
-    def step(batch):
+    def step(batch, i):
         text, offsets = batch
-        snap.query_batch_device_flat(text, offsets, scorer, boosts, K, p_keys, p_scores, p_counts,
+        slot = i % n_blk
+        if works[slot] is not None:  # the block's previous all-gather must have read it
+            works[slot].wait()
+            works[slot] = None
+        block = blocks[slot]
+        base = block.data_ptr()
+        snap.query_batch_device_flat(text, offsets, scorer, boosts, K, base, base + 8 * B * K, base + 16 * B * K,
                                      stream=stream.cuda_stream)
         if world > 1:  # top-k all-gather over xGMI only when the batch spans >1 GPU
-            dist.all_gather_into_tensor(gathered, block)
+            works[slot] = dist.all_gather_into_tensor(gathered[slot], block, async_op=True)
 
     def fence():
+        for slot in range(n_blk):
+            if works[slot] is not None:
+                works[slot].wait()
+                works[slot] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
-        step(packed[s])
+        step(packed[s], s)
     fence()
     snap.kernel_times(reset=True)
     postings = 0
@@ -131,7 +143,7 @@ def main():
     t_start = time.perf_counter()
     for s in range(args.warmup, n_total):
         ts = time.perf_counter()
-        step(packed[s])
+        step(packed[s], s)
         st = snap.last_stats()
         postings += st["postings_visited"]
         layout_bytes += st["layout_bytes"]
@@ -142,6 +154,10 @@ def main():
     elapsed = time.perf_counter() - t_start
     k_total_ms, k_launches = snap.kernel_times(reset=False)
     if world > 1:
+        # the exchange really happened: this rank's slice of the last gathered buffer is its own block
+        last = (n_total - 1) % n_blk
+        n_el = blocks[last].numel()
+        assert torch.equal(gathered[last][rank * n_el:(rank + 1) * n_el], blocks[last]), "all-gather mismatch"
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
