@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdint>
 
 #include "../../include/probly_search_amd.h"
@@ -26,6 +28,9 @@ constexpr int WAVE = 64;
 #define PS_FU 1
 #endif
 constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
+#ifndef PS_HARVEST_UNROLL
+#define PS_HARVEST_UNROLL 4
+#endif
 #ifndef PS_GTHR_SHIFT
 #define PS_GTHR_SHIFT 0
 #endif
@@ -672,25 +677,37 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       double gt = 0.0;
       if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[(size_t)q << GTHR_SHIFT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if (MODE == MODE_BM25) {
-        for (uint32_t c = 0; c < T; c += 2 * WAVE) {
-          double2* slot = reinterpret_cast<double2*>(&acc[c + 2 * lane]);
-          const double2 v = *slot;
-          const bool h0 = v.x > 0.0, h1 = v.y > 0.0;
-          if (h0 || h1) *slot = make_double2(0.0, 0.0);
-          const uint32_t d = tile_base + c + 2 * lane;
-          if (FULL) {
-            full_emit(p, q, lane, h0, v.x, d);
-            full_emit(p, q, lane, h1, v.y, d + 1);
-          } else if (!(PS_ABLATE_BUILD && (p.ablate & 1u))) {
-            // one wave-wide test against the best known lower bound skips the insert logic for
-            // the (usual) chunks that cannot contribute
-            const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
-            if (__any(fmax(v.x, v.y) >= lo && (h0 || h1))) {
-              topk_offer(tk, p.K, lane, h0, v.x, d, gt);
-              topk_offer(tk, p.K, lane, h1, v.y, d + 1, gt);
+        // several 16-byte LDS reads in flight per lane: chunks of PS_HARVEST_UNROLL x 128 documents,
+        // then (tiles of 256 documents) chunks of 2 x 128
+        auto harvest = [&](auto hu_tag, const uint32_t c) {
+          constexpr int HU = decltype(hu_tag)::value;
+          double2 vv[HU];
+#pragma unroll
+          for (int u = 0; u < HU; ++u) vv[u] = *reinterpret_cast<double2*>(&acc[c + u * 2 * WAVE + 2 * lane]);
+#pragma unroll
+          for (int u = 0; u < HU; ++u) {
+            const double2 v = vv[u];
+            const bool h0 = v.x > 0.0, h1 = v.y > 0.0;
+            if (h0 || h1) *reinterpret_cast<double2*>(&acc[c + u * 2 * WAVE + 2 * lane]) = make_double2(0.0, 0.0);
+            const uint32_t d = tile_base + c + u * 2 * WAVE + 2 * lane;
+            if (FULL) {
+              full_emit(p, q, lane, h0, v.x, d);
+              full_emit(p, q, lane, h1, v.y, d + 1);
+            } else if (!(PS_ABLATE_BUILD && (p.ablate & 1u))) {
+              // one wave-wide test against the best known lower bound skips the insert logic for
+              // the (usual) chunks that cannot contribute
+              const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
+              if (__any(fmax(v.x, v.y) >= lo && (h0 || h1))) {
+                topk_offer(tk, p.K, lane, h0, v.x, d, gt);
+                topk_offer(tk, p.K, lane, h1, v.y, d + 1, gt);
+              }
             }
           }
-        }
+        };
+        uint32_t c = 0;
+        for (; c + 2 * WAVE * PS_HARVEST_UNROLL <= T; c += 2 * WAVE * PS_HARVEST_UNROLL)
+          harvest(std::integral_constant<int, PS_HARVEST_UNROLL>{}, c);
+        for (; c < T; c += 2 * WAVE * 2) harvest(std::integral_constant<int, 2>{}, c);
       } else {
         // accumulators are planar ([field][T]); two documents per lane per 16-byte LDS access
         for (uint32_t c = 0; c < T; c += 2 * WAVE) {
