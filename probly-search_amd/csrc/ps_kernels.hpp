@@ -709,33 +709,45 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
           harvest(std::integral_constant<int, PS_HARVEST_UNROLL>{}, c);
         for (; c < T; c += 2 * WAVE * 2) harvest(std::integral_constant<int, 2>{}, c);
       } else {
-        // accumulators are planar ([field][T]); two documents per lane per 16-byte LDS access
-        for (uint32_t c = 0; c < T; c += 2 * WAVE) {
-          // result.score = max(score_by_pool, result.score) over fields, from the dummy 0. (zero_to_one.rs:81,122)
-          double b0 = 0.0, b1 = 0.0;
-          bool h0 = false, h1 = false;
+        // accumulators are planar ([field][T]); two documents per lane per 16-byte LDS access, the
+        // reads of all fields of ZU chunks in flight together
+        constexpr int ZU = F_ ? 2 : 1;
+        for (uint32_t c = 0; c < T; c += 2 * WAVE * ZU) {
+          double2 vv[ZU][FA];
 #pragma unroll
-          for (int x = 0; x < FA; ++x) {
-            if ((uint32_t)x < F) {
-              double2* slot = reinterpret_cast<double2*>(&acc[(uint32_t)x * T + c + 2 * lane]);
-              const double2 v = *slot;
-              if (v.x > 0.0 || v.y > 0.0) {
-                *slot = make_double2(0.0, 0.0);
-                if (TAGS) *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(tag) + (uint32_t)x * T + c + 2 * lane) = make_uint2(0u, 0u);
+          for (int u = 0; u < ZU; ++u)
+#pragma unroll
+            for (int x = 0; x < FA; ++x)
+              if (F_ && (uint32_t)x < F) vv[u][x] = *reinterpret_cast<double2*>(&acc[(uint32_t)x * T + c + u * 2 * WAVE + 2 * lane]);
+#pragma unroll
+          for (int u = 0; u < ZU; ++u) {
+            // result.score = max(score_by_pool, result.score) over fields, from the dummy 0. (zero_to_one.rs:81,122)
+            double b0 = 0.0, b1 = 0.0;
+            bool h0 = false, h1 = false;
+#pragma unroll
+            for (int x = 0; x < FA; ++x) {
+              if ((uint32_t)x < F) {
+                const uint32_t at = (uint32_t)x * T + c + u * 2 * WAVE + 2 * lane;
+                // (any number of fields: one plane at a time, 8 preloaded planes would cost 32 VGPRs)
+                const double2 v = F_ ? vv[u][x] : *reinterpret_cast<double2*>(&acc[at]);
+                if (v.x > 0.0 || v.y > 0.0) {
+                  *reinterpret_cast<double2*>(&acc[at]) = make_double2(0.0, 0.0);
+                  if (TAGS) *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(tag) + at) = make_uint2(0u, 0u);
+                }
+                h0 |= v.x > 0.0; h1 |= v.y > 0.0;
+                b0 = fmax(v.x, b0); b1 = fmax(v.y, b1);
               }
-              h0 |= v.x > 0.0; h1 |= v.y > 0.0;
-              b0 = fmax(v.x, b0); b1 = fmax(v.y, b1);
             }
-          }
-          const uint32_t d = tile_base + c + 2 * lane;
-          if (FULL) {
-            full_emit(p, q, lane, h0, b0, d);
-            full_emit(p, q, lane, h1, b1, d + 1);
-          } else {
-            const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
-            if (__any((h0 && b0 >= lo) || (h1 && b1 >= lo))) {
-              topk_offer(tk, p.K, lane, h0, b0, d, gt);
-              topk_offer(tk, p.K, lane, h1, b1, d + 1, gt);
+            const uint32_t d = tile_base + c + u * 2 * WAVE + 2 * lane;
+            if (FULL) {
+              full_emit(p, q, lane, h0, b0, d);
+              full_emit(p, q, lane, h1, b1, d + 1);
+            } else {
+              const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
+              if (__any((h0 && b0 >= lo) || (h1 && b1 >= lo))) {
+                topk_offer(tk, p.K, lane, h0, b0, d, gt);
+                topk_offer(tk, p.K, lane, h1, b1, d + 1, gt);
+              }
             }
           }
         }
