@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-single-latency", action="store_true",
+                    help="skip the synchronous single-query latency loop (profiling runs: only batch launches)")
     ap.add_argument("--config", default="C2", help="C1..C5 (SURVEY.md App. C); C2 is the headline config")
     ap.add_argument("--n-docs", type=int, default=0, help="override the config's corpus size (debug only)")
     ap.add_argument("--batch", type=int, default=0, help="override queries per rank per step")
@@ -175,8 +177,8 @@ def main():
         achieved = layout_bytes_launch / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
         # latency views: p50 of host-side step submission, and of a synchronous single query
         single = []
-        pool = [q for b in batches for q in b][:220]
-        while len(pool) < 220:
+        pool = [] if args.no_single_latency else [q for b in batches for q in b][:220]
+        while pool and len(pool) < 220:
             pool += pool
         for q in pool[:20]:  # warm the synchronous path (its stream, result buffer, clocks)
             snap.query(q, scorer, None, boosts, top_k=K)
@@ -203,7 +205,7 @@ def main():
                                        cfg["scorer"], cfg["q_terms"], K),
                        "global_batch": world * B, "parallelism": "replicated corpus, query batch sharded x%d" % world,
                        "tile_docs": info["tile_docs"], "postings": info["n_postings"], "pointers": info["n_pointers"]},
-            "p50_single_query_ms": float(np.median(single) * 1e3),
+            "p50_single_query_ms": float(np.median(single) * 1e3) if single else None,
             "p50_batch_submit_ms": float(np.median(lat) * 1e3),
             "host_plan_ms_per_step": plan_ms / steps,
             "postings_per_step": postings / steps,

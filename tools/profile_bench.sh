@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
-BENCH="python bench.py --no-cpu-baseline $*"
+BENCH="python bench.py --no-cpu-baseline --no-single-latency $*"
 run() {  # name, rocprof args...
   local name=$1; shift
   timeout 300 rocprofv3 "$@" -d $OUT/$name -o $name -- $BENCH --steps 3 --warmup 1 > $OUT/$name.bench.json 2> $OUT/$name.err
