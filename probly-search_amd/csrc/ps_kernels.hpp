@@ -28,6 +28,12 @@ constexpr int WAVE = 64;
 #define PS_FU 1
 #endif
 constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
+#ifndef PS_DENSE_RMW
+#define PS_DENSE_RMW 1
+#endif
+#ifndef PS_SPARSE_RMW
+#define PS_SPARSE_RMW 0
+#endif
 #ifndef PS_HARVEST_UNROLL
 #define PS_HARVEST_UNROLL 4
 #endif
@@ -274,8 +280,15 @@ __device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, uin
             t1 = t1 && !(mk.y & mask_bit);
             if (t0 || t1) *zm = make_uint2(mk.x | (t0 ? mask_bit : 0u), mk.y | (t1 ? mask_bit : 0u));
           }
-          if (t0) __hip_atomic_fetch_add(&acc[x * p.T + i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          if (t1) __hip_atomic_fetch_add(&acc[x * p.T + i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (PS_DENSE_RMW) {  // wave-private tile, in-order LDS: plain 16-byte read / add / write
+            double2* slot = reinterpret_cast<double2*>(&acc[x * p.T + i]);
+            double2 a = *slot;
+            a.x += t0 ? v[k].x : 0.0; a.y += t1 ? v[k].y : 0.0;
+            *slot = a;
+          } else {
+            if (t0) __hip_atomic_fetch_add(&acc[x * p.T + i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (t1) __hip_atomic_fetch_add(&acc[x * p.T + i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
         }
       }
     }
@@ -309,6 +322,13 @@ __device__ __forceinline__ void dense_apply(const KParams& p, double* acc, uint1
             acc[i + 1] = (c1v > 0.0) ? (t1 == mytag ? fmax(c1v, v[k].y) : c1v + v[k].y) : v[k].y;
             tag[i + 1] = mytag;
           }
+        } else if (PS_DENSE_RMW) {
+          // plain 16-byte read / add / write: the tile is wave-private and LDS operations of a wave
+          // execute in order; adding the 0.0 of a document without a posting changes nothing
+          double2* slot = reinterpret_cast<double2*>(&acc[i]);
+          double2 a = *slot;
+          a.x += v[k].x; a.y += v[k].y;
+          *slot = a;
         } else {
           if (v[k].x > 0.0) __hip_atomic_fetch_add(&acc[i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           if (v[k].y > 0.0) __hip_atomic_fetch_add(&acc[i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -439,10 +459,19 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
       // one list per query term: always the `+` / assign arm (absent == +0.0).  A list holds a
       // document once, so the LDS f64 add is uncontended; issuing it as a no-return DS op keeps
       // the read-modify-write latency off the wave's critical path.
+      if (PS_SPARSE_RMW) {
+        double cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = ok[u] ? acc[local[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u] && s[u] > 0.0) acc[local[u]] = cur[u] + s[u];
+      } else {
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (ok[u] && s[u] > 0.0)
           __hip_atomic_fetch_add(&acc[local[u]], s[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     }
   } else {
     // zero_to_one.rs:117-120: (min(score / tf, 1.) * tf) / max(field_length, all_query_terms_len)
