@@ -98,6 +98,7 @@ struct Stage {
 struct Tuning {
   uint32_t dense_max_rows = 64;  // PS_DENSE_MAX_ROWS
   uint32_t lpt = 1;  // PS_LPT
+  uint32_t dense_fuse = 3;  // PS_DENSE_FUSE: bit 0 = last entry added while harvesting, bit 1 = first entry written
   uint32_t z21_general_only = 0;  // PS_Z21_GENERAL_ONLY
   uint32_t dense_min_uses = 4;  // PS_DENSE_MIN_USES
   uint32_t dense_min_density_pct = 25;  // PS_DENSE_MIN_DENSITY_PCT
@@ -288,6 +289,7 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 void Tuning::load() {
     dense_max_rows = env_u32("PS_DENSE_MAX_ROWS", dense_max_rows);
     lpt = env_u32("PS_LPT", lpt);
+    dense_fuse = env_u32("PS_DENSE_FUSE", dense_fuse);
     z21_general_only = env_u32("PS_Z21_GENERAL_ONLY", z21_general_only);
     dense_min_uses = env_u32("PS_DENSE_MIN_USES", dense_min_uses);
     dense_min_density_pct = env_u32("PS_DENSE_MIN_DENSITY_PCT", dense_min_density_pct);
@@ -478,9 +480,24 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
         }
         for (size_t q = 0; q < B; ++q) {
           if (z && !(qf[q] & 1u)) continue;
-          for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
+          const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
+          for (uint32_t i = b; i < e; ++i) {
             auto it = row_of.find(key_of(he[i], q));
             if (it != row_of.end()) { he[i].shift |= DENSE_FLAG; he[i].node = it->second; }
+          }
+          // BM25 with one list per query term (plain sum in plan order): two row uses need no
+          // read-modify-write of the LDS tile.  The query's LAST entry, if dense, is added in
+          // registers while the tile is harvested.  A dense entry in position 0 or 1 goes first
+          // (IEEE addition commutes, so (e0 + e1) + ... keeps its bits) and is WRITTEN into the
+          // freshly zeroed tile instead of added to it.
+          if (!z && !plan.multi_expansion && m.tune.dense_fuse && e > b) {
+            if ((m.tune.dense_fuse & 1u) && (he[e - 1].shift & DENSE_FLAG)) he[e - 1].shift |= DENSE_FUSE_FLAG;
+            if ((m.tune.dense_fuse & 2u) && e - b >= 2) {
+              const bool d0 = (he[b].shift & DENSE_FLAG) != 0;
+              const bool d1 = (he[b + 1].shift & DENSE_FLAG) && !(he[b + 1].shift & DENSE_FUSE_FLAG);
+              if (!d0 && d1) std::swap(he[b], he[b + 1]);
+              if (d0 || d1) he[b].shift |= DENSE_ASSIGN_FLAG;
+            }
           }
         }
       }

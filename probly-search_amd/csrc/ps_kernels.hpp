@@ -56,6 +56,8 @@ struct RowDesc {  // one hot (list, idf, expansion_boost) combination of the bat
 };
 
 constexpr uint32_t DENSE_FLAG = 0x80000000u;  // ps_plan_entry::shift bit 31: entry reads dense row `node`
+constexpr uint32_t DENSE_ASSIGN_FLAG = 0x40000000u;  // ... as the tile's first contribution: written, not added
+constexpr uint32_t DENSE_FUSE_FLAG = 0x20000000u;    // ... as the query's last one: added while harvesting
 
 struct KParams {
   const uint32_t* doc;
@@ -297,44 +299,55 @@ __device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, uin
 
 // Merge one dense row's slice for this tile into the wave's LDS tile (same merge rules as
 // score_trip; a row value > 0 <=> the list holds that document).
-template <bool TAGS>
+// One batch of CH x 128 documents of a dense row: CH 16-byte global loads in flight, then the merge.
+template <bool TAGS, bool ASSIGN, int CH>
+__device__ __forceinline__ void dense_chunk(const double* r, double* acc, uint16_t* tag, const int lane,
+                                            const uint32_t c0, const uint16_t mytag) {
+  double2 v[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) v[k] = *reinterpret_cast<const double2*>(r + c0 + k * 2 * WAVE + 2 * lane);
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
+    if (TAGS) {
+      const double c0v = acc[i], c1v = acc[i + 1];
+      const uint16_t t0 = tag[i], t1 = tag[i + 1];
+      if (v[k].x > 0.0) {
+        acc[i] = (c0v > 0.0) ? (t0 == mytag ? fmax(c0v, v[k].x) : c0v + v[k].x) : v[k].x;
+        tag[i] = mytag;
+      }
+      if (v[k].y > 0.0) {
+        acc[i + 1] = (c1v > 0.0) ? (t1 == mytag ? fmax(c1v, v[k].y) : c1v + v[k].y) : v[k].y;
+        tag[i + 1] = mytag;
+      }
+    } else if (ASSIGN) {
+      // the tile is all zeros: 0.0 + v == v.  (Member-wise: copying the whole HIP vector struct out of
+      // the array keeps the array in scratch.)
+      *reinterpret_cast<double2*>(&acc[i]) = make_double2(v[k].x, v[k].y);
+    } else if (PS_DENSE_RMW) {
+      // plain 16-byte read / add / write: the tile is wave-private and LDS operations of a wave
+      // execute in order; adding the 0.0 of a document without a posting changes nothing
+      double2* slot = reinterpret_cast<double2*>(&acc[i]);
+      double2 a = *slot;
+      a.x += v[k].x; a.y += v[k].y;
+      *slot = a;
+    } else {
+      if (v[k].x > 0.0) __hip_atomic_fetch_add(&acc[i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (v[k].y > 0.0) __hip_atomic_fetch_add(&acc[i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  }
+}
+
+// Tile slice of a dense row -> accumulators.  T is a power of two >= 256: batches of 512 documents
+// (1 KiB per load instruction, four in flight), or the single 256-document batch of the smallest tile.
+template <bool TAGS, bool ASSIGN = false>
 __device__ __forceinline__ void dense_apply(const KParams& p, double* acc, uint16_t* tag, const int lane,
                                             const uint32_t row, const uint32_t tile_base, const uint16_t mytag) {
   const double* r = p.rows + (uint64_t)row * p.row_stride + tile_base;
-  constexpr int CH = 4;  // 4 x 128 documents per batch of 16-byte loads (1 KiB per load instruction)
-  for (uint32_t c0 = 0; c0 < p.T; c0 += CH * 2 * WAVE) {
-    double2 v[CH];
-#pragma unroll
-    for (int k = 0; k < CH; ++k)
-      if (c0 + k * 2 * WAVE < p.T) v[k] = *reinterpret_cast<const double2*>(r + c0 + k * 2 * WAVE + 2 * lane);
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      if (c0 + k * 2 * WAVE < p.T) {
-        const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
-        if (TAGS) {
-          const double c0v = acc[i], c1v = acc[i + 1];
-          const uint16_t t0 = tag[i], t1 = tag[i + 1];
-          if (v[k].x > 0.0) {
-            acc[i] = (c0v > 0.0) ? (t0 == mytag ? fmax(c0v, v[k].x) : c0v + v[k].x) : v[k].x;
-            tag[i] = mytag;
-          }
-          if (v[k].y > 0.0) {
-            acc[i + 1] = (c1v > 0.0) ? (t1 == mytag ? fmax(c1v, v[k].y) : c1v + v[k].y) : v[k].y;
-            tag[i + 1] = mytag;
-          }
-        } else if (PS_DENSE_RMW) {
-          // plain 16-byte read / add / write: the tile is wave-private and LDS operations of a wave
-          // execute in order; adding the 0.0 of a document without a posting changes nothing
-          double2* slot = reinterpret_cast<double2*>(&acc[i]);
-          double2 a = *slot;
-          a.x += v[k].x; a.y += v[k].y;
-          *slot = a;
-        } else {
-          if (v[k].x > 0.0) __hip_atomic_fetch_add(&acc[i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          if (v[k].y > 0.0) __hip_atomic_fetch_add(&acc[i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-      }
-    }
+  if (p.T >= 4 * 2 * WAVE) {
+    for (uint32_t c0 = 0; c0 < p.T; c0 += 4 * 2 * WAVE) dense_chunk<TAGS, ASSIGN, 4>(r, acc, tag, lane, c0, mytag);
+  } else {
+    dense_chunk<TAGS, ASSIGN, 2>(r, acc, tag, lane, 0, mytag);
   }
 }
 
@@ -639,7 +652,8 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
     }
 
     EntryC ec[G];
-    uint32_t ec_qterm[G], ec_tbl[G], ec_row[G];
+    uint32_t ec_qterm[G], ec_tbl[G], ec_row[G], ec_flags[G];
+    uint32_t fuse_row = 0xFFFFFFFFu;  // dense row of the query's last entry, added during the harvest
     uint32_t rb[G], re[G];
     uint32_t dv[G][FU], tfv[G][FU][FA], flv[G][FU][FA];
     // phase 1 of a visit (tile VT, entries EG..EG+G): ranges + first trips, all loads in flight together
@@ -655,7 +669,8 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         ec[g].w1 = en.boost;                                                                                    \
         ec_qterm[g] = MODE == MODE_Z21S ? en.qterm_index : en.qterm;                                            \
         ec_tbl[g] = en.tbl_off;                                                                                 \
-        ec_row[g] = (en.shift & DENSE_FLAG) ? en.node : 0xFFFFFFFFu;                     \
+        ec_row[g] = (en.shift & DENSE_FLAG) ? en.node : 0xFFFFFFFFu;                                            \
+        ec_flags[g] = en.shift;                                                                                 \
       }                                                                                                         \
       if (ec_row[g] != 0xFFFFFFFFu) { /* dense row: nothing to fetch up front */                                \
       } else if (sliced) {                                                                                             \
@@ -680,7 +695,9 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         if (eg + g < ne && ec_row[g] != 0xFFFFFFFFu) {
           dirty = true;
           if (PS_ABLATE_BUILD && (p.ablate & 8u)) {
-          } else if (MODE == MODE_BM25) dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
+          } else if (MODE == MODE_BM25 && !TAGS && (ec_flags[g] & DENSE_FUSE_FLAG)) fuse_row = ec_row[g];
+          else if (MODE == MODE_BM25 && !TAGS && (ec_flags[g] & DENSE_ASSIGN_FLAG)) dense_apply<false, true>(p, acc, tag, lane, ec_row[g], tile_base, 0);
+          else if (MODE == MODE_BM25) dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
           else dense_apply_z<TAGS>(p, acc, reinterpret_cast<uint32_t*>(tag), lane, ec_row[g], tile_base,
                                    (ec_qterm[g] >> 31) ? (1u << ((ec_qterm[g] >> 16) & 31u)) : 0u);
         } else if (rb[g] < re[g]) {
@@ -708,16 +725,23 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       if (MODE == MODE_BM25) {
         // several 16-byte LDS reads in flight per lane: chunks of PS_HARVEST_UNROLL x 128 documents,
         // then (tiles of 256 documents) chunks of 2 x 128
-        auto harvest = [&](auto hu_tag, const uint32_t c) {
+        auto harvest = [&](auto hu_tag, auto fused_tag, const uint32_t c) {
           constexpr int HU = decltype(hu_tag)::value;
-          double2 vv[HU];
+          constexpr bool FUSED = decltype(fused_tag)::value;
+          double2 vv[HU], rv[FUSED ? HU : 1];
+          if (FUSED) {
+            const double* r = p.rows + (uint64_t)fuse_row * p.row_stride + tile_base;
+#pragma unroll
+            for (int u = 0; u < HU; ++u) rv[u] = *reinterpret_cast<const double2*>(r + c + u * 2 * WAVE + 2 * lane);
+          }
 #pragma unroll
           for (int u = 0; u < HU; ++u) vv[u] = *reinterpret_cast<double2*>(&acc[c + u * 2 * WAVE + 2 * lane]);
 #pragma unroll
           for (int u = 0; u < HU; ++u) {
-            const double2 v = vv[u];
+            double2 v = vv[u];
+            if (v.x > 0.0 || v.y > 0.0) *reinterpret_cast<double2*>(&acc[c + u * 2 * WAVE + 2 * lane]) = make_double2(0.0, 0.0);
+            if (FUSED) { v.x += rv[u].x; v.y += rv[u].y; }  // the query's last entry, in plan order
             const bool h0 = v.x > 0.0, h1 = v.y > 0.0;
-            if (h0 || h1) *reinterpret_cast<double2*>(&acc[c + u * 2 * WAVE + 2 * lane]) = make_double2(0.0, 0.0);
             const uint32_t d = tile_base + c + u * 2 * WAVE + 2 * lane;
             if (FULL) {
               full_emit(p, q, lane, h0, v.x, d);
@@ -734,9 +758,14 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
           }
         };
         uint32_t c = 0;
-        for (; c + 2 * WAVE * PS_HARVEST_UNROLL <= T; c += 2 * WAVE * PS_HARVEST_UNROLL)
-          harvest(std::integral_constant<int, PS_HARVEST_UNROLL>{}, c);
-        for (; c < T; c += 2 * WAVE * 2) harvest(std::integral_constant<int, 2>{}, c);
+        if (!TAGS && fuse_row != 0xFFFFFFFFu) {
+          for (; c < T; c += 2 * WAVE * 2) harvest(std::integral_constant<int, 2>{}, std::true_type{}, c);
+          fuse_row = 0xFFFFFFFFu;
+        } else {
+          for (; c + 2 * WAVE * PS_HARVEST_UNROLL <= T; c += 2 * WAVE * PS_HARVEST_UNROLL)
+            harvest(std::integral_constant<int, PS_HARVEST_UNROLL>{}, std::false_type{}, c);
+          for (; c < T; c += 2 * WAVE * 2) harvest(std::integral_constant<int, 2>{}, std::false_type{}, c);
+        }
       } else {
         // accumulators are planar ([field][T]); two documents per lane per 16-byte LDS access, the
         // reads of all fields of ZU chunks in flight together

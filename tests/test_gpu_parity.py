@@ -282,6 +282,36 @@ def test_latency_path_small_batches(zero_copy, monkeypatch):
                 assert_same([tuple(r) for r in g], exp[:k] if k else exp, (zero_copy, nb, name, kw, q, k))
 
 
+@pytest.mark.parametrize("fuse", ["3", "2", "1", "0"])
+def test_dense_rows_first_written_last_fused(fuse, monkeypatch):
+    """BM25, one list per query term, every list dense: the query's last entry is added while the
+    tile is harvested and a dense entry in position 0 / 1 is written first (swapped in front of a
+    sparse e0) - the f64 sum must keep the reference's bits for 1..5 terms per query, repeated
+    terms included, non-unit boosts, tiles of 256 and 1024 documents."""
+    monkeypatch.setenv("PS_DENSE_MIN_USES", "1")
+    monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "30")  # only the head lists become rows: mixed plans
+    monkeypatch.setenv("PS_DENSE_FUSE", fuse)
+    cfg = dict(synth.CONFIGS["C2"], n_docs=6_000, vocab=300)
+    corpus = synth.Corpus(**cfg)
+    p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
+    boosts = [1.25, 0.5]
+    queries = []
+    for nt in (1, 2, 3, 4, 5):
+        queries += corpus.queries(24, nt, salt=nt)
+    head = corpus.queries(1, 1)[0]
+    queries += [head + " " + head, head + " zzzz " + head, "zzzz " + head]
+    for tile in (256, 1024):
+        snap = p.snapshot(device=0, tile_docs=tile)
+        sc = product_scorer("bm25")
+        top = snap.query_batch(queries, sc, None, boosts, top_k=10)
+        assert snap.last_stats()["dense_rows"] > 0
+        full = snap.query_batch(queries[::9], sc, None, boosts, top_k=0)
+        for q, t in zip(queries, top):
+            assert_same([tuple(r) for r in t], o.query(q, oracle_scorer("bm25"), boosts)[:10], (fuse, tile, q))
+        for q, f in zip(queries[::9], full):
+            assert_same([tuple(r) for r in f], o.query(q, oracle_scorer("bm25"), boosts), (fuse, tile, q, "full"))
+
+
 def test_wide_prefix_expansion_many_entries():
     """A 1-2 character prefix expanding to hundreds of indexed terms: plans far larger than the
     register-resident group size, table slices disabled (too many entries for LDS), visited-tag
