@@ -310,16 +310,22 @@ __device__ __forceinline__ void dense_chunk(const double* r, double* acc, uint16
   for (int k = 0; k < CH; ++k) {
     const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
     if (TAGS) {
-      const double c0v = acc[i], c1v = acc[i + 1];
-      const uint16_t t0 = tag[i], t1 = tag[i + 1];
+      // two documents per lane: one 16-byte accumulator access and one 4-byte tag access each way
+      double2* slot = reinterpret_cast<double2*>(&acc[i]);
+      uint32_t* tslot = reinterpret_cast<uint32_t*>(&tag[i]);
+      double2 a = *slot;
+      const uint32_t tg = *tslot;
+      uint32_t t0 = tg & 0xFFFFu, t1 = tg >> 16;
       if (v[k].x > 0.0) {
-        acc[i] = (c0v > 0.0) ? (t0 == mytag ? fmax(c0v, v[k].x) : c0v + v[k].x) : v[k].x;
-        tag[i] = mytag;
+        a.x = (a.x > 0.0) ? (t0 == mytag ? fmax(a.x, v[k].x) : a.x + v[k].x) : v[k].x;
+        t0 = mytag;
       }
       if (v[k].y > 0.0) {
-        acc[i + 1] = (c1v > 0.0) ? (t1 == mytag ? fmax(c1v, v[k].y) : c1v + v[k].y) : v[k].y;
-        tag[i + 1] = mytag;
+        a.y = (a.y > 0.0) ? (t1 == mytag ? fmax(a.y, v[k].y) : a.y + v[k].y) : v[k].y;
+        t1 = mytag;
       }
+      *slot = a;
+      *tslot = t0 | (t1 << 16);
     } else if (ASSIGN) {
       // the tile is all zeros: 0.0 + v == v.  (Member-wise: copying the whole HIP vector struct out of
       // the array keeps the array in scratch.)
