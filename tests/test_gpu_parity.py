@@ -217,6 +217,66 @@ def test_full_size_properties_c2_slice():
         assert bits(r.score) == bits(exp)
 
 
+@pytest.fixture(scope="module")
+def c2_full():
+    """BASELINE config 2/3 at its full size: 1 M documents, 2 fields, ~33 M postings."""
+    cfg = dict(synth.CONFIGS["C2"])
+    corpus = synth.Corpus(**cfg)
+    snap = synth.fill(psa.Index(2), corpus).snapshot(device=0)
+    return corpus, snap
+
+
+def test_full_size_c2_properties(c2_full):
+    """Full BASELINE size, no oracle (it would take minutes): properties that hold at any size.
+    (a) the batched top-10 (dense rows, fused / written row uses, LPT order) is the prefix of the
+    full sorted list of the same query asked alone; (b) the 3-term score is ((s1 + s2) + s3) of the
+    1-term scores, bit for bit, for every matching document; (c) splitting the batch (different
+    hot-list selection) changes nothing; (d) doubling the boosts doubles every score exactly."""
+    corpus, snap = c2_full
+    sc = psa.bm25.new()
+    b1 = [1.0, 1.0]
+    queries = corpus.queries(1024, 3)
+    top = snap.query_batch(queries, sc, None, b1, top_k=10)
+    assert snap.last_stats()["dense_rows"] > 0
+    for qi in (0, 17, 333, 1023):
+        full = snap.query(queries[qi], sc, None, b1)
+        assert top[qi] == full[:10], qi
+        keys = [(-r.score, r.key) for r in full]
+        assert keys == sorted(keys) and len({r.key for r in full}) == len(full)
+        terms = queries[qi].split(" ")
+        parts = [{r.key: r.score for r in snap.query(t, sc, None, b1)} for t in terms]
+        assert len(full) == len(set().union(*[set(p_) for p_ in parts]))
+        for r in full:
+            acc = None
+            for p_ in parts:  # plan order == query term order; absent terms contribute nothing
+                if r.key in p_:
+                    acc = p_[r.key] if acc is None else acc + p_[r.key]
+            assert bits(r.score) == bits(acc), (qi, r.key)
+    halves = snap.query_batch(queries[:300], sc, None, b1, top_k=10) + snap.query_batch(queries[300:], sc, None, b1, top_k=10)
+    assert halves == top
+    twice = snap.query_batch(queries[:256], sc, None, [2.0, 2.0], top_k=10)
+    for a, b in zip(top[:256], twice):
+        assert [r.key for r in a] == [r.key for r in b]
+        assert all(bits(2.0 * x.score) == bits(y.score) for x, y in zip(a, b))
+
+
+def test_full_size_c3_properties(c2_full):
+    """zero_to_one at the full size: batched top-10 == prefix of the query asked alone (full list),
+    scores in (0, 1], batch split invariance."""
+    corpus, snap = c2_full
+    sc = psa.zero_to_one.new()
+    b1 = [1.0, 1.0]
+    queries = corpus.queries(512, 3, salt=5)
+    top = snap.query_batch(queries, sc, None, b1, top_k=10)
+    for qi in (1, 100, 511):
+        full = snap.query(queries[qi], sc, None, b1)
+        assert top[qi] == full[:10], qi
+        assert all(0.0 < r.score <= 1.0 for r in full)
+        keys = [(-r.score, r.key) for r in full]
+        assert keys == sorted(keys)
+    assert snap.query_batch(queries[:200], sc, None, b1, top_k=10) + snap.query_batch(queries[200:], sc, None, b1, top_k=10) == top
+
+
 def test_sharded_entry_point_single_rank():
     """probly_search_amd.dist.query_batch_sharded at world_size 1 (no collective) == query_batch."""
     from probly_search_amd import dist as psd
