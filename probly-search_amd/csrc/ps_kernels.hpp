@@ -427,7 +427,8 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
           const uint32_t tfu = tfv[u][x], flu = flv[u][x];
           const bool in_lut = tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x];
           // transposed, odd-stride table: lanes with different field lengths hit different LDS banks
-          tfn[u][x] = lut[in_lut ? tfu * p.lut_stride + p.lut_base[x] + flu : 0u];
+          // (24-bit multiply: full rate, a 32-bit v_mul_lo_u32 is quarter rate; tfu < 16 whenever the index is used)
+          tfn[u][x] = lut[in_lut ? __umul24(tfu, p.lut_stride) + p.lut_base[x] + flu : 0u];
           slow |= ok[u] && tfu > 0 && !in_lut;
         }
       }
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
   const bool mine = MODE == MODE_BM25 || (p.qflags[q] & 1u);  // Z21S: only "simple" queries
   if (MODE == MODE_Z21S && !mine) continue;                   // k_z21 owns this query's candidate slots
   const uint32_t qtl = MODE == MODE_Z21S ? p.qterms_len[q] : 0u;
+  const bool q_assign = MODE == MODE_BM25 && !TAGS && ne != 0 && (p.plan[e0].shift & DENSE_ASSIGN_FLAG);
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
@@ -731,6 +733,9 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       if (MODE == MODE_BM25) {
         // several 16-byte LDS reads in flight per lane: chunks of PS_HARVEST_UNROLL x 128 documents,
         // then (tiles of 256 documents) chunks of 2 x 128
+        // a query whose first entry is a WRITTEN dense row overwrites the whole tile at the start of
+        // its next visit: only the item's last visit has to leave zeros behind
+        const bool zero_tile = TAGS || !q_assign || !more;
         auto harvest = [&](auto hu_tag, auto fused_tag, const uint32_t c) {
           constexpr int HU = decltype(hu_tag)::value;
           constexpr bool FUSED = decltype(fused_tag)::value;
@@ -745,7 +750,8 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
 #pragma unroll
           for (int u = 0; u < HU; ++u) {
             double2 v = vv[u];
-            if (v.x > 0.0 || v.y > 0.0) *reinterpret_cast<double2*>(&acc[c + u * 2 * WAVE + 2 * lane]) = make_double2(0.0, 0.0);
+            if (zero_tile && (v.x > 0.0 || v.y > 0.0))
+              *reinterpret_cast<double2*>(&acc[c + u * 2 * WAVE + 2 * lane]) = make_double2(0.0, 0.0);
             if (FUSED) { v.x += rv[u].x; v.y += rv[u].y; }  // the query's last entry, in plan order
             const bool h0 = v.x > 0.0, h1 = v.y > 0.0;
             const uint32_t d = tile_base + c + u * 2 * WAVE + 2 * lane;
