@@ -106,7 +106,7 @@ struct Tuning {
   uint32_t zero_copy = 1;  // PS_ZERO_COPY
   uint32_t ablate = 0;  // PS_ABLATE
   uint32_t lut = 1;  // PS_LUT
-  uint32_t target_items = 65536;  // PS_TARGET_ITEMS
+  uint32_t target_items = 40960;  // PS_TARGET_ITEMS
   uint32_t tiles_per_run = 0;  // PS_TILES_PER_RUN
   uint32_t slices = 1;  // PS_SLICES
   uint32_t wg8 = 1;  // PS_WG8
