@@ -106,7 +106,7 @@ struct Tuning {
   uint32_t zero_copy = 1;  // PS_ZERO_COPY
   uint32_t ablate = 0;  // PS_ABLATE
   uint32_t lut = 1;  // PS_LUT
-  uint32_t target_items = 40960;  // PS_TARGET_ITEMS
+  uint32_t target_items = 45056;  // PS_TARGET_ITEMS
   uint32_t tiles_per_run = 0;  // PS_TILES_PER_RUN
   uint32_t slices = 1;  // PS_SLICES
   uint32_t wg8 = 1;  // PS_WG8
@@ -168,6 +168,7 @@ struct EngineImpl {
   // event behind the previous asynchronous batch.
   hipStream_t tail_stream = nullptr;
   bool tail_pending = false;
+  std::map<std::pair<const void*, size_t>, size_t> occ_cache;  // (K1 instantiation, LDS bytes) -> waves per CU
   Stage* cur_stage = nullptr;   // slot of the batch being enqueued
   bool cur_zero_copy = false;   // its plan is read in place from pinned host memory
   double kt_total_ms = 0.0;
@@ -315,6 +316,39 @@ void validate(const Snapshot& s, const ps_scorer_desc& sc, const Plan& plan) {
 }
 
 // Uploads the plan + per-query arrays through a pinned staging slot; fills the common KParams.
+// The K1 instantiation a batch will run (same choice as launch_k_score), for occupancy queries.
+const void* k_score_fn(bool bm25, uint32_t F, bool tags, bool full, bool wide) {
+#define PS_FN4(M, FV, TG)                                                                             \
+  (full ? reinterpret_cast<const void*>(&k_score<M, FV, TG, true, WG_WAVES>)                          \
+        : wide ? reinterpret_cast<const void*>(&k_score<M, FV, TG, false, 8>)                         \
+               : reinterpret_cast<const void*>(&k_score<M, FV, TG, false, WG_WAVES>))
+#define PS_FN3(M, FV) (tags ? PS_FN4(M, FV, true) : PS_FN4(M, FV, false))
+#define PS_FN2(M) (F == 1 ? PS_FN3(M, 1) : F == 2 ? PS_FN3(M, 2) : PS_FN3(M, 0))
+  return bm25 ? PS_FN2(MODE_BM25) : PS_FN2(MODE_Z21S);
+#undef PS_FN2
+#undef PS_FN3
+#undef PS_FN4
+}
+
+// Resident K1 waves per CU for a launch geometry (cached: the occupancy query is not free).
+size_t k_score_waves_per_cu(EngineImpl& m, const void* fn, uint32_t wgw, size_t lds) {
+  if (lds > 160 * 1024) return 0;
+  auto key = std::make_pair(fn, lds);
+  auto it = m.occ_cache.find(key);
+  if (it != m.occ_cache.end()) return it->second;
+  if (lds > 65536) PS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  PS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVE * wgw, lds));
+  // The runtime's answer covers registers and waves; for LDS it divides 160 KiB by the request,
+  // but gfx950 hands LDS out in 1280-byte granules (160 KiB / 128): measured on C5, three 4-wave
+  // workgroups of 53 632 B are resident per CU, three of 53 888 B are not.
+  const size_t granule = 1280, rounded = (lds + granule - 1) / granule * granule;
+  const size_t by_lds = rounded ? (160 * 1024) / rounded : (size_t)per_cu;
+  const size_t w = std::min<size_t>((size_t)std::max(0, per_cu), by_lds) * wgw;
+  m.occ_cache.emplace(key, w);
+  return w;
+}
+
 //   topk_path: k_merge follows and leaves the control words zeroed again (no memset next time)
 //   sync_path: the caller waits for the stream before returning, so the slot needs no reuse fence
 void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, hipStream_t st,
@@ -593,11 +627,37 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (S < 1) S = 1;
   if (S > s.n_tiles) S = s.n_tiles;
   if (S > 32) S = 32;  // a run's table slice is fetched by one wave-wide load (lane <-> tile)
+  if (!s_env && m.tune.slices) {
+    // The table slices of a run live in the wave's LDS next to its tile: a longer run must not
+    // cost resident waves (C5, 8 lists per query: 20 tiles per run instead of 16 dropped a 4-wave
+    // workgroup per CU and 35 % of the speed).  Within [S/4, S] take the longest run that keeps
+    // the waves per CU of the shortest one.
+    const bool bm25 = sc.kind == PS_SCORER_BM25;
+    const size_t aw = bm25 ? 1 : s.F;
+    const bool tags = bm25 ? plan.multi_expansion : z_masked != 0;
+    const size_t tile_b = (size_t)s.T * aw * 8 + (tags ? (bm25 ? (size_t)s.T * 2 : (size_t)s.T * aw * 4) : 0);
+    const size_t lut_b = bm25 ? (size_t)kp.lut_stride * LUT_TF * 8 : 0;
+    auto waves_per_cu = [&](uint64_t runs) -> size_t {
+      size_t slice = (((size_t)plan.max_entries * 2 * runs * 4) + 15) & ~(size_t)15;
+      if (slice > 4096) slice = 0;
+      const size_t wave_b = tile_b + slice;
+      const bool wide = topk_path && lut_b + 8 * wave_b <= 80 * 1024 && m.tune.wg8;
+      const uint32_t wgw = wide ? 8u : (uint32_t)WG_WAVES;
+      return k_score_waves_per_cu(m, k_score_fn(bm25, s.F, tags, !topk_path, wide), wgw, lut_b + wgw * wave_b);
+    };
+    const uint64_t s_lo = std::max<uint64_t>(1, S / 4);
+    const size_t best = waves_per_cu(s_lo);
+    while (S > s_lo && waves_per_cu(S) < best) --S;
+  }
   kp.S = (uint32_t)S;
   kp.n_super = (uint32_t)((s.n_tiles + S - 1) / S);
   // per-wave LDS for the table slices: [entry][rb|re][S] u32; fall back to global lookups if large
   const size_t slice = (((size_t)plan.max_entries * 2 * S * 4) + 15) & ~(size_t)15;
   kp.slice_bytes = (slice <= 4096 && m.tune.slices) ? (uint32_t)slice : 0u;
+  static const bool trace = env_u32("PS_TRACE", 0) != 0;
+  if (trace && B > 1)
+    fprintf(stderr, "[ps] geometry     B=%zu tiles=%u S=%u runs=%u items=%zu slice=%u B/wave max_entries=%u rows=%u\n", B,
+            s.n_tiles, kp.S, kp.n_super, B * kp.n_super, kp.slice_bytes, plan.max_entries, n_rows);
 }
 
 void allow_lds(const void* fn, size_t lds) {

@@ -28,6 +28,9 @@ constexpr int WAVE = 64;
 #define PS_FU 1
 #endif
 constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
+#ifndef PS_DENSE_CH8
+#define PS_DENSE_CH8 1
+#endif
 #ifndef PS_DENSE_RMW
 #define PS_DENSE_RMW 1
 #endif
@@ -350,7 +353,9 @@ template <bool TAGS, bool ASSIGN = false>
 __device__ __forceinline__ void dense_apply(const KParams& p, double* acc, uint16_t* tag, const int lane,
                                             const uint32_t row, const uint32_t tile_base, const uint16_t mytag) {
   const double* r = p.rows + (uint64_t)row * p.row_stride + tile_base;
-  if (p.T >= 4 * 2 * WAVE) {
+  if (PS_DENSE_CH8 && p.T >= 8 * 2 * WAVE) {
+    for (uint32_t c0 = 0; c0 < p.T; c0 += 8 * 2 * WAVE) dense_chunk<TAGS, ASSIGN, 8>(r, acc, tag, lane, c0, mytag);
+  } else if (p.T >= 4 * 2 * WAVE) {
     for (uint32_t c0 = 0; c0 < p.T; c0 += 4 * 2 * WAVE) dense_chunk<TAGS, ASSIGN, 4>(r, acc, tag, lane, c0, mytag);
   } else {
     dense_chunk<TAGS, ASSIGN, 2>(r, acc, tag, lane, 0, mytag);
