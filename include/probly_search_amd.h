@@ -194,8 +194,9 @@ typedef struct ps_batch_stats {
                                   20-byte postings for lists read as postings, 8 bytes per document
                                   for lists served from dense score rows, plus building those rows
                                   (postings read + row zero-fill + row writes) and emitted results  */
-  uint32_t dense_rows;         /* hot (list, idf, boost) combinations scored once into dense rows  */
-  uint32_t _pad;
+  uint32_t dense_rows;         /* hot (list, idf, boost) combinations the batch read as dense rows */
+  uint32_t dense_rows_built;   /* ... of which had to be scored for this batch (the rest were resident
+                                  in the snapshot's row slab from earlier batches)                  */
 } ps_batch_stats;
 ps_status ps_snapshot_last_stats(const ps_snapshot* snap, ps_batch_stats* out);
 /* HIP-event time (ms) summed over every launch of the posting-accumulate kernel on this

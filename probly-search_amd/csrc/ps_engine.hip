@@ -97,6 +97,7 @@ struct Stage {
 // measurable share of a single query's round trip).
 struct Tuning {
   uint32_t dense_max_rows = 64;  // PS_DENSE_MAX_ROWS
+  uint32_t row_cache_mb = 4096;  // PS_ROW_CACHE_MB: slab of row slots kept across batches (0: rebuild every batch)
   uint32_t lpt = 1;  // PS_LPT
   uint32_t dense_fuse = 3;  // PS_DENSE_FUSE: bit 0 = last entry added while harvesting, bit 1 = first entry written
   uint32_t z21_general_only = 0;  // PS_Z21_GENERAL_ONLY
@@ -155,7 +156,23 @@ struct EngineImpl {
   KTimer kt[N_KTIMER];
   KTimer* last_kt = nullptr;
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
-  uint32_t last_rows = 0;
+  uint32_t last_rows = 0, last_rows_built = 0;
+  // Row slab: the dense score row of a hot (list, weight) combination only depends on the
+  // snapshot, the scorer parameters and the boosts, so rows stay resident across batches (288 GB
+  // of HBM: a few GB of slots is nothing) and K0b only scores the combinations it has not seen.
+  // LRU over the slots; everything is dropped when the scorer parameters or boosts change.
+  struct RowKey {
+    uint64_t post_off, w, k3;
+    bool operator<(const RowKey& o) const {
+      return post_off != o.post_off ? post_off < o.post_off : w != o.w ? w < o.w : k3 < o.k3;
+    }
+  };
+  struct RowSlot { RowKey key; uint64_t last_use = 0; bool valid = false; };
+  std::map<RowKey, uint32_t> row_slot_of;
+  std::vector<RowSlot> row_slots;
+  std::vector<double> row_sig;  // scorer kind, k1, b, boosts the resident rows were scored with
+  uint64_t row_epoch = 0;
+  std::vector<uint32_t> build_slots;  // slots K0b fills for the batch being enqueued
   int next_kt = 0;
   // control words (item counter + per-query thresholds) are left zeroed by k_merge: no memset per batch
   bool ctl_clean = false;
@@ -289,6 +306,7 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 
 void Tuning::load() {
     dense_max_rows = env_u32("PS_DENSE_MAX_ROWS", dense_max_rows);
+    row_cache_mb = env_u32("PS_ROW_CACHE_MB", row_cache_mb);
     lpt = env_u32("PS_LPT", lpt);
     dense_fuse = env_u32("PS_DENSE_FUSE", dense_fuse);
     z21_general_only = env_u32("PS_Z21_GENERAL_ONLY", z21_general_only);
@@ -390,7 +408,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     if (m.tune.lpt)
       std::stable_sort(qo, qo + B, [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
   }
-  uint32_t n_rows = 0;
+  uint32_t n_rows = 0;   // rows K0b has to score for this batch
+  uint32_t n_used = 0;   // rows the batch reads (resident ones included)
   uint64_t layout_bytes = 0;
   uint32_t n_simple = 0, n_general = 0, z_masked = 0;
   if (z) {
@@ -498,18 +517,60 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       const uint64_t row_bytes = (uint64_t)s.n_tiles * s.T * 8 * planes;
       const uint64_t mem_cap = (uint64_t)m.tune.dense_max_mb << 20;
       while (hot.size() > max_rows || hot.size() * row_bytes > mem_cap) hot.pop_back();
+      // slab geometry: as many slots as the cache budget holds (at least one batch's worth)
+      const uint64_t row_elems = (uint64_t)s.n_tiles * s.T * planes;
+      size_t n_slots = std::max<size_t>(max_rows, std::min<size_t>(4096, ((uint64_t)m.tune.row_cache_mb << 20) / row_bytes));
       if (!hot.empty()) {
+        // resident rows are only valid for the parameters they were scored with
+        std::vector<double> sig{(double)sc.kind, z ? 0.0 : sc.bm25_k1, z ? 0.0 : sc.bm25_b, (double)n_slots};
+        for (uint32_t x = 0; x < s.F; ++x) sig.push_back(z ? 0.0 : boosts[x]);
+        if (sig != m.row_sig || m.row_slots.size() != n_slots || m.tune.row_cache_mb == 0) {
+          m.row_sig = sig;
+          m.row_slot_of.clear();
+          m.row_slots.assign(n_slots, EngineImpl::RowSlot{});
+        }
+        m.d_rows.ensure((size_t)n_slots * row_elems + 16);
+        const uint64_t epoch = ++m.row_epoch;
         RowDesc* rd = reinterpret_cast<RowDesc*>(h + off_r);
         std::map<Key, uint32_t, decltype(kless)> row_of(kless);
+        // first pass: pin the resident rows this batch uses, so the misses cannot evict them
         for (auto& hk : hot) {
+          auto it = m.row_slot_of.find(EngineImpl::RowKey{hk.second.post_off, hk.second.w, hk.second.k3});
+          if (it != m.row_slot_of.end()) m.row_slots[it->second].last_use = epoch;
+        }
+        size_t victim = 0;
+        for (auto& hk : hot) {
+          const EngineImpl::RowKey ck{hk.second.post_off, hk.second.w, hk.second.k3};
+          auto hit = m.row_slot_of.find(ck);
+          if (hit != m.row_slot_of.end()) {
+            row_of[hk.second] = hit->second;
+            ++n_used;
+            continue;
+          }
+          // miss: the least recently used slot no row of this batch lives in
+          uint32_t slot = 0xFFFFFFFFu;
+          uint64_t oldest = ~0ull;
+          for (size_t k = 0; k < n_slots; ++k) {
+            const size_t j = (victim + k) % n_slots;
+            if (!m.row_slots[j].valid) { slot = (uint32_t)j; break; }
+            if (m.row_slots[j].last_use < epoch && m.row_slots[j].last_use < oldest) { oldest = m.row_slots[j].last_use; slot = (uint32_t)j; }
+          }
+          if (slot == 0xFFFFFFFFu) continue;  // cannot happen: n_slots >= rows per batch
+          victim = slot + 1;
+          if (m.row_slots[slot].valid) m.row_slot_of.erase(m.row_slots[slot].key);
+          m.row_slots[slot].key = ck; m.row_slots[slot].valid = true; m.row_slots[slot].last_use = epoch;
+          m.row_slot_of[ck] = slot;
+          ++n_used;
           RowDesc d;
+          d.slot = slot;
+          d._pad2 = 0;
           d.post_off = hk.second.post_off;
           d.len = agg[hk.second].len;
           // zero_to_one: all_query_terms_len (low 16 bits) | required term frequency (high 16 bits)
           d._pad = z ? ((uint32_t)(hk.second.k3 & 0xFFFFu) | ((uint32_t)(hk.second.k3 >> 32) << 16)) : 0u;
           memcpy(&d.idf, &hk.second.w, 8);           // BM25: idf | zero_to_one: ScoreByTerm::score
           if (z) d.eb = 0.0; else memcpy(&d.eb, &hk.second.k3, 8);
-          row_of[hk.second] = n_rows;
+          row_of[hk.second] = slot;
           rd[n_rows++] = d;
         }
         for (size_t q = 0; q < B; ++q) {
@@ -541,7 +602,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   // place from the pinned slot: a few hundred bytes over PCIe per wave, in parallel, instead of a
   // copy-engine hand-over in front of the kernel (latency path of a single query).
   const uint32_t g_regs = (s.F == 1 || s.F == 2) ? (uint32_t)PS_G : 1u;
-  const bool zero_copy = B <= 4 && plan.max_entries <= g_regs && n_rows == 0 && n_general == 0 &&
+  const bool zero_copy = B <= 4 && plan.max_entries <= g_regs && n_used == 0 && n_general == 0 &&
                          m.tune.zero_copy;
   const unsigned char* dbase;
   m.cur_stage = &sg;
@@ -580,11 +641,12 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   }
   kp.row_desc = reinterpret_cast<const RowDesc*>(dbase + off_r);
   kp.n_rows = n_rows;
+  m.build_slots.resize(n_rows);
+  for (uint32_t r = 0; r < n_rows; ++r) m.build_slots[r] = reinterpret_cast<const RowDesc*>(h + off_r)[r].slot;
   kp.row_planes = z ? s.F : 1u;
   kp.row_mode = z ? 1u : 0u;
   kp.row_stride = (uint64_t)s.n_tiles * s.T;
-  if (n_rows) {
-    m.d_rows.ensure((size_t)n_rows * kp.row_planes * kp.row_stride + 16);
+  if (n_used) {
     kp.rows = m.d_rows.p;
   }
   // control words: the persistent waves' item counter and the per-query thresholds.  k_merge
@@ -604,7 +666,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.n_simple = n_simple; kp.n_general = n_general; kp.z_masked = z_masked;
   kp.layout_bytes = layout_bytes;
   m.last_layout_bytes = layout_bytes;
-  m.last_rows = n_rows;
+  m.last_rows = n_used;
+  m.last_rows_built = n_rows;
   kp.P = s.P;
   kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
   kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
@@ -707,9 +770,11 @@ void launch_k_score(const Tuning& tune, KParams& kp, bool tags, int n_cu, hipStr
 #undef PS_LAUNCH_W
 }
 
-void launch_rows(const KParams& kp, hipStream_t st) {
-  if (!kp.n_rows) return;
-  PS_HIP(hipMemsetAsync(const_cast<double*>(kp.rows), 0, (size_t)kp.n_rows * kp.row_planes * kp.row_stride * 8, st));
+void launch_rows(const KParams& kp, const uint32_t* slots, hipStream_t st) {
+  if (!kp.n_rows) return;  // every row this batch reads is resident
+  const size_t row_b = (size_t)kp.row_planes * kp.row_stride * 8;
+  for (uint32_t r = 0; r < kp.n_rows; ++r)
+    PS_HIP(hipMemsetAsync(const_cast<double*>(kp.rows) + (size_t)slots[r] * kp.row_planes * kp.row_stride, 0, row_b, st));
   hipLaunchKernelGGL(k_dense_rows, dim3(256, kp.n_rows), dim3(256), 0, st, kp, const_cast<double*>(kp.rows));
 }
 
@@ -724,10 +789,10 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
       hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
       m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = st;
     }
-    launch_rows(kp, st);
+    launch_rows(kp, m.build_slots.data(), st);
     launch_k_score<MODE_BM25, FULL>(m.tune, kp, plan.multi_expansion, n_cu, st);
   } else {
-    launch_rows(kp, st);
+    launch_rows(kp, m.build_slots.data(), st);
     if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(m.tune, kp, kp.z_masked != 0, n_cu, st);
     if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
@@ -747,6 +812,7 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
 void fill_stats(const EngineImpl& m, ps_batch_stats& st, const Snapshot& s, const Plan& plan, uint64_t emitted) {
   st.layout_bytes = m.last_layout_bytes + emitted * 16;
   st.dense_rows = m.last_rows;
+  st.dense_rows_built = m.last_rows_built;
   st.n_queries = plan.qbeg.size() - 1;
   st.n_plan_entries = plan.entries.size();
   st.postings_visited = plan.postings;

@@ -51,11 +51,13 @@ constexpr int LUT_TF = 16;   // LUT columns: term frequency 0..15
 #define PS_ABLATE_BUILD 0  // profiling builds only: honour KParams::ablate in the hot loops
 #endif
 
-struct RowDesc {  // one hot (list, idf, expansion_boost) combination of the batch
+struct RowDesc {  // one hot (list, idf, expansion_boost) combination K0b has to score into its row slot
   uint64_t post_off;
   uint32_t len;
   uint32_t _pad;
   double idf, eb;
+  uint32_t slot;  // row slot in the snapshot's row slab
+  uint32_t _pad2;
 };
 
 constexpr uint32_t DENSE_FLAG = 0x80000000u;  // ps_plan_entry::shift bit 31: entry reads dense row `node`
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void k_bm25_lut(const KParams p, double* out) 
 // timed step, once per batch.
 __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* rows) {
   const RowDesc rd = p.row_desc[blockIdx.y];
-  double* row = rows + (uint64_t)blockIdx.y * p.row_planes * p.row_stride;
+  double* row = rows + (uint64_t)rd.slot * p.row_planes * p.row_stride;
   if (p.row_mode != 0) {
     // zero_to_one.rs:117-120 per field: (min(score/tf, 1)*tf) / max(field_length, all_query_terms_len)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rd.len; i += gridDim.x * blockDim.x) {

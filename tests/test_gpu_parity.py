@@ -372,6 +372,36 @@ def test_dense_rows_first_written_last_fused(fuse, monkeypatch):
             assert_same([tuple(r) for r in f], o.query(q, oracle_scorer("bm25"), boosts), (fuse, tile, q, "full"))
 
 
+def test_resident_rows_reuse_eviction_and_invalidation(monkeypatch):
+    """Dense rows stay resident in the snapshot's row slab across batches (LRU).  A slab of a few
+    slots and every list forced dense: rows are reused, evicted and rebuilt over a sequence of
+    batches; changing k1 / b / the boosts / the scorer drops them.  Every answer bit-exact."""
+    monkeypatch.setenv("PS_DENSE_MIN_USES", "1")
+    monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "0")
+    monkeypatch.setenv("PS_DENSE_MAX_ROWS", "6")
+    monkeypatch.setenv("PS_ROW_CACHE_MB", "1")
+    cfg = dict(synth.CONFIGS["C2"], n_docs=30_000, vocab=400)   # 240 KB per row: 6 slots (the per-batch minimum)
+    corpus = synth.Corpus(**cfg)
+    p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
+    snap = p.snapshot(device=0, tile_docs=512)
+    seq = [("bm25", {}, [1.0, 1.0]), ("bm25", {}, [1.0, 1.0]), ("bm25", {}, [1.0, 1.0]), ("bm25", {"k1": 2.0, "b": 0.5}, [1.0, 1.0]),
+           ("bm25", {"k1": 2.0, "b": 0.5}, [1.0, 3.0]), ("zero_to_one", {}, [1.0, 1.0]), ("zero_to_one", {}, [1.0, 1.0]),
+           ("bm25", {}, [1.0, 1.0])]
+    built = []
+    for step, (name, kw, boosts) in enumerate(seq):
+        queries = corpus.queries(12, 2, salt=step % 3)  # salts repeat: the same hot lists come back
+        top = snap.query_batch(queries, product_scorer(name, **kw), None, boosts, top_k=10)
+        st = snap.last_stats()
+        built.append((st["dense_rows"], st["dense_rows_built"]))
+        for q, t in zip(queries, top):
+            assert_same([tuple(r) for r in t], o.query(q, oracle_scorer(name, **kw), boosts)[:10], (step, name, kw, boosts, q))
+    assert all(u > 0 for u, _ in built)
+    assert built[0][1] == built[0][0]      # cold: every row scored
+    assert built[3][1] == built[3][0]      # new k1 / b: nothing reusable
+    assert built[4][1] == built[4][0]      # new boosts
+    assert any(b < u for u, b in built), built   # and somewhere a resident row was reused
+
+
 def test_wide_prefix_expansion_many_entries():
     """A 1-2 character prefix expanding to hundreds of indexed terms: plans far larger than the
     register-resident group size, table slices disabled (too many entries for LDS), visited-tag
