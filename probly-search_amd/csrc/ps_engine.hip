@@ -773,8 +773,13 @@ void launch_k_score(const Tuning& tune, KParams& kp, bool tags, int n_cu, hipStr
 void launch_rows(const KParams& kp, const uint32_t* slots, hipStream_t st) {
   if (!kp.n_rows) return;  // every row this batch reads is resident
   const size_t row_b = (size_t)kp.row_planes * kp.row_stride * 8;
-  for (uint32_t r = 0; r < kp.n_rows; ++r)
-    PS_HIP(hipMemsetAsync(const_cast<double*>(kp.rows) + (size_t)slots[r] * kp.row_planes * kp.row_stride, 0, row_b, st));
+  for (uint32_t r = 0; r < kp.n_rows;) {  // one memset per run of adjacent slots
+    uint32_t e = r + 1;
+    while (e < kp.n_rows && slots[e] == slots[e - 1] + 1) ++e;
+    PS_HIP(hipMemsetAsync(const_cast<double*>(kp.rows) + (size_t)slots[r] * kp.row_planes * kp.row_stride, 0,
+                          row_b * (e - r), st));
+    r = e;
+  }
   hipLaunchKernelGGL(k_dense_rows, dim3(256, kp.n_rows), dim3(256), 0, st, kp, const_cast<double*>(kp.rows));
 }
 
