@@ -529,7 +529,18 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
           m.row_slot_of.clear();
           m.row_slots.assign(n_slots, EngineImpl::RowSlot{});
         }
-        m.d_rows.ensure((size_t)n_slots * row_elems + 16);
+        try {
+          m.d_rows.ensure((size_t)n_slots * row_elems + 16);
+        } catch (const std::runtime_error&) {
+          // not enough free HBM for the whole slab: keep one batch's worth of slots
+          (void)hipGetLastError();
+          m.tune.row_cache_mb = 1;  // and stop asking for the big slab
+          n_slots = std::max<size_t>(max_rows, std::min<size_t>(4096, ((uint64_t)1 << 20) / row_bytes));
+          m.row_sig[3] = (double)n_slots;
+          m.row_slot_of.clear();
+          m.row_slots.assign(n_slots, EngineImpl::RowSlot{});
+          m.d_rows.ensure((size_t)n_slots * row_elems + 16);
+        }
         const uint64_t epoch = ++m.row_epoch;
         RowDesc* rd = reinterpret_cast<RowDesc*>(h + off_r);
         std::map<Key, uint32_t, decltype(kless)> row_of(kless);
