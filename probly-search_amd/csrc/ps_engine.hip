@@ -665,7 +665,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   // full-result batch or an error.  The counter has a cache line of its own: sharing one with
   // threshold words cost 70 % of K1's speed (L2 atomics on the line stall the epilogues' loads of
   // the neighbouring thresholds, and the other way round).
-  const size_t n_thr = (B << GTHR_SHIFT) + 2;
+  const size_t n_thr = B + 2;
   const bool fresh = m.d_gthr.ensure(n_thr, true);
   kp.work_counter = m.d_work;
   kp.gthr = m.d_gthr.p;

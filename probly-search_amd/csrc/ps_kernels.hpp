@@ -28,22 +28,9 @@ constexpr int WAVE = 64;
 #define PS_FU 1
 #endif
 constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
-#ifndef PS_DENSE_CH8
-#define PS_DENSE_CH8 1
-#endif
-#ifndef PS_DENSE_RMW
-#define PS_DENSE_RMW 1
-#endif
-#ifndef PS_SPARSE_RMW
-#define PS_SPARSE_RMW 0
-#endif
 #ifndef PS_HARVEST_UNROLL
 #define PS_HARVEST_UNROLL 4
 #endif
-#ifndef PS_GTHR_SHIFT
-#define PS_GTHR_SHIFT 0
-#endif
-constexpr int GTHR_SHIFT = PS_GTHR_SHIFT;  // per-query threshold words are 8 << GTHR_SHIFT bytes apart
 constexpr int MERGE_WAVES = 16;         // most waves per workgroup of K3 (the host sizes it to the candidates)
 constexpr int WG_WAVES = PS_WG_WAVES;  // waves per workgroup of K1; each wave owns its own LDS tile
 constexpr int LUT_TF = 16;   // LUT columns: term frequency 0..15
@@ -287,14 +274,12 @@ __device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, uin
             t1 = t1 && !(mk.y & mask_bit);
             if (t0 || t1) *zm = make_uint2(mk.x | (t0 ? mask_bit : 0u), mk.y | (t1 ? mask_bit : 0u));
           }
-          if (PS_DENSE_RMW) {  // wave-private tile, in-order LDS: plain 16-byte read / add / write
+          {  // wave-private tile, in-order LDS: plain 16-byte read / add / write (two f64 LDS atomics
+             // per lane measured ~2x the LDS time)
             double2* slot = reinterpret_cast<double2*>(&acc[x * p.T + i]);
             double2 a = *slot;
             a.x += t0 ? v[k].x : 0.0; a.y += t1 ? v[k].y : 0.0;
             *slot = a;
-          } else {
-            if (t0) __hip_atomic_fetch_add(&acc[x * p.T + i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (t1) __hip_atomic_fetch_add(&acc[x * p.T + i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           }
         }
       }
@@ -335,16 +320,14 @@ __device__ __forceinline__ void dense_chunk(const double* r, double* acc, uint16
       // the tile is all zeros: 0.0 + v == v.  (Member-wise: copying the whole HIP vector struct out of
       // the array keeps the array in scratch.)
       *reinterpret_cast<double2*>(&acc[i]) = make_double2(v[k].x, v[k].y);
-    } else if (PS_DENSE_RMW) {
+    } else {
       // plain 16-byte read / add / write: the tile is wave-private and LDS operations of a wave
-      // execute in order; adding the 0.0 of a document without a posting changes nothing
+      // execute in order; adding the 0.0 of a document without a posting changes nothing.  (Two
+      // f64 LDS atomics per lane measured ~2x the LDS time of one b128 read + write.)
       double2* slot = reinterpret_cast<double2*>(&acc[i]);
       double2 a = *slot;
       a.x += v[k].x; a.y += v[k].y;
       *slot = a;
-    } else {
-      if (v[k].x > 0.0) __hip_atomic_fetch_add(&acc[i], v[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      if (v[k].y > 0.0) __hip_atomic_fetch_add(&acc[i + 1], v[k].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   }
 }
@@ -355,7 +338,7 @@ template <bool TAGS, bool ASSIGN = false>
 __device__ __forceinline__ void dense_apply(const KParams& p, double* acc, uint16_t* tag, const int lane,
                                             const uint32_t row, const uint32_t tile_base, const uint16_t mytag) {
   const double* r = p.rows + (uint64_t)row * p.row_stride + tile_base;
-  if (PS_DENSE_CH8 && p.T >= 8 * 2 * WAVE) {
+  if (p.T >= 8 * 2 * WAVE) {
     for (uint32_t c0 = 0; c0 < p.T; c0 += 8 * 2 * WAVE) dense_chunk<TAGS, ASSIGN, 8>(r, acc, tag, lane, c0, mytag);
   } else if (p.T >= 4 * 2 * WAVE) {
     for (uint32_t c0 = 0; c0 < p.T; c0 += 4 * 2 * WAVE) dense_chunk<TAGS, ASSIGN, 4>(r, acc, tag, lane, c0, mytag);
@@ -486,19 +469,10 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
       // one list per query term: always the `+` / assign arm (absent == +0.0).  A list holds a
       // document once, so the LDS f64 add is uncontended; issuing it as a no-return DS op keeps
       // the read-modify-write latency off the wave's critical path.
-      if (PS_SPARSE_RMW) {
-        double cur[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = ok[u] ? acc[local[u]] : 0.0;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (ok[u] && s[u] > 0.0) acc[local[u]] = cur[u] + s[u];
-      } else {
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (ok[u] && s[u] > 0.0)
           __hip_atomic_fetch_add(&acc[local[u]], s[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
     }
   } else {
     // zero_to_one.rs:117-120: (min(score / tf, 1.) * tf) / max(field_length, all_query_terms_len)
@@ -736,7 +710,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       if (harvest) {
       // tile epilogue: harvest + reset (two f64 per lane per LDS access where the layout allows)
       double gt = 0.0;
-      if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[(size_t)q << GTHR_SHIFT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if (MODE == MODE_BM25) {
         // several 16-byte LDS reads in flight per lane: chunks of PS_HARVEST_UNROLL x 128 documents,
         // then (tiles of 256 documents) chunks of 2 x 128
@@ -831,7 +805,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       }
       if (!FULL && tk.n == p.K && tk.thr_s > gt) {
         // publish this run's K-th best: the final K-th best of the query can only be higher
-        if (lane == 0) atomicMax(&p.gthr[(size_t)q << GTHR_SHIFT], (unsigned long long)__double_as_longlong(tk.thr_s));
+        if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
       }
       if (TAGS && MODE == MODE_BM25) {
         tagbase += p.max_qterms;
@@ -983,7 +957,7 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
   const uint32_t K = p.K;
-  const double gt = __longlong_as_double((long long)p.gthr[(size_t)q << GTHR_SHIFT]);
+  const double gt = __longlong_as_double((long long)p.gthr[q]);
   // candidate c of the query = (run c / K, rank c % K); run `sup` lives at item = sup * B + q
   const uint32_t n_c = p.n_super * K;
   const uint32_t n_waves = blockDim.x >> 6;
@@ -1024,7 +998,7 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
   }
   if (lane == 0) {
     p.out_counts[q] = tk.n;
-    p.gthr[(size_t)q << GTHR_SHIFT] = 0ull;
+    p.gthr[q] = 0ull;
     if (q == 0) *p.work_counter = 0u;
   }
 }
