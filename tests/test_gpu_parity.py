@@ -193,6 +193,38 @@ def test_batches_on_different_streams_are_ordered():
                 assert int(hk[i, k]) == x.key and bits(float(hs[i, k])) == bits(x.score), (r, i, k)
 
 
+def test_snapshot_queries_from_several_threads():
+    """A ps_snapshot is immutable and its query entry points are thread-safe (`query(&self)`,
+    src/query.rs:21-27): four threads hammering one snapshot with single queries, small batches
+    and full-result calls get exactly the answers of a sequential run."""
+    import threading
+    cfg = dict(synth.CONFIGS["C2"], n_docs=40_000, vocab=2_000)
+    corpus = synth.Corpus(**cfg)
+    snap = synth.fill(psa.Index(2), corpus).snapshot(device=0)
+    queries = corpus.queries(96, 3)
+    b1 = [1.0, 1.0]
+
+    def work(tid):
+        out = []
+        for i in range(tid, len(queries), 4):
+            sc = psa.bm25.new() if (i // 4) % 2 == 0 else psa.zero_to_one.new()
+            out.append((i, "one", snap.query(queries[i], sc, None, b1, top_k=10)))
+            if i % 3 == 0:
+                out.append((i, "batch", snap.query_batch(queries[i:i + 5], sc, None, b1, top_k=5)))
+            if i % 8 == 0:
+                out.append((i, "full", snap.query(queries[i], sc, None, b1)))
+        return out
+
+    expect = {tid: work(tid) for tid in range(4)}
+    got = {}
+    threads = [threading.Thread(target=lambda t=t: got.__setitem__(t, work(t))) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert got == expect
+
+
 def test_full_size_properties_c2_slice():
     """Size-independent properties on a larger index (no oracle): top-k is a prefix of the full
     list, full list is sorted canonically, scores of a 1-term query are invariant to batching."""
