@@ -22,14 +22,14 @@ constexpr int WAVE = 64;
 #define PS_WG_WAVES 4
 #endif
 #ifndef PS_G
-#define PS_G 4
+#define PS_G 3
 #endif
 #ifndef PS_FU
 #define PS_FU 1
 #endif
 constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
 #ifndef PS_HARVEST_UNROLL
-#define PS_HARVEST_UNROLL 4
+#define PS_HARVEST_UNROLL 8
 #endif
 constexpr int MERGE_WAVES = 16;         // most waves per workgroup of K3 (the host sizes it to the candidates)
 constexpr int WG_WAVES = PS_WG_WAVES;  // waves per workgroup of K1; each wave owns its own LDS tile
@@ -757,6 +757,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         } else {
           for (; c + 2 * WAVE * PS_HARVEST_UNROLL <= T; c += 2 * WAVE * PS_HARVEST_UNROLL)
             harvest(std::integral_constant<int, PS_HARVEST_UNROLL>{}, std::false_type{}, c);
+          for (; c + 2 * WAVE * 4 <= T; c += 2 * WAVE * 4) harvest(std::integral_constant<int, 4>{}, std::false_type{}, c);
           for (; c < T; c += 2 * WAVE * 2) harvest(std::integral_constant<int, 2>{}, std::false_type{}, c);
         }
       } else {
