@@ -596,7 +596,10 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
           // registers while the tile is harvested.  A dense entry in position 0 or 1 goes first
           // (IEEE addition commutes, so (e0 + e1) + ... keeps its bits) and is WRITTEN into the
           // freshly zeroed tile instead of added to it.
-          if (!z && !plan.multi_expansion && m.tune.dense_fuse && e > b) {
+          // (zero_to_one simple queries without consumed-term masks sum their records the same way,
+          // in sorted order: same two tricks, for 1 or 2 fields)
+          const bool plain_sum = z ? (z_masked == 0 && s.F <= 2) : !plan.multi_expansion;
+          if (plain_sum && m.tune.dense_fuse && e > b) {
             if ((m.tune.dense_fuse & 1u) && (he[e - 1].shift & DENSE_FLAG)) he[e - 1].shift |= DENSE_FUSE_FLAG;
             if ((m.tune.dense_fuse & 2u) && e - b >= 2) {
               const bool d0 = (he[b].shift & DENSE_FLAG) != 0;

@@ -251,44 +251,53 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
 // zero_to_one rows: plane x of the row goes to accumulator plane x of the tile ([F][T] in LDS).
 // mask_bit != 0: the query has several expansions per query term; a (doc, field) takes the row
 // value only if its consumed-query-term mask does not hold the bit yet (zero_to_one.rs:101-103).
-template <bool MASKS>
+// zero_to_one: one batch of CH x 128 documents of one field plane of a dense row
+template <bool MASKS, bool ASSIGN, int CH>
+__device__ __forceinline__ void dense_chunk_z(const double* r, double* accx, uint32_t* zmaskx, const int lane,
+                                              const uint32_t c0, const uint32_t mask_bit) {
+  double2 v[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) v[k] = *reinterpret_cast<const double2*>(r + c0 + k * 2 * WAVE + 2 * lane);
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
+    if (ASSIGN) {  // first contribution to a zeroed tile (no masks on this path)
+      *reinterpret_cast<double2*>(&accx[i]) = make_double2(v[k].x, v[k].y);
+      continue;
+    }
+    bool t0 = v[k].x > 0.0, t1 = v[k].y > 0.0;
+    if (MASKS && mask_bit) {
+      uint2* zm = reinterpret_cast<uint2*>(zmaskx + i);
+      const uint2 mk = *zm;
+      t0 = t0 && !(mk.x & mask_bit);
+      t1 = t1 && !(mk.y & mask_bit);
+      if (t0 || t1) *zm = make_uint2(mk.x | (t0 ? mask_bit : 0u), mk.y | (t1 ? mask_bit : 0u));
+    }
+    // wave-private tile, in-order LDS: plain 16-byte read / add / write
+    double2* slot = reinterpret_cast<double2*>(&accx[i]);
+    double2 a = *slot;
+    a.x += t0 ? v[k].x : 0.0; a.y += t1 ? v[k].y : 0.0;
+    *slot = a;
+  }
+}
+
+template <bool MASKS, bool ASSIGN = false>
 __device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, uint32_t* zmask, const int lane,
                                               const uint32_t row, const uint32_t tile_base, const uint32_t mask_bit) {
   for (uint32_t x = 0; x < p.F; ++x) {
     const double* r = p.rows + ((uint64_t)row * p.F + x) * p.row_stride + tile_base;
-    constexpr int CH = 4;
-    for (uint32_t c0 = 0; c0 < p.T; c0 += CH * 2 * WAVE) {
-      double2 v[CH];
-#pragma unroll
-      for (int k = 0; k < CH; ++k)
-        if (c0 + k * 2 * WAVE < p.T) v[k] = *reinterpret_cast<const double2*>(r + c0 + k * 2 * WAVE + 2 * lane);
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        if (c0 + k * 2 * WAVE < p.T) {
-          const uint32_t i = c0 + k * 2 * WAVE + 2 * lane;
-          bool t0 = v[k].x > 0.0, t1 = v[k].y > 0.0;
-          if (MASKS && mask_bit) {
-            uint2* zm = reinterpret_cast<uint2*>(zmask + x * p.T + i);
-            const uint2 mk = *zm;
-            t0 = t0 && !(mk.x & mask_bit);
-            t1 = t1 && !(mk.y & mask_bit);
-            if (t0 || t1) *zm = make_uint2(mk.x | (t0 ? mask_bit : 0u), mk.y | (t1 ? mask_bit : 0u));
-          }
-          {  // wave-private tile, in-order LDS: plain 16-byte read / add / write (two f64 LDS atomics
-             // per lane measured ~2x the LDS time)
-            double2* slot = reinterpret_cast<double2*>(&acc[x * p.T + i]);
-            double2 a = *slot;
-            a.x += t0 ? v[k].x : 0.0; a.y += t1 ? v[k].y : 0.0;
-            *slot = a;
-          }
-        }
-      }
+    double* accx = acc + x * p.T;
+    uint32_t* zmx = zmask + x * p.T;
+    if (p.T >= 8 * 2 * WAVE) {
+      for (uint32_t c0 = 0; c0 < p.T; c0 += 8 * 2 * WAVE) dense_chunk_z<MASKS, ASSIGN, 8>(r, accx, zmx, lane, c0, mask_bit);
+    } else if (p.T >= 4 * 2 * WAVE) {
+      for (uint32_t c0 = 0; c0 < p.T; c0 += 4 * 2 * WAVE) dense_chunk_z<MASKS, ASSIGN, 4>(r, accx, zmx, lane, c0, mask_bit);
+    } else {
+      dense_chunk_z<MASKS, ASSIGN, 2>(r, accx, zmx, lane, 0, mask_bit);
     }
   }
 }
 
-// Merge one dense row's slice for this tile into the wave's LDS tile (same merge rules as
-// score_trip; a row value > 0 <=> the list holds that document).
 // One batch of CH x 128 documents of a dense row: CH 16-byte global loads in flight, then the merge.
 template <bool TAGS, bool ASSIGN, int CH>
 __device__ __forceinline__ void dense_chunk(const double* r, double* acc, uint16_t* tag, const int lane,
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
   const bool mine = MODE == MODE_BM25 || (p.qflags[q] & 1u);  // Z21S: only "simple" queries
   if (MODE == MODE_Z21S && !mine) continue;                   // k_z21 owns this query's candidate slots
   const uint32_t qtl = MODE == MODE_Z21S ? p.qterms_len[q] : 0u;
-  const bool q_assign = MODE == MODE_BM25 && !TAGS && ne != 0 && (p.plan[e0].shift & DENSE_ASSIGN_FLAG);
+  const bool q_assign = !TAGS && ne != 0 && (p.plan[e0].shift & DENSE_ASSIGN_FLAG);
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
@@ -687,6 +696,9 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
           } else if (MODE == MODE_BM25 && !TAGS && (ec_flags[g] & DENSE_FUSE_FLAG)) fuse_row = ec_row[g];
           else if (MODE == MODE_BM25 && !TAGS && (ec_flags[g] & DENSE_ASSIGN_FLAG)) dense_apply<false, true>(p, acc, tag, lane, ec_row[g], tile_base, 0);
           else if (MODE == MODE_BM25) dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
+          else if (!TAGS && F_ != 0 && (ec_flags[g] & DENSE_FUSE_FLAG)) fuse_row = ec_row[g];
+          else if (!TAGS && F_ != 0 && (ec_flags[g] & DENSE_ASSIGN_FLAG))
+            dense_apply_z<false, true>(p, acc, reinterpret_cast<uint32_t*>(tag), lane, ec_row[g], tile_base, 0u);
           else dense_apply_z<TAGS>(p, acc, reinterpret_cast<uint32_t*>(tag), lane, ec_row[g], tile_base,
                                    (ec_qterm[g] >> 31) ? (1u << ((ec_qterm[g] >> 16) & 31u)) : 0u);
         } else if (rb[g] < re[g]) {
@@ -711,12 +723,12 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       // tile epilogue: harvest + reset (two f64 per lane per LDS access where the layout allows)
       double gt = 0.0;
       if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const bool zero_tile = TAGS || !q_assign || !more;
       if (MODE == MODE_BM25) {
         // several 16-byte LDS reads in flight per lane: chunks of PS_HARVEST_UNROLL x 128 documents,
         // then (tiles of 256 documents) chunks of 2 x 128
         // a query whose first entry is a WRITTEN dense row overwrites the whole tile at the start of
         // its next visit: only the item's last visit has to leave zeros behind
-        const bool zero_tile = TAGS || !q_assign || !more;
         auto harvest = [&](auto hu_tag, auto fused_tag, const uint32_t c) {
           constexpr int HU = decltype(hu_tag)::value;
           constexpr bool FUSED = decltype(fused_tag)::value;
@@ -765,7 +777,16 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         // reads of all fields of ZU chunks in flight together
         constexpr int ZU = F_ ? 2 : 1;
         for (uint32_t c = 0; c < T; c += 2 * WAVE * ZU) {
-          double2 vv[ZU][FA];
+          double2 vv[ZU][FA], rv[ZU][F_ ? FA : 1];
+          const bool fused = !TAGS && F_ != 0 && fuse_row != 0xFFFFFFFFu;  // the query's last entry is a dense row
+          if (fused) {
+#pragma unroll
+            for (int u = 0; u < ZU; ++u)
+#pragma unroll
+              for (int x = 0; x < (F_ ? FA : 1); ++x)
+                rv[u][x] = *reinterpret_cast<const double2*>(p.rows + ((uint64_t)fuse_row * F + x) * p.row_stride + tile_base +
+                                                             c + u * 2 * WAVE + 2 * lane);
+          }
 #pragma unroll
           for (int u = 0; u < ZU; ++u)
 #pragma unroll
@@ -781,11 +802,12 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
               if ((uint32_t)x < F) {
                 const uint32_t at = (uint32_t)x * T + c + u * 2 * WAVE + 2 * lane;
                 // (any number of fields: one plane at a time, 8 preloaded planes would cost 32 VGPRs)
-                const double2 v = F_ ? vv[u][x] : *reinterpret_cast<double2*>(&acc[at]);
-                if (v.x > 0.0 || v.y > 0.0) {
+                double2 v = F_ ? vv[u][x] : *reinterpret_cast<double2*>(&acc[at]);
+                if (zero_tile && (v.x > 0.0 || v.y > 0.0)) {
                   *reinterpret_cast<double2*>(&acc[at]) = make_double2(0.0, 0.0);
                   if (TAGS) *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(tag) + at) = make_uint2(0u, 0u);
                 }
+                if (F_ != 0 && fused) { v.x += rv[u][F_ ? x : 0].x; v.y += rv[u][F_ ? x : 0].y; }  // last record, in sorted order
                 h0 |= v.x > 0.0; h1 |= v.y > 0.0;
                 b0 = fmax(v.x, b0); b1 = fmax(v.y, b1);
               }
@@ -804,6 +826,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
           }
         }
       }
+      fuse_row = 0xFFFFFFFFu;
       if (!FULL && tk.n == p.K && tk.thr_s > gt) {
         // publish this run's K-th best: the final K-th best of the query can only be higher
         if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));

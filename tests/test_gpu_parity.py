@@ -394,14 +394,15 @@ def test_dense_rows_first_written_last_fused(fuse, monkeypatch):
     queries += [head + " " + head, head + " zzzz " + head, "zzzz " + head]
     for tile in (256, 1024):
         snap = p.snapshot(device=0, tile_docs=tile)
-        sc = product_scorer("bm25")
-        top = snap.query_batch(queries, sc, None, boosts, top_k=10)
-        assert snap.last_stats()["dense_rows"] > 0
-        full = snap.query_batch(queries[::9], sc, None, boosts, top_k=0)
-        for q, t in zip(queries, top):
-            assert_same([tuple(r) for r in t], o.query(q, oracle_scorer("bm25"), boosts)[:10], (fuse, tile, q))
-        for q, f in zip(queries[::9], full):
-            assert_same([tuple(r) for r in f], o.query(q, oracle_scorer("bm25"), boosts), (fuse, tile, q, "full"))
+        for name in ("bm25", "zero_to_one"):  # zero_to_one: the same tricks on its per-field planes (sorted record order)
+            sc = product_scorer(name)
+            top = snap.query_batch(queries, sc, None, boosts, top_k=10)
+            assert snap.last_stats()["dense_rows"] > 0
+            full = snap.query_batch(queries[::9], sc, None, boosts, top_k=0)
+            for q, t in zip(queries, top):
+                assert_same([tuple(r) for r in t], o.query(q, oracle_scorer(name), boosts)[:10], (fuse, tile, name, q))
+            for q, f in zip(queries[::9], full):
+                assert_same([tuple(r) for r in f], o.query(q, oracle_scorer(name), boosts), (fuse, tile, name, q, "full"))
 
 
 def test_resident_rows_reuse_eviction_and_invalidation(monkeypatch):
