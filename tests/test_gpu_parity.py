@@ -374,8 +374,9 @@ def test_latency_path_small_batches(zero_copy, monkeypatch):
                 assert_same([tuple(r) for r in g], exp[:k] if k else exp, (zero_copy, nb, name, kw, q, k))
 
 
+@pytest.mark.parametrize("fields", [2, 1])
 @pytest.mark.parametrize("fuse", ["3", "2", "1", "0"])
-def test_dense_rows_first_written_last_fused(fuse, monkeypatch):
+def test_dense_rows_first_written_last_fused(fuse, fields, monkeypatch):
     """BM25, one list per query term, every list dense: the query's last entry is added while the
     tile is harvested and a dense entry in position 0 / 1 is written first (swapped in front of a
     sparse e0) - the f64 sum must keep the reference's bits for 1..5 terms per query, repeated
@@ -383,10 +384,10 @@ def test_dense_rows_first_written_last_fused(fuse, monkeypatch):
     monkeypatch.setenv("PS_DENSE_MIN_USES", "1")
     monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "30")  # only the head lists become rows: mixed plans
     monkeypatch.setenv("PS_DENSE_FUSE", fuse)
-    cfg = dict(synth.CONFIGS["C2"], n_docs=6_000, vocab=300)
+    cfg = dict(synth.CONFIGS["C2" if fields == 2 else "C1"], n_docs=6_000, vocab=300)
     corpus = synth.Corpus(**cfg)
-    p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
-    boosts = [1.25, 0.5]
+    p, o = synth.fill(psa.Index(fields), corpus), synth.fill(orc.Index(fields), corpus)
+    boosts = [1.25, 0.5][:fields]
     queries = []
     for nt in (1, 2, 3, 4, 5):
         queries += corpus.queries(24, nt, salt=nt)
