@@ -367,116 +367,151 @@ size_t k_score_waves_per_cu(EngineImpl& m, const void* fn, uint32_t wgw, size_t 
   return w;
 }
 
-//   topk_path: k_merge follows and leaves the control words zeroed again (no memset next time)
-//   sync_path: the caller waits for the stream before returning, so the slot needs no reuse fence
-void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, hipStream_t st,
-                KParams& kp, bool topk_path, bool sync_path) {
-  const Snapshot& s = *m.snap;
-  const size_t B = plan.qbeg.size() - 1;
-  const size_t ne = plan.entries.size();
-  const bool z = sc.kind == PS_SCORER_ZERO_TO_ONE;
-  const size_t off_e = 0;
-  const size_t off_q = off_e + ne * sizeof(ps_plan_entry);
-  const size_t off_l = off_q + (B + 1) * 4;
-  const size_t off_o = off_l + B * 4;
-  const size_t off_z = off_o + B * 4;
-  const size_t off_f = off_z + ne * 4;
-  const size_t off_g = off_f + B * 4;
-  const size_t off_r = (off_g + B * 4 + 15) & ~(size_t)15;
-  const size_t max_rows = m.tune.dense_max_rows;
-  const size_t total = off_r + max_rows * sizeof(RowDesc);
+// The staged batch: the pinned slot holds exactly what the device reads
+// (entries | qbeg | qterms_len | qorder | zorder | qflags | gen_queries | row descriptors).
+struct BatchImage {
+  size_t B = 0, ne = 0;
+  size_t off_e = 0, off_q = 0, off_l = 0, off_o = 0, off_z = 0, off_f = 0, off_g = 0, off_r = 0, total = 0;
+  Stage* slot = nullptr;
+  unsigned char* h = nullptr;    // the slot's host pointer
+  ps_plan_entry* he = nullptr;   // entries as uploaded (zero_to_one simple queries: pre-sorted; dense flags set)
+  bool z = false;                // zero_to_one
+  uint32_t n_rows = 0;           // rows K0b has to score for this batch
+  uint32_t n_used = 0;           // rows the batch reads (resident ones included)
+  uint32_t n_simple = 0, n_general = 0, z_masked = 0;
+};
+
+// Claims the next pinned slot and copies the plan's arrays into it.
+BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan) {
+  BatchImage img;
+  const size_t B = img.B = plan.qbeg.size() - 1;
+  const size_t ne = img.ne = plan.entries.size();
+  img.z = sc.kind == PS_SCORER_ZERO_TO_ONE;
+  img.off_e = 0;
+  img.off_q = img.off_e + ne * sizeof(ps_plan_entry);
+  img.off_l = img.off_q + (B + 1) * 4;
+  img.off_o = img.off_l + B * 4;
+  img.off_z = img.off_o + B * 4;
+  img.off_f = img.off_z + ne * 4;
+  img.off_g = img.off_f + B * 4;
+  img.off_r = (img.off_g + B * 4 + 15) & ~(size_t)15;
+  img.total = img.off_r + (size_t)m.tune.dense_max_rows * sizeof(RowDesc);
   Stage& sg = m.stage[m.next_stage];
   m.next_stage = (m.next_stage + 1) % N_STAGE;
-  sg.ensure(total + 16);
-  unsigned char* h = sg.p;
-  ps_plan_entry* he = reinterpret_cast<ps_plan_entry*>(h + off_e);
-  if (ne) memcpy(he, plan.entries.data(), ne * sizeof(ps_plan_entry));
-  memcpy(h + off_q, plan.qbeg.data(), (B + 1) * 4);
-  if (B) memcpy(h + off_l, plan.qterms_len.data(), B * 4);
-  {
-    // K1 hands out the items of a run heaviest query first (longest-processing-time order): the
-    // last items a launch hands out are then its cheapest ones, which shortens the tail where
-    // most waves have run dry while a few still chew on a head-term query
-    uint32_t* qo = reinterpret_cast<uint32_t*>(h + off_o);
-    std::vector<uint64_t> cost(B, 0);
-    for (size_t q = 0; q < B; ++q) {
-      uint64_t c = 0;
-      for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) c += plan.entries[i].len;
-      cost[q] = c;
-      qo[q] = (uint32_t)q;
-    }
-    if (m.tune.lpt)
-      std::stable_sort(qo, qo + B, [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+  sg.ensure(img.total + 16);
+  img.slot = &sg;
+  img.h = sg.p;
+  img.he = reinterpret_cast<ps_plan_entry*>(img.h + img.off_e);
+  if (ne) memcpy(img.he, plan.entries.data(), ne * sizeof(ps_plan_entry));
+  memcpy(img.h + img.off_q, plan.qbeg.data(), (B + 1) * 4);
+  if (B) memcpy(img.h + img.off_l, plan.qterms_len.data(), B * 4);
+  return img;
+}
+
+// qorder: K1 hands out the items of a run heaviest query first (longest-processing-time order).
+// The last items a launch hands out are then its cheapest ones, which shortens the tail where
+// most waves have run dry while a few still chew on a head-term query.
+void order_queries(const EngineImpl& m, const Plan& plan, BatchImage& img) {
+  const size_t B = img.B;
+  uint32_t* qo = reinterpret_cast<uint32_t*>(img.h + img.off_o);
+  std::vector<uint64_t> cost(B, 0);
+  for (size_t q = 0; q < B; ++q) {
+    uint64_t c = 0;
+    for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) c += plan.entries[i].len;
+    cost[q] = c;
+    qo[q] = (uint32_t)q;
   }
-  uint32_t n_rows = 0;   // rows K0b has to score for this batch
-  uint32_t n_used = 0;   // rows the batch reads (resident ones included)
-  uint64_t layout_bytes = 0;
-  uint32_t n_simple = 0, n_general = 0, z_masked = 0;
-  if (z) {
-    // per query: entry indices stably sorted by ScoreByTerm::score desc (zero_to_one.rs:98);
-    // the records' push order == plan order (query term asc, expansion order, newest version first).
-    // A query whose entries all have their own trie node, their own query term and a single
-    // version layer is "simple": finalize's greedy scan can never skip a record, so k_score sums
-    // the contributions in that sorted order directly; its entries are uploaded pre-sorted.
-    uint32_t* zo = reinterpret_cast<uint32_t*>(h + off_z);
-    uint32_t* qf = reinterpret_cast<uint32_t*>(h + off_f);
-    uint32_t* gq = reinterpret_cast<uint32_t*>(h + off_g);  // queries the general kernel has to run
-    std::vector<ps_plan_entry> tmp;
-    for (size_t q = 0; q < B; ++q) {
-      const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
-      for (uint32_t i = b; i < e; ++i) zo[i] = i;
-      std::stable_sort(zo + b, zo + e,
-                       [&](uint32_t a, uint32_t c) { return plan.entries[c].boost < plan.entries[a].boost; });
-      // simple: one entry per query term and a single version layer.  The same trie node may
-      // appear several times ("abc abc"): the k-th record of a node in the sorted order is consumed
-      // iff the node's pool still holds something, i.e. iff term_frequency >= k (zero_to_one.rs:104-113)
-      bool simple = true, masked = false;
+  if (m.tune.lpt) std::stable_sort(qo, qo + B, [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+}
+
+// zero_to_one: classifies every query (simple / masked / general) and pre-sorts the entries of the
+// simple ones into the record-sort order.
+void classify_zero_to_one(const EngineImpl& m, const Plan& plan, BatchImage& img) {
+  const Snapshot& s = *m.snap;
+  const size_t B = img.B;
+  unsigned char* h = img.h;
+  ps_plan_entry* he = img.he;
+  const size_t off_z = img.off_z, off_f = img.off_f, off_g = img.off_g;
+  uint32_t& n_simple = img.n_simple;
+  uint32_t& n_general = img.n_general;
+  uint32_t& z_masked = img.z_masked;
+  // per query: entry indices stably sorted by ScoreByTerm::score desc (zero_to_one.rs:98);
+  // the records' push order == plan order (query term asc, expansion order, newest version first).
+  // A query whose entries all have their own trie node, their own query term and a single
+  // version layer is "simple": finalize's greedy scan can never skip a record, so k_score sums
+  // the contributions in that sorted order directly; its entries are uploaded pre-sorted.
+  uint32_t* zo = reinterpret_cast<uint32_t*>(h + off_z);
+  uint32_t* qf = reinterpret_cast<uint32_t*>(h + off_f);
+  uint32_t* gq = reinterpret_cast<uint32_t*>(h + off_g);  // queries the general kernel has to run
+  std::vector<ps_plan_entry> tmp;
+  for (size_t q = 0; q < B; ++q) {
+    const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
+    for (uint32_t i = b; i < e; ++i) zo[i] = i;
+    std::stable_sort(zo + b, zo + e,
+                     [&](uint32_t a, uint32_t c) { return plan.entries[c].boost < plan.entries[a].boost; });
+    // simple: one entry per query term and a single version layer.  The same trie node may
+    // appear several times ("abc abc"): the k-th record of a node in the sorted order is consumed
+    // iff the node's pool still holds something, i.e. iff term_frequency >= k (zero_to_one.rs:104-113)
+    bool simple = true, masked = false;
+    for (uint32_t i = b; i < e && simple; ++i) {
+      if (plan.entries[i].shift >> 8) simple = false;
+      for (uint32_t j = b; j < i && simple; ++j) {
+        const bool same_q = plan.entries[j].qterm == plan.entries[i].qterm;
+        const bool same_n = plan.entries[j].node == plan.entries[i].node;
+        // several expansions of one query term: fine as long as every record has its own node
+        // (then the pool never blocks and only consumed_index decides) -> mask variant
+        if (same_q) masked = true;
+        if (same_q && same_n) simple = false;
+      }
+    }
+    if (masked) {
+      // masks are u32 per (doc, field); mixing "same node under two query terms" with
+      // expansions needs the full pool bookkeeping of the general kernel
       for (uint32_t i = b; i < e && simple; ++i) {
-        if (plan.entries[i].shift >> 8) simple = false;
-        for (uint32_t j = b; j < i && simple; ++j) {
-          const bool same_q = plan.entries[j].qterm == plan.entries[i].qterm;
-          const bool same_n = plan.entries[j].node == plan.entries[i].node;
-          // several expansions of one query term: fine as long as every record has its own node
-          // (then the pool never blocks and only consumed_index decides) -> mask variant
-          if (same_q) masked = true;
-          if (same_q && same_n) simple = false;
-        }
-      }
-      if (masked) {
-        // masks are u32 per (doc, field); mixing "same node under two query terms" with
-        // expansions needs the full pool bookkeeping of the general kernel
-        for (uint32_t i = b; i < e && simple; ++i) {
-          if (plan.entries[i].qterm >= 32) simple = false;
-          for (uint32_t j = b; j < i && simple; ++j)
-            if (plan.entries[j].node == plan.entries[i].node) simple = false;
-        }
-      }
-      // the simple path keeps F f64 accumulators per document of the tile in LDS
-      if ((size_t)WG_WAVES * ((size_t)s.T * s.F * 8 + 4096) > 160 * 1024) simple = false;
-      if (masked && (size_t)WG_WAVES * ((size_t)s.T * s.F * 12 + 4096) > 160 * 1024) simple = false;
-      if (m.tune.z21_general_only) simple = false;
-      qf[q] = simple ? 1u : 0u;
-      if (!simple) masked = false;
-      if (simple) {
-        ++n_simple;
-        tmp.assign(plan.entries.begin() + b, plan.entries.begin() + e);
-        for (uint32_t i = b; i < e; ++i) {
-          he[i] = tmp[zo[i] - b];
-          uint32_t need = 1;  // occurrence rank of the node among the sorted records
-          for (uint32_t j = b; j < i; ++j)
-            if (he[j].node == he[i].node) ++need;
-          he[i].qterm_index = need | ((he[i].qterm & 31u) << 16) | (masked ? 0x80000000u : 0u);
-        }
-        if (masked) { z_masked = 1; qf[q] |= 2u; }
-      } else {
-        gq[n_general++] = (uint32_t)q;  // empty queries too: somebody has to write their (empty) candidate slots
-        if (e - b > 64) throw std::length_error("zero_to_one with repeated terms supports at most 64 expanded lists per query on the GPU");
+        if (plan.entries[i].qterm >= 32) simple = false;
+        for (uint32_t j = b; j < i && simple; ++j)
+          if (plan.entries[j].node == plan.entries[i].node) simple = false;
       }
     }
+    // the simple path keeps F f64 accumulators per document of the tile in LDS
+    if ((size_t)WG_WAVES * ((size_t)s.T * s.F * 8 + 4096) > 160 * 1024) simple = false;
+    if (masked && (size_t)WG_WAVES * ((size_t)s.T * s.F * 12 + 4096) > 160 * 1024) simple = false;
+    if (m.tune.z21_general_only) simple = false;
+    qf[q] = simple ? 1u : 0u;
+    if (!simple) masked = false;
+    if (simple) {
+      ++n_simple;
+      tmp.assign(plan.entries.begin() + b, plan.entries.begin() + e);
+      for (uint32_t i = b; i < e; ++i) {
+        he[i] = tmp[zo[i] - b];
+        uint32_t need = 1;  // occurrence rank of the node among the sorted records
+        for (uint32_t j = b; j < i; ++j)
+          if (he[j].node == he[i].node) ++need;
+        he[i].qterm_index = need | ((he[i].qterm & 31u) << 16) | (masked ? 0x80000000u : 0u);
+      }
+      if (masked) { z_masked = 1; qf[q] |= 2u; }
+    } else {
+      gq[n_general++] = (uint32_t)q;  // empty queries too: somebody has to write their (empty) candidate slots
+      if (e - b > 64) throw std::length_error("zero_to_one with repeated terms supports at most 64 expanded lists per query on the GPU");
+    }
   }
-  // ---- hot dense lists (see k_dense_rows) -------------------------------------------------------
-  // BM25: key = (list, idf, expansion_boost).  zero_to_one (simple queries only): key = (list,
-  // ScoreByTerm::score, all_query_terms_len); a row then holds one plane per field.
+}
+
+// ---- hot dense lists (see k_dense_rows) -------------------------------------------------------
+// BM25: key = (list, idf, expansion_boost).  zero_to_one (simple queries only): key = (list,
+// ScoreByTerm::score, all_query_terms_len); a row then holds one plane per field.
+void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan,
+                       BatchImage& img) {
+  const Snapshot& s = *m.snap;
+  const size_t B = img.B, ne = img.ne;
+  unsigned char* h = img.h;
+  ps_plan_entry* he = img.he;
+  const bool z = img.z;
+  const size_t off_f = img.off_f, off_r = img.off_r;
+  const size_t max_rows = m.tune.dense_max_rows;
+  uint32_t& n_rows = img.n_rows;
+  uint32_t& n_used = img.n_used;
+  const uint32_t z_masked = img.z_masked;
   {
     bool sane = max_rows > 0 && s.n_docs > 0;
     if (!z) {
@@ -612,91 +647,28 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       }
     }
   }
-  // A tiny batch whose plans stay in SGPRs for a whole run (<= G entries per query) is read in
-  // place from the pinned slot: a few hundred bytes over PCIe per wave, in parallel, instead of a
-  // copy-engine hand-over in front of the kernel (latency path of a single query).
-  const uint32_t g_regs = (s.F == 1 || s.F == 2) ? (uint32_t)PS_G : 1u;
-  const bool zero_copy = B <= 4 && plan.max_entries <= g_regs && n_used == 0 && n_general == 0 &&
-                         m.tune.zero_copy;
-  const unsigned char* dbase;
-  m.cur_stage = &sg;
-  m.cur_zero_copy = zero_copy;
-  if (zero_copy) {
-    dbase = sg.dp;
-  } else {
-    // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | qorder | zorder | qflags)
-    m.d_stage.ensure(total + 64);
-    PS_HIP(hipMemcpyAsync(m.d_stage.p, h, n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z),
-                          hipMemcpyHostToDevice, st));
-    if (!sync_path) {
-      PS_HIP(hipEventRecord(sg.done, st));
-      sg.pending = true;
-    }
-    dbase = m.d_stage.p;
-  }
+}
 
-  memset(&kp, 0, sizeof(kp));
-  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys;
-  kp.plan = reinterpret_cast<const ps_plan_entry*>(dbase + off_e);
-  kp.qbeg = reinterpret_cast<const uint32_t*>(dbase + off_q);
-  kp.qterms_len = reinterpret_cast<const uint32_t*>(dbase + off_l);
-  kp.qorder = reinterpret_cast<const uint32_t*>(dbase + off_o);
-  kp.zorder = reinterpret_cast<const uint32_t*>(dbase + off_z);
-  kp.qflags = reinterpret_cast<const uint32_t*>(dbase + off_f);
-  kp.gen_queries = reinterpret_cast<const uint32_t*>(dbase + off_g);
-  {
-    // bytes of the layout actually used (never claim the wider figure for a narrower stream)
-    const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.n_tiles * s.T * 8 * (z ? s.F : 1u);
-    uint64_t lb = 0;
-    for (size_t i = 0; i < ne; ++i) lb += (he[i].shift & DENSE_FLAG) ? row_bytes : (uint64_t)he[i].len * pb;
-    const RowDesc* rd = reinterpret_cast<const RowDesc*>(h + off_r);
-    for (uint32_t r = 0; r < n_rows; ++r) lb += (uint64_t)rd[r].len * (pb + 8 * (z ? s.F : 1u)) + row_bytes;
-    layout_bytes = lb;
-  }
-  kp.row_desc = reinterpret_cast<const RowDesc*>(dbase + off_r);
-  kp.n_rows = n_rows;
-  m.build_slots.resize(n_rows);
-  for (uint32_t r = 0; r < n_rows; ++r) m.build_slots[r] = reinterpret_cast<const RowDesc*>(h + off_r)[r].slot;
-  kp.row_planes = z ? s.F : 1u;
-  kp.row_mode = z ? 1u : 0u;
-  kp.row_stride = (uint64_t)s.n_tiles * s.T;
-  if (n_used) {
-    kp.rows = m.d_rows.p;
-  }
-  // control words: the persistent waves' item counter and the per-query thresholds.  k_merge
-  // zeroes them again behind itself, so a memset is only needed after a (re)allocation, a
-  // full-result batch or an error.  The counter has a cache line of its own: sharing one with
-  // threshold words cost 70 % of K1's speed (L2 atomics on the line stall the epilogues' loads of
-  // the neighbouring thresholds, and the other way round).
-  const size_t n_thr = B + 2;
-  const bool fresh = m.d_gthr.ensure(n_thr, true);
-  kp.work_counter = m.d_work;
-  kp.gthr = m.d_gthr.p;
-  if (!(m.ctl_clean && topk_path && !fresh)) {
-    PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
-    PS_HIP(hipMemsetAsync(m.d_work, 0, 256, st));
-  }
-  m.ctl_clean = false;  // enqueue_topk sets it once k_merge is in the stream
-  kp.n_simple = n_simple; kp.n_general = n_general; kp.z_masked = z_masked;
-  kp.layout_bytes = layout_bytes;
-  m.last_layout_bytes = layout_bytes;
-  m.last_rows = n_used;
-  m.last_rows_built = n_rows;
-  kp.P = s.P;
-  kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
-  kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
-  kp.ablate = m.tune.ablate;
-  kp.k1 = sc.bm25_k1; kp.b = sc.bm25_b;
-  kp.k1p1 = sc.bm25_k1 + 1.0;        // (self.bm25k1 + 1_f64), bm25.rs:78 — same IEEE add on the host
-  kp.one_minus_b = 1.0 - sc.bm25_b;  // (1_f64 - self.bm25b),  bm25.rs:80
-  for (uint32_t x = 0; x < s.F; ++x) { kp.avg[x] = s.avg[x]; kp.boost[x] = boosts[x]; }
-  if (sc.kind == PS_SCORER_BM25 && m.tune.lut) {
-    kp.lut = m.d_lut;
-    kp.lut_rows = s.lut_rows;
-    kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;  // odd stride; LUT bytes = stride*128, so tiles stay 16-B aligned
-    for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
-  }
-  // work decomposition: one wave per (query, run of S tiles)
+// Bytes of the layout the batch actually streams (never claim the wider figure for a
+// narrower stream): 4+8F per sparse posting, 8 per document and field plane of a dense-row use,
+// plus scoring the rows that were not resident.
+uint64_t layout_bytes_of(const EngineImpl& m, const BatchImage& img) {
+  const Snapshot& s = *m.snap;
+  const uint32_t planes = img.z ? s.F : 1u;
+  const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.n_tiles * s.T * 8 * planes;
+  uint64_t lb = 0;
+  for (size_t i = 0; i < img.ne; ++i) lb += (img.he[i].shift & DENSE_FLAG) ? row_bytes : (uint64_t)img.he[i].len * pb;
+  const RowDesc* rd = reinterpret_cast<const RowDesc*>(img.h + img.off_r);
+  for (uint32_t r = 0; r < img.n_rows; ++r) lb += (uint64_t)rd[r].len * (pb + 8 * planes) + row_bytes;
+  return lb;
+}
+
+// Work decomposition: one wave per (query, run of S tiles).  Sets kp.S / n_super / slice_bytes.
+void choose_run_length(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, const BatchImage& img, bool topk_path,
+                       KParams& kp) {
+  const Snapshot& s = *m.snap;
+  const size_t B = img.B;
+  const uint32_t z_masked = img.z_masked;
   const uint64_t target = m.tune.target_items;
   uint64_t S = ((uint64_t)s.n_tiles * std::max<size_t>(B, 1) + target - 1) / target;
   const uint32_t s_env = m.tune.tiles_per_run;
@@ -731,6 +703,101 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   // per-wave LDS for the table slices: [entry][rb|re][S] u32; fall back to global lookups if large
   const size_t slice = (((size_t)plan.max_entries * 2 * S * 4) + 15) & ~(size_t)15;
   kp.slice_bytes = (slice <= 4096 && m.tune.slices) ? (uint32_t)slice : 0u;
+}
+
+//   topk_path: k_merge follows and leaves the control words zeroed again (no memset next time)
+//   sync_path: the caller waits for the stream before returning, so the slot needs no reuse fence
+void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, hipStream_t st,
+                KParams& kp, bool topk_path, bool sync_path) {
+  const Snapshot& s = *m.snap;
+  BatchImage img = lay_out_batch(m, sc, plan);
+  const size_t B = img.B;
+  const bool z = img.z;
+  order_queries(m, plan, img);
+  if (z) classify_zero_to_one(m, plan, img);
+  select_dense_rows(m, sc, boosts, plan, img);
+  const uint32_t n_rows = img.n_rows, n_used = img.n_used, n_general = img.n_general;
+  Stage& sg = *img.slot;
+  unsigned char* h = img.h;
+  const size_t off_e = img.off_e, off_q = img.off_q, off_l = img.off_l, off_o = img.off_o, off_z = img.off_z,
+               off_f = img.off_f, off_g = img.off_g, off_r = img.off_r, total = img.total;
+  // A tiny batch whose plans stay in SGPRs for a whole run (<= G entries per query) is read in
+  // place from the pinned slot: a few hundred bytes over PCIe per wave, in parallel, instead of a
+  // copy-engine hand-over in front of the kernel (latency path of a single query).
+  const uint32_t g_regs = (s.F == 1 || s.F == 2) ? (uint32_t)PS_G : 1u;
+  const bool zero_copy = B <= 4 && plan.max_entries <= g_regs && n_used == 0 && n_general == 0 &&
+                         m.tune.zero_copy;
+  const unsigned char* dbase;
+  m.cur_stage = &sg;
+  m.cur_zero_copy = zero_copy;
+  if (zero_copy) {
+    dbase = sg.dp;
+  } else {
+    // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | qorder | zorder | qflags)
+    m.d_stage.ensure(total + 64);
+    PS_HIP(hipMemcpyAsync(m.d_stage.p, h, n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z),
+                          hipMemcpyHostToDevice, st));
+    if (!sync_path) {
+      PS_HIP(hipEventRecord(sg.done, st));
+      sg.pending = true;
+    }
+    dbase = m.d_stage.p;
+  }
+
+  memset(&kp, 0, sizeof(kp));
+  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys;
+  kp.plan = reinterpret_cast<const ps_plan_entry*>(dbase + off_e);
+  kp.qbeg = reinterpret_cast<const uint32_t*>(dbase + off_q);
+  kp.qterms_len = reinterpret_cast<const uint32_t*>(dbase + off_l);
+  kp.qorder = reinterpret_cast<const uint32_t*>(dbase + off_o);
+  kp.zorder = reinterpret_cast<const uint32_t*>(dbase + off_z);
+  kp.qflags = reinterpret_cast<const uint32_t*>(dbase + off_f);
+  kp.gen_queries = reinterpret_cast<const uint32_t*>(dbase + off_g);
+  const uint64_t layout_bytes = layout_bytes_of(m, img);
+  kp.row_desc = reinterpret_cast<const RowDesc*>(dbase + off_r);
+  kp.n_rows = n_rows;
+  m.build_slots.resize(n_rows);
+  for (uint32_t r = 0; r < n_rows; ++r) m.build_slots[r] = reinterpret_cast<const RowDesc*>(h + off_r)[r].slot;
+  kp.row_planes = z ? s.F : 1u;
+  kp.row_mode = z ? 1u : 0u;
+  kp.row_stride = (uint64_t)s.n_tiles * s.T;
+  if (n_used) {
+    kp.rows = m.d_rows.p;
+  }
+  // control words: the persistent waves' item counter and the per-query thresholds.  k_merge
+  // zeroes them again behind itself, so a memset is only needed after a (re)allocation, a
+  // full-result batch or an error.  The counter has a cache line of its own: sharing one with
+  // threshold words cost 70 % of K1's speed (L2 atomics on the line stall the epilogues' loads of
+  // the neighbouring thresholds, and the other way round).
+  const size_t n_thr = B + 2;
+  const bool fresh = m.d_gthr.ensure(n_thr, true);
+  kp.work_counter = m.d_work;
+  kp.gthr = m.d_gthr.p;
+  if (!(m.ctl_clean && topk_path && !fresh)) {
+    PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
+    PS_HIP(hipMemsetAsync(m.d_work, 0, 256, st));
+  }
+  m.ctl_clean = false;  // enqueue_topk sets it once k_merge is in the stream
+  kp.n_simple = img.n_simple; kp.n_general = n_general; kp.z_masked = img.z_masked;
+  kp.layout_bytes = layout_bytes;
+  m.last_layout_bytes = layout_bytes;
+  m.last_rows = n_used;
+  m.last_rows_built = n_rows;
+  kp.P = s.P;
+  kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
+  kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
+  kp.ablate = m.tune.ablate;
+  kp.k1 = sc.bm25_k1; kp.b = sc.bm25_b;
+  kp.k1p1 = sc.bm25_k1 + 1.0;        // (self.bm25k1 + 1_f64), bm25.rs:78 — same IEEE add on the host
+  kp.one_minus_b = 1.0 - sc.bm25_b;  // (1_f64 - self.bm25b),  bm25.rs:80
+  for (uint32_t x = 0; x < s.F; ++x) { kp.avg[x] = s.avg[x]; kp.boost[x] = boosts[x]; }
+  if (sc.kind == PS_SCORER_BM25 && m.tune.lut) {
+    kp.lut = m.d_lut;
+    kp.lut_rows = s.lut_rows;
+    kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;  // odd stride; LUT bytes = stride*128, so tiles stay 16-B aligned
+    for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
+  }
+  choose_run_length(m, sc, plan, img, topk_path, kp);
   static const bool trace = env_u32("PS_TRACE", 0) != 0;
   if (trace && B > 1)
     fprintf(stderr, "[ps] geometry     B=%zu tiles=%u S=%u runs=%u items=%zu slice=%u B/wave max_entries=%u rows=%u\n", B,
