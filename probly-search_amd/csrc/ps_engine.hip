@@ -172,7 +172,7 @@ struct EngineImpl {
   std::vector<RowSlot> row_slots;
   std::vector<double> row_sig;  // scorer kind, k1, b, boosts the resident rows were scored with
   uint64_t row_epoch = 0;
-  std::vector<uint32_t> build_slots;  // slots K0b fills for the batch being enqueued
+  std::vector<uint32_t> build_slots;  // row slots of the batch being enqueued that need a host-side zero fill
   int next_kt = 0;
   // control words (item counter + per-query thresholds) are left zeroed by k_merge: no memset per batch
   bool ctl_clean = false;
@@ -524,7 +524,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
     const uint32_t planes = z ? s.F : 1u;
     if (sane && ne) {
       struct Key { uint64_t post_off, w, k3; };
-      struct Agg { uint32_t uses, len; };
+      struct Agg { uint32_t uses, len, tbl_off, shift; };
       auto kless = [](const Key& a, const Key& b) {
         return a.post_off != b.post_off ? a.post_off < b.post_off : a.w != b.w ? a.w < b.w : a.k3 < b.k3;
       };
@@ -543,6 +543,8 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
           Agg& a = agg[key_of(he[i], q)];
           a.uses++;
           a.len = he[i].len;
+          a.tbl_off = he[i].tbl_off;
+          a.shift = he[i].shift & 0xFFu;
         }
       }
       std::vector<std::pair<uint64_t, Key>> hot;  // (saved posting visits, key)
@@ -609,7 +611,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
           ++n_used;
           RowDesc d;
           d.slot = slot;
-          d._pad2 = 0;
+          d.tbl_off = agg[hk.second].shift == 0 ? agg[hk.second].tbl_off : NO_TABLE;  // one table slot per tile
           d.post_off = hk.second.post_off;
           d.len = agg[hk.second].len;
           // zero_to_one: all_query_terms_len (low 16 bits) | required term frequency (high 16 bits)
@@ -756,8 +758,11 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const uint64_t layout_bytes = layout_bytes_of(m, img);
   kp.row_desc = reinterpret_cast<const RowDesc*>(dbase + off_r);
   kp.n_rows = n_rows;
-  m.build_slots.resize(n_rows);
-  for (uint32_t r = 0; r < n_rows; ++r) m.build_slots[r] = reinterpret_cast<const RowDesc*>(h + off_r)[r].slot;
+  m.build_slots.clear();  // rows the host has to zero-fill for K0b
+  for (uint32_t r = 0; r < n_rows; ++r) {
+    const RowDesc& d = reinterpret_cast<const RowDesc*>(h + off_r)[r];
+    if (d.tbl_off == NO_TABLE) m.build_slots.push_back(d.slot);
+  }
   kp.row_planes = z ? s.F : 1u;
   kp.row_mode = z ? 1u : 0u;
   kp.row_stride = (uint64_t)s.n_tiles * s.T;
@@ -851,17 +856,13 @@ void launch_k_score(const Tuning& tune, KParams& kp, bool tags, int n_cu, hipStr
 #undef PS_LAUNCH_W
 }
 
-void launch_rows(const KParams& kp, const uint32_t* slots, hipStream_t st) {
+void launch_rows(const KParams& kp, const std::vector<uint32_t>& zero_slots, hipStream_t st) {
   if (!kp.n_rows) return;  // every row this batch reads is resident
   const size_t row_b = (size_t)kp.row_planes * kp.row_stride * 8;
-  for (uint32_t r = 0; r < kp.n_rows;) {  // one memset per run of adjacent slots
-    uint32_t e = r + 1;
-    while (e < kp.n_rows && slots[e] == slots[e - 1] + 1) ++e;
-    PS_HIP(hipMemsetAsync(const_cast<double*>(kp.rows) + (size_t)slots[r] * kp.row_planes * kp.row_stride, 0,
-                          row_b * (e - r), st));
-    r = e;
-  }
+  for (uint32_t slot : zero_slots)  // lists without a per-tile table (never the dense ones in practice)
+    PS_HIP(hipMemsetAsync(const_cast<double*>(kp.rows) + (size_t)slot * kp.row_planes * kp.row_stride, 0, row_b, st));
   hipLaunchKernelGGL(k_dense_rows, dim3(256, kp.n_rows), dim3(256), 0, st, kp, const_cast<double*>(kp.rows));
+  PS_HIP(hipGetLastError());
 }
 
 template <bool FULL>
@@ -875,10 +876,10 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
       hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
       m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = st;
     }
-    launch_rows(kp, m.build_slots.data(), st);
+    launch_rows(kp, m.build_slots, st);
     launch_k_score<MODE_BM25, FULL>(m.tune, kp, plan.multi_expansion, n_cu, st);
   } else {
-    launch_rows(kp, m.build_slots.data(), st);
+    launch_rows(kp, m.build_slots, st);
     if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(m.tune, kp, kp.z_masked != 0, n_cu, st);
     if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget

@@ -43,9 +43,10 @@ struct RowDesc {  // one hot (list, idf, expansion_boost) combination K0b has to
   uint32_t len;
   uint32_t _pad;
   double idf, eb;
-  uint32_t slot;  // row slot in the snapshot's row slab
-  uint32_t _pad2;
+  uint32_t slot;     // row slot in the snapshot's row slab
+  uint32_t tbl_off;  // the list's tile-offset table (one slot per tile), or NO_TABLE: the host zero-fills the row
 };
+constexpr uint32_t NO_TABLE = 0xFFFFFFFFu;
 
 constexpr uint32_t DENSE_FLAG = 0x80000000u;  // ps_plan_entry::shift bit 31: entry reads dense row `node`
 constexpr uint32_t DENSE_ASSIGN_FLAG = 0x40000000u;  // ... as the tile's first contribution: written, not added
@@ -220,9 +221,30 @@ __global__ __launch_bounds__(256) void k_bm25_lut(const KParams p, double* out) 
 __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* rows) {
   const RowDesc rd = p.row_desc[blockIdx.y];
   double* row = rows + (uint64_t)rd.slot * p.row_planes * p.row_stride;
+  // Each workgroup owns a range of tiles of the row: it zero-fills that range (coalesced 16-byte
+  // stores), then scatters the scores of the postings that fall into it - found through the list's
+  // tile-offset table - so the row needs no separate memset pass and every line is written while
+  // it is still in L2.  (A list without a per-tile table is zero-filled by the host instead.)
+  uint32_t pb = 0, pe = rd.len;
+  if (rd.tbl_off != NO_TABLE) {
+    const uint32_t tpb = (p.n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = min(p.n_tiles, blockIdx.x * tpb), t1 = min(p.n_tiles, t0 + tpb);
+    if (t0 == t1) return;
+    for (uint32_t x = 0; x < p.row_planes; ++x) {
+      double2* z = reinterpret_cast<double2*>(row + (uint64_t)x * p.row_stride + (uint64_t)t0 * p.T);
+      for (uint32_t i = threadIdx.x; i < (t1 - t0) * p.T / 2; i += blockDim.x) z[i] = make_double2(0.0, 0.0);
+    }
+    pb = p.table[rd.tbl_off + t0];
+    pe = p.table[rd.tbl_off + t1];
+    __syncthreads();  // the zeros are in place before any score of this range is stored
+  } else {
+    const uint32_t per = (rd.len + gridDim.x - 1) / gridDim.x;
+    pb = min(rd.len, blockIdx.x * per);
+    pe = min(rd.len, pb + per);
+  }
   if (p.row_mode != 0) {
     // zero_to_one.rs:117-120 per field: (min(score/tf, 1)*tf) / max(field_length, all_query_terms_len)
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rd.len; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = pb + threadIdx.x; i < pe; i += blockDim.x) {
       const uint64_t pi = rd.post_off + i;
       const uint32_t d = p.doc[pi];
       const uint32_t qtl = rd._pad & 0xFFFFu, need = rd._pad >> 16;
@@ -237,7 +259,7 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
     }
     return;
   }
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rd.len; i += gridDim.x * blockDim.x) {
+  for (uint32_t i = pb + threadIdx.x; i < pe; i += blockDim.x) {
     const uint64_t pi = rd.post_off + i;
     double s = 0.0;
     for (uint32_t x = 0; x < p.F; ++x) {
