@@ -99,6 +99,7 @@ struct Tuning {
   uint32_t dense_max_rows = 64;  // PS_DENSE_MAX_ROWS
   uint32_t row_cache_mb = 4096;  // PS_ROW_CACHE_MB: slab of row slots kept across batches (0: rebuild every batch)
   uint32_t lpt = 1;  // PS_LPT
+  uint32_t kernel_upload = 1;  // PS_KERNEL_UPLOAD: plan upload by a copy kernel instead of the copy engine
   uint32_t dense_fuse = 3;  // PS_DENSE_FUSE: bit 0 = last entry added while harvesting, bit 1 = first entry written
   uint32_t z21_general_only = 0;  // PS_Z21_GENERAL_ONLY
   uint32_t dense_min_uses = 4;  // PS_DENSE_MIN_USES
@@ -308,6 +309,7 @@ void Tuning::load() {
     dense_max_rows = env_u32("PS_DENSE_MAX_ROWS", dense_max_rows);
     row_cache_mb = env_u32("PS_ROW_CACHE_MB", row_cache_mb);
     lpt = env_u32("PS_LPT", lpt);
+    kernel_upload = env_u32("PS_KERNEL_UPLOAD", kernel_upload);
     dense_fuse = env_u32("PS_DENSE_FUSE", dense_fuse);
     z21_general_only = env_u32("PS_Z21_GENERAL_ONLY", z21_general_only);
     dense_min_uses = env_u32("PS_DENSE_MIN_USES", dense_min_uses);
@@ -737,8 +739,16 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   } else {
     // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | qorder | zorder | qflags)
     m.d_stage.ensure(total + 64);
-    PS_HIP(hipMemcpyAsync(m.d_stage.p, h, n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z),
-                          hipMemcpyHostToDevice, st));
+    const size_t up_bytes = n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z);
+    if (m.tune.kernel_upload && up_bytes <= ((size_t)4 << 20)) {
+      const size_t n16 = (up_bytes + 15) / 16;  // slot and device buffer are both padded past `total`
+      const uint32_t blocks = (uint32_t)std::min<size_t>(256, (n16 + 255) / 256);
+      hipLaunchKernelGGL(k_upload, dim3(std::max(1u, blocks)), dim3(256), 0, st, reinterpret_cast<const uint4*>(sg.dp),
+                         reinterpret_cast<uint4*>(m.d_stage.p), n16);
+      PS_HIP(hipGetLastError());
+    } else {
+      PS_HIP(hipMemcpyAsync(m.d_stage.p, h, up_bytes, hipMemcpyHostToDevice, st));
+    }
     if (!sync_path) {
       PS_HIP(hipEventRecord(sg.done, st));
       sg.pending = true;

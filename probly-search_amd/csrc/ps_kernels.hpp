@@ -1049,6 +1049,13 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
   }
 }
 
+// Plan upload without the copy engine: the staged batch is read from the pinned, device-mapped
+// slot with coalesced 16-byte loads.  (An SDMA copy between two kernels costs a 20-30 us hand-over
+// per batch; this is a few microseconds for the ~150 KB of a 1024-query plan.)
+__global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ src, uint4* __restrict__ dst, const size_t n16) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // Full-result mode: the first (out_off[q+1] - out_off[q]) sorted results of run q -> {key, score}.
 __global__ __launch_bounds__(256) void k_pack_results(const uint32_t* doc, const double* score, const uint64_t* run_off,
                                                       const uint64_t* out_off, const uint64_t* keys, ps_result* out) {
