@@ -28,6 +28,9 @@ constexpr int WAVE = 64;
 #define PS_FU 1
 #endif
 constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
+#ifndef PS_FUSED_UNROLL
+#define PS_FUSED_UNROLL 4
+#endif
 #ifndef PS_HARVEST_UNROLL
 #define PS_HARVEST_UNROLL 8
 #endif
@@ -786,6 +789,8 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         };
         uint32_t c = 0;
         if (!TAGS && fuse_row != 0xFFFFFFFFu) {
+          for (; c + 2 * WAVE * PS_FUSED_UNROLL <= T; c += 2 * WAVE * PS_FUSED_UNROLL)
+            harvest(std::integral_constant<int, PS_FUSED_UNROLL>{}, std::true_type{}, c);
           for (; c < T; c += 2 * WAVE * 2) harvest(std::integral_constant<int, 2>{}, std::true_type{}, c);
           fuse_row = 0xFFFFFFFFu;
         } else {
