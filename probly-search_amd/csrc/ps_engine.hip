@@ -369,6 +369,16 @@ size_t k_score_waves_per_cu(EngineImpl& m, const void* fn, uint32_t wgw, size_t 
   return w;
 }
 
+// Workgroups of 8 waves share one LUT copy: two of them (16 waves) fit a CU's 160 KiB when a
+// wave's tile is small enough; otherwise - or when the instantiation's registers allow fewer
+// resident waves that way - 4-wave workgroups pack the CU better.
+bool wide_workgroups(EngineImpl& m, bool bm25, uint32_t F, bool tags, bool full, size_t lut_b, size_t wave_b) {
+  if (full || !m.tune.wg8 || lut_b + 8 * wave_b > 80 * 1024) return false;
+  const size_t w8 = k_score_waves_per_cu(m, k_score_fn(bm25, F, tags, false, true), 8, lut_b + 8 * wave_b);
+  const size_t w4 = k_score_waves_per_cu(m, k_score_fn(bm25, F, tags, false, false), WG_WAVES, lut_b + WG_WAVES * wave_b);
+  return w8 >= w4;
+}
+
 // The staged batch: the pinned slot holds exactly what the device reads
 // (entries | qbeg | qterms_len | qorder | zorder | qflags | gen_queries | row descriptors).
 struct BatchImage {
@@ -694,7 +704,7 @@ void choose_run_length(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan
       size_t slice = (((size_t)plan.max_entries * 2 * runs * 4) + 15) & ~(size_t)15;
       if (slice > 4096) slice = 0;
       const size_t wave_b = tile_b + slice;
-      const bool wide = topk_path && lut_b + 8 * wave_b <= 80 * 1024 && m.tune.wg8;
+      const bool wide = wide_workgroups(m, bm25, s.F, tags, !topk_path, lut_b, wave_b);
       const uint32_t wgw = wide ? 8u : (uint32_t)WG_WAVES;
       return k_score_waves_per_cu(m, k_score_fn(bm25, s.F, tags, !topk_path, wide), wgw, lut_b + wgw * wave_b);
     };
@@ -826,7 +836,7 @@ void allow_lds(const void* fn, size_t lds) {
 }
 
 template <int MODE, bool FULL>
-void launch_k_score(const Tuning& tune, KParams& kp, bool tags, int n_cu, hipStream_t st) {
+void launch_k_score(EngineImpl& m, KParams& kp, bool tags, int n_cu, hipStream_t st) {
   const uint32_t n_items = kp.B * kp.n_super;
   const uint32_t aw = MODE == MODE_Z21S ? kp.F : 1u;
   const size_t lut_b = MODE == MODE_BM25 ? (size_t)kp.lut_stride * LUT_TF * 8 : 0;
@@ -834,7 +844,7 @@ void launch_k_score(const Tuning& tune, KParams& kp, bool tags, int n_cu, hipStr
                         kp.slice_bytes;
   // Workgroups of 8 waves share one LUT copy: two of them (16 waves) fit a CU's 160 KiB when a
   // wave's tile is small enough; otherwise 4-wave workgroups pack the LDS better.
-  const bool wide = !FULL && lut_b + 8 * wave_b <= 80 * 1024 && tune.wg8;
+  const bool wide = wide_workgroups(m, MODE == MODE_BM25, kp.F, tags, FULL, lut_b, wave_b);
   const uint32_t wgw = wide ? 8u : (uint32_t)WG_WAVES;
   uint32_t n_wg = (n_items + wgw - 1) / wgw;
   const size_t lds = lut_b + wgw * wave_b;
@@ -842,9 +852,8 @@ void launch_k_score(const Tuning& tune, KParams& kp, bool tags, int n_cu, hipStr
   do {                                                                                                 \
     const void* fn = reinterpret_cast<const void*>(&k_score<MODE, FV, TG, FULL, W>);                   \
     allow_lds(fn, lds);                                                                                \
-    int per_cu = 0;                                                                                    \
-    PS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVE * W, lds));                  \
-    const uint32_t resident = (uint32_t)std::max(1, per_cu) * (uint32_t)n_cu;                          \
+    const uint32_t per_cu = (uint32_t)(k_score_waves_per_cu(m, fn, W, lds) / (W));                     \
+    const uint32_t resident = std::max(1u, per_cu) * (uint32_t)n_cu;                                   \
     if (n_wg > resident) n_wg = resident;                                                              \
     hipLaunchKernelGGL((k_score<MODE, FV, TG, FULL, W>), dim3(n_wg), dim3(WAVE * W), lds, st, kp);     \
   } while (0)
@@ -887,10 +896,10 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
       m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = st;
     }
     launch_rows(kp, m.build_slots, st);
-    launch_k_score<MODE_BM25, FULL>(m.tune, kp, plan.multi_expansion, n_cu, st);
+    launch_k_score<MODE_BM25, FULL>(m, kp, plan.multi_expansion, n_cu, st);
   } else {
     launch_rows(kp, m.build_slots, st);
-    if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(m.tune, kp, kp.z_masked != 0, n_cu, st);
+    if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(m, kp, kp.z_masked != 0, n_cu, st);
     if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
       kp.z_nodes = std::max<uint32_t>(1, plan.max_nodes);
