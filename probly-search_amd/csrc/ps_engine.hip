@@ -7,11 +7,12 @@
 // (src/score/default/zero_to_one.rs:44-126), max_score_merger (src/query.rs:150-164) and the
 // result materialisation + sort (src/query.rs:97-105) with:
 //
-//   K0  k_bm25_lut   per batch: saturated-tf table tfn(field, tf < 16, field length), same f64 expression
-//   K0b k_dense_rows per batch: per-document score rows of the hot (list, idf, boost) combinations
+//       k_upload     per batch: the staged plan, read from the device-mapped pinned slot
+//   K0  k_bm25_lut   per (k1, b): saturated-tf table tfn(field, tf < 16, field length), same f64 expression
+//   K0b k_dense_rows per-document score rows of the hot (list, idf, boost) combinations not yet resident
 //   K1  k_score      persistent waves, one (query, run of S doc tiles) item at a time; wave-private
 //                    LDS tile of f64 accumulators; plan entries in plan order: first trips of up
-//                    to 4 lists in flight together, double-buffered streaming for long slices,
+//                    to 3 lists in flight together, double-buffered streaming for long slices,
 //                    dense-row slices for hot lists; branch-free scoring (LUT gather, exact
 //                    association, no FMA contraction); add / max / assign merge with u16 visited
 //                    tags; per tile harvest into a register-resident wave top-K with a per-query
@@ -138,7 +139,7 @@ struct EngineImpl {
   uint64_t bytes = 0;
   std::mutex mu;
   // per-batch device buffers (grow-only; reuse is ordered by the stream)
-  DevBuf<unsigned char> d_stage;  // plan entries + per-query arrays, one H2D copy per batch
+  DevBuf<unsigned char> d_stage;  // plan entries + per-query arrays, uploaded once per batch (k_upload)
   DevBuf<uint32_t> d_cand_doc, d_out_counts, d_full_doc, d_full_cnt;
   DevBuf<double> d_cand_score, d_out_scores, d_full_score;
   DevBuf<uint64_t> d_out_keys, d_full_off;
@@ -747,7 +748,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (zero_copy) {
     dbase = sg.dp;
   } else {
-    // one H2D copy: the device image has the staging layout (entries | qbeg | qterms_len | qorder | zorder | qflags)
+    // one upload: the device image has the staging layout (entries | qbeg | qterms_len | qorder | zorder | qflags)
     m.d_stage.ensure(total + 64);
     const size_t up_bytes = n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z);
     if (m.tune.kernel_upload && up_bytes <= ((size_t)4 << 20)) {
