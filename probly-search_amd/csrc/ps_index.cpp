@@ -89,8 +89,8 @@ int32_t Index::find_child(int32_t node, uint32_t ch) const {
 // Walk / extend the trie for one term.  New children are prepended to their parent's child
 // list (src/index.rs:409-419, 437-452), which fixes the expansion order seen by queries.
 int32_t Index::find_or_create(std::string_view term) {
-  auto hit = term_cache_.find(std::string(term));
-  if (hit != term_cache_.end()) return hit->second;
+  const int32_t hit = term_cache_.find(term);
+  if (hit >= 0) return hit;
   int32_t node = 0;
   size_t i = 0;
   while (i < term.size()) {
@@ -110,7 +110,7 @@ int32_t Index::find_or_create(std::string_view term) {
     node = c;
     i = j;
   }
-  term_cache_.emplace(std::string(term), node);
+  term_cache_.insert(term, node);
   return node;
 }
 

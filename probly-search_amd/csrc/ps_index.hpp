@@ -9,6 +9,7 @@
 // flat per-term arrays that the flattener (ps_snapshot.cpp) turns into CSR planes for the GPU.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -49,6 +50,58 @@ std::vector<std::string_view> tokenize(std::string_view s, ps_tokenizer_fn fn, v
 // Decodes one UTF-8 scalar starting at s[i]; advances i.
 uint32_t next_char(std::string_view s, size_t& i);
 void append_utf8(std::string& s, uint32_t cp);
+
+// term bytes -> trie node, open addressing over a byte arena: one hash of the token's bytes and
+// (almost always) one probe per indexed token, no std::string temporary.
+class TermCache {
+ public:
+  int32_t find(std::string_view t) const {
+    if (slots_.empty()) return -1;
+    const uint64_t h = hash(t);
+    for (size_t i = h & mask_;; i = (i + 1) & mask_) {
+      const Slot& s = slots_[i];
+      if (s.node < 0) return -1;
+      if (s.hash == h && s.len == t.size() && memcmp(arena_.data() + s.off, t.data(), t.size()) == 0) return s.node;
+    }
+  }
+  void insert(std::string_view t, int32_t node) {
+    if ((used_ + 1) * 2 > slots_.size()) grow();
+    Slot s{hash(t), arena_.size(), (uint32_t)t.size(), node};
+    arena_.append(t.data(), t.size());
+    place(s);
+    ++used_;
+  }
+  void clear() {
+    slots_.clear();
+    arena_.clear();
+    used_ = 0;
+    mask_ = 0;
+  }
+
+ private:
+  struct Slot { uint64_t hash; size_t off; uint32_t len; int32_t node; };
+  static uint64_t hash(std::string_view t) {  // FNV-1a with a final mix
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : t) { h ^= c; h *= 1099511628211ull; }
+    h ^= h >> 32;
+    return h * 0x9E3779B97F4A7C15ull;
+  }
+  void place(const Slot& s) {
+    for (size_t i = s.hash & mask_;; i = (i + 1) & mask_)
+      if (slots_[i].node < 0) { slots_[i] = s; return; }
+  }
+  void grow() {
+    std::vector<Slot> old;
+    old.swap(slots_);
+    slots_.assign(old.empty() ? 1024 : old.size() * 2, Slot{0, 0, 0, -1});
+    mask_ = slots_.size() - 1;
+    for (const Slot& s : old)
+      if (s.node >= 0) place(s);
+  }
+  std::vector<Slot> slots_;
+  std::string arena_;
+  size_t used_ = 0, mask_ = 0;
+};
 
 class Index {
  public:
@@ -96,7 +149,7 @@ class Index {
   std::unordered_set<uint64_t> removed_;
   // term -> node cache so bulk indexing does one hash probe per token instead of a trie walk
   // over linked sibling lists; dropped whenever vacuum prunes nodes.
-  std::unordered_map<std::string, int32_t> term_cache_;
+  TermCache term_cache_;
   uint64_t epoch_ = 0;
   // add_document scratch
   std::vector<const char*> sp_;
