@@ -1,6 +1,6 @@
 // ps_kernels.hpp — device code of the query-scoring path (gfx950 / CDNA4): kernel parameter
 // block, wave-level top-K, K0 k_bm25_lut, K0b k_dense_rows, K1 k_score, K2 k_z21, K3 k_merge,
-// k_pack_results.  Included by ps_engine.hip only (one translation unit); see that file's header
+// k_upload, k_pack_results.  Included by ps_engine.hip only (one translation unit); see that file's header
 // comment for the kernel overview and DESIGN.md section 3 for the design.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,31 +15,33 @@ namespace ps {
 
 constexpr int MAX_F = 8;
 constexpr int WAVE = 64;
+// Build-time shape of K1 (the defaults are the measured optimum on C2..C5; K1 must stay within
+// 128 VGPRs for 4 waves per SIMD - tools/kernel_resources.py):
 #ifndef PS_UNROLL
-#define PS_UNROLL 2
+#define PS_UNROLL 2          // 64-posting trips per lane in flight in the streaming loop
 #endif
 #ifndef PS_WG_WAVES
-#define PS_WG_WAVES 4
+#define PS_WG_WAVES 4        // waves per workgroup when two 8-wave workgroups do not fit a CU
 #endif
 #ifndef PS_G
-#define PS_G 3
+#define PS_G 3               // plan entries whose ranges + first trips are requested together
 #endif
 #ifndef PS_FU
-#define PS_FU 1
-#endif
-constexpr int UNROLL = PS_UNROLL;      // postings per lane per trip of the streaming loop
-#ifndef PS_FUSED_UNROLL
-#define PS_FUSED_UNROLL 4
+#define PS_FU 1              // postings per lane in a prefetched first trip
 #endif
 #ifndef PS_HARVEST_UNROLL
-#define PS_HARVEST_UNROLL 8
+#define PS_HARVEST_UNROLL 8  // 16-byte LDS reads in flight per lane while a tile is harvested
 #endif
-constexpr int MERGE_WAVES = 16;         // most waves per workgroup of K3 (the host sizes it to the candidates)
-constexpr int WG_WAVES = PS_WG_WAVES;  // waves per workgroup of K1; each wave owns its own LDS tile
-constexpr int LUT_TF = 16;   // LUT columns: term frequency 0..15
+#ifndef PS_FUSED_UNROLL
+#define PS_FUSED_UNROLL 4    // ... when a dense row is added during the harvest (row loads fly too)
+#endif
 #ifndef PS_ABLATE_BUILD
-#define PS_ABLATE_BUILD 0  // profiling builds only: honour KParams::ablate in the hot loops
+#define PS_ABLATE_BUILD 0    // profiling builds only: honour KParams::ablate in the hot loops
 #endif
+constexpr int UNROLL = PS_UNROLL;
+constexpr int WG_WAVES = PS_WG_WAVES;   // each wave owns its own LDS tile
+constexpr int MERGE_WAVES = 16;         // most waves per workgroup of K3 (the host sizes it to the candidates)
+constexpr int LUT_TF = 16;              // LUT columns: term frequency 0..15
 
 struct RowDesc {  // one hot (list, idf, expansion_boost) combination K0b has to score into its row slot
   uint64_t post_off;
