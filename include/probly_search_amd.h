@@ -33,11 +33,13 @@ typedef enum ps_status {
   PS_ENOMEM = 2,
   PS_EHIP = 3,         /* a HIP runtime call failed */
   PS_EUNSUPPORTED = 4, /* input exceeds a documented engine limit */
-  PS_ENODEVICE = 5     /* no usable HIP device / snapshot is host-only */
+  PS_ENODEVICE = 5,    /* no usable HIP device / snapshot is host-only */
+  PS_ERCCL = 6         /* an RCCL call failed (ps_comm_*, ps_snapshot_query_batch_allgather_flat) */
 } ps_status;
 
 typedef struct ps_index ps_index;       /* mutable host index  == Index<u64>  (src/index.rs:19-33) */
 typedef struct ps_snapshot ps_snapshot; /* immutable flattened CSR postings resident in HBM       */
+typedef struct ps_comm ps_comm;         /* RCCL communicator of the ranks that share a sharded batch */
 
 /* &str */
 typedef struct ps_str {
@@ -59,13 +61,74 @@ typedef struct ps_result {
 typedef size_t (*ps_tokenizer_fn)(const char* s, size_t len, const char** tok_ptr, size_t* tok_len, size_t cap,
                                   void* user);
 
-/* The two ScoreCalculator implementations the reference ships (src/score/default/). */
-enum { PS_SCORER_BM25 = 1, PS_SCORER_ZERO_TO_ONE = 2 };
+/* ---- ScoreCalculator plugin surface (src/score/calculator.rs:9-70) ---------------------------
+ * The trait's arguments are host references into the index (HashMap, arena indices), so a custom
+ * implementation cannot run on the device.  The two calculators the reference ships
+ * (src/score/default/) are built in and run on the GPU; any other implementation is handed over as
+ * three C callbacks (PS_SCORER_HOST_CALLBACKS) and runs a host walk inside the library with the
+ * reference's exact call sequence (src/query.rs:29-105): per expansion `before_each`, per
+ * non-removed DocumentPointer in list order (newest first, one call per occurrence) `score` +
+ * max_score_merger, once `finalize`, then the stable sort by score desc. */
+/* TermData (src/score/calculator.rs:9-19) */
+typedef struct ps_term_data {
+  size_t query_term_index;
+  ps_str query_term;
+  ps_str query_term_expanded;
+  size_t query_terms_len;     /* counts every token the tokenizer returned, empty ones included (src/query.rs:32) */
+} ps_term_data;
+/* FieldDetails (src/index.rs:391-396) */
+typedef struct ps_field_details {
+  uint64_t sum;
+  double avg;
+} ps_field_details;
+/* FieldData (src/score/calculator.rs:21-26) */
+typedef struct ps_field_data {
+  const double* fields_boost;
+  size_t n_boost;
+  const ps_field_details* fields;
+  size_t n_fields;
+} ps_field_data;
+/* DocumentPointer (src/index.rs:354-361) without the list link */
+typedef struct ps_document_pointer {
+  uint64_t details_key;
+  const uint32_t* term_frequency; /* [fields_num] */
+} ps_document_pointer;
+/* DocumentDetails (src/index.rs:342-349) */
+typedef struct ps_document_details {
+  uint64_t key;
+  const uint32_t* field_length;   /* [fields_num] */
+} ps_document_details;
+typedef struct ps_score_callbacks {
+  /* before_each(&mut self, &TermData, document_frequency, &documents) -> Option<M>
+   * (calculator.rs:43-50).  Return 1 and set *memory for Some(M), 0 for None.  `n_documents` is
+   * documents.len(); `idx` may be passed to the ps_index_* read functions for anything else the
+   * `documents` map would have answered.  NULL = the trait's default (None). */
+  int (*before_each)(void* user, const ps_term_data* term_expansion, size_t document_frequency, size_t n_documents,
+                     const ps_index* idx, void** memory);
+  /* score(&mut self, Option<&M>, &DocumentPointer, &DocumentDetails, &index_node, &FieldData,
+   * &TermData) -> Option<f64> (calculator.rs:58-66).  Return 1 and set *out for Some(score), 0 for
+   * None.  `memory` is before_each's M (NULL for None); `index_node` is a unique id of the expanded
+   * term's trie node.  Required. */
+  int (*score)(void* user, const void* memory, const ps_document_pointer* document_pointer,
+               const ps_document_details* document_details, uint64_t index_node, const ps_field_data* field_data,
+               const ps_term_data* term_expansion, double* out);
+  /* finalize(&mut self, &mut Vec<QueryResult>) (calculator.rs:69): may rewrite scores in place and
+   * drop results (return the new length <= n).  NULL = the trait's default (no-op). */
+  size_t (*finalize)(void* user, ps_result* results, size_t n);
+  /* drop(M) once the expansion's posting walk is over.  NULL = nothing to free. */
+  void (*drop_memory)(void* user, void* memory);
+  void* user;
+} ps_score_callbacks;
+
+enum { PS_SCORER_BM25 = 1, PS_SCORER_ZERO_TO_ONE = 2, PS_SCORER_HOST_CALLBACKS = 3 };
 typedef struct ps_scorer_desc {
   int32_t kind;   /* PS_SCORER_*                                                        */
   int32_t _pad;
   double bm25_k1; /* BM25::bm25k1, default 1.2  (src/score/default/bm25.rs:14-26)       */
   double bm25_b;  /* BM25::bm25b,  default 0.75                                         */
+  const ps_score_callbacks* callbacks; /* PS_SCORER_HOST_CALLBACKS only (else NULL).  Accepted by
+                     ps_index_query (the entry that owns the posting lists in the reference's
+                     order); the snapshot entry points return PS_EINVAL for it.             */
 } ps_scorer_desc;
 
 const char* ps_last_error(void);
@@ -118,6 +181,11 @@ size_t ps_index_expand_term(const ps_index* idx, const char* term, size_t len, c
  * it exists so the flattener and planner can be inspected on machines without a GPU.
  * tile_docs = documents per LDS accumulator tile (power of two, 256..4096; 0 = default 1024). */
 ps_status ps_index_snapshot(const ps_index* idx, int device, uint32_t tile_docs, ps_snapshot** out);
+/* Multi-device form (SURVEY 8b "device_mask"): flatten ONCE, upload the same planes to every
+ * device of `devices[0..n_devices)`; out[i] is the replica on devices[i].  The replicas share the
+ * host copy (planner, frozen trie); each is freed with ps_snapshot_free. */
+ps_status ps_index_snapshot_multi(const ps_index* idx, const int* devices, size_t n_devices, uint32_t tile_docs,
+                                  ps_snapshot** out);
 void ps_snapshot_free(ps_snapshot* snap);
 /* On-disk form of a snapshot (the reference has no persistence): a versioned dump of
  * the flattened arrays.  ps_snapshot_load needs no ps_index; device = -1 loads host-only. */
@@ -180,6 +248,35 @@ ps_status ps_snapshot_query_batch_device_flat(ps_snapshot* snap, const ps_scorer
                                               size_t n_boost, ps_tokenizer_fn tokenizer, void* user, size_t top_k,
                                               void* d_keys, void* d_scores, void* d_counts, void* hip_stream);
 
+/* ---- multi-GPU: replicated corpus, query batch sharded across ranks, RCCL all-gather of top-k ----
+ * Queries are independent (each Index::query owns its scores / visited maps, src/query.rs:31,37),
+ * so no collective runs while scoring; the only exchange is one ncclAllGather of every rank's
+ * top-k block, and only when the batch spans more than one rank.  One process per GPU.
+ *   rank 0: ps_comm_get_unique_id(id) -> ship the 128 bytes to the other ranks (any channel)
+ *   every rank: ps_comm_init_rank(id, world, rank, device, &comm)
+ * librccl.so.1 is loaded on first use (a process that never creates a communicator never loads it).
+ * PS_COMM_TRANSPORT=hostshm selects a debugging transport through POSIX shared memory for ranks
+ * that share one GPU (RCCL refuses two ranks on one device); it is not a product path. */
+#define PS_COMM_ID_BYTES 128
+ps_status ps_comm_get_unique_id(void* id_out /* PS_COMM_ID_BYTES */);
+ps_status ps_comm_init_rank(const void* id, int world_size, int rank, int device, ps_comm** out);
+void ps_comm_free(ps_comm* comm);
+int ps_comm_world_size(const ps_comm* comm);
+int ps_comm_rank(const ps_comm* comm);
+/* A rank's top-k block: [n_queries*top_k u64 keys | n_queries*top_k f64 scores | n_queries u32
+ * counts, padded to a multiple of 16 bytes]; unused slots key = ~0, score = 0. */
+size_t ps_topk_block_bytes(size_t n_queries, size_t top_k);
+/* Scores this rank's shard (text/offsets as in ps_snapshot_query_batch_device_flat; every rank
+ * passes the same n_queries, padding its shard with empty queries if needed) into d_local_block
+ * and all-gathers the blocks into d_all_blocks (world_size blocks, rank order) with ncclAllGather
+ * on `hip_stream` (NULL = the snapshot's own stream, synchronous).  comm == NULL or world_size 1:
+ * no collective; d_all_blocks receives the local block. */
+ps_status ps_snapshot_query_batch_allgather_flat(ps_snapshot* snap, ps_comm* comm, const ps_scorer_desc* scorer,
+                                                 const char* text, const uint64_t* offsets, size_t n_queries,
+                                                 const double* fields_boost, size_t n_boost, ps_tokenizer_fn tokenizer,
+                                                 void* user, size_t top_k, void* d_local_block, void* d_all_blocks,
+                                                 void* hip_stream);
+
 /* Timing / roofline accounting of the most recent batch executed on this snapshot. */
 typedef struct ps_batch_stats {
   uint64_t n_queries;
@@ -203,6 +300,17 @@ ps_status ps_snapshot_last_stats(const ps_snapshot* snap, ps_batch_stats* out);
  * snapshot since the last reset, and the number of launches; waits for outstanding launches.
  * Works for caller-stream (pipelined) batches too: the events are recorded on that stream. */
 ps_status ps_snapshot_kernel_times(ps_snapshot* snap, double* total_ms, uint64_t* launches, int reset);
+/* The same with the kernels in front of it separated and the kernel named: score_ms covers the
+ * posting-accumulate kernel ALONE (K1 k_score / K1d k_daat / K2 k_z21), rows_ms K0 k_bm25_lut + K0b
+ * k_dense_rows, summed over `launches` batches.  score_kernel is the demangled symbol of the most
+ * recent batch's scoring kernel, as rocprofv3 --kernel-trace prints it. */
+typedef struct ps_kernel_times {
+  double score_ms;
+  double rows_ms;
+  uint64_t launches;
+  char score_kernel[96];
+} ps_kernel_times;
+ps_status ps_snapshot_kernel_breakdown(ps_snapshot* snap, ps_kernel_times* out, int reset);
 
 /* ------------------------------------------------------------------ host-side inspection ---- */
 /* The query plan the host hands to the kernels (tokenise -> expand_term -> before_each), one

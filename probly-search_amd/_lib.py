@@ -16,7 +16,8 @@ class PsError(RuntimeError):
         self.status = status
 
 
-PS_OK, PS_EINVAL, PS_ENOMEM, PS_EHIP, PS_EUNSUPPORTED, PS_ENODEVICE = range(6)
+PS_OK, PS_EINVAL, PS_ENOMEM, PS_EHIP, PS_EUNSUPPORTED, PS_ENODEVICE, PS_ERCCL = range(7)
+PS_COMM_ID_BYTES = 128
 
 
 class Str(C.Structure):
@@ -27,8 +28,49 @@ class Result(C.Structure):
     _fields_ = [("key", C.c_uint64), ("score", C.c_double)]
 
 
+class TermData(C.Structure):
+    _fields_ = [("query_term_index", C.c_size_t), ("query_term", Str), ("query_term_expanded", Str),
+                ("query_terms_len", C.c_size_t)]
+
+
+class FieldDetailsC(C.Structure):
+    _fields_ = [("sum", C.c_uint64), ("avg", C.c_double)]
+
+
+class FieldData(C.Structure):
+    _fields_ = [("fields_boost", C.POINTER(C.c_double)), ("n_boost", C.c_size_t),
+                ("fields", C.POINTER(FieldDetailsC)), ("n_fields", C.c_size_t)]
+
+
+class DocumentPointer(C.Structure):
+    _fields_ = [("details_key", C.c_uint64), ("term_frequency", C.POINTER(C.c_uint32))]
+
+
+class DocumentDetails(C.Structure):
+    _fields_ = [("key", C.c_uint64), ("field_length", C.POINTER(C.c_uint32))]
+
+
+BEFORE_EACH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TermData), C.c_size_t, C.c_size_t, C.c_void_p,
+                             C.POINTER(C.c_void_p))
+SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(DocumentPointer), C.POINTER(DocumentDetails),
+                       C.c_uint64, C.POINTER(FieldData), C.POINTER(TermData), C.POINTER(C.c_double))
+FINALIZE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(Result), C.c_size_t)
+DROP_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+class ScoreCallbacks(C.Structure):
+    _fields_ = [("before_each", BEFORE_EACH_FN), ("score", SCORE_FN), ("finalize", FINALIZE_FN),
+                ("drop_memory", DROP_FN), ("user", C.c_void_p)]
+
+
 class ScorerDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("bm25_k1", C.c_double), ("bm25_b", C.c_double)]
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("bm25_k1", C.c_double), ("bm25_b", C.c_double),
+                ("callbacks", C.POINTER(ScoreCallbacks))]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("score_ms", C.c_double), ("rows_ms", C.c_double), ("launches", C.c_uint64),
+                ("score_kernel", C.c_char * 96)]
 
 
 class SnapshotInfo(C.Structure):
@@ -106,6 +148,17 @@ SYMBOLS = {
                                                       _P, _P]),
     "ps_snapshot_last_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "ps_snapshot_kernel_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "ps_snapshot_kernel_breakdown": (C.c_int, [_P, C.POINTER(KernelTimes), C.c_int]),
+    "ps_index_snapshot_multi": (C.c_int, [_P, C.POINTER(C.c_int), C.c_size_t, C.c_uint32, C.POINTER(_P)]),
+    "ps_comm_get_unique_id": (C.c_int, [_P]),
+    "ps_comm_init_rank": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "ps_comm_free": (None, [_P]),
+    "ps_comm_world_size": (C.c_int, [_P]),
+    "ps_comm_rank": (C.c_int, [_P]),
+    "ps_topk_block_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t]),
+    "ps_snapshot_query_batch_allgather_flat": (C.c_int, [_P, _P, C.POINTER(ScorerDesc), _P, _P, C.c_size_t,
+                                                         C.POINTER(C.c_double), C.c_size_t, _P, _P, C.c_size_t, _P,
+                                                         _P, _P]),
     "ps_snapshot_plan": (C.c_int, [_P, C.POINTER(ScorerDesc), C.c_char_p, C.c_size_t, _P, _P,
                                    C.POINTER(C.POINTER(PlanEntry)), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ps_snapshot_host_csr": (C.c_int, [_P, C.POINTER(HostCsr)]),

@@ -9,20 +9,12 @@
 #include <string>
 
 #include "../../include/probly_search_amd.h"
+#include "ps_capi_internal.hpp"
 #include "ps_engine.hpp"
+#include "ps_errors.hpp"
 #include "ps_index.hpp"
 #include "ps_pool.hpp"
 #include "ps_snapshot.hpp"
-
-struct ps_snapshot {
-  std::unique_ptr<ps::Snapshot> snap;
-  std::unique_ptr<ps::Engine> engine;  // null for host-only snapshots
-  int device = -1;
-  std::mutex stats_mu;
-  ps_batch_stats last{};
-  std::mutex pool_mu;
-  std::unique_ptr<ps::Pool> pool;  // planner threads, created on the first large batch
-};
 
 struct ps_index {
   ps::Index idx;
@@ -48,9 +40,15 @@ ps_status guard(Fn&& fn) {
   } catch (const std::length_error& e) {
     g_err = e.what();
     return PS_EUNSUPPORTED;
+  } catch (const ps::NoDeviceError& e) {
+    g_err = e.what();
+    return PS_ENODEVICE;
+  } catch (const ps::RcclError& e) {
+    g_err = e.what();
+    return PS_ERCCL;
   } catch (const std::exception& e) {
     g_err = e.what();
-    return g_err.find("no HIP device") != std::string::npos ? PS_ENODEVICE : PS_EHIP;
+    return PS_EHIP;
   } catch (...) {
     g_err = "unknown error";
     return PS_EHIP;
@@ -64,6 +62,8 @@ ps_status fail(ps_status s, const char* msg) {
 
 ps_status check_query_args(const ps_snapshot* snap, const ps_scorer_desc* sc, const double* boosts, size_t n_boost) {
   if (!snap || !sc) return fail(PS_EINVAL, "null snapshot or scorer");
+  if (sc->kind == PS_SCORER_HOST_CALLBACKS)
+    return fail(PS_EINVAL, "PS_SCORER_HOST_CALLBACKS walks the host index in the reference's list order: use ps_index_query");
   if (sc->kind != PS_SCORER_BM25 && sc->kind != PS_SCORER_ZERO_TO_ONE) return fail(PS_EINVAL, "unknown scorer kind");
   // the reference indexes fields_boost[x] for x < fields_num and panics if it is shorter (bm25.rs:85)
   if (n_boost < snap->snap->F || (snap->snap->F && !boosts)) return fail(PS_EINVAL, "fields_boost shorter than fields_num");
@@ -131,6 +131,41 @@ double wall_ms() {
 }
 
 }  // namespace
+
+static ps_status run_device_views(ps_snapshot* snap, const ps_scorer_desc* scorer,
+                                  const std::vector<std::string_view>& qs, const double* fields_boost, size_t n_boost,
+                                  ps_tokenizer_fn tokenizer, void* user, size_t top_k, void* d_keys, void* d_scores,
+                                  void* d_counts, void* hip_stream) {
+  ps_status st = check_query_args(snap, scorer, fields_boost, n_boost);
+  if (st != PS_OK) return st;
+  if (!d_keys || !d_scores || !d_counts) return fail(PS_EINVAL, "null argument");
+  const double t0 = wall_ms();
+  ps::Plan plan;
+  plan_batch(snap, *scorer, qs, tokenizer, user, plan);
+  const double t1 = wall_ms();
+  ps_batch_stats stats;
+  snap->engine->run_device(*scorer, fields_boost, plan, top_k, d_keys, d_scores, d_counts, hip_stream, stats);
+  stats.plan_ms = t1 - t0;
+  stats.total_ms = wall_ms() - t0;
+  set_stats(snap, stats);
+  return PS_OK;
+}
+
+namespace ps {
+ps_status set_error(ps_status st, const char* msg) { return fail(st, msg); }
+
+ps_status run_device_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text, const uint64_t* offsets,
+                          size_t n_queries, const double* fields_boost, size_t n_boost, ps_tokenizer_fn tokenizer,
+                          void* user, size_t top_k, void* d_keys, void* d_scores, void* d_counts, void* hip_stream) {
+  return guard([&]() -> ps_status {
+    if (n_queries && (!text || !offsets)) return fail(PS_EINVAL, "null argument");
+    std::vector<std::string_view> qs(n_queries);
+    for (size_t i = 0; i < n_queries; ++i) qs[i] = std::string_view(text + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
+    return run_device_views(snap, scorer, qs, fields_boost, n_boost, tokenizer, user, top_k, d_keys, d_scores, d_counts,
+                            hip_stream);
+  });
+}
+}  // namespace ps
 
 extern "C" {
 
@@ -270,6 +305,24 @@ ps_status ps_index_snapshot(const ps_index* idx, int device, uint32_t tile_docs,
   });
 }
 
+ps_status ps_index_snapshot_multi(const ps_index* idx, const int* devices, size_t n_devices, uint32_t tile_docs,
+                                  ps_snapshot** out) {
+  return guard([&]() -> ps_status {
+    if (!idx || !out || (n_devices && !devices)) return fail(PS_EINVAL, "null argument");
+    std::shared_ptr<ps::Snapshot> host(new ps::Snapshot(idx->idx, tile_docs));  // flattened once
+    std::vector<std::unique_ptr<ps_snapshot>> reps;
+    for (size_t i = 0; i < n_devices; ++i) {
+      std::unique_ptr<ps_snapshot> s(new ps_snapshot());
+      s->snap = host;
+      s->device = devices[i];
+      if (devices[i] >= 0) s->engine.reset(new ps::Engine(*host, devices[i]));
+      reps.push_back(std::move(s));
+    }
+    for (size_t i = 0; i < n_devices; ++i) out[i] = reps[i].release();
+    return PS_OK;
+  });
+}
+
 void ps_snapshot_free(ps_snapshot* snap) { delete snap; }
 
 ps_status ps_snapshot_save(const ps_snapshot* snap, const char* path) {
@@ -362,6 +415,25 @@ ps_status ps_index_query(ps_index* idx, const ps_scorer_desc* scorer, const char
                          const double* fields_boost, size_t n_boost, ps_tokenizer_fn tokenizer, void* user,
                          size_t top_k, ps_result** out, size_t* out_len) {
   if (!idx) return fail(PS_EINVAL, "null index");
+  if (scorer && scorer->kind == PS_SCORER_HOST_CALLBACKS) {
+    // a custom ScoreCalculator: the reference's driver loop on the host, the callbacks do the scoring
+    return guard([&]() -> ps_status {
+      if (!out || !out_len) return fail(PS_EINVAL, "null argument");
+      if (!scorer->callbacks) return fail(PS_EINVAL, "PS_SCORER_HOST_CALLBACKS without callbacks");
+      if (n_boost < idx->idx.fields_len() || (idx->idx.fields_len() && !fields_boost))
+        return fail(PS_EINVAL, "fields_boost shorter than fields_num");
+      std::vector<ps_result> res;
+      idx->idx.query_callbacks(*scorer->callbacks, std::string_view(query ? query : "", query_len), tokenizer, user,
+                               fields_boost, n_boost, idx, res);
+      if (top_k && res.size() > top_k) res.resize(top_k);
+      ps_result* r = (ps_result*)malloc(sizeof(ps_result) * (res.size() ? res.size() : 1));
+      if (!r) return fail(PS_ENOMEM, "out of memory");
+      if (!res.empty()) memcpy(r, res.data(), sizeof(ps_result) * res.size());
+      *out = r;
+      *out_len = res.size();
+      return PS_OK;
+    });
+  }
   if (!idx->cached || idx->cached->snap->src_epoch != idx->idx.epoch()) {
     if (idx->cached) { ps_snapshot_free(idx->cached); idx->cached = nullptr; }
     ps_status st = ps_index_snapshot(idx, 0, 0, &idx->cached);
@@ -369,25 +441,6 @@ ps_status ps_index_query(ps_index* idx, const ps_scorer_desc* scorer, const char
   }
   return ps_snapshot_query(idx->cached, scorer, query, query_len, fields_boost, n_boost, tokenizer, user, top_k, out,
                            out_len);
-}
-
-static ps_status run_device_views(ps_snapshot* snap, const ps_scorer_desc* scorer,
-                                  const std::vector<std::string_view>& qs, const double* fields_boost, size_t n_boost,
-                                  ps_tokenizer_fn tokenizer, void* user, size_t top_k, void* d_keys, void* d_scores,
-                                  void* d_counts, void* hip_stream) {
-  ps_status st = check_query_args(snap, scorer, fields_boost, n_boost);
-  if (st != PS_OK) return st;
-  if (!d_keys || !d_scores || !d_counts) return fail(PS_EINVAL, "null argument");
-  const double t0 = wall_ms();
-  ps::Plan plan;
-  plan_batch(snap, *scorer, qs, tokenizer, user, plan);
-  const double t1 = wall_ms();
-  ps_batch_stats stats;
-  snap->engine->run_device(*scorer, fields_boost, plan, top_k, d_keys, d_scores, d_counts, hip_stream, stats);
-  stats.plan_ms = t1 - t0;
-  stats.total_ms = wall_ms() - t0;
-  set_stats(snap, stats);
-  return PS_OK;
 }
 
 ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc* scorer, const ps_str* queries,
@@ -405,13 +458,8 @@ ps_status ps_snapshot_query_batch_device_flat(ps_snapshot* snap, const ps_scorer
                                               const uint64_t* offsets, size_t n_queries, const double* fields_boost,
                                               size_t n_boost, ps_tokenizer_fn tokenizer, void* user, size_t top_k,
                                               void* d_keys, void* d_scores, void* d_counts, void* hip_stream) {
-  return guard([&]() -> ps_status {
-    if (n_queries && (!text || !offsets)) return fail(PS_EINVAL, "null argument");
-    std::vector<std::string_view> qs(n_queries);
-    for (size_t i = 0; i < n_queries; ++i) qs[i] = std::string_view(text + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
-    return run_device_views(snap, scorer, qs, fields_boost, n_boost, tokenizer, user, top_k, d_keys, d_scores, d_counts,
-                            hip_stream);
-  });
+  return ps::run_device_flat(snap, scorer, text, offsets, n_queries, fields_boost, n_boost, tokenizer, user, top_k, d_keys,
+                             d_scores, d_counts, hip_stream);
 }
 
 ps_status ps_snapshot_last_stats(const ps_snapshot* snap, ps_batch_stats* out) {
@@ -426,7 +474,19 @@ ps_status ps_snapshot_kernel_times(ps_snapshot* snap, double* total_ms, uint64_t
   return guard([&]() -> ps_status {
     if (!snap) return fail(PS_EINVAL, "null snapshot");
     if (!snap->engine) return fail(PS_ENODEVICE, "host-only snapshot");
-    snap->engine->kernel_times(total_ms, launches, reset != 0);
+    ps_kernel_times kt;
+    snap->engine->kernel_times(kt, reset != 0);
+    if (total_ms) *total_ms = kt.score_ms;
+    if (launches) *launches = kt.launches;
+    return PS_OK;
+  });
+}
+
+ps_status ps_snapshot_kernel_breakdown(ps_snapshot* snap, ps_kernel_times* out, int reset) {
+  return guard([&]() -> ps_status {
+    if (!snap || !out) return fail(PS_EINVAL, "null argument");
+    if (!snap->engine) return fail(PS_ENODEVICE, "host-only snapshot");
+    snap->engine->kernel_times(*out, reset != 0);
     return PS_OK;
   });
 }

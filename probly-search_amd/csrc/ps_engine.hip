@@ -35,6 +35,7 @@
 #include <string>
 
 #include "ps_engine.hpp"
+#include "ps_errors.hpp"
 #include "ps_kernels.hpp"
 #include "ps_sort.hpp"
 
@@ -154,7 +155,8 @@ struct EngineImpl {
   Stage result;  // download staging (engine stream only)
   // HIP-event pairs around every launch of the scoring kernel (K1/K2), harvested lazily so a
   // caller that pipelines batches on its own stream still gets per-launch durations.
-  struct KTimer { hipEvent_t a = nullptr, b = nullptr; bool pending = false; };
+  // a: before K0/K0b, m: before the scoring kernel (K1 / K2 / K1d), b: after it
+  struct KTimer { hipEvent_t a = nullptr, m = nullptr, b = nullptr; bool pending = false; };
   KTimer kt[N_KTIMER];
   KTimer* last_kt = nullptr;
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
@@ -190,14 +192,17 @@ struct EngineImpl {
   std::map<std::pair<const void*, size_t>, size_t> occ_cache;  // (K1 instantiation, LDS bytes) -> waves per CU
   Stage* cur_stage = nullptr;   // slot of the batch being enqueued
   bool cur_zero_copy = false;   // its plan is read in place from pinned host memory
-  double kt_total_ms = 0.0;
+  double kt_total_ms = 0.0;  // scoring kernel alone (m -> b)
+  double kt_rows_ms = 0.0;   // K0 + K0b in front of it (a -> m)
   uint64_t kt_launches = 0;
+  std::string score_kernel_name;  // demangled symbol of the scoring kernel of the most recent batch
   void harvest(KTimer& t, bool wait) {
     if (!t.pending) return;
     if (!wait && hipEventQuery(t.b) != hipSuccess) return;
     if (wait) (void)hipEventSynchronize(t.b);
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { kt_total_ms += ms; kt_launches++; }
+    float ms = 0, ms0 = 0;
+    if (hipEventElapsedTime(&ms, t.m, t.b) == hipSuccess) { kt_total_ms += ms; kt_launches++; }
+    if (hipEventElapsedTime(&ms0, t.a, t.m) == hipSuccess) kt_rows_ms += ms0;
     t.pending = false;
   }
 };
@@ -216,8 +221,8 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
-      throw std::runtime_error("no HIP device available (this engine has no CPU scoring fallback)");
-    if (device < 0 || device >= n) throw std::runtime_error("device index out of range");
+      throw NoDeviceError("no HIP device available (this engine has no CPU scoring fallback)");
+    if (device < 0 || device >= n) throw std::invalid_argument("device index out of range");
     PS_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     PS_HIP(hipGetDeviceProperties(&prop, device));
@@ -230,7 +235,7 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     for (auto& ev : m.ev) PS_HIP(hipEventCreate(&ev));
     for (auto& sg : m.stage) PS_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&m.result.done, hipEventDisableTiming));
-    for (auto& t : m.kt) { PS_HIP(hipEventCreate(&t.a)); PS_HIP(hipEventCreate(&t.b)); }
+    for (auto& t : m.kt) { PS_HIP(hipEventCreate(&t.a)); PS_HIP(hipEventCreate(&t.m)); PS_HIP(hipEventCreate(&t.b)); }
     const size_t P = snap.P, F = snap.F;
     PS_HIP(hipMalloc((void**)&m.d_doc, P * 4));
     PS_HIP(hipMalloc((void**)&m.d_tf, P * F * 4));
@@ -275,6 +280,7 @@ Engine::~Engine() {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& t : m.kt) {
     if (t.a) (void)hipEventDestroy(t.a);
+    if (t.m) (void)hipEventDestroy(t.m);
     if (t.b) (void)hipEventDestroy(t.b);
   }
   if (m.stream) (void)hipStreamDestroy(m.stream);
@@ -282,14 +288,17 @@ Engine::~Engine() {
 }
 
 uint64_t Engine::device_bytes() const { return impl_->bytes; }
-void Engine::kernel_times(double* total_ms, uint64_t* launches, bool reset) {
+void Engine::kernel_times(ps_kernel_times& out, bool reset) {
   EngineImpl& m = *impl_;
   std::lock_guard<std::mutex> lock(m.mu);
   (void)hipSetDevice(m.device);
   for (auto& t : m.kt) m.harvest(t, true);
-  if (total_ms) *total_ms = m.kt_total_ms;
-  if (launches) *launches = m.kt_launches;
-  if (reset) { m.kt_total_ms = 0.0; m.kt_launches = 0; }
+  memset(&out, 0, sizeof(out));
+  out.score_ms = m.kt_total_ms;
+  out.rows_ms = m.kt_rows_ms;
+  out.launches = m.kt_launches;
+  snprintf(out.score_kernel, sizeof(out.score_kernel), "%s", m.score_kernel_name.c_str());
+  if (reset) { m.kt_total_ms = 0.0; m.kt_rows_ms = 0.0; m.kt_launches = 0; }
 }
 int Engine::device() const { return impl_->device; }
 
@@ -859,6 +868,10 @@ void launch_k_score(EngineImpl& m, KParams& kp, bool tags, int n_cu, hipStream_t
     const uint32_t per_cu = (uint32_t)(k_score_waves_per_cu(m, fn, W, lds) / (W));                     \
     const uint32_t resident = std::max(1u, per_cu) * (uint32_t)n_cu;                                   \
     if (n_wg > resident) n_wg = resident;                                                              \
+    char nm[96];                                                                                       \
+    snprintf(nm, sizeof(nm), "ps::k_score<%d, %d, %s, %s, %d>", (int)MODE, (int)(FV), (TG) ? "true" : "false",          \
+             FULL ? "true" : "false", (int)(W));                                                       \
+    m.score_kernel_name = nm;                                                                          \
     hipLaunchKernelGGL((k_score<MODE, FV, TG, FULL, W>), dim3(n_wg), dim3(WAVE * W), lds, st, kp);     \
   } while (0)
 #define PS_LAUNCH(FV, TG)                                                                              \
@@ -888,10 +901,15 @@ void launch_rows(const KParams& kp, const std::vector<uint32_t>& zero_slots, hip
   PS_HIP(hipGetLastError());
 }
 
+// `mid` (may be null): recorded between K0 / K0b and the scoring kernel, so the latter is timed alone
 template <bool FULL>
-void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n_cu, hipStream_t st) {
+void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KParams& kp, int n_cu, hipStream_t st,
+                  hipEvent_t mid) {
   const uint32_t n_items = kp.B * kp.n_super;
-  if (n_items == 0) return;
+  if (n_items == 0) {
+    if (mid) PS_HIP(hipEventRecord(mid, st));
+    return;
+  }
   if (sc.kind == PS_SCORER_BM25) {
     // K0 runs when (k1, b) change (or the stream does: no cross-stream ordering is assumed)
     if (kp.lut_rows && !(m.lut_valid && m.lut_k1 == sc.bm25_k1 && m.lut_b == sc.bm25_b && m.lut_stream == st &&
@@ -900,9 +918,11 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
       m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = st;
     }
     launch_rows(kp, m.build_slots, st);
+    if (mid) PS_HIP(hipEventRecord(mid, st));
     launch_k_score<MODE_BM25, FULL>(m, kp, plan.multi_expansion, n_cu, st);
   } else {
     launch_rows(kp, m.build_slots, st);
+    if (mid) PS_HIP(hipEventRecord(mid, st));
     if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(m, kp, kp.z_masked != 0, n_cu, st);
     if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
@@ -913,6 +933,7 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
       while (zt > (uint32_t)WAVE && (size_t)zt * per_doc > budget) zt >>= 1;
       if ((size_t)zt * per_doc > 65536) throw std::length_error("zero_to_one: fields x expanded terms exceed the LDS tile");
       kp.z_tile = zt;
+      if (!kp.n_simple) m.score_kernel_name = FULL ? "ps::k_z21<true>" : "ps::k_z21<false>";
       hipLaunchKernelGGL((k_z21<FULL>), dim3(kp.n_general * kp.n_super), dim3(WAVE), (size_t)zt * per_doc, st, kp);
     }
   }
@@ -970,7 +991,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     TT("harvest");
     PS_HIP(hipEventRecord(kt->a, st));
   }
-  launch_score<false>(m, sc, plan, kp, m.n_cu, st);
+  launch_score<false>(m, sc, plan, kp, m.n_cu, st, timed ? kt->m : nullptr);
   TT("launch");
   if (timed) {
     PS_HIP(hipEventRecord(kt->b, st));
@@ -1010,11 +1031,12 @@ void sync_stream(hipStream_t st) {
 
 // After a stream sync: duration of the batch's scoring kernel from its HIP-event pair.
 void read_kernel_times(EngineImpl& m, ps_batch_stats& stats) {
-  float b = 0;
-  if (m.last_kt && hipEventElapsedTime(&b, m.last_kt->a, m.last_kt->b) != hipSuccess) b = 0;
+  float b = 0, r = 0;
+  if (m.last_kt && hipEventElapsedTime(&b, m.last_kt->m, m.last_kt->b) != hipSuccess) b = 0;
+  if (m.last_kt && hipEventElapsedTime(&r, m.last_kt->a, m.last_kt->m) != hipSuccess) r = 0;
   stats.h2d_ms = 0;
-  stats.score_kernel_ms = b;
-  stats.kernel_ms = b;
+  stats.score_kernel_ms = b;  // the posting-accumulate kernel alone
+  stats.kernel_ms = b + r;    // ... plus K0 / K0b in front of it
 }
 
 Plan sub_plan(const Plan& plan, size_t b, size_t e) {
@@ -1168,7 +1190,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   m.next_kt = (m.next_kt + 1) % N_KTIMER;
   m.harvest(kt, true);
   PS_HIP(hipEventRecord(kt.a, st));
-  launch_score<true>(m, sc, plan, kp, m.n_cu, st);
+  launch_score<true>(m, sc, plan, kp, m.n_cu, st, kt.m);
   PS_HIP(hipEventRecord(kt.b, st));
   kt.pending = true;
   m.last_kt = &kt;

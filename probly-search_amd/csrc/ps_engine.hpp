@@ -28,9 +28,9 @@ class Engine {
   void run_device(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,
                   void* d_scores, void* d_counts, void* stream, ps_batch_stats& stats);
 
-  // Sum of HIP-event durations of every scoring-kernel launch since the last reset (waits for
-  // outstanding launches).
-  void kernel_times(double* total_ms, uint64_t* launches, bool reset);
+  // HIP-event durations summed over every batch since the last reset: the scoring kernel alone and
+  // K0 / K0b in front of it (waits for outstanding launches).
+  void kernel_times(ps_kernel_times& out, bool reset);
   uint64_t device_bytes() const;
   int device() const;
 

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <stdexcept>
 
 namespace ps {
 
@@ -300,6 +301,72 @@ std::vector<std::string> Index::expand_term(std::string_view term) const {
     expand_from(node, t, out);
   }
   return out;
+}
+
+// The reference's Index::query driver (src/query.rs:29-105) for a custom ScoreCalculator handed
+// over as C callbacks.  One `score` call per DocumentPointer: a (document, term) record stands
+// for sum(tf) identical pointers, newest document first (src/index.rs:119-157, 422-433).
+void Index::query_callbacks(const ps_score_callbacks& cb, std::string_view query, ps_tokenizer_fn tok, void* tok_user,
+                            const double* fields_boost, size_t n_boost, const ps_index* handle,
+                            std::vector<ps_result>& out) const {
+  if (!cb.score) throw std::invalid_argument("ps_score_callbacks.score is required");
+  const size_t F = fields_.size();
+  std::vector<const char*> sp;
+  std::vector<size_t> sl;
+  const std::vector<std::string_view> terms = tokenize(query, tok, tok_user, sp, sl);
+  std::vector<ps_field_details> fd(F);
+  for (size_t x = 0; x < F; ++x) fd[x] = ps_field_details{fields_[x].sum, fields_[x].avg};
+  const ps_field_data field_data{fields_boost, n_boost, fd.data(), F};
+  std::unordered_map<uint64_t, double> scores;  // query.rs:31
+  for (size_t qi = 0; qi < terms.size(); ++qi) {
+    const std::string_view qt = terms[qi];
+    if (qt.empty()) continue;  // query.rs:35
+    std::unordered_set<uint64_t> visited;  // query.rs:37
+    for (const std::string& expanded : expand_term(qt)) {
+      const int32_t node = find_node(expanded);  // query.rs:39-43
+      if (node == NIL) continue;
+      const long df = count_documents(node);  // query.rs:45
+      const int32_t li = nodes_[(size_t)node].list;
+      if (li == NIL || lists_[(size_t)li].keys.empty() || df <= 0) continue;  // query.rs:47-48
+      const ps_term_data td{qi, ps_str{qt.data(), qt.size()}, ps_str{expanded.data(), expanded.size()}, terms.size()};
+      void* memory = nullptr;
+      const bool some = cb.before_each && cb.before_each(cb.user, &td, (size_t)df, docs_.size(), handle, &memory) != 0;
+      const PostingList& pl = lists_[(size_t)li];
+      for (size_t r = pl.keys.size(); r-- > 0;) {  // newest first
+        const uint64_t key = pl.keys[r];
+        uint64_t copies = 0;
+        for (size_t x = 0; x < F; ++x) copies += pl.tf[r * F + x];
+        const bool live = !is_removed(key);
+        const DocDetails* dd = live ? doc(key) : nullptr;
+        for (uint64_t c = 0; c < copies; ++c) {
+          if (dd) {  // query.rs:65-66
+            const ps_document_pointer dp{key, pl.tf.data() + r * F};
+            const ps_document_details det{key, dd->field_length.data()};
+            double s = 0.0;
+            if (cb.score(cb.user, some ? memory : nullptr, &dp, &det, (uint64_t)node, &field_data, &td, &s) != 0) {
+              auto it = scores.find(key);  // max_score_merger, query.rs:150-164
+              if (it == scores.end()) scores.emplace(key, s);
+              else it->second = visited.count(key) ? std::max(it->second, s) : it->second + s;
+            }
+          }
+          visited.insert(key);  // query.rs:87
+        }
+      }
+      if (some && cb.drop_memory) cb.drop_memory(cb.user, memory);
+    }
+  }
+  out.clear();
+  out.reserve(scores.size());
+  for (const auto& kv : scores) out.push_back(ps_result{kv.first, kv.second});
+  std::sort(out.begin(), out.end(), [](const ps_result& a, const ps_result& b) { return a.key < b.key; });
+  if (cb.finalize) {
+    const size_t n = cb.finalize(cb.user, out.data(), out.size());
+    if (n < out.size()) out.resize(n);
+  }
+  for (const ps_result& r : out)
+    if (r.score != r.score) throw std::invalid_argument("a score is NaN (the reference panics: partial_cmp().unwrap(), query.rs:103)");
+  // query.rs:103 is a stable sort by score desc; over key-ascending input that is the canonical order
+  std::stable_sort(out.begin(), out.end(), [](const ps_result& a, const ps_result& b) { return a.score > b.score; });
 }
 
 std::vector<uint32_t> Index::children(int32_t node) const {

@@ -123,6 +123,14 @@ class Index {
   std::vector<std::string> expand_term(std::string_view term) const;
   std::vector<uint32_t> children(int32_t node) const;
 
+  // Index::query for a caller-supplied ScoreCalculator (PS_SCORER_HOST_CALLBACKS): the reference's
+  // driver loop (src/query.rs:29-105) over this index's posting lists, calling the three
+  // callbacks in the reference's order.  Results in canonical order (score desc, key asc).
+  // `handle` is what the before_each callback receives as `idx`.
+  void query_callbacks(const ps_score_callbacks& cb, std::string_view query, ps_tokenizer_fn tok, void* tok_user,
+                       const double* fields_boost, size_t n_boost, const ps_index* handle,
+                       std::vector<ps_result>& out) const;
+
   // flattener access
   const std::vector<TrieNode>& nodes() const { return nodes_; }
   const std::vector<PostingList>& lists() const { return lists_; }

@@ -2,6 +2,7 @@
 // parallel_for(n, fn) runs fn(chunk, n_chunks) on the workers and on the calling thread.
 #pragma once
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -33,10 +34,19 @@ class Pool {
     ++gen_;
     l.unlock();
     cv_.notify_all();
-    fn(0, size());
+    std::exception_ptr mine;
+    try {
+      fn(0, size());
+    } catch (...) {
+      mine = std::current_exception();
+    }
     l.lock();
     done_.wait(l, [this] { return pending_ == 0; });
     fn_ = nullptr;
+    // an exception thrown on a worker (e.g. bad_alloc in plan_query) surfaces on the calling thread
+    std::exception_ptr err = mine ? mine : err_;
+    err_ = nullptr;
+    if (err) std::rethrow_exception(err);
   }
 
  private:
@@ -49,8 +59,14 @@ class Pool {
       if (stop_) return;
       const std::function<void(unsigned, unsigned)>* fn = fn_;
       l.unlock();
-      if (fn) (*fn)(id, size());
+      std::exception_ptr e;
+      try {
+        if (fn) (*fn)(id, size());
+      } catch (...) {
+        e = std::current_exception();
+      }
       l.lock();
+      if (e && !err_) err_ = e;
       if (--pending_ == 0) done_.notify_one();
     }
   }
@@ -60,6 +76,7 @@ class Pool {
   const std::function<void(unsigned, unsigned)>* fn_ = nullptr;
   unsigned gen_ = 0, pending_ = 0;
   bool stop_ = false;
+  std::exception_ptr err_;
 };
 
 }  // namespace ps

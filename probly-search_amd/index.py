@@ -59,9 +59,83 @@ class FieldDetails:
 def _scorer_desc(score_calculator):
     kind = getattr(score_calculator, "kind", None)
     if kind not in (1, 2):
-        raise TypeError("score_calculator must be score.bm25.new() or score.zero_to_one.new(); custom "
-                        "ScoreCalculator callbacks cannot run on the device")
-    return _lib.ScorerDesc(kind, 0, float(score_calculator.bm25k1), float(score_calculator.bm25b))
+        raise TypeError("score_calculator must be score.bm25.new() or score.zero_to_one.new() here; a custom "
+                        "ScoreCalculator runs through Index.query (host callbacks), not on a snapshot")
+    return _lib.ScorerDesc(kind, 0, float(score_calculator.bm25k1), float(score_calculator.bm25b), None)
+
+
+class _Documents:
+    """What before_each sees as `documents`: len() == documents.len()."""
+
+    def __init__(self, n):
+        self._n = n
+
+    def __len__(self):
+        return self._n
+
+
+def _callbacks_desc(calc, fields_num):
+    """ps_scorer_desc {PS_SCORER_HOST_CALLBACKS} around a Python ScoreCalculator.  Returns the
+    descriptor plus the objects that must stay alive during the call; exceptions raised inside a
+    callback are re-raised by the caller after the C call returns."""
+    from . import score as sc
+    memories, errors = {}, []
+
+    def term_data(td):
+        t = td.contents
+        return sc.TermData(t.query_term_index, C.string_at(t.query_term.ptr, t.query_term.len).decode("utf-8"),
+                           C.string_at(t.query_term_expanded.ptr, t.query_term_expanded.len).decode("utf-8"),
+                           t.query_terms_len)
+
+    def before_each(_user, td, df, n_docs, _idx, mem_out):
+        try:
+            m = calc.before_each(term_data(td), df, _Documents(n_docs))
+        except Exception as e:  # noqa: BLE001 - must not unwind through C
+            errors.append(e)
+            return 0
+        if m is None:
+            return 0
+        tok = len(memories) + 1
+        memories[tok] = m
+        mem_out[0] = tok
+        return 1
+
+    def score(_user, mem, dp, dd, node, fd, td, out):
+        try:
+            f = fd.contents
+            field_data = sc.FieldData([f.fields_boost[i] for i in range(f.n_boost)],
+                                      [FieldDetails(f.fields[i].sum, f.fields[i].avg) for i in range(f.n_fields)])
+            p, d = dp.contents, dd.contents
+            s = calc.score(memories.get(mem) if mem else None,
+                           sc.DocumentPointer(p.details_key, [p.term_frequency[i] for i in range(fields_num)]),
+                           sc.DocumentDetails(d.key, [d.field_length[i] for i in range(fields_num)]),
+                           node, field_data, term_data(td))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            return 0
+        if s is None:
+            return 0
+        out[0] = float(s)
+        return 1
+
+    def finalize(_user, res, n):
+        try:
+            lst = [QueryResult(res[i].key, res[i].score) for i in range(n)]
+            calc.finalize(lst)
+            for i, r in enumerate(lst[:n]):
+                res[i].key, res[i].score = r.key, r.score
+            return min(len(lst), n)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            return n
+
+    def drop(_user, mem):
+        memories.pop(mem, None)
+
+    cbs = _lib.ScoreCallbacks(_lib.BEFORE_EACH_FN(before_each), _lib.SCORE_FN(score), _lib.FINALIZE_FN(finalize),
+                              _lib.DROP_FN(drop), None)
+    desc = _lib.ScorerDesc(3, 0, 0.0, 0.0, C.pointer(cbs))
+    return desc, (cbs, memories, errors)
 
 
 class _Tok:
@@ -240,6 +314,14 @@ class Snapshot:
         _lib.check(self._L.ps_snapshot_kernel_times(self._h, C.byref(t), C.byref(n), 1 if reset else 0))
         return t.value, n.value
 
+    def kernel_breakdown(self, reset=False):
+        """dict(score_ms, rows_ms, launches, score_kernel): the scoring kernel alone, K0/K0b in front
+        of it, and the scoring kernel's demangled symbol (ps_snapshot_kernel_breakdown)."""
+        kt = _lib.KernelTimes()
+        _lib.check(self._L.ps_snapshot_kernel_breakdown(self._h, C.byref(kt), 1 if reset else 0))
+        return {"score_ms": kt.score_ms, "rows_ms": kt.rows_ms, "launches": kt.launches,
+                "score_kernel": kt.score_kernel.decode("utf-8", "replace")}
+
     def plan(self, query, score_calculator, tokenizer=None):
         """Host query plan (tokenise -> expand_term -> before_each): (entries, query_terms_len)."""
         qb = query.encode("utf-8")
@@ -343,7 +425,11 @@ class Index:
         every matching document, score desc (ties: key asc).  Runs on the GPU; the flattened
         snapshot is rebuilt lazily after mutations."""
         qb = query.encode("utf-8")
-        desc = _scorer_desc(score_calculator)
+        keep = None
+        if getattr(score_calculator, "kind", None) == 3:  # a custom ScoreCalculator: host callbacks
+            desc, keep = _callbacks_desc(score_calculator, self.fields_num)
+        else:
+            desc = _scorer_desc(score_calculator)
         b, nb = _boosts(fields_boost)
         tok = _Tok(tokenizer)
         out, n = C.POINTER(_lib.Result)(), C.c_size_t()
@@ -351,7 +437,12 @@ class Index:
             _lib.check(self._L.ps_index_query(self._h, C.byref(desc), qb, len(qb), b, nb, tok.ptr, None, top_k,
                                               C.byref(out), C.byref(n)))
         except PsError as e:
+            if keep and keep[2]:
+                raise keep[2][0]
             _raise(e)
+        if keep and keep[2]:
+            self._L.ps_free(out)
+            raise keep[2][0]
         return _take_results(self._L, out, n.value)
 
     def snapshot(self, device=0, tile_docs=0):

@@ -1,0 +1,168 @@
+"""ScoreCalculator plugin surface (src/score/calculator.rs:33-70) through the C ABI:
+PS_SCORER_HOST_CALLBACKS runs the reference's driver loop (src/query.rs:29-105) inside the product
+library and calls the user's before_each / score / finalize.  Re-implementing the two shipped
+calculators as plugins must reproduce the oracle bit-for-bit - that pins the call sequence
+(one score call per DocumentPointer, newest first; max_score_merger; visited set; finalize)."""
+import math
+import os
+import subprocess
+
+import pytest
+
+import probly_search_amd as psa
+from adapters import ProductIndex, oracle_scorer, replay
+from corpus_util import build_script, random_queries
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "probly-search_amd", "csrc")
+
+
+class PluginBM25(psa.ScoreCalculator):
+    """BM25 (src/score/default/bm25.rs:35-93) written against the plugin trait."""
+
+    def __init__(self, k1=1.2, b=0.75):
+        self.k1, self.b = k1, b
+        self.calls = []
+
+    def before_each(self, te, df, documents):
+        self.calls.append(("before_each", te.query_term_expanded, df))
+        n = len(documents)
+        f = min(n, df)
+        idf = math.log(1.0 + ((n - f) + 0.5) / (f + 0.5))
+        eb = 1.0 if te.query_term_expanded == te.query_term else math.log(
+            1.0 + (1.0 / (1.0 + len(te.query_term_expanded.encode()) - len(te.query_term.encode()))))
+        return (idf, eb)
+
+    def score(self, before_output, dp, dd, index_node, fd, te):
+        idf, eb = before_output
+        s = 0.0
+        for x in range(len(fd.fields)):
+            tf = dp.term_frequency[x]
+            if tf > 0:
+                tfn = ((self.k1 + 1.0) * tf) / (self.k1 * ((1.0 - self.b) + self.b * (dd.field_length[x] / fd.fields[x].avg)) + tf)
+                s += tfn * idf * fd.fields_boost[x] * eb
+        return s if s > 0.0 else None
+
+
+class PluginZeroToOne(psa.ScoreCalculator):
+    """zero_to_one (src/score/default/zero_to_one.rs:44-126) written against the plugin trait."""
+
+    def __init__(self):
+        self.by_doc = {}
+
+    def score(self, before_output, dp, dd, index_node, fd, te):
+        le, lq = len(te.query_term_expanded.encode()), len(te.query_term.encode())
+        sc = 1.0 - abs(float(le) - float(lq)) / float(le)
+        per_field = self.by_doc.setdefault(dp.details_key, [[] for _ in fd.fields])
+        for x in range(len(fd.fields)):
+            if dp.term_frequency[x] > 0:
+                per_field[x].append((sc, te.query_term_index, te.query_terms_len, index_node, dp.term_frequency[x],
+                                     dd.field_length[x]))
+        return 0.0
+
+    def finalize(self, scores):
+        for r in scores:
+            for recs in self.by_doc.get(r.key, []):
+                recs = sorted(recs, key=lambda t: -t[0])  # stable, score desc (:98)
+                consumed, pool, acc = set(), {}, 0.0
+                for sc, qi, qtl, node, tf, fl in recs:
+                    if qi in consumed:
+                        continue
+                    if node in pool:
+                        if pool[node] <= 0:
+                            continue
+                        pool[node] -= 1
+                    else:
+                        pool[node] = tf - 1
+                    consumed.add(qi)
+                    acc += (min(sc / tf, 1.0) * tf) / max(fl, qtl)
+                r.score = max(acc, r.score)
+        self.by_doc.clear()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_plugin_bm25_and_zero_to_one_match_oracle(seed):
+    fields, steps, vocab = build_script(seed, n_docs=30, fields=2, vocab_size=20, mutate=True)
+    p, o = ProductIndex(fields), orc.Index(fields)
+    replay(steps, fields, p, o)
+    boosts = [1.0, 0.5]
+    for q in random_queries(seed, vocab, n=12):
+        got = [(r.key, r.score) for r in p.idx.query(q, PluginBM25(), None, boosts)]
+        assert got == o.query(q, oracle_scorer("bm25"), boosts), q
+        got = [(r.key, r.score) for r in p.idx.query(q, PluginZeroToOne(), None, boosts)]
+        assert got == o.query(q, oracle_scorer("zero_to_one"), boosts), q
+
+
+def test_call_sequence_one_score_per_pointer_newest_first():
+    """integrations_tests.rs corpus; 'a' occurs twice in doc 1 -> two pointers, both scored."""
+    idx = psa.Index(1)
+    idx.add_field_values(0, ["a b"])
+    idx.add_field_values(1, ["a a c"])
+    seen = []
+
+    class Spy(psa.ScoreCalculator):
+        def before_each(self, te, df, documents):
+            seen.append(("before", te.query_term_expanded, df, len(documents), te.query_terms_len))
+            return None
+
+        def score(self, before_output, dp, dd, node, fd, te):
+            seen.append(("score", dp.details_key, tuple(dp.term_frequency), tuple(dd.field_length), before_output))
+            return 1.0
+
+        def finalize(self, scores):
+            seen.append(("finalize", sorted(r.key for r in scores)))
+            del scores[1:]  # finalize may drop results
+
+    r = idx.query("a  x", Spy(), None, [1.0])
+    assert seen == [("before", "a", 3, 2, 3), ("score", 1, (2,), (3,), None), ("score", 1, (2,), (3,), None),
+                    ("score", 0, (1,), (2,), None), ("finalize", [0, 1])]
+    assert [(x.key, x.score) for x in r] == [(0, 1.0)]
+
+
+def test_plugin_exception_propagates_and_snapshot_refuses():
+    idx = psa.Index(1)
+    idx.add_field_values(0, ["a"])
+
+    class Boom(psa.ScoreCalculator):
+        def score(self, *a):
+            raise ValueError("boom")
+
+    with pytest.raises(ValueError):
+        idx.query("a", Boom(), None, [1.0])
+    with pytest.raises(TypeError):  # custom calculators need the host index's list order
+        idx.snapshot(device=-1).query("a", Boom(), None, [1.0])
+
+
+def _build_c(tmp_path):
+    exe = str(tmp_path / "callbacks_bm25")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi", "callbacks_bm25.c"), "-o", exe, "-L", CSRC,
+                    "-lprobly_search_amd", "-lm", "-Wl,-rpath," + CSRC], check=True)
+    return exe
+
+
+def test_c_callbacks_bm25_matches_oracle(tmp_path):
+    """A C99 ScoreCalculator (BM25 via the three callbacks) gets the oracle's bits; no GPU involved."""
+    r = subprocess.run([_build_c(tmp_path), "host"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    o = orc.Index(2)
+    o.add_document(0, [["abc"], ["dfg"]])
+    o.add_document(1, [["dfgh abc"], ["abcd"]])
+    o.add_document(2, [["x"], ["abc abc q"]])
+    import struct
+    for q in ("abc", "ab dfg", "q x abc"):
+        exp = [(k, "%016x" % struct.unpack("<Q", struct.pack("<d", s))[0]) for k, s in o.query(q, orc.bm25(), [1.0, 2.0])]
+        got = [(int(l.split()[-2]), l.split()[-1]) for l in r.stdout.splitlines() if l.startswith("cb [%s] " % q)]
+        assert got == exp, (q, got, exp)
+
+
+@pytest.mark.gpu
+def test_c_callbacks_bm25_matches_gpu_builtin_bit_for_bit(tmp_path):
+    """The same binary also runs the built-in BM25 on the GPU (ps_index_query, kind BM25) and
+    compares the two result lists itself; the built-in kind must not have taken the host path
+    (its callbacks counter stays 0)."""
+    r = subprocess.run([_build_c(tmp_path), "gpu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "gpu == callbacks: 3 queries bit-identical" in r.stdout
+    assert "callback invocations during built-in queries: 0" in r.stdout
