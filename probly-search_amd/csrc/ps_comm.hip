@@ -268,7 +268,8 @@ ps_status ps_snapshot_query_batch_allgather_flat(ps_snapshot* snap, ps_comm* com
     const int world = comm ? comm->world : 1;
     const int rank = comm ? comm->rank : 0;
     hipStream_t s = (hipStream_t)hip_stream;
-    if (world == 1) {  // batch fits one GPU: no exchange at all
+    static const bool force = getenv("PS_COMM_FORCE_COLLECTIVE") && *getenv("PS_COMM_FORCE_COLLECTIVE") == '1';  // tests
+    if (world == 1 && !(force && comm && comm->nccl)) {  // batch fits one GPU: no exchange at all
       if (d_all_blocks != d_local_block) {
         if (s) hip_check(hipMemcpyAsync(d_all_blocks, d_local_block, bytes, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
         else hip_check(hipMemcpy(d_all_blocks, d_local_block, bytes, hipMemcpyDeviceToDevice), "hipMemcpy");

@@ -159,6 +159,7 @@ struct EngineImpl {
   struct KTimer { hipEvent_t a = nullptr, m = nullptr, b = nullptr; bool pending = false; };
   KTimer kt[N_KTIMER];
   KTimer* last_kt = nullptr;
+  KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0, last_rows_built = 0;
   // Row slab: the dense score row of a hot (list, weight) combination only depends on the
@@ -940,6 +941,15 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
   PS_HIP(hipGetLastError());
 }
 
+// A throw between select_dense_rows (which books row slots) and the launch of K0b would leave
+// slots marked resident whose rows were never scored: drop the whole slab's bookkeeping instead.
+void forget_rows(EngineImpl& m) {
+  m.row_slot_of.clear();
+  for (auto& sl : m.row_slots) sl = EngineImpl::RowSlot{};
+  m.ctl_clean = false;
+  m.lut_valid = false;
+}
+
 void fill_stats(const EngineImpl& m, ps_batch_stats& st, const Snapshot& s, const Plan& plan, uint64_t emitted) {
   st.layout_bytes = m.last_layout_bytes + emitted * 16;
   st.dense_rows = m.last_rows;
@@ -969,6 +979,9 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   };
   if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
   m.tail_pending = false;
+  const bool timed = !sync_path || B >= 8 || time_all;
+  EngineImpl::KTimer* kt = nullptr;
+  try {
   stage_plan(m, sc, boosts, plan, st, kp, true, sync_path);
   TT("stage_plan");
   kp.K = (uint32_t)top_k;
@@ -981,9 +994,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   kp.out_keys = (uint64_t*)d_keys;
   kp.out_scores = (double*)d_scores;
   kp.out_counts = (uint32_t*)d_counts;
-  const bool timed = !sync_path || B >= 8 || time_all;
   m.last_kt = nullptr;
-  EngineImpl::KTimer* kt = nullptr;
   if (timed) {
     kt = &m.kt[m.next_kt];
     m.next_kt = (m.next_kt + 1) % N_KTIMER;
@@ -992,6 +1003,10 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     PS_HIP(hipEventRecord(kt->a, st));
   }
   launch_score<false>(m, sc, plan, kp, m.n_cu, st, timed ? kt->m : nullptr);
+  } catch (...) {
+    forget_rows(m);
+    throw;
+  }
   TT("launch");
   if (timed) {
     PS_HIP(hipEventRecord(kt->b, st));
@@ -1143,7 +1158,8 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   }
   const uint64_t total_cap = cap[B];
   const uint64_t budget = (uint64_t)m.tune.full_budget_mb << 20;
-  if (total_cap * 12 > budget && B > 1) {
+  if (B <= 1 && total_cap >= 0xFFFFFFF0ull) throw std::length_error("full-result batch too large for one pass");
+  if ((total_cap * 12 > budget || total_cap >= 0xFFFFFFF0ull) && B > 1) {
     // keep the result buffers bounded: run the two halves of the batch one after the other
     const size_t half = B / 2;
     std::vector<ps_result> o1, o2;
@@ -1170,6 +1186,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   KParams kp;
   if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
   m.tail_pending = false;
+  try {
   stage_plan(m, sc, boosts, plan, st, kp, false, false);
   kp.K = 1;
   m.d_full_doc.ensure(total_cap + 1);
@@ -1182,15 +1199,21 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   kp.full_cnt = m.d_full_cnt.p;
   m.result.ensure((B + 1) * 12 + 64);
   uint64_t* h_off = reinterpret_cast<uint64_t*>(m.result.p);
-  uint32_t* h_cnt = reinterpret_cast<uint32_t*>(m.result.p + (B + 1) * 8);
   memcpy(h_off, cap.data(), (B + 1) * 8);
   PS_HIP(hipMemcpyAsync(m.d_full_off.p, h_off, (B + 1) * 8, hipMemcpyHostToDevice, st));
   PS_HIP(hipMemsetAsync(m.d_full_cnt.p, 0, (B + 1) * 4, st));
   EngineImpl::KTimer& kt = m.kt[m.next_kt];
+  m.last_kt_pending = &kt;
   m.next_kt = (m.next_kt + 1) % N_KTIMER;
   m.harvest(kt, true);
   PS_HIP(hipEventRecord(kt.a, st));
   launch_score<true>(m, sc, plan, kp, m.n_cu, st, kt.m);
+  } catch (...) {
+    forget_rows(m);
+    throw;
+  }
+  EngineImpl::KTimer& kt = *m.last_kt_pending;
+  uint32_t* h_cnt = reinterpret_cast<uint32_t*>(m.result.p + (B + 1) * 8);
   PS_HIP(hipEventRecord(kt.b, st));
   kt.pending = true;
   m.last_kt = &kt;
@@ -1200,7 +1223,6 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   }
   // K4 (query.rs:97-105, "materialise + sort"): canonical order (score desc, doc id asc == key asc)
   // of every query's run, on the device (ps_sort.hip)
-  if (total_cap >= 0xFFFFFFF0ull) throw std::length_error("full-result batch too large for one pass");
   m.d_sort_doc.ensure(total_cap + 1);
   m.d_sort_score.ensure(total_cap + 1);
   m.d_seg.ensure(2 * (B + 1));

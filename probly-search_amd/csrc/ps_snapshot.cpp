@@ -13,6 +13,12 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <type_traits>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace ps {
 
@@ -38,8 +44,33 @@ struct PhaseTimer {  // PS_TRACE=1: where the flattener's time goes
 };
 }  // namespace
 
+struct SnapshotStorage {
+  std::vector<uint64_t> keys;
+  std::vector<double> avg;
+  std::vector<TermInfo> terms;
+  std::vector<LayerInfo> layers;
+  std::vector<FrozenNode> fnodes;
+  std::vector<uint32_t> fchar, fchild;
+  PlaneVec doc, tf, fl, table;
+  std::vector<uint32_t> max_fl, lut_cap, lut_base;
+};
+
+void Snapshot::bind(const SnapshotStorage& st) {
+  auto v = [](const auto& vec) { return View<typename std::decay_t<decltype(vec)>::value_type>{vec.data(), vec.size()}; };
+  keys = v(st.keys); avg = v(st.avg); terms = v(st.terms); layers = v(st.layers); fnodes = v(st.fnodes);
+  fchar = v(st.fchar); fchild = v(st.fchild); doc = v(st.doc); tf = v(st.tf); fl = v(st.fl); table = v(st.table);
+  max_fl = v(st.max_fl); lut_cap = v(st.lut_cap); lut_base = v(st.lut_base);
+}
+
 Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   PhaseTimer pt;
+  own_.reset(new SnapshotStorage());
+  // the flattener fills the owned vectors (these references shadow the read-only views, which are
+  // bound to the finished vectors at the end)
+  auto& keys = own_->keys; auto& avg = own_->avg; auto& terms = own_->terms; auto& layers = own_->layers;
+  auto& fnodes = own_->fnodes; auto& fchar = own_->fchar; auto& fchild = own_->fchild;
+  auto& doc = own_->doc; auto& tf = own_->tf; auto& fl = own_->fl; auto& table = own_->table;
+  auto& max_fl = own_->max_fl; auto& lut_cap = own_->lut_cap; auto& lut_base = own_->lut_base;
   F = (uint32_t)idx.fields_len();
   T = tile_docs ? tile_docs : 1024;
   if (T < 256 || T > 4096 || (T & (T - 1))) throw std::invalid_argument("tile_docs must be a power of two in [256, 4096]");
@@ -321,62 +352,177 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   });
   { std::vector<TermFlat>().swap(flat); }
   pt.mark("planes");
+  bind(*own_);
 }
 
 // ---- on-disk snapshot ---------------------------------------------------------------------------
+// File = one 4096-byte header page + 14 sections, each starting on a 4096-byte boundary and holding
+// one array exactly as it lives in memory (little-endian, natural alignment):
+//   header: magic "PSNAP002" | u64 file_bytes | u64 scalars[10] | 14 x {u64 offset, u64 bytes, u64 checksum}
+// Loading maps the file read-only and points the views at the sections; nothing is parsed or copied.
 namespace {
-constexpr char MAGIC[8] = {'P', 'S', 'N', 'A', 'P', '0', '0', '1'};
-
-struct File {
-  FILE* f;
-  File(const std::string& path, const char* mode) : f(fopen(path.c_str(), mode)) {
-    if (!f) throw std::invalid_argument("cannot open snapshot file: " + path);
-  }
-  ~File() { if (f) fclose(f); }
-  void put(const void* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) throw std::runtime_error("snapshot write failed"); }
-  void get(void* p, size_t n) { if (n && fread(p, 1, n, f) != n) throw std::invalid_argument("snapshot file truncated"); }
-  template <typename Vec> void put_vec(const Vec& v) {
-    uint64_t n = v.size();
-    put(&n, 8);
-    put(v.data(), n * sizeof(typename Vec::value_type));
-  }
-  template <typename Vec> void get_vec(Vec& v) {
-    uint64_t n = 0;
-    get(&n, 8);
-    if (n > (1ull << 40) / sizeof(typename Vec::value_type)) throw std::invalid_argument("snapshot file corrupt");
-    v.resize((size_t)n);
-    get(v.data(), n * sizeof(typename Vec::value_type));
-  }
+constexpr char MAGIC[8] = {'P', 'S', 'N', 'A', 'P', '0', '0', '2'};
+constexpr size_t PAGE = 4096;
+constexpr int N_SECTIONS = 14;
+struct SectionRef { uint64_t offset, bytes, checksum; };
+struct FileHeader {
+  char magic[8];
+  uint64_t file_bytes;
+  uint64_t scalars[10];  // F, T, n_tiles, n_docs, P, n_postings, n_pointers, n_live_terms, max_layers, lut_rows
+  SectionRef sec[N_SECTIONS];
 };
+static_assert(sizeof(FileHeader) <= PAGE, "header fits one page");
+
+// word-wise multiply-xor checksum (not cryptographic: catches truncation, bit rot, spliced files)
+uint64_t checksum(const void* p, size_t bytes) {
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
+  size_t i = 0;
+  for (; i + 8 <= bytes; i += 8) {
+    uint64_t w;
+    memcpy(&w, b + i, 8);
+    h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+    h ^= h >> 29;
+  }
+  for (; i < bytes; ++i) h = (h ^ b[i]) * 0x100000001B3ull;
+  return h;
+}
 }  // namespace
 
 void Snapshot::save(const std::string& path) const {
-  File f(path, "wb");
-  f.put(MAGIC, 8);
-  const uint64_t hdr[10] = {F, T, n_tiles, n_docs, P, n_postings, n_pointers, n_live_terms, max_layers, lut_rows};
-  f.put(hdr, sizeof(hdr));
-  f.put_vec(keys); f.put_vec(avg); f.put_vec(terms); f.put_vec(layers); f.put_vec(fnodes);
-  f.put_vec(fchar); f.put_vec(fchild); f.put_vec(doc); f.put_vec(tf); f.put_vec(fl); f.put_vec(table);
-  f.put_vec(max_fl); f.put_vec(lut_cap); f.put_vec(lut_base);
+  struct Sec { const void* p; size_t bytes; };
+  const Sec secs[N_SECTIONS] = {
+      {keys.data(), keys.size() * 8}, {avg.data(), avg.size() * 8}, {terms.data(), terms.size() * sizeof(TermInfo)},
+      {layers.data(), layers.size() * sizeof(LayerInfo)}, {fnodes.data(), fnodes.size() * sizeof(FrozenNode)},
+      {fchar.data(), fchar.size() * 4}, {fchild.data(), fchild.size() * 4}, {doc.data(), doc.size() * 4},
+      {tf.data(), tf.size() * 4}, {fl.data(), fl.size() * 4}, {table.data(), table.size() * 4},
+      {max_fl.data(), max_fl.size() * 4}, {lut_cap.data(), lut_cap.size() * 4}, {lut_base.data(), lut_base.size() * 4}};
+  FileHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, MAGIC, 8);
+  const uint64_t sc[10] = {F, T, n_tiles, n_docs, P, n_postings, n_pointers, n_live_terms, max_layers, lut_rows};
+  memcpy(h.scalars, sc, sizeof(sc));
+  uint64_t off = PAGE;
+  for (int i = 0; i < N_SECTIONS; ++i) {
+    h.sec[i] = SectionRef{off, secs[i].bytes, checksum(secs[i].p, secs[i].bytes)};
+    off = (off + secs[i].bytes + PAGE - 1) / PAGE * PAGE;
+  }
+  h.file_bytes = off;
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) throw std::invalid_argument("cannot open snapshot file: " + path);
+  bool ok = true;
+  std::vector<unsigned char> page(PAGE, 0);
+  memcpy(page.data(), &h, sizeof(h));
+  ok = ok && fwrite(page.data(), 1, PAGE, f) == PAGE;
+  std::fill(page.begin(), page.end(), 0);
+  for (int i = 0; i < N_SECTIONS && ok; ++i) {
+    if (secs[i].bytes) ok = fwrite(secs[i].p, 1, secs[i].bytes, f) == secs[i].bytes;
+    const size_t pad = (PAGE - secs[i].bytes % PAGE) % PAGE;
+    if (ok && pad) ok = fwrite(page.data(), 1, pad, f) == pad;
+  }
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) throw std::runtime_error("snapshot write failed: " + path);
+}
+
+Snapshot::~Snapshot() {
+  if (map_base_) munmap(map_base_, map_bytes_);
 }
 
 Snapshot::Snapshot(const std::string& path) {
-  File f(path, "rb");
-  char magic[8];
-  f.get(magic, 8);
-  if (memcmp(magic, MAGIC, 8) != 0) throw std::invalid_argument("not a probly-search_amd snapshot (bad magic/version)");
-  uint64_t hdr[10];
-  f.get(hdr, sizeof(hdr));
-  F = (uint32_t)hdr[0]; T = (uint32_t)hdr[1]; n_tiles = (uint32_t)hdr[2]; n_docs = hdr[3]; P = hdr[4];
-  n_postings = hdr[5]; n_pointers = hdr[6]; n_live_terms = hdr[7]; max_layers = (uint32_t)hdr[8];
-  lut_rows = (uint32_t)hdr[9];
-  f.get_vec(keys); f.get_vec(avg); f.get_vec(terms); f.get_vec(layers); f.get_vec(fnodes);
-  f.get_vec(fchar); f.get_vec(fchild); f.get_vec(doc); f.get_vec(tf); f.get_vec(fl); f.get_vec(table);
-  f.get_vec(max_fl); f.get_vec(lut_cap); f.get_vec(lut_base);
-  if (keys.size() != n_docs || avg.size() != F || doc.size() != P || tf.size() != (size_t)P * F ||
-      fl.size() != (size_t)P * F || fnodes.empty() || T < 256 || (T & (T - 1)))
-    throw std::invalid_argument("snapshot file inconsistent");
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw std::invalid_argument("cannot open snapshot file: " + path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (size_t)st.st_size < PAGE) {
+    close(fd);
+    throw std::invalid_argument("snapshot file truncated");
+  }
+  map_bytes_ = (size_t)st.st_size;
+  void* m = mmap(nullptr, map_bytes_, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) throw std::invalid_argument("cannot map snapshot file: " + path);
+  map_base_ = m;
+  const unsigned char* base = static_cast<const unsigned char*>(m);
+  FileHeader h;
+  memcpy(&h, base, sizeof(h));
+  if (memcmp(h.magic, MAGIC, 8) != 0) throw std::invalid_argument("not a probly-search_amd snapshot (bad magic/version)");
+  if (h.file_bytes != map_bytes_) throw std::invalid_argument("snapshot file truncated or padded");
+  F = (uint32_t)h.scalars[0]; T = (uint32_t)h.scalars[1]; n_tiles = (uint32_t)h.scalars[2]; n_docs = h.scalars[3];
+  P = h.scalars[4]; n_postings = h.scalars[5]; n_pointers = h.scalars[6]; n_live_terms = h.scalars[7];
+  max_layers = (uint32_t)h.scalars[8]; lut_rows = (uint32_t)h.scalars[9];
+  const size_t elem[N_SECTIONS] = {8, 8, sizeof(TermInfo), sizeof(LayerInfo), sizeof(FrozenNode), 4, 4, 4, 4, 4, 4, 4, 4, 4};
+  for (int i = 0; i < N_SECTIONS; ++i) {
+    const SectionRef& s = h.sec[i];
+    if (s.offset % PAGE || s.offset < PAGE || s.offset > map_bytes_ || s.bytes > map_bytes_ - s.offset || s.bytes % elem[i])
+      throw std::invalid_argument("snapshot file corrupt: section out of range");
+    if (checksum(base + s.offset, s.bytes) != s.checksum) throw std::invalid_argument("snapshot file corrupt: checksum mismatch");
+  }
+  auto view = [&](int i, auto* tag) {
+    using E = std::remove_pointer_t<decltype(tag)>;
+    return View<E>{reinterpret_cast<const E*>(base + h.sec[i].offset), (size_t)(h.sec[i].bytes / sizeof(E))};
+  };
+  keys = view(0, (uint64_t*)nullptr); avg = view(1, (double*)nullptr); terms = view(2, (TermInfo*)nullptr);
+  layers = view(3, (LayerInfo*)nullptr); fnodes = view(4, (FrozenNode*)nullptr); fchar = view(5, (uint32_t*)nullptr);
+  fchild = view(6, (uint32_t*)nullptr); doc = view(7, (uint32_t*)nullptr); tf = view(8, (uint32_t*)nullptr);
+  fl = view(9, (uint32_t*)nullptr); table = view(10, (uint32_t*)nullptr); max_fl = view(11, (uint32_t*)nullptr);
+  lut_cap = view(12, (uint32_t*)nullptr); lut_base = view(13, (uint32_t*)nullptr);
+  validate();
   src_epoch = ~0ull;
+}
+
+// Every index the planner or the kernels follow is checked against the array it points into, so a
+// damaged file is refused here instead of turning into out-of-bounds reads on the host or the GPU.
+void Snapshot::validate() const {
+  auto bad = [](const char* what) { throw std::invalid_argument(std::string("snapshot file inconsistent: ") + what); };
+  if (F > 8) bad("more than 8 fields");
+  if (T < 256 || T > 4096 || (T & (T - 1))) bad("tile_docs");
+  if (n_docs >= 0xFFFFFFF0ull) bad("n_docs");
+  const uint64_t want_tiles = std::max<uint64_t>(1, (n_docs + T - 1) / T);
+  if (n_tiles != want_tiles) bad("n_tiles");
+  if (keys.size() != n_docs || avg.size() != F) bad("keys / avg size");
+  if (P < 4 || P % 4 || doc.size() != P || tf.size() != (size_t)P * F || fl.size() != (size_t)P * F) bad("plane sizes");
+  if (table.empty()) bad("empty table");
+  if (max_fl.size() != F || lut_cap.size() != F || lut_base.size() != F) bad("LUT vectors");
+  uint64_t rows = 0;
+  for (uint32_t x = 0; x < F; ++x) {
+    if (lut_base[x] != rows) bad("lut_base");
+    rows += lut_cap[x];
+  }
+  if (rows != lut_rows || lut_rows > 64) bad("lut_rows");
+  for (size_t i = 1; i < keys.size(); ++i)
+    if (keys[i - 1] >= keys[i]) bad("keys not strictly ascending");
+  if (fnodes.empty() || fchar.size() != fchild.size()) bad("frozen trie");
+  for (size_t n = 0; n < fnodes.size(); ++n) {
+    const FrozenNode& fn = fnodes[n];
+    if ((uint64_t)fn.child_begin + fn.child_count > fchar.size()) bad("fnode child range");
+    if (fn.term_begin > fn.term_end || fn.term_end > terms.size()) bad("fnode term range");
+    for (uint32_t c = 0; c < fn.child_count; ++c) {
+      if (fchild[fn.child_begin + c] >= fnodes.size() || fchild[fn.child_begin + c] <= n) bad("fchild target");
+      if (c && fchar[fn.child_begin + c - 1] >= fchar[fn.child_begin + c]) bad("fchar order");
+    }
+  }
+  for (size_t o = 0; o < terms.size(); ++o) {
+    const TermInfo& t = terms[o];
+    if (t.fnode >= fnodes.size()) bad("term fnode");
+    if (t.n_layers && ((uint64_t)t.first_layer + t.n_layers > layers.size())) bad("term layer range");
+  }
+  for (size_t l = 0; l < layers.size(); ++l) {
+    const LayerInfo& L = layers[l];
+    if (L.post_off % 4 || L.post_off > P || L.len > P - L.post_off) bad("layer posting range");
+    if (L.shift > 31) bad("layer shift");
+    const uint64_t slots = (((uint64_t)n_tiles - 1) >> L.shift) + 1;
+    if ((uint64_t)L.tbl_off + slots + 1 > table.size()) bad("layer table range");
+    uint32_t prev = 0;
+    for (uint64_t sl = 0; sl <= slots; ++sl) {
+      const uint32_t v = table[L.tbl_off + sl];
+      if (v < prev || v > L.len) bad("table offsets");
+      prev = v;
+    }
+    if (table[L.tbl_off + slots] != L.len) bad("table end");
+    for (uint32_t i = 0; i < L.len; ++i) {
+      const uint32_t d = doc[L.post_off + i];
+      if (d >= n_docs || (i && doc[L.post_off + i - 1] >= d)) bad("posting doc ids");
+    }
+  }
 }
 
 int64_t Snapshot::find_fnode(std::string_view term) const {

@@ -68,38 +68,66 @@ struct DefaultInitAllocator : std::allocator<T> {
 };
 using PlaneVec = std::vector<uint32_t, DefaultInitAllocator<uint32_t>>;
 
+// Read-only view of one snapshot array: the storage is either the flattener's vectors or a
+// read-only mmap of a snapshot file (the two constructors of Snapshot).
+template <typename T>
+struct View {
+  const T* p = nullptr;
+  size_t n = 0;
+  const T* data() const { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  const T& operator[](size_t i) const { return p[i]; }
+  const T* begin() const { return p; }
+  const T* end() const { return p + n; }
+  const T& back() const { return p[n - 1]; }
+};
+
+struct SnapshotStorage;  // the flattener's vectors (ps_snapshot.cpp)
+
 class Snapshot {
  public:
   Snapshot(const Index& idx, uint32_t tile_docs);
   // On-disk form of the flattened snapshot (the reference has no persistence at
-  // all): a versioned little-endian dump of the arrays below, loadable without the source Index.
+  // all): a versioned little-endian file whose page-aligned sections ARE the arrays below, so
+  // loading is one read-only mmap (no parse, no copy; the planes go from the page cache straight
+  // to the device) plus a validation pass over every offset the planner or the kernels follow.
   explicit Snapshot(const std::string& path);
+  ~Snapshot();
+  Snapshot(const Snapshot&) = delete;
+  Snapshot& operator=(const Snapshot&) = delete;
   void save(const std::string& path) const;
+  bool mapped() const { return map_base_ != nullptr; }
 
   // host planner: tokenise -> expand_term -> before_each (src/query.rs:29-60, bm25.rs:35-58)
   void plan_query(const ps_scorer_desc& sc, std::string_view q, ps_tokenizer_fn tok, void* user, Plan& plan) const;
 
   uint32_t F, T, n_tiles;
   uint64_t n_docs;  // docs.len()
-  std::vector<uint64_t> keys;
-  std::vector<double> avg;
-  std::vector<TermInfo> terms;
-  std::vector<LayerInfo> layers;
-  std::vector<FrozenNode> fnodes;  // [0] = root
-  std::vector<uint32_t> fchar, fchild;
+  View<uint64_t> keys;
+  View<double> avg;
+  View<TermInfo> terms;
+  View<LayerInfo> layers;
+  View<FrozenNode> fnodes;  // [0] = root
+  View<uint32_t> fchar, fchild;
   // CSR planes (host copy)
   uint64_t P = 0;  // padded plane length
-  PlaneVec doc, tf, fl, table;
+  View<uint32_t> doc, tf, fl, table;
   uint64_t n_postings = 0, n_pointers = 0, n_live_terms = 0;
   uint32_t max_layers = 1;
   uint64_t src_epoch = 0;
   // geometry of the BM25 saturated-tf LUT the engine builds per batch (rows of 16 doubles):
   // field x owns rows [lut_base[x], lut_base[x] + lut_cap[x]), one per field length < lut_cap[x]
-  std::vector<uint32_t> max_fl, lut_cap, lut_base;
+  View<uint32_t> max_fl, lut_cap, lut_base;
   uint32_t lut_rows = 0;
 
  private:
   int64_t find_fnode(std::string_view term) const;
+  void bind(const SnapshotStorage& st);
+  void validate() const;  // throws std::invalid_argument on any out-of-range offset
+  std::unique_ptr<SnapshotStorage> own_;  // set when flattened from an Index
+  void* map_base_ = nullptr;              // set when mapped from a file
+  size_t map_bytes_ = 0;
 };
 
 }  // namespace ps

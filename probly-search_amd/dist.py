@@ -7,8 +7,17 @@ are independent — each `Index::query` call owns its `scores` / `visited` maps 
 read-only under `&self` (src/query.rs:21-37).  No collective is needed while scoring; the only
 exchange is the final all-gather of (B/G) x K x {u64 key, f64 score} blocks, and only when every
 rank needs every query's results.
+
+The collective of the product path lives BEHIND the C ABI (ps_comm_*,
+ps_snapshot_query_batch_allgather_flat -> ncclAllGather in librccl); `Comm` / `query_batch_sharded`
+below are thin callers.  `all_gather_topk` is the torch.distributed form of the same exchange, kept
+for hosts that already own a process group (and for the gloo plumbing test on CPU).
 """
+import ctypes as C
+
 import numpy as np
+
+from . import _lib
 
 
 def shard_bounds(n, world, rank):
@@ -75,25 +84,138 @@ def all_gather_topk(keys, scores, counts, shard_sizes, top_k, group=None):
     return tuple(outs)
 
 
-def query_batch_sharded(snapshot, queries, score_calculator, fields_boost, top_k, device, group=None):
+class Comm:
+    """ps_comm: the RCCL communicator behind the C ABI (include/probly_search_amd.h, ps_comm_*).
+    One process per GPU.  The 128-byte id is made by rank 0 and shipped by whatever channel the
+    host application has; `from_torch_distributed` uses an initialised torch.distributed group of
+    any backend for that single broadcast (the data-path collective itself is ncclAllGather inside
+    the library, not torch)."""
+
+    def __init__(self, handle, world, rank, device):
+        self._L = _lib.load()
+        self._h = handle
+        self.world, self.rank, self.device = world, rank, device
+
+    @staticmethod
+    def unique_id():
+        L = _lib.load()
+        buf = C.create_string_buffer(_lib.PS_COMM_ID_BYTES)
+        _lib.check(L.ps_comm_get_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, uid, world, rank, device):
+        L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(L.ps_comm_init_rank(C.c_char_p(uid), world, rank, device, C.byref(h)))
+        return cls(h, world, rank, device)
+
+    @classmethod
+    def from_torch_distributed(cls, device, group=None):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls.init_rank(box[0], world, rank, device)
+
+    def free(self):
+        if self._h:
+            self._L.ps_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def block_bytes(n_queries, top_k):
+    return _lib.load().ps_topk_block_bytes(n_queries, top_k)
+
+
+def unpack_blocks(raw, world, n_queries, top_k, shard_sizes):
+    """bytes of `world` top-k blocks (ps_topk_block_bytes each) -> list[list[(key, score)]] in
+    global-batch order, dropping each shard's padding queries."""
+    bb = block_bytes(n_queries, top_k)
+    out = []
+    for r in range(world):
+        blk = raw[r * bb:(r + 1) * bb]
+        nk = n_queries * top_k
+        keys = np.frombuffer(blk, dtype=np.int64, count=nk, offset=0)
+        scores = np.frombuffer(blk, dtype=np.float64, count=nk, offset=nk * 8)
+        counts = np.frombuffer(blk, dtype=np.uint32, count=n_queries, offset=nk * 16)
+        out.extend(unpack_topk(keys, scores, counts[:shard_sizes[r]], top_k)[:shard_sizes[r]])
+    return out
+
+
+def query_batch_sharded(snapshot, queries, score_calculator, fields_boost, top_k, comm=None):
     """Scores this rank's contiguous shard of `queries` on its GPU (replicated snapshot) and
-    all-gathers the top-k blocks: every rank returns the results of the whole batch."""
-    import torch
-    import torch.distributed as dist
-    world, rank = (dist.get_world_size(group), dist.get_rank(group)) if dist.is_initialized() else (1, 0)
+    all-gathers the top-k blocks through the C ABI (ps_snapshot_query_batch_allgather_flat ->
+    ncclAllGather): every rank returns the results of the whole batch.  comm=None: one rank."""
+    from . import synth
+    from .index import _boosts, _scorer_desc
+    L = _lib.load()
+    world, rank = (comm.world, comm.rank) if comm is not None else (1, 0)
     sizes = [shard_bounds(len(queries), world, r)[1] - shard_bounds(len(queries), world, r)[0] for r in range(world)]
+    per = max(sizes) if sizes else 0
     lo, hi = shard_bounds(len(queries), world, rank)
-    n = hi - lo
-    dev = torch.device("cuda", device)
-    dk = torch.full((max(n, 1) * top_k,), -1, dtype=torch.int64, device=dev)
-    ds = torch.zeros(max(n, 1) * top_k, dtype=torch.float64, device=dev)
-    dc = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    if n:
-        snapshot.query_batch_device(queries[lo:hi], score_calculator, None, fields_boost, top_k, dk.data_ptr(),
-                                    ds.data_ptr(), dc.data_ptr(), stream=stream.cuda_stream)
-    if world == 1:
-        stream.synchronize()
-        return unpack_topk(dk.cpu().numpy(), ds.cpu().numpy(), dc.cpu().numpy()[:n], top_k)
-    gk, gs, gc = all_gather_topk(dk[:n * top_k], ds[:n * top_k], dc[:n], sizes, top_k, group)
-    return unpack_topk(gk.cpu().numpy(), gs.cpu().numpy(), gc.cpu().numpy(), top_k)
+    mine = list(queries[lo:hi]) + [""] * (per - (hi - lo))  # equal blocks: pad with empty queries
+    if per == 0:
+        return []
+    text, offsets = synth.pack_queries(mine)
+    bb = block_bytes(per, top_k)
+    local = _DeviceBuffer(bb)
+    gathered = _DeviceBuffer(bb * world)
+    desc = _scorer_desc(score_calculator)
+    b, nb = _boosts(fields_boost)
+    # stream NULL: the library scores on the snapshot's own stream, gathers on the communicator's,
+    # and returns when both are done
+    _lib.check(L.ps_snapshot_query_batch_allgather_flat(snapshot._h, comm._h if comm is not None else None, C.byref(desc),
+                                                        text.ctypes.data, offsets.ctypes.data, per, b, nb, None, None,
+                                                        top_k, local.ptr, gathered.ptr, None))
+    raw = gathered.to_host()
+    return unpack_blocks(raw, world, per, top_k, sizes)
+
+
+class _DeviceBuffer:
+    """hipMalloc'd scratch through the HIP runtime the library itself uses (no torch needed)."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            _lib.load()
+            for name in ("libamdhip64.so.7", "libamdhip64.so"):
+                try:
+                    cls._hip = C.CDLL(name)
+                    break
+                except OSError:
+                    continue
+            if cls._hip is None:
+                raise _lib.LibraryNotBuilt("libamdhip64 not found")
+            cls._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            cls._hip.hipFree.argtypes = [C.c_void_p]
+            cls._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        return cls._hip
+
+    def __init__(self, nbytes):
+        self.nbytes = nbytes
+        p = C.c_void_p()
+        if self.hip().hipMalloc(C.byref(p), max(nbytes, 16)) != 0:
+            raise MemoryError("hipMalloc(%d) failed" % nbytes)
+        self.ptr = p
+
+    def to_host(self):
+        buf = C.create_string_buffer(self.nbytes)
+        if self.hip().hipMemcpy(buf, self.ptr, self.nbytes, 2) != 0:  # hipMemcpyDeviceToHost
+            raise RuntimeError("hipMemcpy D2H failed")
+        return buf.raw
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.hip().hipFree(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass

@@ -1,0 +1,102 @@
+"""The multi-GPU exchange lives behind the C ABI (ps_comm_*, ps_snapshot_query_batch_allgather_flat):
+  * CPU: the entry points exist, bad arguments are refused, the block layout is the documented one;
+  * GPU: a C program forks 2 ranks that share the box's single GPU (PS_COMM_TRANSPORT=hostshm, the
+    debugging transport - RCCL refuses two ranks on one device) and each must print the oracle's
+    answer for the WHOLE batch; a world-of-1 communicator goes through real RCCL
+    (ncclCommInitRank + ncclAllGather) via the Python thin caller."""
+import os
+import struct
+import subprocess
+
+import pytest
+
+import probly_search_amd as psa
+from probly_search_amd import _lib, dist as psd, synth
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "probly-search_amd", "csrc")
+
+
+def test_block_layout_and_argument_checks():
+    L = _lib.load()
+    assert L.ps_topk_block_bytes(3, 10) == 3 * 10 * 16 + 16
+    assert L.ps_topk_block_bytes(1024, 10) == 1024 * 10 * 16 + 4096
+    assert L.ps_comm_world_size(None) == 1 and L.ps_comm_rank(None) == 0
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.ps_comm_init_rank(None, 2, 0, 0, C.byref(h)) == _lib.PS_EINVAL
+    assert L.ps_comm_init_rank(b"\0" * 128, 2, 5, 0, C.byref(h)) == _lib.PS_EINVAL
+
+
+def _corpus_file(tmp_path, n_docs=300, n_queries=7):
+    cfg = dict(synth.CONFIGS["C2"], n_docs=n_docs, vocab=120)
+    corpus = synth.Corpus(**cfg)
+    o = orc.Index(2)
+    lines = []
+    for keys, text, offsets in corpus.chunks(n_docs):
+        raw = text.tobytes()
+        for i, k in enumerate(keys):
+            f0 = raw[int(offsets[2 * i]):int(offsets[2 * i + 1])].decode()
+            f1 = raw[int(offsets[2 * i + 1]):int(offsets[2 * i + 2])].decode()
+            lines.append("D %d\t%s\t%s" % (k, f0, f1))
+            o.add_document(int(k), [[f0], [f1]])
+    queries = corpus.queries(n_queries, 3)
+    lines += ["Q " + q for q in queries]
+    path = str(tmp_path / "corpus.txt")
+    open(path, "w").write("\n".join(lines) + "\n")
+    return path, o, queries
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "two_ranks")
+    subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                    "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi", "two_ranks.c"), "-o", exe,
+                    "-L", CSRC, "-lprobly_search_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_two_rank_c_driver_builds(tmp_path):
+    _build(tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_two_ranks_one_gpu_through_the_abi(tmp_path, world):
+    path, o, queries = _corpus_file(tmp_path)
+    top_k = 5
+    env = dict(os.environ, PS_COMM_TRANSPORT="hostshm")
+    r = subprocess.run([_build(tmp_path), path, str(world), str(top_k)], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = []
+    for q in queries:
+        res = o.query(q, orc.bm25(), [1.0, 1.0])[:top_k]
+        exp.append(["%d:%016x" % (k, struct.unpack("<Q", struct.pack("<d", s))[0]) for k, s in res])
+    for rank in range(world):
+        got = {}
+        for line in r.stdout.splitlines():
+            p = line.split()
+            if p[:2] == ["rank", str(rank)]:
+                got[int(p[3])] = p[5:]
+        assert [got.get(i) for i in range(len(queries))] == exp, (rank, r.stdout)
+
+
+@pytest.mark.gpu
+def test_world_of_one_goes_through_rccl(monkeypatch):
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllGather really run (PS_COMM_FORCE_COLLECTIVE makes
+    the 1-rank call issue the collective it would otherwise skip)."""
+    monkeypatch.delenv("PS_COMM_TRANSPORT", raising=False)
+    monkeypatch.setenv("PS_COMM_FORCE_COLLECTIVE", "1")
+    cfg = dict(synth.CONFIGS["C2"], n_docs=3000, vocab=400)
+    corpus = synth.Corpus(**cfg)
+    p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
+    snap = p.snapshot(device=0, tile_docs=256)
+    comm = psd.Comm.init_rank(psd.Comm.unique_id(), 1, 0, 0)
+    queries = corpus.queries(9, 3)
+    got = psd.query_batch_sharded(snap, queries, psa.bm25.new(), [1.0, 1.0], 10, comm)
+    exp = [o.query(q, orc.bm25(), [1.0, 1.0])[:10] for q in queries]
+    assert got == exp
+    comm.free()
+    assert psd.query_batch_sharded(snap, queries, psa.bm25.new(), [1.0, 1.0], 10, None) == exp

