@@ -303,6 +303,20 @@ class Snapshot:
         except PsError as e:
             _raise(e)
 
+    def query_batch_allgather_flat(self, comm, text, offsets, score_calculator, fields_boost, top_k, d_local_block,
+                                   d_all_blocks, stream=None):
+        """ps_snapshot_query_batch_allgather_flat: score this rank's shard into d_local_block and
+        all-gather every rank's block into d_all_blocks (ncclAllGather inside the library, ordered on
+        `stream`).  comm: dist.Comm or None (one rank: no collective)."""
+        desc = _scorer_desc(score_calculator)
+        b, nb = _boosts(fields_boost)
+        try:
+            _lib.check(self._L.ps_snapshot_query_batch_allgather_flat(
+                self._h, comm._h if comm is not None else None, C.byref(desc), text.ctypes.data, offsets.ctypes.data,
+                len(offsets) - 1, b, nb, None, None, top_k, d_local_block, d_all_blocks, stream if stream else None))
+        except PsError as e:
+            _raise(e)
+
     def last_stats(self):
         s = _lib.BatchStats()
         _lib.check(self._L.ps_snapshot_last_stats(self._h, C.byref(s)))

@@ -1,0 +1,45 @@
+"""bench.py --gpus N: the flag is honoured (self-spawned ranks or a loud failure), never ignored."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "PS_BENCH_DEBUG_ONE_GPU"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          env=e, timeout=timeout)
+
+
+def test_more_gpus_than_devices_fails_loudly():
+    import probly_search_amd as psa
+    have = psa.load().ps_device_count()
+    r = _run(["--gpus", str(max(2, have + 1)), "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "HIP device(s) are visible" in (r.stderr + r.stdout)
+
+
+def test_world_size_must_match_gpus():
+    r = _run(["--gpus", "1", "--steps", "1", "--warmup", "0"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_two_ranks_debug_one_gpu_end_to_end():
+    """Self-spawned 2-rank run on the box's single GPU (debug transport): the N>1 path of bench.py -
+    snapshot file shared between ranks, sharded batch, library-side all-gather - runs end to end."""
+    r = _run(["--gpus", "2", "--n-docs", "20000", "--batch", "64", "--steps", "3", "--warmup", "1",
+              "--no-cpu-baseline", "--no-single-latency"], env={"PS_BENCH_DEBUG_ONE_GPU": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0
+    assert "DEBUG" in d["data"]
