@@ -323,7 +323,7 @@ typedef struct ps_plan_entry {
   uint32_t qterm;      /* ordinal of the query term (visited-set scope, src/query.rs:37)          */
   double idf;          /* BM25TermCalculations::idf | zero_to_one: u64 bitmask of same-node entries */
   double boost;        /* BM25TermCalculations::expansion_boost | zero_to_one: ScoreByTerm::score */
-  uint32_t node;       /* zero_to_one: ordinal of the distinct trie node within the query         */
+  uint32_t node;       /* zero_to_one: ordinal of the distinct trie node within the query | BM25: ordinal of the list (layer) in the snapshot */
   uint32_t qterm_index;/* TermData::query_term_index (position in the token list)                 */
 } ps_plan_entry;
 ps_status ps_snapshot_plan(const ps_snapshot* snap, const ps_scorer_desc* scorer, const char* query,

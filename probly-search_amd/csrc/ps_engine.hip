@@ -29,7 +29,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <thread>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -117,6 +119,11 @@ struct Tuning {
   uint32_t lut_cache = 1;  // PS_LUT_CACHE
   uint32_t z21_lds = 20480;  // PS_Z21_LDS
   uint32_t full_budget_mb = 4096;  // PS_FULL_BUDGET_MB
+  uint32_t daat = 1;             // PS_DAAT: BM25 top-k batches take K1d k_daat (exact dynamic pruning)
+  uint32_t daat_min_batch = 8;   // PS_DAAT_MIN_BATCH: smaller batches keep the k_score latency path
+  uint32_t daat_chunk = 4096;    // PS_DAAT_CHUNK: smallest chunk of a list one item covers
+  uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
+  uint32_t daat_persistent = 0;  // PS_DAAT_PERSISTENT: persistent waves + item counter instead of one wave per item
   void load();
 };
 
@@ -146,6 +153,15 @@ struct EngineImpl {
   DevBuf<uint64_t> d_out_keys, d_full_off;
   DevBuf<unsigned long long> d_gthr;
   DevBuf<double> d_rows;  // dense per-document score rows of the batch's hot lists
+  DevBuf<uint32_t> d_cand_cnt;  // K1d: candidates per item
+  // K1d: per list (layer) upper bounds of the saturated term frequency, exact for the current
+  // (k1, b): M[l*F+x] = max tfn_x over the list's postings, J[l] = max over postings of
+  // sum_x boost_x * tfn_x.  Host pass over the planes, once per (k1, b, boosts).
+  struct ListBounds {
+    bool valid = false;
+    double k1 = 0, b = 0;
+    std::vector<double> boosts, M, J;
+  } bounds;
   DevBuf<uint32_t> d_sort_doc, d_seg;  // K4 scratch
   DevBuf<uint64_t> d_sort_score, d_pack_off;
   DevBuf<unsigned char> d_sort_tmp;
@@ -159,6 +175,7 @@ struct EngineImpl {
   struct KTimer { hipEvent_t a = nullptr, m = nullptr, b = nullptr; bool pending = false; };
   KTimer kt[N_KTIMER];
   KTimer* last_kt = nullptr;
+  uint32_t daat_max_slots = 0;  // K1d: most candidate slots of one query in the batch being enqueued
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0, last_rows_built = 0;
@@ -268,7 +285,7 @@ Engine::~Engine() {
   m.d_stage.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
-  m.d_gthr.release(); m.d_rows.release();
+  m.d_gthr.release(); m.d_rows.release(); m.d_cand_cnt.release();
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
   m.d_sort_tmp.release(); m.d_pack.release();
   for (auto& sg : m.stage) {
@@ -336,6 +353,11 @@ void Tuning::load() {
     lut_cache = env_u32("PS_LUT_CACHE", lut_cache);
     z21_lds = env_u32("PS_Z21_LDS", z21_lds);
     full_budget_mb = env_u32("PS_FULL_BUDGET_MB", full_budget_mb);
+    daat = env_u32("PS_DAAT", daat);
+    daat_min_batch = env_u32("PS_DAAT_MIN_BATCH", daat_min_batch);
+    daat_chunk = std::max(256u, env_u32("PS_DAAT_CHUNK", daat_chunk));
+    daat_rows = env_u32("PS_DAAT_ROWS", daat_rows);
+    daat_persistent = env_u32("PS_DAAT_PERSISTENT", daat_persistent);
 }
 
 namespace {
@@ -402,10 +424,19 @@ struct BatchImage {
   uint32_t n_rows = 0;           // rows K0b has to score for this batch
   uint32_t n_used = 0;           // rows the batch reads (resident ones included)
   uint32_t n_simple = 0, n_general = 0, z_masked = 0;
+  // K1d
+  bool daat = false;
+  size_t off_d = 0, off_i = 0, off_s = 0, n_ditems = 0;
+};
+
+struct DaatWork {
+  std::vector<DEntry> dentry;
+  std::vector<DItem> items;
+  std::vector<uint32_t> qslot;
 };
 
 // Claims the next pinned slot and copies the plan's arrays into it.
-BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan) {
+BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, const DaatWork* dw) {
   BatchImage img;
   const size_t B = img.B = plan.qbeg.size() - 1;
   const size_t ne = img.ne = plan.entries.size();
@@ -419,6 +450,14 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
   img.off_g = img.off_f + B * 4;
   img.off_r = (img.off_g + B * 4 + 15) & ~(size_t)15;
   img.total = img.off_r + (size_t)m.tune.dense_max_rows * sizeof(RowDesc);
+  if (dw) {
+    img.daat = true;
+    img.n_ditems = dw->items.size();
+    img.off_d = (img.total + 15) & ~(size_t)15;
+    img.off_i = img.off_d + ne * sizeof(DEntry);
+    img.off_s = img.off_i + img.n_ditems * sizeof(DItem);
+    img.total = img.off_s + (B + 1) * 4;
+  }
   Stage& sg = m.stage[m.next_stage];
   m.next_stage = (m.next_stage + 1) % N_STAGE;
   sg.ensure(img.total + 16);
@@ -428,7 +467,184 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
   if (ne) memcpy(img.he, plan.entries.data(), ne * sizeof(ps_plan_entry));
   memcpy(img.h + img.off_q, plan.qbeg.data(), (B + 1) * 4);
   if (B) memcpy(img.h + img.off_l, plan.qterms_len.data(), B * 4);
+  if (dw) {
+    if (ne) memcpy(img.h + img.off_d, dw->dentry.data(), ne * sizeof(DEntry));
+    if (img.n_ditems) memcpy(img.h + img.off_i, dw->items.data(), img.n_ditems * sizeof(DItem));
+    memcpy(img.h + img.off_s, dw->qslot.data(), (B + 1) * 4);
+  }
   return img;
+}
+
+inline bool sync_path_small(const Plan&) { return false; }
+
+// ---- K1d: bounds and work descriptors ------------------------------------------------------------
+bool bm25_params_sane(const Snapshot& s, const ps_scorer_desc& sc, const double* boosts) {
+  bool sane = s.n_docs > 0 && std::isfinite(sc.bm25_k1) && sc.bm25_k1 >= 0.0 && sc.bm25_b >= 0.0 && sc.bm25_b <= 1.0;
+  for (uint32_t x = 0; x < s.F && sane; ++x)
+    sane = std::isfinite(boosts[x]) && boosts[x] > 0.0 && std::isfinite(s.avg[x]) && s.avg[x] > 0.0;
+  return sane;
+}
+
+// Exact per-list maxima of the saturated term frequency (the same f64 expression the kernels
+// evaluate: bm25.rs:78-82) and of the boosted per-posting sum.  One pass over the host planes.
+void compute_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts) {
+  const Snapshot& s = *m.snap;
+  EngineImpl::ListBounds& lb = m.bounds;
+  const uint32_t F = s.F;
+  std::vector<double> bv(boosts, boosts + F);
+  if (lb.valid && lb.k1 == sc.bm25_k1 && lb.b == sc.bm25_b && lb.boosts == bv) return;
+  const size_t nl = s.layers.size();
+  lb.M.assign(nl * F, 0.0);
+  lb.J.assign(nl, 0.0);
+  const double k1 = sc.bm25_k1, b = sc.bm25_b, k1p1 = sc.bm25_k1 + 1.0, omb = 1.0 - sc.bm25_b;
+  auto tfn_of = [&](uint32_t x, uint32_t tfu, uint32_t flu) {
+    const double tfd = (double)tfu, fld = (double)flu;
+    return (k1p1 * tfd) / (k1 * (omb + b * (fld / s.avg[x])) + tfd);
+  };
+  // memo for the common small (tf, fl) pairs
+  constexpr uint32_t MT = 16, ML = 128;
+  std::vector<double> memo((size_t)F * MT * ML);
+  for (uint32_t x = 0; x < F; ++x)
+    for (uint32_t t = 0; t < MT; ++t)
+      for (uint32_t l = 0; l < ML; ++l) memo[((size_t)x * MT + t) * ML + l] = t ? tfn_of(x, t, l) : 0.0;
+  auto body = [&](size_t l) {
+    const LayerInfo& L = s.layers[l];
+    double J = 0.0;
+    for (uint32_t i = 0; i < L.len; ++i) {
+      const uint64_t pi = L.post_off + i;
+      double sum = 0.0;
+      for (uint32_t x = 0; x < F; ++x) {
+        const uint32_t tfu = s.tf[(size_t)x * s.P + pi];
+        if (!tfu) continue;
+        const uint32_t flu = s.fl[(size_t)x * s.P + pi];
+        const double t = (tfu < MT && flu < ML) ? memo[((size_t)x * MT + tfu) * ML + flu] : tfn_of(x, tfu, flu);
+        if (t > lb.M[l * F + x]) lb.M[l * F + x] = t;
+        sum += boosts[x] * t;
+      }
+      if (sum > J) J = sum;
+    }
+    lb.J[l] = J;
+  };
+  unsigned n_thr = s.n_postings > (1u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+  if (n_thr <= 1) {
+    for (size_t l = 0; l < nl; ++l) body(l);
+  } else {
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      for (;;) {
+        const size_t b0 = next.fetch_add(64);
+        if (b0 >= nl) break;
+        for (size_t l = b0; l < std::min(nl, b0 + 64); ++l) body(l);
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < n_thr; ++i) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+  }
+  lb.k1 = sc.bm25_k1; lb.b = sc.bm25_b; lb.boosts = bv; lb.valid = true;
+}
+
+// Upper bound of any posting score of plan entry `e` (list e.node), rounding included: the per-field
+// form pushes the maxima through the kernels' own expression (every operation is monotone), the joint
+// form bounds the real-number value and is inflated past the few roundings between them.
+double entry_upper_bound(const EngineImpl& m, const ps_plan_entry& e, const double* boosts) {
+  const uint32_t F = m.snap->F;
+  const EngineImpl::ListBounds& lb = m.bounds;
+  double ub_m = 0.0;
+  for (uint32_t x = 0; x < F; ++x) {
+    const double t = lb.M[(size_t)e.node * F + x];
+    if (t > 0.0) ub_m += t * e.idf * boosts[x] * e.boost;
+  }
+  const double ub_j = (e.idf * e.boost) * lb.J[e.node] * (1.0 + 1e-12);
+  return std::min(ub_m, ub_j);
+}
+
+// Work descriptors of a BM25 top-k batch: per entry its bounds and rank, per (entry, chunk) one item,
+// items ordered highest-bound lists first (rank-major), candidate slots query-major.
+void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& dw) {
+  const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size();
+  constexpr double SLACK = 1.0 + 1e-9;  // the bounds are summed in another order than the scores
+  dw.dentry.assign(ne, DEntry{});
+  dw.qslot.assign(B + 1, 0);
+  std::vector<double> ub(ne);
+  std::vector<uint32_t> chunk(ne), nchunk(ne), first_slot(ne);
+  std::vector<uint32_t> ord;
+  std::vector<std::pair<uint32_t, double>> gmax;  // (qterm, max bound)
+  for (size_t i = 0; i < ne; ++i) ub[i] = entry_upper_bound(m, plan.entries[i], boosts);
+  uint32_t slot = 0;
+  for (size_t q = 0; q < B; ++q) {
+    const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
+    dw.qslot[q] = slot;
+    ord.resize(e - b);
+    for (uint32_t i = b; i < e; ++i) ord[i - b] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) { return ub[a] > ub[c]; });
+    // group maxima over ALL entries (what the other query terms can add to a candidate)
+    gmax.clear();
+    auto group_of = [&](uint32_t qt) -> std::pair<uint32_t, double>& {
+      for (auto& g : gmax)
+        if (g.first == qt) return g;
+      gmax.emplace_back(qt, 0.0);
+      return gmax.back();
+    };
+    for (uint32_t i = b; i < e; ++i) {
+      auto& g = group_of(plan.entries[i].qterm);
+      g.second = std::max(g.second, ub[i]);
+    }
+    for (uint32_t r = 0; r < e - b; ++r) {
+      const uint32_t i = ord[r];
+      DEntry& d = dw.dentry[i];
+      d.rank = r;
+      d.q = (uint32_t)q;
+      // what every other entry can add: the other groups' maxima + the best other entry of its own group
+      double alt = 0.0;
+      for (uint32_t j = b; j < e; ++j)
+        if (j != i && plan.entries[j].qterm == plan.entries[i].qterm) alt = std::max(alt, ub[j]);
+      double rest = 0.0;
+      for (auto& g : gmax)
+        if (g.first != plan.entries[i].qterm) rest += g.second;
+      d.others = (rest + alt) * SLACK;
+      if (!(d.others >= 0.0)) d.others = INFINITY;
+    }
+    // skip thresholds: entries in ascending bound order; a document that only occurs in the first k
+    // of them scores at most sum over query terms of the largest bound among those of its lists
+    std::vector<std::pair<uint32_t, double>> pm;  // per query term: max bound within the prefix
+    for (uint32_t r = e - b; r-- > 0;) {
+      const uint32_t i = ord[r];
+      bool found = false;
+      for (auto& g : pm)
+        if (g.first == plan.entries[i].qterm) { g.second = std::max(g.second, ub[i]); found = true; }
+      if (!found) pm.emplace_back(plan.entries[i].qterm, ub[i]);
+      double bound = 0.0;
+      for (auto& g : pm) bound += g.second;
+      dw.dentry[i].skip_thr = bound * SLACK;
+      if (!(dw.dentry[i].skip_thr >= 0.0)) dw.dentry[i].skip_thr = INFINITY;
+    }
+    for (uint32_t i = b; i < e; ++i) {
+      const uint32_t len = plan.entries[i].len;
+      uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + 63) / 64 + 255) & ~255u);
+      chunk[i] = c;
+      nchunk[i] = (len + c - 1) / c;
+      first_slot[i] = slot;
+      slot += nchunk[i];
+    }
+  }
+  dw.qslot[B] = slot;
+  // processing order: rank-major (every query's highest-bound list first), longest lists first within
+  // a rank, so thresholds exist before the long low-bound lists come up and the launch ends on skips
+  std::vector<uint32_t> eo(ne);
+  for (size_t i = 0; i < ne; ++i) eo[i] = (uint32_t)i;
+  std::stable_sort(eo.begin(), eo.end(), [&](uint32_t a, uint32_t c) {
+    if (dw.dentry[a].rank != dw.dentry[c].rank) return dw.dentry[a].rank < dw.dentry[c].rank;
+    return plan.entries[a].len > plan.entries[c].len;
+  });
+  dw.items.clear();
+  dw.items.reserve(slot);
+  for (uint32_t i : eo) {
+    const uint32_t len = plan.entries[i].len;
+    for (uint32_t k = 0; k < nchunk[i]; ++k)
+      dw.items.push_back(DItem{i, k * chunk[i], std::min(chunk[i], len - k * chunk[i]), first_slot[i] + k});
+  }
 }
 
 // qorder: K1 hands out the items of a run heaviest query first (longest-processing-time order).
@@ -535,6 +751,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
   uint32_t& n_rows = img.n_rows;
   uint32_t& n_used = img.n_used;
   const uint32_t z_masked = img.z_masked;
+  if (img.daat && !m.tune.daat_rows) return;  // K1d without rows: every lookup is a binary search
   {
     bool sane = max_rows > 0 && s.n_docs > 0;
     if (!z) {
@@ -659,7 +876,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
           // (zero_to_one simple queries without consumed-term masks sum their records the same way,
           // in sorted order: same two tricks, for 1 or 2 fields)
           const bool plain_sum = z ? (z_masked == 0 && s.F <= 2) : !plan.multi_expansion;
-          if (plain_sum && m.tune.dense_fuse && e > b) {
+          if (plain_sum && m.tune.dense_fuse && e > b && !img.daat) {  // (K1d keeps plan order: no tile to write into)
             if ((m.tune.dense_fuse & 1u) && (he[e - 1].shift & DENSE_FLAG)) he[e - 1].shift |= DENSE_FUSE_FLAG;
             if ((m.tune.dense_fuse & 2u) && e - b >= 2) {
               const bool d0 = (he[b].shift & DENSE_FLAG) != 0;
@@ -738,7 +955,17 @@ void choose_run_length(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan
 void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, hipStream_t st,
                 KParams& kp, bool topk_path, bool sync_path) {
   const Snapshot& s = *m.snap;
-  BatchImage img = lay_out_batch(m, sc, plan);
+  // K1d (exact dynamic pruning) takes BM25 top-k batches whose parameters make every score a
+  // positive, monotone function of the saturated term frequency; everything else stays on K1
+  DaatWork dw;
+  bool use_daat = false;
+  if (topk_path && !sync_path_small(plan) && sc.kind == PS_SCORER_BM25 && m.tune.daat && m.tune.lut &&
+      plan.qbeg.size() - 1 >= m.tune.daat_min_batch && !plan.entries.empty() && bm25_params_sane(s, sc, boosts)) {
+    compute_list_bounds(m, sc, boosts);
+    plan_daat(m, boosts, plan, dw);
+    use_daat = !dw.items.empty();
+  }
+  BatchImage img = lay_out_batch(m, sc, plan, use_daat ? &dw : nullptr);
   const size_t B = img.B;
   const bool z = img.z;
   order_queries(m, plan, img);
@@ -754,7 +981,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   // copy-engine hand-over in front of the kernel (latency path of a single query).
   const uint32_t g_regs = (s.F == 1 || s.F == 2) ? (uint32_t)PS_G : 1u;
   const bool zero_copy = B <= 4 && plan.max_entries <= g_regs && n_used == 0 && n_general == 0 &&
-                         m.tune.zero_copy;
+                         m.tune.zero_copy && !img.daat;
   const unsigned char* dbase;
   m.cur_stage = &sg;
   m.cur_zero_copy = zero_copy;
@@ -763,7 +990,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   } else {
     // one upload: the device image has the staging layout (entries | qbeg | qterms_len | qorder | zorder | qflags)
     m.d_stage.ensure(total + 64);
-    const size_t up_bytes = n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z);
+    const size_t up_bytes = img.daat ? total : n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z);
     if (m.tune.kernel_upload && up_bytes <= ((size_t)4 << 20)) {
       const size_t n16 = (up_bytes + 15) / 16;  // slot and device buffer are both padded past `total`
       const uint32_t blocks = (uint32_t)std::min<size_t>(256, (n16 + 255) / 256);
@@ -792,6 +1019,15 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const uint64_t layout_bytes = layout_bytes_of(m, img);
   kp.row_desc = reinterpret_cast<const RowDesc*>(dbase + off_r);
   kp.n_rows = n_rows;
+  if (img.daat) {
+    kp.dentry = reinterpret_cast<const DEntry*>(dbase + img.off_d);
+    kp.ditems = reinterpret_cast<const DItem*>(dbase + img.off_i);
+    kp.qslot = reinterpret_cast<const uint32_t*>(dbase + img.off_s);
+    kp.n_ditems = (uint32_t)img.n_ditems;
+    uint32_t max_slots = 0;
+    for (size_t q = 0; q < B; ++q) max_slots = std::max(max_slots, dw.qslot[q + 1] - dw.qslot[q]);
+    m.daat_max_slots = max_slots;
+  }
   m.build_slots.clear();  // rows the host has to zero-fill for K0b
   for (uint32_t r = 0; r < n_rows; ++r) {
     const RowDesc& d = reinterpret_cast<const RowDesc*>(h + off_r)[r];
@@ -823,6 +1059,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   m.last_rows = n_used;
   m.last_rows_built = n_rows;
   kp.P = s.P;
+  kp.t_log2 = 0;
+  while ((1u << kp.t_log2) < s.T) ++kp.t_log2;
   kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
   kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
   kp.ablate = m.tune.ablate;
@@ -893,6 +1131,29 @@ void launch_k_score(EngineImpl& m, KParams& kp, bool tags, int n_cu, hipStream_t
 #undef PS_LAUNCH_W
 }
 
+// K1d: persistent 8-wave workgroups (the LUT is the only LDS), items from the device-scope counter
+void launch_daat(EngineImpl& m, KParams& kp, bool multi, int n_cu, hipStream_t st) {
+  const size_t lds = (size_t)kp.lut_stride * LUT_TF * 8;
+#define PS_DAAT(FV, MU)                                                                                  \
+  do {                                                                                                   \
+    const void* fn = reinterpret_cast<const void*>(&k_daat<FV, MU>);                                     \
+    const uint32_t per_cu = (uint32_t)(k_score_waves_per_cu(m, fn, 8, lds) / 8);                         \
+    const uint32_t n_wg = m.tune.daat_persistent                                                         \
+        ? std::min<uint32_t>((kp.n_ditems + 7) / 8, std::max(1u, per_cu) * (uint32_t)n_cu)                 \
+        : (kp.n_ditems + 7) / 8;                                                                         \
+    char nm[96];                                                                                         \
+    snprintf(nm, sizeof(nm), "ps::k_daat<%d, %s>", (int)(FV), (MU) ? "true" : "false");                  \
+    m.score_kernel_name = nm;                                                                            \
+    hipLaunchKernelGGL((k_daat<FV, MU>), dim3(n_wg), dim3(WAVE * 8), lds, st, kp);                       \
+  } while (0)
+  if (multi) {
+    if (kp.F == 1) PS_DAAT(1, true); else if (kp.F == 2) PS_DAAT(2, true); else PS_DAAT(0, true);
+  } else {
+    if (kp.F == 1) PS_DAAT(1, false); else if (kp.F == 2) PS_DAAT(2, false); else PS_DAAT(0, false);
+  }
+#undef PS_DAAT
+}
+
 void launch_rows(const KParams& kp, const std::vector<uint32_t>& zero_slots, hipStream_t st) {
   if (!kp.n_rows) return;  // every row this batch reads is resident
   const size_t row_b = (size_t)kp.row_planes * kp.row_stride * 8;
@@ -920,7 +1181,8 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
     }
     launch_rows(kp, m.build_slots, st);
     if (mid) PS_HIP(hipEventRecord(mid, st));
-    launch_k_score<MODE_BM25, FULL>(m, kp, plan.multi_expansion, n_cu, st);
+    if (!FULL && kp.n_ditems) launch_daat(m, kp, plan.multi_expansion, n_cu, st);
+    else launch_k_score<MODE_BM25, FULL>(m, kp, plan.multi_expansion, n_cu, st);
   } else {
     launch_rows(kp, m.build_slots, st);
     if (mid) PS_HIP(hipEventRecord(mid, st));
@@ -985,11 +1247,15 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   stage_plan(m, sc, boosts, plan, st, kp, true, sync_path);
   TT("stage_plan");
   kp.K = (uint32_t)top_k;
-  const size_t n_cand = (size_t)B * kp.n_super * top_k;
+  const size_t n_cand = kp.n_ditems ? (size_t)kp.n_ditems * top_k : (size_t)B * kp.n_super * top_k;
   m.d_cand_score.ensure(n_cand + 1);
   m.d_cand_doc.ensure(n_cand + 1);
   kp.cand_score = m.d_cand_score.p;
   kp.cand_doc = m.d_cand_doc.p;
+  if (kp.n_ditems) {
+    m.d_cand_cnt.ensure((size_t)kp.n_ditems + 1);
+    kp.cand_cnt = m.d_cand_cnt.p;
+  }
   TT("ctl");
   kp.out_keys = (uint64_t*)d_keys;
   kp.out_scores = (double*)d_scores;
@@ -1015,8 +1281,13 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   }
   if (B) {
     // one wave per ~4 wave-wide candidate loads, at most MERGE_WAVES
+    if (kp.n_ditems) {
+      const uint32_t mw = std::min<uint32_t>(MERGE_WAVES, std::max<uint32_t>(1, (m.daat_max_slots + 7) / 8));
+      hipLaunchKernelGGL(k_merge_items, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
+    } else {
     const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));
     hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
+    }
     PS_HIP(hipGetLastError());
     m.ctl_clean = true;  // k_merge zeroes the control words behind itself
   }

@@ -53,6 +53,21 @@ struct RowDesc {  // one hot (list, idf, expansion_boost) combination K0b has to
 };
 constexpr uint32_t NO_TABLE = 0xFFFFFFFFu;
 
+// K1d work descriptors (host: stage_daat in ps_engine.hip)
+struct DEntry {        // per plan entry
+  double skip_thr;     // upper bound of any document that only occurs in this list and lists with lower bounds
+  double others;       // upper bound of what every OTHER entry of the query can add to a document of this list
+  uint32_t rank;       // position in the query's processing order (0 = highest upper bound); the dedupe order
+  uint32_t q;          // query of the entry
+  uint32_t _pad[2];
+};
+struct DItem {         // a chunk of one list
+  uint32_t entry;      // plan entry
+  uint32_t begin;      // first posting of the chunk within the list
+  uint32_t count;
+  uint32_t slot;       // candidate slot (query-major)
+};
+
 constexpr uint32_t DENSE_FLAG = 0x80000000u;  // ps_plan_entry::shift bit 31: entry reads dense row `node`
 constexpr uint32_t DENSE_ASSIGN_FLAG = 0x40000000u;  // ... as the tile's first contribution: written, not added
 constexpr uint32_t DENSE_FUSE_FLAG = 0x20000000u;    // ... as the query's last one: added while harvesting
@@ -90,6 +105,12 @@ struct KParams {
   uint32_t z_masked;             // host-side: some simple query needs the consumed-query-term masks
   uint32_t n_simple, n_general;  // host-side bookkeeping (zero_to_one query classes in this batch)
   uint32_t ablate;  // PS_ABLATE debug bit mask (profiling only): 1 = no top-k offer, 2 = no scoring
+  // K1d k_daat (exact dynamic pruning, see there)
+  const struct DEntry* dentry;  // [n_plan_entries], parallel to plan[]
+  const struct DItem* ditems;   // [n_ditems] in processing order (highest upper bound first)
+  const uint32_t* qslot;        // [B+1] candidate slots (= items) of query q: [qslot[q], qslot[q+1])
+  uint32_t n_ditems, t_log2;
+  uint32_t* cand_cnt;           // [n_ditems] candidates an item left in its slot
   uint32_t* work_counter;    // next (query, run) item for the persistent waves of k_score
   unsigned long long* gthr;  // [B] bits of the best published local K-th score per query (0 = none)
   double* cand_score;  // [B * n_super * K]
@@ -1033,6 +1054,222 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
       const bool has = d[u] != 0xFFFFFFFFu;
       if (__any(has && v[u] >= gt)) topk_offer(tk, K, lane, has, v[u], d[u], gt);
     }
+  }
+  sh_s[wave][lane] = tk.s;
+  sh_d[wave][lane] = tk.d;
+  if (lane == 0) sh_n[wave] = tk.n;
+  __syncthreads();
+  if (wave != 0) return;
+  for (uint32_t w = 1; w < n_waves; ++w) {
+    const bool has = (uint32_t)lane < sh_n[w];
+    topk_offer(tk, K, lane, has, sh_s[w][lane], sh_d[w][lane]);
+  }
+  if ((uint32_t)lane < K) {
+    const bool ok = (uint32_t)lane < tk.n;
+    const uint64_t o = (uint64_t)q * K + lane;
+    p.out_keys[o] = ok ? p.keys[tk.d] : ~0ull;
+    p.out_scores[o] = ok ? tk.s : 0.0;
+  }
+  if (lane == 0) {
+    p.out_counts[q] = tk.n;
+    p.gthr[q] = 0ull;
+    if (q == 0) *p.work_counter = 0u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1d: k_daat — exact top-K with dynamic pruning (BM25, positive boosts).   [same results as
+//      query.rs:61-105 + bm25.rs:60-93 restricted to the first K of the canonical order]
+//
+// The reference scores every posting of every list.  For a top-K answer most of that work cannot
+// matter: with U(e) an upper bound of any posting score of list e (host: exact per-list maxima of
+// the saturated term frequency, pushed through THE SAME f64 expression, so it bounds the computed
+// value, rounding included) and theta a lower bound of the query's final K-th best score,
+//   * a document that only occurs in lists whose bounds sum to less than theta cannot enter the
+//     top-K (strictly below the K-th best, so ties are unaffected): with the lists sorted by U,
+//     the longest such prefix is "non-essential" and is never traversed (MaxScore);
+//   * every other document occurs in at least one essential list: it is evaluated exactly once,
+//     from the posting of its highest-bound list (the "rank" order), by looking its other
+//     contributions up (dense row read, or binary search in the list's tile slice) and folding
+//     them IN PLAN ORDER through the same add / max state machine as k_score - same operands, same
+//     order, same bits;
+//   * a posting whose own score plus everything the other lists could add is below theta is
+//     dropped before any lookup.
+// theta is the running K-th best of any wave of the query, shared through the same device-scope
+// word k_score uses; items are handed out highest-bound lists first, so by the time the long
+// low-idf lists come up most of them are skipped whole.  No LDS tiles, no harvest over N documents.
+// ------------------------------------------------------------------------------------------
+template <int F_>
+__device__ __forceinline__ double posting_score(const KParams& p, const double* lut, const uint64_t pi, const double idf,
+                                                const double eb) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+  uint32_t tfv[FA], flv[FA];
+#pragma unroll
+  for (int x = 0; x < FA; ++x)
+    if ((uint32_t)x < F) { tfv[x] = p.tf[(uint64_t)x * p.P + pi]; flv[x] = p.fl[(uint64_t)x * p.P + pi]; }
+  double s = 0.0;
+#pragma unroll
+  for (int x = 0; x < FA; ++x) {
+    if ((uint32_t)x < F) {
+      const uint32_t tfu = tfv[x], flu = flv[x];
+      const bool in_lut = tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x];
+      double tfn = lut[in_lut ? __umul24(tfu, p.lut_stride) + p.lut_base[x] + flu : 0u];
+      if (!in_lut && tfu > 0) tfn = bm25_tfn_cold(p.k1, p.k1p1, p.one_minus_b, p.b, p.avg[x], tfu, flu);
+      const double term = tfn * idf * p.boost[x] * eb;  // bm25.rs:83-86: ((tfn*idf)*boost)*expansion_boost
+      s += (tfu > 0) ? term : 0.0;
+    }
+  }
+  return s;
+}
+
+// Score of document d in list `en` (0.0 = the list does not hold d).
+template <int F_>
+__device__ __forceinline__ double lookup_score(const KParams& p, const double* lut, const ps_plan_entry& en, const uint32_t d) {
+  if (en.shift & DENSE_FLAG) return p.rows[(uint64_t)en.node * p.row_stride + d];
+  const uint32_t slot = (d >> p.t_log2) >> (en.shift & 0xFFu);
+  uint32_t lo = p.table[en.tbl_off + slot];
+  const uint32_t end = p.table[en.tbl_off + slot + 1];
+  uint32_t hi = end;
+  const uint32_t* docs = p.doc + en.post_off;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (docs[mid] < d) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= end || docs[lo] != d) return 0.0;
+  return posting_score<F_>(p, lut, en.post_off + lo, en.idf, en.boost);
+}
+
+template <int F_, bool MULTI>
+__global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const double* lut = reinterpret_cast<const double*>(smem);
+  {
+    double* l = reinterpret_cast<double*>(smem);
+    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * 8) l[i] = p.lut[i];
+    __syncthreads();  // the only workgroup-level synchronisation
+  }
+  // A grid that covers every item with its own wave assigns them by index (workgroups are dispatched
+  // in index order, so the processing order still holds approximately); otherwise the waves are
+  // persistent and pull items from the device-scope counter.
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool by_index = p.n_ditems <= gridDim.x * 8u;
+  bool first = true;
+  for (;;) {
+    uint32_t id = 0;
+    if (by_index) {
+      if (!first) break;
+      first = false;
+      id = blockIdx.x * 8u + (uint32_t)wave;
+    } else {
+      if (lane == 0) id = atomicAdd(p.work_counter, 1u);
+      id = __builtin_amdgcn_readfirstlane(id);
+    }
+    if (id >= p.n_ditems) break;
+    const DItem it = p.ditems[id];
+    const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
+    const ps_plan_entry& own = p.plan[e_own];
+    const DEntry de = p.dentry[e_own];
+    const uint32_t q = __builtin_amdgcn_readfirstlane(de.q);
+    const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
+    const double own_idf = own.idf, own_eb = own.boost;
+    const uint64_t own_off = own.post_off;
+    const uint32_t own_rank = de.rank;
+    const double skip_thr = de.skip_thr, others = de.others;
+    TopK tk;
+    tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+    double published = 0.0;
+    const uint32_t end = (p.ablate & 16u) ? it.begin : it.begin + it.count;  // (debug: 16 = no postings)
+    bool essential = true;  // wave-uniform
+    for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE) {
+      // the query's current threshold: a lower bound of its final K-th best score (0 = none yet).
+      // One load instruction returns one value to the whole wave; readfirstlane tells the compiler.
+      const unsigned long long tbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)),
+                                            __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits));
+      essential = !(skip_thr < theta);  // false: the whole list has become non-essential
+      const uint32_t i = i0 + lane;
+      const bool valid = essential && i < end;
+      const uint64_t pi = own_off + (i < end ? i : end - 1);
+      const uint32_t d = p.doc[pi];
+      const double s_own = posting_score<F_>(p, lut, pi, own_idf, own_eb);
+      // everything the other entries could add, at most: below theta the document is out
+      bool alive = valid && (s_own + others >= theta) && !(p.ablate & 32u);  // (debug: 32 = no lookups)
+      if (__any(alive)) {
+        double P = 0.0;
+        bool present = false, visited = false, dup = false;
+        uint32_t cur_qterm = 0xFFFFFFFFu;
+        for (uint32_t j = e0; j < e1; ++j) {  // plan order (query.rs:33-89)
+          const ps_plan_entry& en = p.plan[j];
+          if (MULTI && en.qterm != cur_qterm) { cur_qterm = en.qterm; visited = false; }  // query.rs:37
+          double s = 0.0;
+          if (j == e_own) s = s_own;
+          else if (alive) s = lookup_score<F_>(p, lut, en, d);
+          if (alive && s > 0.0) {
+            // the document is evaluated from its highest-bound list only
+            if (j != e_own && p.dentry[j].rank < own_rank) dup = true;
+            if (MULTI) {
+              // max_score_merger (query.rs:150-164)
+              P = present ? (visited ? fmax(P, s) : P + s) : s;
+              visited = true;
+            } else {
+              P += s;  // one list per query term: the `+` / assign arm (0.0 + s == s)
+            }
+            present = true;
+          }
+        }
+        alive = alive && !dup && present;
+        if (__any(alive && P >= theta)) topk_offer(tk, p.K, lane, alive, P, d, theta);
+        if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta) {
+          // this wave's K-th best so far: the final K-th best of the query can only be higher
+          published = tk.thr_s;
+          if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+        }
+      }
+    }
+    if ((uint32_t)lane < p.K) {
+      const uint64_t o = (uint64_t)it.slot * p.K + lane;
+      const bool ok = (uint32_t)lane < tk.n;
+      p.cand_score[o] = ok ? tk.s : 0.0;
+      p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
+      if (lane == 0) p.cand_cnt[it.slot] = tk.n;
+    }
+  }
+}
+
+// K3d: merge of the items' candidate lists of a query -> final top-K, doc id -> key.  A document is
+// evaluated by exactly one item, so the lists are disjoint.  Leaves the control words zeroed.
+__global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge_items(const KParams p) {
+  __shared__ double sh_s[MERGE_WAVES][WAVE];
+  __shared__ uint32_t sh_d[MERGE_WAVES][WAVE];
+  __shared__ uint32_t sh_n[MERGE_WAVES];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t q = blockIdx.x;
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+  const uint32_t K = p.K;
+  const double gt = __longlong_as_double((long long)p.gthr[q]);
+  const uint32_t s0 = p.qslot[q], s1 = p.qslot[q + 1];
+  const uint32_t n_waves = blockDim.x >> 6;
+  constexpr int U = 4;
+  for (uint32_t sb = s0 + (uint32_t)wave * U; sb < s1; sb += n_waves * U) {
+    double v[U];
+    uint32_t d[U];
+    bool has[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t sl = sb + u;
+      const uint32_t cnt = sl < s1 ? p.cand_cnt[sl] : 0u;
+      has[u] = (uint32_t)lane < cnt;
+      const uint64_t o = (uint64_t)sl * K + lane;
+      v[u] = has[u] ? p.cand_score[o] : 0.0;
+      d[u] = has[u] ? p.cand_doc[o] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (__any(has[u] && v[u] >= gt)) topk_offer(tk, K, lane, has[u], v[u], d[u], gt);
   }
   sh_s[wave][lane] = tk.s;
   sh_d[wave][lane] = tk.d;

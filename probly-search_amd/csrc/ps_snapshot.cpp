@@ -586,6 +586,7 @@ void Snapshot::plan_query(const ps_scorer_desc& sc, std::string_view q, ps_token
           e.len = L.len;
           e.tbl_off = L.tbl_off;
           e.shift = L.shift | (l << 8);  // bits 8.. = version layer (0 = newest)
+          if (sc.kind == PS_SCORER_BM25) e.node = t.first_layer + l;  // ordinal of the list (the engine's per-list bounds)
           plan.entries.push_back(e);
           plan.postings += L.len;
         }

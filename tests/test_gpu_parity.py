@@ -17,6 +17,15 @@ from probly_search_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["daat", "k_score"])
+def scoring_kernel(request, monkeypatch):
+    """Every test of this module runs twice: BM25 top-k batches on K1d k_daat (the default) and on
+    K1 k_score (PS_DAAT=0; still the kernel of full-result mode, zero_to_one, small batches and
+    non-positive boosts).  The knob is read when a snapshot's engine is created."""
+    monkeypatch.setenv("PS_DAAT", "1" if request.param == "daat" else "0")
+    return request.param
+
+
 def assert_same(got, exp, ctx):
     assert [k for k, _ in got] == [k for k, _ in exp], (ctx, got[:5], exp[:5], len(got), len(exp))
     for (k, a), (_, b) in zip(got, exp):
@@ -318,7 +327,7 @@ def test_sharded_entry_point_single_rank():
     snap = p.snapshot(device=0)
     queries = corpus.queries(33, 3)
     a = snap.query_batch(queries, psa.bm25.new(), None, [1.0, 1.0], top_k=7)
-    b = psd.query_batch_sharded(snap, queries, psa.bm25.new(), [1.0, 1.0], 7, device=0)
+    b = psd.query_batch_sharded(snap, queries, psa.bm25.new(), [1.0, 1.0], 7)
     assert [[tuple(r) for r in x] for x in a] == b
 
 
