@@ -325,6 +325,8 @@ typedef struct ps_plan_entry {
   double boost;        /* BM25TermCalculations::expansion_boost | zero_to_one: ScoreByTerm::score */
   uint32_t node;       /* zero_to_one: ordinal of the distinct trie node within the query | BM25: ordinal of the list (layer) in the snapshot */
   uint32_t qterm_index;/* TermData::query_term_index (position in the token list)                 */
+  uint32_t bm_off;     /* BM25: first word of the list's membership bitmap, 0xFFFFFFFF = none     */
+  uint32_t _pad;
 } ps_plan_entry;
 ps_status ps_snapshot_plan(const ps_snapshot* snap, const ps_scorer_desc* scorer, const char* query,
                            size_t query_len, ps_tokenizer_fn tokenizer, void* user, ps_plan_entry** out,

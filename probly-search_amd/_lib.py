@@ -91,7 +91,7 @@ class BatchStats(C.Structure):
 class PlanEntry(C.Structure):
     _fields_ = [("post_off", C.c_uint64), ("len", C.c_uint32), ("tbl_off", C.c_uint32), ("shift", C.c_uint32),
                 ("qterm", C.c_uint32), ("idf", C.c_double), ("boost", C.c_double), ("node", C.c_uint32),
-                ("qterm_index", C.c_uint32)]
+                ("qterm_index", C.c_uint32), ("bm_off", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class HostCsr(C.Structure):

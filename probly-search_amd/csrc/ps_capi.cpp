@@ -88,7 +88,7 @@ void plan_batch(ps_snapshot* snap, const ps_scorer_desc& sc, const std::vector<s
   if (tok == nullptr && n >= 128) {
     const char* env = getenv("PS_PLAN_THREADS");
     unsigned hw = std::thread::hardware_concurrency();
-    want = env && *env ? (unsigned)strtoul(env, nullptr, 10) : std::min(8u, hw ? hw : 1u);
+    want = env && *env ? (unsigned)strtoul(env, nullptr, 10) : std::min(16u, hw ? hw : 1u);
     if (want < 1) want = 1;
   }
   if (want == 1) {

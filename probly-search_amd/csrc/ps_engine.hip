@@ -31,6 +31,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <thread>
 #include <mutex>
 #include <stdexcept>
@@ -39,6 +40,7 @@
 #include "ps_engine.hpp"
 #include "ps_errors.hpp"
 #include "ps_kernels.hpp"
+#include "ps_pool.hpp"
 #include "ps_sort.hpp"
 
 namespace ps {
@@ -124,6 +126,9 @@ struct Tuning {
   uint32_t daat_chunk = 4096;    // PS_DAAT_CHUNK: smallest chunk of a list one item covers
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
   uint32_t daat_persistent = 0;  // PS_DAAT_PERSISTENT: persistent waves + item counter instead of one wave per item
+  uint32_t daat_threads = 8;     // PS_DAAT_THREADS: host threads that build the K1d descriptors of a large batch
+  uint32_t daat_multi = 0;       // PS_DAAT_MULTI: also take batches with several expansions per query term (K1 is faster there today)
+  uint32_t daat_split = 0;       // PS_DAAT_SPLIT: the queries' highest-bound lists in a launch of their own, first
   void load();
 };
 
@@ -139,6 +144,7 @@ struct EngineImpl {
   uint32_t* d_tf = nullptr;
   uint32_t* d_fl = nullptr;
   uint32_t* d_table = nullptr;
+  uint32_t* d_bits = nullptr;
   uint64_t* d_keys = nullptr;
   double* d_lut = nullptr;
   uint32_t* d_work = nullptr;
@@ -175,7 +181,11 @@ struct EngineImpl {
   struct KTimer { hipEvent_t a = nullptr, m = nullptr, b = nullptr; bool pending = false; };
   KTimer kt[N_KTIMER];
   KTimer* last_kt = nullptr;
-  uint32_t daat_max_slots = 0;  // K1d: most candidate slots of one query in the batch being enqueued
+  std::unique_ptr<Pool> pool;  // K1d descriptor building for large batches
+  struct DaatWork* daat_work = nullptr;  // reused across batches (defined below)
+  std::vector<uint32_t> daat_chunk_of, daat_nchunk_of, daat_entry_order, daat_first_slot;
+  uint32_t daat_max_slots = 0;
+  uint32_t daat_first_items = 0;  // K1d: items of the queries' rank-0 lists (they lead the item order)  // K1d: most candidate slots of one query in the batch being enqueued
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0, last_rows_built = 0;
@@ -249,6 +259,7 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     m.n_cu = prop.multiProcessorCount;
     m.tune.load();
     PS_HIP(hipMalloc((void**)&m.d_work, 256));
+    PS_HIP(hipMemset(m.d_work, 0, 256));
     PS_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     for (auto& ev : m.ev) PS_HIP(hipEventCreate(&ev));
     for (auto& sg : m.stage) PS_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
@@ -259,6 +270,8 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     PS_HIP(hipMalloc((void**)&m.d_tf, P * F * 4));
     PS_HIP(hipMalloc((void**)&m.d_fl, P * F * 4));
     PS_HIP(hipMalloc((void**)&m.d_table, snap.table.size() * 4));
+    PS_HIP(hipMalloc((void**)&m.d_bits, snap.bits.size() * 4));
+    PS_HIP(hipMemcpy(m.d_bits, snap.bits.data(), snap.bits.size() * 4, hipMemcpyHostToDevice));
     PS_HIP(hipMalloc((void**)&m.d_keys, std::max<size_t>(1, snap.keys.size()) * 8));
     PS_HIP(hipMalloc((void**)&m.d_lut, ((size_t)snap.lut_rows + 4) * LUT_TF * 8));
     PS_HIP(hipMemcpy(m.d_doc, snap.doc.data(), P * 4, hipMemcpyHostToDevice));
@@ -267,7 +280,7 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     PS_HIP(hipMemcpy(m.d_table, snap.table.data(), snap.table.size() * 4, hipMemcpyHostToDevice));
     if (!snap.keys.empty())
       PS_HIP(hipMemcpy(m.d_keys, snap.keys.data(), snap.keys.size() * 8, hipMemcpyHostToDevice));
-    m.bytes = P * 4 + 2 * P * F * 4 + snap.table.size() * 4 + snap.keys.size() * 8;
+    m.bytes = P * 4 + 2 * P * F * 4 + snap.table.size() * 4 + snap.keys.size() * 8 + snap.bits.size() * 4;
   } catch (...) {
     delete impl_;
     impl_ = nullptr;
@@ -275,17 +288,20 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
   }
 }
 
+void free_daat_work(struct DaatWork* w);
+
 Engine::~Engine() {
   if (!impl_) return;
   EngineImpl& m = *impl_;
   (void)hipSetDevice(m.device);
   (void)hipDeviceSynchronize();
-  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work})
+  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_bits, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work})
     if (p) (void)hipFree(p);
   m.d_stage.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
   m.d_gthr.release(); m.d_rows.release(); m.d_cand_cnt.release();
+  free_daat_work(m.daat_work);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
   m.d_sort_tmp.release(); m.d_pack.release();
   for (auto& sg : m.stage) {
@@ -311,6 +327,13 @@ void Engine::kernel_times(ps_kernel_times& out, bool reset) {
   std::lock_guard<std::mutex> lock(m.mu);
   (void)hipSetDevice(m.device);
   for (auto& t : m.kt) m.harvest(t, true);
+  if (m.tune.ablate & 64u) {  // PS_ABLATE=64: K1d statistics since the last call
+    uint32_t w[32];
+    (void)hipMemcpy(w, m.d_work, 128, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[ps] k_daat stats: items=%u skipped_whole=%u trips=%u (postings<=%llu) reached_lookups=%u offers=%u\n", w[20],
+            w[19], w[16], (unsigned long long)w[16] * 64ull, w[17], w[18]);
+    (void)hipMemset(m.d_work + 16, 0, 64);
+  }
   memset(&out, 0, sizeof(out));
   out.score_ms = m.kt_total_ms;
   out.rows_ms = m.kt_rows_ms;
@@ -358,6 +381,9 @@ void Tuning::load() {
     daat_chunk = std::max(256u, env_u32("PS_DAAT_CHUNK", daat_chunk));
     daat_rows = env_u32("PS_DAAT_ROWS", daat_rows);
     daat_persistent = env_u32("PS_DAAT_PERSISTENT", daat_persistent);
+    daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
+    daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
+    daat_threads = std::max(1u, std::min(env_u32("PS_DAAT_THREADS", daat_threads), std::max(1u, std::thread::hardware_concurrency())));
 }
 
 namespace {
@@ -426,14 +452,17 @@ struct BatchImage {
   uint32_t n_simple = 0, n_general = 0, z_masked = 0;
   // K1d
   bool daat = false;
-  size_t off_d = 0, off_i = 0, off_s = 0, n_ditems = 0;
+  size_t off_d = 0, off_i = 0, off_s = 0, off_ro = 0, n_ditems = 0;
 };
 
+}  // namespace
 struct DaatWork {
   std::vector<DEntry> dentry;
   std::vector<DItem> items;
-  std::vector<uint32_t> qslot;
+  std::vector<uint32_t> qslot, rorder;
 };
+void free_daat_work(DaatWork* w) { delete w; }
+namespace {
 
 // Claims the next pinned slot and copies the plan's arrays into it.
 BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, const DaatWork* dw) {
@@ -456,7 +485,8 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
     img.off_d = (img.total + 15) & ~(size_t)15;
     img.off_i = img.off_d + ne * sizeof(DEntry);
     img.off_s = img.off_i + img.n_ditems * sizeof(DItem);
-    img.total = img.off_s + (B + 1) * 4;
+    img.off_ro = img.off_s + (B + 1) * 4;
+    img.total = img.off_ro + ne * 4;
   }
   Stage& sg = m.stage[m.next_stage];
   m.next_stage = (m.next_stage + 1) % N_STAGE;
@@ -471,6 +501,7 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
     if (ne) memcpy(img.h + img.off_d, dw->dentry.data(), ne * sizeof(DEntry));
     if (img.n_ditems) memcpy(img.h + img.off_i, dw->items.data(), img.n_ditems * sizeof(DItem));
     memcpy(img.h + img.off_s, dw->qslot.data(), (B + 1) * 4);
+    if (ne) memcpy(img.h + img.off_ro, dw->rorder.data(), ne * 4);
   }
   return img;
 }
@@ -561,89 +592,120 @@ double entry_upper_bound(const EngineImpl& m, const ps_plan_entry& e, const doub
 }
 
 // Work descriptors of a BM25 top-k batch: per entry its bounds and rank, per (entry, chunk) one item,
-// items ordered highest-bound lists first (rank-major), candidate slots query-major.
+// items ordered highest-bound lists first (rank-major), candidate slots query-major.  The per-query
+// part runs on the engine's small thread pool for large batches (it sits on the host's critical path:
+// at ~0.7 ms of GPU time per 1024-query batch, 0.3 ms of serial descriptor building would show).
 void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& dw) {
   const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size();
   constexpr double SLACK = 1.0 + 1e-9;  // the bounds are summed in another order than the scores
-  dw.dentry.assign(ne, DEntry{});
+  dw.dentry.resize(ne);
   dw.qslot.assign(B + 1, 0);
-  std::vector<double> ub(ne);
-  std::vector<uint32_t> chunk(ne), nchunk(ne), first_slot(ne);
-  std::vector<uint32_t> ord;
-  std::vector<std::pair<uint32_t, double>> gmax;  // (qterm, max bound)
-  for (size_t i = 0; i < ne; ++i) ub[i] = entry_upper_bound(m, plan.entries[i], boosts);
-  uint32_t slot = 0;
-  for (size_t q = 0; q < B; ++q) {
-    const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
-    dw.qslot[q] = slot;
-    ord.resize(e - b);
-    for (uint32_t i = b; i < e; ++i) ord[i - b] = i;
-    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) { return ub[a] > ub[c]; });
-    // group maxima over ALL entries (what the other query terms can add to a candidate)
-    gmax.clear();
-    auto group_of = [&](uint32_t qt) -> std::pair<uint32_t, double>& {
-      for (auto& g : gmax)
-        if (g.first == qt) return g;
-      gmax.emplace_back(qt, 0.0);
-      return gmax.back();
-    };
-    for (uint32_t i = b; i < e; ++i) {
-      auto& g = group_of(plan.entries[i].qterm);
-      g.second = std::max(g.second, ub[i]);
+  dw.rorder.resize(ne);
+  std::vector<uint32_t>& chunk = m.daat_chunk_of;
+  std::vector<uint32_t>& nchunk = m.daat_nchunk_of;
+  chunk.resize(ne);
+  nchunk.resize(ne);
+  auto per_query = [&](size_t q0, size_t q1) {
+    std::vector<uint32_t> ord;
+    std::vector<double> ub;
+    std::vector<std::pair<uint32_t, double>> gmax, pm;  // (query term, max bound)
+    for (size_t q = q0; q < q1; ++q) {
+      const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
+      const uint32_t n = e - b;
+      ord.resize(n);
+      ub.resize(n);
+      for (uint32_t i = 0; i < n; ++i) { ord[i] = i; ub[i] = entry_upper_bound(m, plan.entries[b + i], boosts); }
+      std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) { return ub[a] > ub[c]; });
+      // group maxima over ALL entries (what the other query terms can add to a candidate)
+      gmax.clear();
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t qt = plan.entries[b + i].qterm;
+        bool found = false;
+        for (auto& g : gmax)
+          if (g.first == qt) { g.second = std::max(g.second, ub[i]); found = true; }
+        if (!found) gmax.emplace_back(qt, ub[i]);
+      }
+      for (uint32_t r = 0; r < n; ++r) {
+        const uint32_t i = ord[r];
+        DEntry& d = dw.dentry[b + i];
+        d.rank = r;
+        d.q = (uint32_t)q;
+        d.ub = ub[i];
+        dw.rorder[b + r] = b + i;
+        // what every other entry can add: the other groups' maxima + the best other entry of its own group
+        const uint32_t qt = plan.entries[b + i].qterm;
+        double alt = 0.0, rest = 0.0;
+        if (plan.multi_expansion)
+          for (uint32_t j = 0; j < n; ++j)
+            if (j != i && plan.entries[b + j].qterm == qt) alt = std::max(alt, ub[j]);
+        for (auto& g : gmax)
+          if (g.first != qt) rest += g.second;
+        d.others = (rest + alt) * SLACK;
+        if (!(d.others >= 0.0)) d.others = INFINITY;
+      }
+      // skip thresholds: entries in ascending bound order; a document that only occurs in the first k
+      // of them scores at most sum over query terms of the largest bound among those of its lists
+      pm.clear();
+      for (uint32_t r = n; r-- > 0;) {
+        const uint32_t i = ord[r];
+        const uint32_t qt = plan.entries[b + i].qterm;
+        bool found = false;
+        for (auto& g : pm)
+          if (g.first == qt) { g.second = std::max(g.second, ub[i]); found = true; }
+        if (!found) pm.emplace_back(qt, ub[i]);
+        double bound = 0.0;
+        for (auto& g : pm) bound += g.second;
+        DEntry& d = dw.dentry[b + i];
+        d.skip_thr = bound * SLACK;
+        if (!(d.skip_thr >= 0.0)) d.skip_thr = INFINITY;
+      }
+      uint32_t slots = 0;
+      for (uint32_t i = b; i < e; ++i) {
+        const uint32_t len = plan.entries[i].len;
+        const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + 63) / 64 + 255) & ~255u);
+        chunk[i] = c;
+        nchunk[i] = (len + c - 1) / c;
+        slots += nchunk[i];
+      }
+      dw.qslot[q + 1] = slots;  // turned into a prefix sum below
     }
-    for (uint32_t r = 0; r < e - b; ++r) {
-      const uint32_t i = ord[r];
-      DEntry& d = dw.dentry[i];
-      d.rank = r;
-      d.q = (uint32_t)q;
-      // what every other entry can add: the other groups' maxima + the best other entry of its own group
-      double alt = 0.0;
-      for (uint32_t j = b; j < e; ++j)
-        if (j != i && plan.entries[j].qterm == plan.entries[i].qterm) alt = std::max(alt, ub[j]);
-      double rest = 0.0;
-      for (auto& g : gmax)
-        if (g.first != plan.entries[i].qterm) rest += g.second;
-      d.others = (rest + alt) * SLACK;
-      if (!(d.others >= 0.0)) d.others = INFINITY;
-    }
-    // skip thresholds: entries in ascending bound order; a document that only occurs in the first k
-    // of them scores at most sum over query terms of the largest bound among those of its lists
-    std::vector<std::pair<uint32_t, double>> pm;  // per query term: max bound within the prefix
-    for (uint32_t r = e - b; r-- > 0;) {
-      const uint32_t i = ord[r];
-      bool found = false;
-      for (auto& g : pm)
-        if (g.first == plan.entries[i].qterm) { g.second = std::max(g.second, ub[i]); found = true; }
-      if (!found) pm.emplace_back(plan.entries[i].qterm, ub[i]);
-      double bound = 0.0;
-      for (auto& g : pm) bound += g.second;
-      dw.dentry[i].skip_thr = bound * SLACK;
-      if (!(dw.dentry[i].skip_thr >= 0.0)) dw.dentry[i].skip_thr = INFINITY;
-    }
-    for (uint32_t i = b; i < e; ++i) {
-      const uint32_t len = plan.entries[i].len;
-      uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + 63) / 64 + 255) & ~255u);
-      chunk[i] = c;
-      nchunk[i] = (len + c - 1) / c;
-      first_slot[i] = slot;
-      slot += nchunk[i];
-    }
+  };
+  if (B >= 256 && m.tune.daat_threads > 1) {
+    if (!m.pool || m.pool->size() != m.tune.daat_threads) m.pool.reset(new Pool(m.tune.daat_threads - 1));
+    m.pool->run([&](unsigned part, unsigned parts) { per_query(B * part / parts, B * (part + 1) / parts); });
+  } else {
+    per_query(0, B);
   }
-  dw.qslot[B] = slot;
+  for (size_t q = 0; q < B; ++q) dw.qslot[q + 1] += dw.qslot[q];
   // processing order: rank-major (every query's highest-bound list first), longest lists first within
   // a rank, so thresholds exist before the long low-bound lists come up and the launch ends on skips
-  std::vector<uint32_t> eo(ne);
+  std::vector<uint32_t>& eo = m.daat_entry_order;
+  eo.resize(ne);
   for (size_t i = 0; i < ne; ++i) eo[i] = (uint32_t)i;
-  std::stable_sort(eo.begin(), eo.end(), [&](uint32_t a, uint32_t c) {
-    if (dw.dentry[a].rank != dw.dentry[c].rank) return dw.dentry[a].rank < dw.dentry[c].rank;
-    return plan.entries[a].len > plan.entries[c].len;
-  });
-  dw.items.clear();
-  dw.items.reserve(slot);
+  {  // counting sort by rank, then the rank-0 bucket (the lists that set the thresholds) longest first
+    std::vector<uint32_t> cnt(plan.max_entries + 2, 0);
+    for (size_t i = 0; i < ne; ++i) cnt[dw.dentry[i].rank + 1]++;
+    for (size_t r = 1; r < cnt.size(); ++r) cnt[r] += cnt[r - 1];
+    const uint32_t n0 = cnt[1];
+    for (size_t i = 0; i < ne; ++i) eo[cnt[dw.dentry[i].rank]++] = (uint32_t)i;
+    std::sort(eo.begin(), eo.begin() + n0, [&](uint32_t a, uint32_t c) {
+      if (plan.entries[a].len != plan.entries[c].len) return plan.entries[a].len > plan.entries[c].len;
+      return a < c;
+    });
+  }
+  // candidate slots are query-major: slot of (entry, chunk) = qslot[q] + chunks of the query's earlier entries + chunk
+  std::vector<uint32_t>& first_slot = m.daat_first_slot;
+  first_slot.resize(ne);
+  for (size_t q = 0; q < B; ++q) {
+    uint32_t sl = dw.qslot[q];
+    for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) { first_slot[i] = sl; sl += nchunk[i]; }
+  }
+  dw.items.resize(dw.qslot[B]);
+  size_t at = 0;
   for (uint32_t i : eo) {
     const uint32_t len = plan.entries[i].len;
     for (uint32_t k = 0; k < nchunk[i]; ++k)
-      dw.items.push_back(DItem{i, k * chunk[i], std::min(chunk[i], len - k * chunk[i]), first_slot[i] + k});
+      dw.items[at++] = DItem{i, k * chunk[i], std::min(chunk[i], len - k * chunk[i]), first_slot[i] + k};
   }
 }
 
@@ -957,20 +1019,34 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const Snapshot& s = *m.snap;
   // K1d (exact dynamic pruning) takes BM25 top-k batches whose parameters make every score a
   // positive, monotone function of the saturated term frequency; everything else stays on K1
-  DaatWork dw;
+  if (!m.daat_work) m.daat_work = new DaatWork();
+  DaatWork& dw = *m.daat_work;
   bool use_daat = false;
+  static const bool trace_sp = env_u32("PS_TRACE", 0) != 0;
+  double tsp = now_ms();
+  auto SP = [&](const char* what) {
+    if (!trace_sp) return;
+    const double n = now_ms();
+    fprintf(stderr, "[ps]   stage %-10s %.3f ms\n", what, n - tsp);
+    tsp = n;
+  };
   if (topk_path && !sync_path_small(plan) && sc.kind == PS_SCORER_BM25 && m.tune.daat && m.tune.lut &&
-      plan.qbeg.size() - 1 >= m.tune.daat_min_batch && !plan.entries.empty() && bm25_params_sane(s, sc, boosts)) {
+      plan.qbeg.size() - 1 >= m.tune.daat_min_batch && !plan.entries.empty() && bm25_params_sane(s, sc, boosts) &&
+      (!plan.multi_expansion || m.tune.daat_multi)) {
     compute_list_bounds(m, sc, boosts);
     plan_daat(m, boosts, plan, dw);
     use_daat = !dw.items.empty();
   }
+  SP("daat");
   BatchImage img = lay_out_batch(m, sc, plan, use_daat ? &dw : nullptr);
+  SP("layout");
   const size_t B = img.B;
   const bool z = img.z;
-  order_queries(m, plan, img);
+  if (!img.daat) order_queries(m, plan, img);  // (K1d has its own item order)
   if (z) classify_zero_to_one(m, plan, img);
+  SP("order");
   select_dense_rows(m, sc, boosts, plan, img);
+  SP("rows");
   const uint32_t n_rows = img.n_rows, n_used = img.n_used, n_general = img.n_general;
   Stage& sg = *img.slot;
   unsigned char* h = img.h;
@@ -1008,7 +1084,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   }
 
   memset(&kp, 0, sizeof(kp));
-  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys;
+  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys; kp.bits = m.d_bits;
   kp.plan = reinterpret_cast<const ps_plan_entry*>(dbase + off_e);
   kp.qbeg = reinterpret_cast<const uint32_t*>(dbase + off_q);
   kp.qterms_len = reinterpret_cast<const uint32_t*>(dbase + off_l);
@@ -1023,10 +1099,14 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     kp.dentry = reinterpret_cast<const DEntry*>(dbase + img.off_d);
     kp.ditems = reinterpret_cast<const DItem*>(dbase + img.off_i);
     kp.qslot = reinterpret_cast<const uint32_t*>(dbase + img.off_s);
+    kp.rorder = reinterpret_cast<const uint32_t*>(dbase + img.off_ro);
     kp.n_ditems = (uint32_t)img.n_ditems;
     uint32_t max_slots = 0;
     for (size_t q = 0; q < B; ++q) max_slots = std::max(max_slots, dw.qslot[q + 1] - dw.qslot[q]);
     m.daat_max_slots = max_slots;
+    uint32_t first = 0;
+    while (first < dw.items.size() && dw.dentry[dw.items[first].entry].rank == 0) ++first;
+    m.daat_first_items = first;
   }
   m.build_slots.clear();  // rows the host has to zero-fill for K0b
   for (uint32_t r = 0; r < n_rows; ++r) {
@@ -1074,7 +1154,9 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;  // odd stride; LUT bytes = stride*128, so tiles stay 16-B aligned
     for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
   }
-  choose_run_length(m, sc, plan, img, topk_path, kp);
+  if (!img.daat) choose_run_length(m, sc, plan, img, topk_path, kp);
+  else { kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0; }
+  SP("rest");
   static const bool trace = env_u32("PS_TRACE", 0) != 0;
   if (trace && B > 1)
     fprintf(stderr, "[ps] geometry     B=%zu tiles=%u S=%u runs=%u items=%zu slice=%u B/wave max_entries=%u rows=%u\n", B,
@@ -1144,7 +1226,17 @@ void launch_daat(EngineImpl& m, KParams& kp, bool multi, int n_cu, hipStream_t s
     char nm[96];                                                                                         \
     snprintf(nm, sizeof(nm), "ps::k_daat<%d, %s>", (int)(FV), (MU) ? "true" : "false");                  \
     m.score_kernel_name = nm;                                                                            \
-    hipLaunchKernelGGL((k_daat<FV, MU>), dim3(n_wg), dim3(WAVE * 8), lds, st, kp);                       \
+    if (m.tune.daat_split && !m.tune.daat_persistent && m.daat_first_items && m.daat_first_items < kp.n_ditems) { \
+      /* thresholds first: every query's highest-bound list, then (stream order) everything else */    \
+      KParams a = kp, b = kp;                                                                            \
+      a.n_ditems = m.daat_first_items;                                                                   \
+      b.item_base = m.daat_first_items;                                                                  \
+      b.n_ditems = kp.n_ditems - m.daat_first_items;                                                     \
+      hipLaunchKernelGGL((k_daat<FV, MU>), dim3((a.n_ditems + 7) / 8), dim3(WAVE * 8), lds, st, a);      \
+      hipLaunchKernelGGL((k_daat<FV, MU>), dim3((b.n_ditems + 7) / 8), dim3(WAVE * 8), lds, st, b);      \
+    } else {                                                                                             \
+      hipLaunchKernelGGL((k_daat<FV, MU>), dim3(n_wg), dim3(WAVE * 8), lds, st, kp);                     \
+    }                                                                                                    \
   } while (0)
   if (multi) {
     if (kp.F == 1) PS_DAAT(1, true); else if (kp.F == 2) PS_DAAT(2, true); else PS_DAAT(0, true);

@@ -57,9 +57,9 @@ constexpr uint32_t NO_TABLE = 0xFFFFFFFFu;
 struct DEntry {        // per plan entry
   double skip_thr;     // upper bound of any document that only occurs in this list and lists with lower bounds
   double others;       // upper bound of what every OTHER entry of the query can add to a document of this list
+  double ub;           // upper bound of any posting score of this list
   uint32_t rank;       // position in the query's processing order (0 = highest upper bound); the dedupe order
   uint32_t q;          // query of the entry
-  uint32_t _pad[2];
 };
 struct DItem {         // a chunk of one list
   uint32_t entry;      // plan entry
@@ -109,7 +109,10 @@ struct KParams {
   const struct DEntry* dentry;  // [n_plan_entries], parallel to plan[]
   const struct DItem* ditems;   // [n_ditems] in processing order (highest upper bound first)
   const uint32_t* qslot;        // [B+1] candidate slots (= items) of query q: [qslot[q], qslot[q+1])
+  const uint32_t* rorder;       // [n_plan_entries] per query: its entries in rank order (highest bound first)
+  const uint32_t* bits;         // membership bitmaps of the denser lists (ps_plan_entry::bm_off)
   uint32_t n_ditems, t_log2;
+  uint32_t item_base;           // first item of this launch (the batch may be split into two launches)
   uint32_t* cand_cnt;           // [n_ditems] candidates an item left in its slot
   uint32_t* work_counter;    // next (query, run) item for the persistent waves of k_score
   unsigned long long* gthr;  // [B] bits of the best published local K-th score per query (0 = none)
@@ -1099,50 +1102,114 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
 // word k_score uses; items are handed out highest-bound lists first, so by the time the long
 // low-idf lists come up most of them are skipped whole.  No LDS tiles, no harvest over N documents.
 // ------------------------------------------------------------------------------------------
-template <int F_>
-__device__ __forceinline__ double posting_score(const KParams& p, const double* lut, const uint64_t pi, const double idf,
-                                                const double eb) {
+// Scores of U postings per lane (indices pi[u]); all loads of the trip are issued before the arithmetic.
+template <int F_, int U>
+__device__ __forceinline__ void posting_scores(const KParams& p, const double* lut, const uint64_t (&pi)[U], const bool (&on)[U],
+                                               const double idf, const double eb, double (&s)[U]) {
   constexpr int FA = F_ ? F_ : MAX_F;
   const uint32_t F = F_ ? (uint32_t)F_ : p.F;
-  uint32_t tfv[FA], flv[FA];
+  uint32_t tfv[U][FA], flv[U][FA];
 #pragma unroll
-  for (int x = 0; x < FA; ++x)
-    if ((uint32_t)x < F) { tfv[x] = p.tf[(uint64_t)x * p.P + pi]; flv[x] = p.fl[(uint64_t)x * p.P + pi]; }
-  double s = 0.0;
+  for (int u = 0; u < U; ++u) {
 #pragma unroll
-  for (int x = 0; x < FA; ++x) {
-    if ((uint32_t)x < F) {
-      const uint32_t tfu = tfv[x], flu = flv[x];
-      const bool in_lut = tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x];
-      double tfn = lut[in_lut ? __umul24(tfu, p.lut_stride) + p.lut_base[x] + flu : 0u];
-      if (!in_lut && tfu > 0) tfn = bm25_tfn_cold(p.k1, p.k1p1, p.one_minus_b, p.b, p.avg[x], tfu, flu);
-      const double term = tfn * idf * p.boost[x] * eb;  // bm25.rs:83-86: ((tfn*idf)*boost)*expansion_boost
-      s += (tfu > 0) ? term : 0.0;
+    for (int x = 0; x < FA; ++x) {
+      tfv[u][x] = 0; flv[u][x] = 0;
+      if ((uint32_t)x < F && on[u]) { tfv[u][x] = p.tf[(uint64_t)x * p.P + pi[u]]; flv[u][x] = p.fl[(uint64_t)x * p.P + pi[u]]; }
     }
   }
-  return s;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    double acc = 0.0;
+#pragma unroll
+    for (int x = 0; x < FA; ++x) {
+      if ((uint32_t)x < F) {
+        const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+        const bool in_lut = tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x];
+        double tfn = lut[in_lut ? __umul24(tfu, p.lut_stride) + p.lut_base[x] + flu : 0u];
+        if (!in_lut && tfu > 0) tfn = bm25_tfn_cold(p.k1, p.k1p1, p.one_minus_b, p.b, p.avg[x], tfu, flu);
+        const double term = tfn * idf * p.boost[x] * eb;  // bm25.rs:83-86: ((tfn*idf)*boost)*expansion_boost
+        acc += (tfu > 0) ? term : 0.0;
+      }
+    }
+    s[u] = on[u] ? acc : 0.0;
+  }
 }
 
-// Score of document d in list `en` (0.0 = the list does not hold d).
-template <int F_>
-__device__ __forceinline__ double lookup_score(const KParams& p, const double* lut, const ps_plan_entry& en, const uint32_t d) {
-  if (en.shift & DENSE_FLAG) return p.rows[(uint64_t)en.node * p.row_stride + d];
-  const uint32_t slot = (d >> p.t_log2) >> (en.shift & 0xFFu);
-  uint32_t lo = p.table[en.tbl_off + slot];
-  const uint32_t end = p.table[en.tbl_off + slot + 1];
-  uint32_t hi = end;
-  const uint32_t* docs = p.doc + en.post_off;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (docs[mid] < d) lo = mid + 1; else hi = mid;
+// Scores of documents d[u] (where on[u]) in list `en`; 0.0 = the list does not hold the document.
+// The U lookups advance together: every step issues U independent loads.
+template <int F_, int U>
+__device__ __forceinline__ void lookup_scores(const KParams& p, const double* lut, const ps_plan_entry& en, const uint32_t (&d)[U],
+                                              const bool (&on)[U], double (&s)[U]) {
+  if (en.shift & DENSE_FLAG) {  // a dense score row: the value itself
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = on[u] ? p.rows[(uint64_t)en.node * p.row_stride + d[u]] : 0.0;
+    return;
   }
-  if (lo >= end || docs[lo] != d) return 0.0;
-  return posting_score<F_>(p, lut, en.post_off + lo, en.idf, en.boost);
+  bool found[U];
+  uint64_t pi[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = 0.0;
+  if (en.bm_off != 0xFFFFFFFFu) {
+    // denser lists carry a bitmap of {bits, postings before} cells: one 8-byte load answers
+    // "is d in the list" (usually no) and, if so, where its posting is
+    uint2 cell[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      cell[u] = on[u] ? *reinterpret_cast<const uint2*>(p.bits + (uint64_t)en.bm_off + 2 * (uint64_t)(d[u] >> 5)) : make_uint2(0u, 0u);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t bit = d[u] & 31u;
+      found[u] = on[u] && ((cell[u].x >> bit) & 1u);
+      pi[u] = en.post_off + cell[u].y + (uint32_t)__popc(cell[u].x & ((1u << bit) - 1u));
+    }
+  } else {
+    // sparse lists: the tile-offset table slot holds a handful of postings - short binary search
+    const uint32_t* docs = p.doc + en.post_off;
+    uint32_t lo[U], hi[U], end[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      lo[u] = 0; hi[u] = 0; end[u] = 0;
+      if (on[u]) {
+        const uint32_t slot = (d[u] >> p.t_log2) >> (en.shift & 0xFFu);
+        lo[u] = p.table[en.tbl_off + slot];
+        end[u] = p.table[en.tbl_off + slot + 1];
+        hi[u] = end[u];
+      }
+    }
+    bool more = true;  // wave-uniform
+    while (more) {
+      uint32_t v[U], mid[U];
+      bool act[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        act[u] = lo[u] < hi[u];
+        mid[u] = (lo[u] + hi[u]) >> 1;
+        v[u] = act[u] ? docs[mid[u]] : 0u;
+      }
+      bool any_act = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (act[u]) { if (v[u] < d[u]) lo[u] = mid[u] + 1; else hi[u] = mid[u]; }
+        any_act |= lo[u] < hi[u];
+      }
+      more = __any(any_act);
+    }
+    uint32_t chk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) chk[u] = (on[u] && lo[u] < end[u]) ? docs[lo[u]] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { found[u] = on[u] && lo[u] < end[u] && chk[u] == d[u]; pi[u] = en.post_off + (found[u] ? lo[u] : 0u); }
+  }
+  bool any_found = false;
+#pragma unroll
+  for (int u = 0; u < U; ++u) any_found |= found[u];
+  if (__any(any_found)) posting_scores<F_, U>(p, lut, pi, found, en.idf, en.boost, s);
 }
 
 template <int F_, bool MULTI>
 __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int U = F_ ? 4 : 2;  // postings per lane in flight
   const int lane = threadIdx.x & (WAVE - 1);
   const double* lut = reinterpret_cast<const double*>(smem);
   {
@@ -1167,7 +1234,7 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
       id = __builtin_amdgcn_readfirstlane(id);
     }
     if (id >= p.n_ditems) break;
-    const DItem it = p.ditems[id];
+    const DItem it = p.ditems[p.item_base + id];
     const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
     const ps_plan_entry& own = p.plan[e_own];
     const DEntry de = p.dentry[e_own];
@@ -1182,45 +1249,136 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
     double published = 0.0;
     const uint32_t end = (p.ablate & 16u) ? it.begin : it.begin + it.count;  // (debug: 16 = no postings)
     bool essential = true;  // wave-uniform
-    for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE) {
+    uint32_t st_trips = 0, st_alive = 0, st_offers = 0;  // PS_ABLATE=64 statistics
+    for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
       // the query's current threshold: a lower bound of its final K-th best score (0 = none yet).
       // One load instruction returns one value to the whole wave; readfirstlane tells the compiler.
       const unsigned long long tbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const double theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)),
                                             __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits));
       essential = !(skip_thr < theta);  // false: the whole list has become non-essential
-      const uint32_t i = i0 + lane;
-      const bool valid = essential && i < end;
-      const uint64_t pi = own_off + (i < end ? i : end - 1);
-      const uint32_t d = p.doc[pi];
-      const double s_own = posting_score<F_>(p, lut, pi, own_idf, own_eb);
-      // everything the other entries could add, at most: below theta the document is out
-      bool alive = valid && (s_own + others >= theta) && !(p.ablate & 32u);  // (debug: 32 = no lookups)
-      if (__any(alive)) {
-        double P = 0.0;
-        bool present = false, visited = false, dup = false;
-        uint32_t cur_qterm = 0xFFFFFFFFu;
-        for (uint32_t j = e0; j < e1; ++j) {  // plan order (query.rs:33-89)
-          const ps_plan_entry& en = p.plan[j];
-          if (MULTI && en.qterm != cur_qterm) { cur_qterm = en.qterm; visited = false; }  // query.rs:37
-          double s = 0.0;
-          if (j == e_own) s = s_own;
-          else if (alive) s = lookup_score<F_>(p, lut, en, d);
-          if (alive && s > 0.0) {
-            // the document is evaluated from its highest-bound list only
-            if (j != e_own && p.dentry[j].rank < own_rank) dup = true;
-            if (MULTI) {
-              // max_score_merger (query.rs:150-164)
-              P = present ? (visited ? fmax(P, s) : P + s) : s;
-              visited = true;
-            } else {
-              P += s;  // one list per query term: the `+` / assign arm (0.0 + s == s)
+      uint32_t d[U];
+      uint64_t pi[U];
+      bool alive[U];
+      double s_own[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t i = i0 + u * WAVE + lane;
+        alive[u] = essential && i < end;
+        pi[u] = own_off + (i < end ? i : end - 1);
+        d[u] = p.doc[pi[u]];
+      }
+      posting_scores<F_, U>(p, lut, pi, alive, own_idf, own_eb, s_own);
+      bool any_alive = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // everything the other entries could add, at most: below theta the document is out
+        alive[u] = alive[u] && (s_own[u] + others >= theta) && !(p.ablate & 32u);  // (debug: 32 = no lookups)
+        any_alive |= alive[u];
+        st_alive += (uint32_t)__popcll(__ballot(alive[u]));
+      }
+      if (essential) ++st_trips;
+      any_alive = __any(any_alive);
+      double P[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) P[u] = 0.0;
+      if (any_alive) {
+        const uint32_t ne = e1 - e0;
+        if (!MULTI && ne <= 64u) {
+          // Pass 1, highest-bound lists first: every lookup replaces a list's bound by what it really
+          // adds (usually nothing), and a document is dropped as soon as what is left cannot reach
+          // theta.  `others` is inflated by 1e-9, far above the rounding of this running sum.
+          double bound[U];
+          unsigned long long hits[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) { bound[u] = s_own[u] + others; hits[u] = 0ull; }
+          for (uint32_t r = e0; r < e1 && any_alive; ++r) {
+            const uint32_t j = p.rorder[r];
+            if (j != e_own) {
+              const ps_plan_entry& en = p.plan[j];
+              const DEntry dj = p.dentry[j];
+              double s[U];
+              lookup_scores<F_, U>(p, lut, en, d, alive, s);
+              bool any = false;
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                if (alive[u]) {
+                  bound[u] = (bound[u] - dj.ub) + s[u];
+                  if (s[u] > 0.0) hits[u] |= 1ull << (j - e0);
+                  // (dj.rank < own_rank: the document is evaluated from its highest-bound list only)
+                  if (bound[u] < theta || (s[u] > 0.0 && dj.rank < own_rank)) alive[u] = false;
+                }
+                any |= alive[u];
+              }
+              any_alive = __any(any);
             }
-            present = true;
           }
+          // Pass 2, the few survivors: the sum in PLAN order (query.rs:33-89; one list per query term:
+          // always the `+` / assign arm, 0.0 + s == s), same operands, same order, same bits
+          if (any_alive) {
+            for (uint32_t j = e0; j < e1; ++j) {
+              const ps_plan_entry& en = p.plan[j];
+              double s[U];
+              if (j == e_own) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) s[u] = s_own[u];
+              } else {
+                bool want[U];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u) { want[u] = alive[u] && ((hits[u] >> (j - e0)) & 1ull); any |= want[u]; s[u] = 0.0; }
+                if (__any(any)) lookup_scores<F_, U>(p, lut, en, d, want, s);
+              }
+#pragma unroll
+              for (int u = 0; u < U; ++u)
+                if (alive[u] && s[u] > 0.0) P[u] += s[u];
+            }
+          }
+        } else {
+          bool present[U], visited[U], dup[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) { present[u] = false; visited[u] = false; dup[u] = false; }
+          uint32_t cur_qterm = 0xFFFFFFFFu;
+          for (uint32_t j = e0; j < e1; ++j) {  // plan order (query.rs:33-89)
+            const ps_plan_entry& en = p.plan[j];
+            if (MULTI && en.qterm != cur_qterm) {  // query.rs:37
+              cur_qterm = en.qterm;
+#pragma unroll
+              for (int u = 0; u < U; ++u) visited[u] = false;
+            }
+            double s[U];
+            if (j == e_own) {
+#pragma unroll
+              for (int u = 0; u < U; ++u) s[u] = s_own[u];
+            } else {
+              lookup_scores<F_, U>(p, lut, en, d, alive, s);
+            }
+            const uint32_t j_rank = p.dentry[j].rank;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (alive[u] && s[u] > 0.0) {
+                // the document is evaluated from its highest-bound list only
+                if (j != e_own && j_rank < own_rank) dup[u] = true;
+                if (MULTI) {
+                  // max_score_merger (query.rs:150-164)
+                  P[u] = present[u] ? (visited[u] ? fmax(P[u], s[u]) : P[u] + s[u]) : s[u];
+                  visited[u] = true;
+                } else {
+                  P[u] += s[u];
+                }
+                present[u] = true;
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) alive[u] = alive[u] && !dup[u] && present[u];
         }
-        alive = alive && !dup && present;
-        if (__any(alive && P >= theta)) topk_offer(tk, p.K, lane, alive, P, d, theta);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool offer = alive[u] && P[u] >= theta;
+          st_offers += (uint32_t)__popcll(__ballot(offer));
+          if (__any(offer)) topk_offer(tk, p.K, lane, alive[u], P[u], d[u], theta);
+        }
         if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta) {
           // this wave's K-th best so far: the final K-th best of the query can only be higher
           published = tk.thr_s;
@@ -1234,6 +1392,13 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
       p.cand_score[o] = ok ? tk.s : 0.0;
       p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
       if (lane == 0) p.cand_cnt[it.slot] = tk.n;
+    }
+    if ((p.ablate & 64u) && lane == 0) {  // PS_ABLATE=64 (debug): trips scanned, postings that reached the lookups, offers
+      atomicAdd(&p.work_counter[16], st_trips);
+      atomicAdd(&p.work_counter[17], st_alive);
+      atomicAdd(&p.work_counter[18], st_offers);
+      atomicAdd(&p.work_counter[19], st_trips ? 0u : 1u);
+      atomicAdd(&p.work_counter[20], 1u);
     }
   }
 }

@@ -52,13 +52,14 @@ struct SnapshotStorage {
   std::vector<FrozenNode> fnodes;
   std::vector<uint32_t> fchar, fchild;
   PlaneVec doc, tf, fl, table;
+  std::vector<uint32_t> bits;
   std::vector<uint32_t> max_fl, lut_cap, lut_base;
 };
 
 void Snapshot::bind(const SnapshotStorage& st) {
   auto v = [](const auto& vec) { return View<typename std::decay_t<decltype(vec)>::value_type>{vec.data(), vec.size()}; };
   keys = v(st.keys); avg = v(st.avg); terms = v(st.terms); layers = v(st.layers); fnodes = v(st.fnodes);
-  fchar = v(st.fchar); fchild = v(st.fchild); doc = v(st.doc); tf = v(st.tf); fl = v(st.fl); table = v(st.table);
+  fchar = v(st.fchar); fchild = v(st.fchild); doc = v(st.doc); tf = v(st.tf); fl = v(st.fl); table = v(st.table); bits = v(st.bits);
   max_fl = v(st.max_fl); lut_cap = v(st.lut_cap); lut_base = v(st.lut_base);
 }
 
@@ -69,7 +70,7 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   // bound to the finished vectors at the end)
   auto& keys = own_->keys; auto& avg = own_->avg; auto& terms = own_->terms; auto& layers = own_->layers;
   auto& fnodes = own_->fnodes; auto& fchar = own_->fchar; auto& fchild = own_->fchild;
-  auto& doc = own_->doc; auto& tf = own_->tf; auto& fl = own_->fl; auto& table = own_->table;
+  auto& doc = own_->doc; auto& tf = own_->tf; auto& fl = own_->fl; auto& table = own_->table; auto& bits = own_->bits;
   auto& max_fl = own_->max_fl; auto& lut_cap = own_->lut_cap; auto& lut_base = own_->lut_base;
   F = (uint32_t)idx.fields_len();
   T = tile_docs ? tile_docs : 1024;
@@ -266,7 +267,8 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
 
   // serial: place every layer (4-aligned starts, so 16-byte vector loads never straddle lists)
   // and its tile-offset table
-  uint64_t cursor = 0, tcursor = 0;
+  uint64_t cursor = 0, tcursor = 0, bcursor = 0;
+  const uint64_t bm_words = 2 * (((uint64_t)n_tiles * T + 31) / 32);  // {bits, postings before} per 32 documents
   for (size_t o = 0; o < terms.size(); ++o) {
     TermInfo& ti = terms[o];
     TermFlat& tfl = flat[o];
@@ -277,7 +279,7 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
     ti.n_layers = tfl.sorted_desc ? 1u : (uint32_t)tfl.lay.size();
     max_layers = std::max(max_layers, ti.n_layers);
     for (uint32_t l = 0; l < ti.n_layers; ++l) {
-      LayerInfo L{0, 0, 0, 0};
+      LayerInfo L{0, 0, 0, 0, NO_BITMAP};
       L.post_off = cursor;
       L.len = tfl.sorted_desc ? tfl.live : (uint32_t)tfl.lay[l].size();
       cursor = (cursor + L.len + 3) & ~(uint64_t)3;
@@ -291,6 +293,10 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
       if (tcursor + slots + 1 >= 0xFFFFFFFFull) throw std::length_error("tile-offset table exceeds 2^32 entries");
       L.tbl_off = (uint32_t)tcursor;
       tcursor += slots + 1;
+      if ((uint64_t)L.len * 128 >= n_docs && L.len >= 64 && bcursor + bm_words < 0xFFFFFFF0ull) {
+        L.bm_off = (uint32_t)bcursor;
+        bcursor += bm_words;
+      }
       layers.push_back(L);
     }
   }
@@ -300,6 +306,7 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   fl.resize((size_t)P * F);
   table.resize(std::max<uint64_t>(tcursor, 1));
   if (tcursor == 0) table[0] = 0;
+  bits.assign(std::max<uint64_t>(bcursor, 1), 0u);
   if (cursor == 0) {
     std::fill(doc.begin(), doc.end(), 0xFFFFFFFFu);
     std::fill(tf.begin(), tf.end(), 0u);
@@ -348,6 +355,12 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
         table[L.tbl_off + sl] = pos;
       }
       table[L.tbl_off + slots] = L.len;
+      if (L.bm_off != NO_BITMAP) {
+        uint32_t* bm = bits.data() + L.bm_off;
+        for (uint32_t i = 0; i < L.len; ++i) bm[2 * (size_t)(d[i] >> 5)] |= 1u << (d[i] & 31u);
+        uint32_t before = 0;
+        for (uint64_t w = 0; w < bm_words / 2; ++w) { bm[2 * w + 1] = before; before += (uint32_t)__builtin_popcount(bm[2 * w]); }
+      }
     }
   });
   { std::vector<TermFlat>().swap(flat); }
@@ -356,14 +369,14 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
 }
 
 // ---- on-disk snapshot ---------------------------------------------------------------------------
-// File = one 4096-byte header page + 14 sections, each starting on a 4096-byte boundary and holding
+// File = one 4096-byte header page + 15 sections, each starting on a 4096-byte boundary and holding
 // one array exactly as it lives in memory (little-endian, natural alignment):
-//   header: magic "PSNAP002" | u64 file_bytes | u64 scalars[10] | 14 x {u64 offset, u64 bytes, u64 checksum}
+//   header: magic "PSNAP003" | u64 file_bytes | u64 scalars[10] | 14 x {u64 offset, u64 bytes, u64 checksum}
 // Loading maps the file read-only and points the views at the sections; nothing is parsed or copied.
 namespace {
-constexpr char MAGIC[8] = {'P', 'S', 'N', 'A', 'P', '0', '0', '2'};
+constexpr char MAGIC[8] = {'P', 'S', 'N', 'A', 'P', '0', '0', '3'};
 constexpr size_t PAGE = 4096;
-constexpr int N_SECTIONS = 14;
+constexpr int N_SECTIONS = 15;
 struct SectionRef { uint64_t offset, bytes, checksum; };
 struct FileHeader {
   char magic[8];
@@ -396,7 +409,7 @@ void Snapshot::save(const std::string& path) const {
       {layers.data(), layers.size() * sizeof(LayerInfo)}, {fnodes.data(), fnodes.size() * sizeof(FrozenNode)},
       {fchar.data(), fchar.size() * 4}, {fchild.data(), fchild.size() * 4}, {doc.data(), doc.size() * 4},
       {tf.data(), tf.size() * 4}, {fl.data(), fl.size() * 4}, {table.data(), table.size() * 4},
-      {max_fl.data(), max_fl.size() * 4}, {lut_cap.data(), lut_cap.size() * 4}, {lut_base.data(), lut_base.size() * 4}};
+      {max_fl.data(), max_fl.size() * 4}, {lut_cap.data(), lut_cap.size() * 4}, {lut_base.data(), lut_base.size() * 4}, {bits.data(), bits.size() * 4}};
   FileHeader h;
   memset(&h, 0, sizeof(h));
   memcpy(h.magic, MAGIC, 8);
@@ -449,7 +462,7 @@ Snapshot::Snapshot(const std::string& path) {
   F = (uint32_t)h.scalars[0]; T = (uint32_t)h.scalars[1]; n_tiles = (uint32_t)h.scalars[2]; n_docs = h.scalars[3];
   P = h.scalars[4]; n_postings = h.scalars[5]; n_pointers = h.scalars[6]; n_live_terms = h.scalars[7];
   max_layers = (uint32_t)h.scalars[8]; lut_rows = (uint32_t)h.scalars[9];
-  const size_t elem[N_SECTIONS] = {8, 8, sizeof(TermInfo), sizeof(LayerInfo), sizeof(FrozenNode), 4, 4, 4, 4, 4, 4, 4, 4, 4};
+  const size_t elem[N_SECTIONS] = {8, 8, sizeof(TermInfo), sizeof(LayerInfo), sizeof(FrozenNode), 4, 4, 4, 4, 4, 4, 4, 4, 4, 4};
   for (int i = 0; i < N_SECTIONS; ++i) {
     const SectionRef& s = h.sec[i];
     if (s.offset % PAGE || s.offset < PAGE || s.offset > map_bytes_ || s.bytes > map_bytes_ - s.offset || s.bytes % elem[i])
@@ -464,7 +477,7 @@ Snapshot::Snapshot(const std::string& path) {
   layers = view(3, (LayerInfo*)nullptr); fnodes = view(4, (FrozenNode*)nullptr); fchar = view(5, (uint32_t*)nullptr);
   fchild = view(6, (uint32_t*)nullptr); doc = view(7, (uint32_t*)nullptr); tf = view(8, (uint32_t*)nullptr);
   fl = view(9, (uint32_t*)nullptr); table = view(10, (uint32_t*)nullptr); max_fl = view(11, (uint32_t*)nullptr);
-  lut_cap = view(12, (uint32_t*)nullptr); lut_base = view(13, (uint32_t*)nullptr);
+  lut_cap = view(12, (uint32_t*)nullptr); lut_base = view(13, (uint32_t*)nullptr); bits = view(14, (uint32_t*)nullptr);
   validate();
   src_epoch = ~0ull;
 }
@@ -480,7 +493,7 @@ void Snapshot::validate() const {
   if (n_tiles != want_tiles) bad("n_tiles");
   if (keys.size() != n_docs || avg.size() != F) bad("keys / avg size");
   if (P < 4 || P % 4 || doc.size() != P || tf.size() != (size_t)P * F || fl.size() != (size_t)P * F) bad("plane sizes");
-  if (table.empty()) bad("empty table");
+  if (table.empty() || bits.empty()) bad("empty table");
   if (max_fl.size() != F || lut_cap.size() != F || lut_base.size() != F) bad("LUT vectors");
   uint64_t rows = 0;
   for (uint32_t x = 0; x < F; ++x) {
@@ -518,9 +531,21 @@ void Snapshot::validate() const {
       prev = v;
     }
     if (table[L.tbl_off + slots] != L.len) bad("table end");
+    const uint64_t bm_words = 2 * (((uint64_t)n_tiles * T + 31) / 32);
+    if (L.bm_off != NO_BITMAP && ((L.bm_off & 1u) || (uint64_t)L.bm_off + bm_words > bits.size())) bad("layer bitmap range");
+    uint64_t set = 0;
     for (uint32_t i = 0; i < L.len; ++i) {
       const uint32_t d = doc[L.post_off + i];
       if (d >= n_docs || (i && doc[L.post_off + i - 1] >= d)) bad("posting doc ids");
+      if (L.bm_off != NO_BITMAP) {
+        const uint32_t w = bits[(size_t)L.bm_off + 2 * (size_t)(d >> 5)], before = bits[(size_t)L.bm_off + 2 * (size_t)(d >> 5) + 1];
+        if (!((w >> (d & 31u)) & 1u) || before + (uint32_t)__builtin_popcount(w & ((1u << (d & 31u)) - 1u)) != i)
+          bad("bitmap does not lead to the posting");
+      }
+    }
+    if (L.bm_off != NO_BITMAP) {
+      for (uint64_t w = 0; w < bm_words / 2; ++w) set += (uint64_t)__builtin_popcount(bits[(size_t)L.bm_off + 2 * w]);
+      if (set != L.len) bad("bitmap holds documents the list does not");
     }
   }
 }
@@ -563,6 +588,7 @@ void Snapshot::plan_query(const ps_scorer_desc& sc, std::string_view q, ps_token
         memset(&e, 0, sizeof(e));
         e.qterm = qord;
         e.qterm_index = (uint32_t)qi;
+        e.bm_off = NO_BITMAP;
         if (sc.kind == PS_SCORER_BM25) {
           // BM25::before_each, src/score/default/bm25.rs:35-58
           uint64_t frequency = std::min<uint64_t>(n_docs, t.df_raw);
@@ -586,7 +612,10 @@ void Snapshot::plan_query(const ps_scorer_desc& sc, std::string_view q, ps_token
           e.len = L.len;
           e.tbl_off = L.tbl_off;
           e.shift = L.shift | (l << 8);  // bits 8.. = version layer (0 = newest)
-          if (sc.kind == PS_SCORER_BM25) e.node = t.first_layer + l;  // ordinal of the list (the engine's per-list bounds)
+          if (sc.kind == PS_SCORER_BM25) {
+            e.node = t.first_layer + l;  // ordinal of the list (the engine's per-list bounds)
+            e.bm_off = L.bm_off;         // the list's membership bitmap (K1d lookups)
+          }
           plan.entries.push_back(e);
           plan.postings += L.len;
         }

@@ -39,7 +39,9 @@ struct LayerInfo {
   uint32_t len;
   uint32_t tbl_off;
   uint32_t shift;
+  uint32_t bm_off;    // first word of the list's membership bitmap in Snapshot::bits, or NO_BITMAP
 };
+constexpr uint32_t NO_BITMAP = 0xFFFFFFFFu;
 
 struct FrozenNode {
   uint32_t child_begin, child_count;  // into fchar/fchild, sorted by char
@@ -113,6 +115,10 @@ class Snapshot {
   // CSR planes (host copy)
   uint64_t P = 0;  // padded plane length
   View<uint32_t> doc, tf, fl, table;
+  // Membership bitmaps of the denser lists (len >= n_docs / 128): per 32 documents one cell
+  // {bits, postings of the list before these documents}.  K1d resolves "is document d in this list,
+  // and where" with ONE 8-byte load instead of a table lookup + binary search.
+  View<uint32_t> bits;
   uint64_t n_postings = 0, n_pointers = 0, n_live_terms = 0;
   uint32_t max_layers = 1;
   uint64_t src_epoch = 0;

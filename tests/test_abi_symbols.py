@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
 
 
 def test_struct_sizes_match_header():
-    assert ctypes.sizeof(_lib.PlanEntry) == 48
+    assert ctypes.sizeof(_lib.PlanEntry) == 56
     assert ctypes.sizeof(_lib.Result) == 16
     assert ctypes.sizeof(_lib.ScorerDesc) == 32
     assert ctypes.sizeof(_lib.KernelTimes) == 120

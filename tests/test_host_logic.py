@@ -155,7 +155,7 @@ def test_snapshot_load_rejects_damaged_files(tmp_path):
     path = str(tmp_path / "s.bin")
     snap.save(path)
     good = open(path, "rb").read()
-    assert len(good) % 4096 == 0 and good[:8] == b"PSNAP002"
+    assert len(good) % 4096 == 0 and good[:8] == b"PSNAP003"
     psa.Snapshot.load(path, device=-1)
     hdr_secs = 8 + 8 + 80  # magic | file_bytes | scalars[10]
 
