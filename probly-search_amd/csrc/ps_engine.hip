@@ -662,6 +662,8 @@ void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& 
       uint32_t slots = 0;
       for (uint32_t i = b; i < e; ++i) {
         const uint32_t len = plan.entries[i].len;
+        // (a fixed chunk for every list measured slower: C2 0.563 vs 0.536 ms, C4 2.16 vs 1.90 ms - the
+        // long low-bound lists are skipped whole, and fewer, larger skips are cheaper)
         const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + 63) / 64 + 255) & ~255u);
         chunk[i] = c;
         nchunk[i] = (len + c - 1) / c;

@@ -35,6 +35,9 @@ constexpr int WAVE = 64;
 #ifndef PS_FUSED_UNROLL
 #define PS_FUSED_UNROLL 4    // ... when a dense row is added during the harvest (row loads fly too)
 #endif
+#ifndef PS_DAAT_U
+#define PS_DAAT_U 4          // K1d: postings per lane whose lookups are in flight together
+#endif
 #ifndef PS_ABLATE_BUILD
 #define PS_ABLATE_BUILD 0    // profiling builds only: honour KParams::ablate in the hot loops
 #endif
@@ -1209,19 +1212,34 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
 template <int F_, bool MULTI>
 __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int U = F_ ? 4 : 2;  // postings per lane in flight
+  constexpr int U = F_ ? PS_DAAT_U : 2;  // postings per lane in flight
   const int lane = threadIdx.x & (WAVE - 1);
   const double* lut = reinterpret_cast<const double*>(smem);
-  {
-    double* l = reinterpret_cast<double*>(smem);
-    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * 8) l[i] = p.lut[i];
-    __syncthreads();  // the only workgroup-level synchronisation
-  }
   // A grid that covers every item with its own wave assigns them by index (workgroups are dispatched
   // in index order, so the processing order still holds approximately); otherwise the waves are
   // persistent and pull items from the device-scope counter.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool by_index = p.n_ditems <= gridDim.x * 8u;
+  if (by_index) {
+    // most workgroups of a launch only hold chunks of lists that are already non-essential: they
+    // leave before they stage the LUT
+    const uint32_t id = blockIdx.x * 8u + (uint32_t)wave;
+    int need = 0;
+    if (id < p.n_ditems) {
+      const DEntry de = p.dentry[p.ditems[p.item_base + id].entry];
+      const double theta = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      need = !(de.skip_thr < theta);
+    }
+    if (!__syncthreads_or(need)) {
+      if (id < p.n_ditems && lane == 0) p.cand_cnt[p.ditems[p.item_base + id].slot] = 0u;
+      return;
+    }
+  }
+  {
+    double* l = reinterpret_cast<double*>(smem);
+    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * 8) l[i] = p.lut[i];
+    __syncthreads();  // the last workgroup-level synchronisation
+  }
   bool first = true;
   for (;;) {
     uint32_t id = 0;

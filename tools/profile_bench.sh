@@ -1,15 +1,19 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + PMC passes of bench.py, each pass
-# under its own timeout, summaries (text) into gpurun_out/prof_<tag>/.
-#   usage: tools/profile_bench.sh <tag> [bench args...]
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + PMC passes of bench.py (each pass its own
+# run and its own timeout; counters never share a run with a trace domain), text summaries into
+# gpurun_out/prof_<tag>/, then tools/derive_roofline.py turns them into the derivation JSON that
+# bench.py prices its roofline against (copy both into profiles/ to have them judged).
+#   usage: tools/profile_bench.sh <tag> <git head> [bench args...]
 set -u
 TAG=$1; shift
+HEAD=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 BENCH="python bench.py --no-cpu-baseline --no-single-latency $*"
+echo "rocprofv3 <pass> -- $BENCH --steps 3 --warmup 1" > $OUT/command.txt
 run() {  # name, rocprof args...
   local name=$1; shift
   timeout 300 rocprofv3 "$@" -d $OUT/$name -o $name -- $BENCH --steps 3 --warmup 1 > $OUT/$name.bench.json 2> $OUT/$name.err
@@ -23,21 +27,6 @@ run pmc_write --pmc WRITE_SIZE
 run pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run pmc_sq2 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE
-python - <<PY
-import json, re
-out = "$OUT"
-def val(fn, ctr):
-    for line in open(fn):
-        if "k_score" in line or "k_z21" in line:
-            m = re.search(ctr + r"\s+dispatches=\d+\s+avg=([0-9.e+]+)", line)
-            if m: return float(m.group(1))
-    return None
-f, w = val(out + "/pmc_fetch.txt", "FETCH_SIZE"), val(out + "/pmc_write.txt", "WRITE_SIZE")
-# FETCH_SIZE / WRITE_SIZE are in KiB of 64-byte requests; on gfx950 a wide coalesced read stream
-# is tallied at half its bytes (MI355X_MICROARCH.md, HBM section) -> double the read side.
-d = {"tag": "$TAG", "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
-     "hbm_bytes_per_launch": None if f is None else (2 * f + (w or 0)) * 1024,
-     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per-dispatch average over the dominant kernel; read side doubled per the gfx950 correction"}
-json.dump(d, open(out + "/traffic.json", "w"), indent=1)
-print(d)
-PY
+run pmc_sq3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA
+python tools/derive_roofline.py $OUT "$TAG" "$HEAD" $* > $OUT/derive.log 2>&1
+cat $OUT/derive.log | tail -30
