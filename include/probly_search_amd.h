@@ -321,7 +321,7 @@ typedef struct ps_plan_entry {
   uint32_t tbl_off;    /* first entry of the list's tile-offset table                             */
   uint32_t shift;      /* bits 0-7: table slot of tile t is t >> shift; bits 8+: version layer    */
   uint32_t qterm;      /* ordinal of the query term (visited-set scope, src/query.rs:37)          */
-  double idf;          /* BM25TermCalculations::idf | zero_to_one: u64 bitmask of same-node entries */
+  double idf;          /* BM25TermCalculations::idf | zero_to_one: unused                          */
   double boost;        /* BM25TermCalculations::expansion_boost | zero_to_one: ScoreByTerm::score */
   uint32_t node;       /* zero_to_one: ordinal of the distinct trie node within the query | BM25: ordinal of the list (layer) in the snapshot */
   uint32_t qterm_index;/* TermData::query_term_index (position in the token list)                 */

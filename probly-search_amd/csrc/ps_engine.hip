@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <memory>
@@ -450,6 +451,7 @@ struct BatchImage {
   uint32_t n_rows = 0;           // rows K0b has to score for this batch
   uint32_t n_used = 0;           // rows the batch reads (resident ones included)
   uint32_t n_simple = 0, n_general = 0, z_masked = 0;
+  uint32_t z_qterms = 0;  // most query terms with entries in one general zero_to_one query
   // K1d
   bool daat = false;
   size_t off_d = 0, off_i = 0, off_s = 0, off_ro = 0, n_ditems = 0;
@@ -795,7 +797,14 @@ void classify_zero_to_one(const EngineImpl& m, const Plan& plan, BatchImage& img
       if (masked) { z_masked = 1; qf[q] |= 2u; }
     } else {
       gq[n_general++] = (uint32_t)q;  // empty queries too: somebody has to write their (empty) candidate slots
-      if (e - b > 64) throw std::length_error("zero_to_one with repeated terms supports at most 64 expanded lists per query on the GPU");
+      // k_z21 keeps consumed_index as one bit per query term THAT HAS ENTRIES: renumber the terms densely
+      // (plan.qterm counts every non-empty token, also those that matched nothing)
+      uint32_t dense = 0, prev = 0xFFFFFFFFu;
+      for (uint32_t i = b; i < e; ++i) {
+        if (plan.entries[i].qterm != prev) { prev = plan.entries[i].qterm; ++dense; }
+        he[i].qterm = dense - 1;
+      }
+      img.z_qterms = std::max(img.z_qterms, dense);
     }
   }
 }
@@ -1136,6 +1145,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   }
   m.ctl_clean = false;  // enqueue_topk sets it once k_merge is in the stream
   kp.n_simple = img.n_simple; kp.n_general = n_general; kp.z_masked = img.z_masked;
+  kp.z_qwords = std::max<uint32_t>(1, (img.z_qterms + 31) / 32);
   kp.layout_bytes = layout_bytes;
   m.last_layout_bytes = layout_bytes;
   m.last_rows = n_used;
@@ -1283,14 +1293,23 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
     if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(m, kp, kp.z_masked != 0, n_cu, st);
     if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
+      // (any number of expanded lists per query: the per-node pool lives in the record words, the
+      // consumed query terms in an LDS bit array; the sub-tile shrinks until a wave's state fits)
       kp.z_nodes = std::max<uint32_t>(1, plan.max_nodes);
-      const uint32_t per_doc = (kp.z_nodes * kp.F + kp.F) * 4;
+      const size_t per_doc = ((size_t)kp.z_nodes * kp.F + kp.F + kp.z_qwords) * 4;
       uint32_t zt = kp.T;
       const uint32_t budget = m.tune.z21_lds;
       while (zt > (uint32_t)WAVE && (size_t)zt * per_doc > budget) zt >>= 1;
-      if ((size_t)zt * per_doc > 65536) throw std::length_error("zero_to_one: fields x expanded terms exceed the LDS tile");
+      while (zt > 8u && (size_t)zt * per_doc > 160 * 1024) zt >>= 1;  // very wide plans: fewer documents per pass
+      if ((size_t)zt * per_doc > 160 * 1024) throw std::length_error("zero_to_one: fields x distinct expanded terms exceed 160 KiB of LDS even for 8 documents");
+      if (m.snap->max_fl.size() && *std::max_element(m.snap->max_fl.begin(), m.snap->max_fl.end()) >= 0xFFFFu)
+        throw std::length_error("zero_to_one: field lengths >= 65535 tokens are not supported by the general kernel");
       kp.z_tile = zt;
       if (!kp.n_simple) m.score_kernel_name = FULL ? "ps::k_z21<true>" : "ps::k_z21<false>";
+      {
+        const void* fn = FULL ? reinterpret_cast<const void*>(&k_z21<true>) : reinterpret_cast<const void*>(&k_z21<false>);
+        allow_lds(fn, (size_t)zt * per_doc);
+      }
       hipLaunchKernelGGL((k_z21<FULL>), dim3(kp.n_general * kp.n_super), dim3(WAVE), (size_t)zt * per_doc, st, kp);
     }
   }

@@ -90,7 +90,7 @@ struct KParams {
   uint32_t slice_bytes;        // per-wave LDS for the table slices (0 = look ranges up in global memory)
   const uint32_t* zorder;      // zero_to_one: per query, entry indices sorted by (score desc, plan order)
   uint64_t P;
-  uint32_t B, n_tiles, T, S, n_super, K, n_docs, F, max_qterms, z_nodes, z_tile;
+  uint32_t B, n_tiles, T, S, n_super, K, n_docs, F, max_qterms, z_nodes, z_tile, z_qwords;
   double k1, k1p1, one_minus_b, b;
   double avg[MAX_F], boost[MAX_F];
   // saturated-tf LUT (see k_bm25_lut): rows of LUT_TF doubles, row = lut_base[x] + field_length
@@ -924,10 +924,13 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
 template <bool FULL>
 __global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t F = p.F, ZN = p.z_nodes, ZT = p.z_tile;
+  const uint32_t F = p.F, ZN = p.z_nodes, ZT = p.z_tile, QW = p.z_qwords;
   const uint32_t stride = ZN * F;
-  uint32_t* rec = reinterpret_cast<uint32_t*>(smem);  // [ZT][ZN][F] term frequencies
-  uint32_t* fls = rec + (size_t)ZT * stride;           // [ZT][F]     field lengths
+  // rec word = term frequency (low 16 bits) | records of this node consumed so far in the field being
+  // finalised (high 16 bits: the per-node pool of zero_to_one.rs:104-113, any number of entries)
+  uint32_t* rec = reinterpret_cast<uint32_t*>(smem);  // [ZT][ZN][F]
+  uint32_t* fls = rec + (size_t)ZT * stride;           // [ZT][F]  field lengths
+  uint32_t* cq = fls + (size_t)ZT * F;                 // [ZT][QW] consumed_index: one bit per query term with entries
   const int lane = threadIdx.x;
   // grid = n_general x n_super: only the queries the simple path could not take
   const uint32_t q = p.gen_queries[blockIdx.x % p.n_general];
@@ -974,26 +977,28 @@ __global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
         // finalize (zero_to_one.rs:84-126): one lane per document of the sub-tile
         for (uint32_t c = 0; c < ZT; c += WAVE) {
           const uint32_t local = c + lane;
+          const bool mine = local < ZT;  // sub-tiles narrower than a wave leave lanes idle
           bool has = false;
           double best = 0.0;  // the merged dummy Some(0.) (zero_to_one.rs:81,122)
-          for (uint32_t x = 0; x < F; ++x) {
-            unsigned long long consumed_q = 0ull;  // consumed_index: bit = query-term ordinal
-            unsigned long long consumed_e = 0ull;  // consumed entries: bit = position in the query
-            double pool = 0.0;                     // score_by_pool
+          for (uint32_t x = 0; x < F && mine; ++x) {
+            for (uint32_t w = 0; w < QW; ++w) cq[local * QW + w] = 0u;
+            double pool = 0.0;  // score_by_pool
             bool any = false;
             for (uint32_t z = e0; z < e1; ++z) {
               const uint32_t e = p.zorder[z];
               const uint32_t node = p.plan[e].node;
-              const uint32_t tfu = rec[local * stride + node * F + x];
+              uint32_t* r = &rec[local * stride + node * F + x];
+              const uint32_t word = *r;
+              const uint32_t tfu = word & 0xFFFFu;
               if (tfu == 0) continue;  // no record for this (entry, doc, field)
               any = true;
-              const uint32_t qt = p.plan[e].qterm;
-              if ((consumed_q >> qt) & 1ull) continue;  // :101-103
+              const uint32_t qt = p.plan[e].qterm;  // dense ordinal among the query's terms that have entries
+              uint32_t* cw = &cq[local * QW + (qt >> 5)];
+              if ((*cw >> (qt & 31u)) & 1u) continue;  // :101-103
               // df_pool_by_id (:104-113): a node may be consumed term_frequency times in total
-              const unsigned long long same_node = (unsigned long long)__double_as_longlong(p.plan[e].idf);
-              if ((uint32_t)__popcll(consumed_e & same_node) >= tfu) continue;
-              consumed_e |= 1ull << (e - e0);
-              consumed_q |= 1ull << qt;
+              if ((word >> 16) >= tfu) continue;
+              *r = word + 0x10000u;
+              *cw |= 1u << (qt & 31u);
               const double sc = p.plan[e].boost;
               const double df = (double)tfu;
               const uint32_t fl = fls[local * F + x];

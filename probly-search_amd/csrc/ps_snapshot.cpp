@@ -624,17 +624,6 @@ void Snapshot::plan_query(const ps_scorer_desc& sc, std::string_view q, ps_token
     if (plan.entries.size() - before > 1) plan.multi_expansion = true;
     ++qord;
   }
-  if (sc.kind == PS_SCORER_ZERO_TO_ONE && plan.entries.size() - e_begin <= 64) {
-    // zero_to_one's per-node pool (zero_to_one.rs:104-113) is tracked on the GPU as "how many
-    // already-consumed entries of this query share my trie node": ship that relation as a bitmask
-    // over the query's entries in the otherwise unused idf slot.
-    for (size_t i = e_begin; i < plan.entries.size(); ++i) {
-      uint64_t mask = 0;
-      for (size_t j = e_begin; j < plan.entries.size(); ++j)
-        if (plan.entries[j].node == plan.entries[i].node) mask |= 1ull << (j - e_begin);
-      memcpy(&plan.entries[i].idf, &mask, 8);
-    }
-  }
   plan.qbeg.push_back((uint32_t)plan.entries.size());
   plan.qterms_len.push_back((uint32_t)tokens.size());
   plan.n_nodes.push_back((uint32_t)seen_nodes.size());

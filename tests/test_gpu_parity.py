@@ -472,16 +472,43 @@ def test_wide_prefix_expansion_many_entries():
         exp = o.query(q, orc.zero_to_one(), [1.0])
         got = [tuple(r) for r in snap.query(q, psa.zero_to_one.new(), None, [1.0])]
         assert_same(got, exp, ("wide-z21", q))
-    # ... the same nodes under two query terms need the general kernel, whose limit is 64 lists per
-    # query: a documented PS_EUNSUPPORTED, never a wrong answer or a CPU fallback
-    with pytest.raises(psa.PsError) as ei:
-        snap.query("ab ab", psa.zero_to_one.new(), None, [1.0])
-    assert ei.value.status == 4  # PS_EUNSUPPORTED
-    # ... while a narrower prefix (<= 64 expansions) goes through it bit-exactly
-    narrow = next(pfx for pfx in ("abcd", "abce", "abda", "abab", "abhh", "abgg") if 1 < len(o.expand_term(pfx)) <= 64)
-    exp = o.query(narrow + " " + narrow, orc.zero_to_one(), [1.0])
-    got = [tuple(r) for r in snap.query(narrow + " " + narrow, psa.zero_to_one.new(), None, [1.0])]
-    assert_same(got, exp, ("wide-z21", narrow))
+    # ... the same nodes under two query terms need the general kernel (per-node pools): any number of
+    # expanded lists per query (round 1 refused more than 64 with PS_EUNSUPPORTED)
+    for q in ("ab ab", "a ab abc", "abc ab a ab"):
+        exp = o.query(q, orc.zero_to_one(), [1.0])
+        got = [tuple(r) for r in snap.query(q, psa.zero_to_one.new(), None, [1.0])]
+        assert_same(got, exp, ("wide-z21-general", q))
+        top = [tuple(r) for r in snap.query(q, psa.zero_to_one.new(), None, [1.0], top_k=10)]
+        assert_same(top, exp[:10], ("wide-z21-general-top", q))
+    ents, _ = snap.plan("ab ab", psa.zero_to_one.new())
+    assert len(ents) > 64
+
+
+def test_zero_to_one_many_query_terms_mostly_out_of_vocabulary():
+    """consumed_index is tracked per query term WITH entries: a query of 80 tokens, most of them
+    matching nothing, whose matching terms sit at token ordinals >= 64 (the advisor's aliasing case:
+    `1ull << qterm` wrapped), combined with prefix expansion and repeated terms (general kernel)."""
+    o, p = orc.Index(2), ProductIndex(2)
+    import random
+    rng = random.Random(11)
+    vocab = ["abc", "abcd", "abce", "abd", "xyz", "xyzz", "q", "qq"]
+    for k in range(300):
+        f0 = " ".join(rng.choice(vocab) for _ in range(rng.randint(1, 4)))
+        f1 = " ".join(rng.choice(vocab) for _ in range(rng.randint(2, 7)))
+        o.add_document(k, [f0, f1])
+        p.add_document(k, [f0, f1])
+    snap = p.idx.snapshot(device=0, tile_docs=256)
+    oov = ["zz%d" % i for i in range(70)]
+    queries = [" ".join(oov + ["ab", "abc", "ab"]), " ".join(oov[:66] + ["abc"] + oov[66:] + ["abc", "xy", "q"]),
+               " ".join(["ab"] + oov + ["ab", "xyz"])]
+    for q in queries:
+        for top_k in (0, 5):
+            exp = o.query(q, orc.zero_to_one(), [1.0, 1.0])
+            got = [tuple(r) for r in snap.query(q, psa.zero_to_one.new(), None, [1.0, 1.0], top_k=top_k)]
+            assert_same(got, exp if top_k == 0 else exp[:top_k], ("many-terms", q[:20], top_k))
+    got = snap.query_batch(queries, psa.zero_to_one.new(), None, [1.0, 1.0], top_k=0)
+    for q, g in zip(queries, got):
+        assert_same([tuple(r) for r in g], o.query(q, orc.zero_to_one(), [1.0, 1.0]), ("many-terms batch", q[:20]))
 
 
 def test_snapshot_loaded_from_disk_scores_identically(tmp_path):
