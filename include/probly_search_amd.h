@@ -181,6 +181,29 @@ size_t ps_index_expand_term(const ps_index* idx, const char* term, size_t len, c
  * it exists so the flattener and planner can be inspected on machines without a GPU.
  * tile_docs = documents per LDS accumulator tile (power of two, 256..4096; 0 = default 1024). */
 ps_status ps_index_snapshot(const ps_index* idx, int device, uint32_t tile_docs, ps_snapshot** out);
+/* The same with room to grow: headroom_pct > 0 reserves that share of extra documents, postings and
+ * table entries, so that ps_snapshot_update can append documents in place (0 = exact fit: removals
+ * can still be applied as a delta, additions re-flatten). */
+ps_status ps_index_snapshot_ex(const ps_index* idx, int device, uint32_t tile_docs, uint32_t headroom_pct,
+                               ps_snapshot** out);
+/* Incremental re-flatten: brings `snap` - made from `idx` by ps_index_snapshot* - up to
+ * the index's current state.  Documents removed since (Index::remove_document, src/index.rs:161-191)
+ * get their alive bit cleared and df is re-counted on the device; documents added since with keys
+ * above every key the snapshot holds are appended as delta lists of their terms (the frozen trie is
+ * rebuilt when they brought new terms).  Host work and uploads are O(changes), not O(postings).  What
+ * cannot be expressed that way (vacuum, re-added or out-of-order keys, headroom exhausted) is handled
+ * by a full re-flatten inside the same call.  Not to be called while queries run on `snap`; replicas
+ * made by ps_index_snapshot_multi share their host copy and are refused (PS_EUNSUPPORTED). */
+typedef struct ps_update_stats {
+  int32_t mode;              /* 0 = already current, 1 = delta applied, 2 = full re-flatten */
+  int32_t trie_refrozen;     /* delta: the added documents brought new terms                 */
+  uint64_t docs_added, docs_removed;
+  uint64_t postings_uploaded; /* delta: postings appended to the planes (mode 2: all of them) */
+  uint64_t bytes_uploaded;
+  uint64_t delta_layers, delta_postings; /* accumulated since the last full flatten          */
+  double host_ms, device_ms;
+} ps_update_stats;
+ps_status ps_snapshot_update(ps_snapshot* snap, const ps_index* idx, ps_update_stats* out);
 /* Multi-device form (SURVEY 8b "device_mask"): flatten ONCE, upload the same planes to every
  * device of `devices[0..n_devices)`; out[i] is the replica on devices[i].  The replicas share the
  * host copy (planner, frozen trie); each is freed with ps_snapshot_free. */
@@ -203,6 +226,10 @@ typedef struct ps_snapshot_info {
   uint64_t device_bytes;
   int32_t device;
   int32_t max_layers;      /* >1 only if some key was re-added without removal                 */
+  uint64_t n_ids;          /* doc id space: n_docs + documents removed by delta updates         */
+  uint32_t tiles_cap;      /* tiles the tables / bitmaps are laid out for (headroom)            */
+  uint32_t delta_layers;   /* delta lists appended by ps_snapshot_update since the last flatten */
+  uint64_t delta_postings;
 } ps_snapshot_info;
 ps_status ps_snapshot_get_info(const ps_snapshot* snap, ps_snapshot_info* out);
 
@@ -340,6 +367,7 @@ typedef struct ps_host_csr {
   const uint64_t* keys;      /* [n_docs] doc id -> key (ascending keys) */
   const double* avg;         /* [F] FieldDetails::avg                   */
   uint64_t plane_stride;     /* n_postings_padded                       */
+  const uint32_t* alive;     /* one bit per doc id (cleared: removed by a delta update) */
 } ps_host_csr;
 ps_status ps_snapshot_host_csr(const ps_snapshot* snap, ps_host_csr* out);
 

@@ -68,6 +68,13 @@ class ScorerDesc(C.Structure):
                 ("callbacks", C.POINTER(ScoreCallbacks))]
 
 
+class UpdateStats(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("trie_refrozen", C.c_int32), ("docs_added", C.c_uint64),
+                ("docs_removed", C.c_uint64), ("postings_uploaded", C.c_uint64), ("bytes_uploaded", C.c_uint64),
+                ("delta_layers", C.c_uint64), ("delta_postings", C.c_uint64), ("host_ms", C.c_double),
+                ("device_ms", C.c_double)]
+
+
 class KernelTimes(C.Structure):
     _fields_ = [("score_ms", C.c_double), ("rows_ms", C.c_double), ("launches", C.c_uint64),
                 ("score_kernel", C.c_char * 96)]
@@ -77,7 +84,8 @@ class SnapshotInfo(C.Structure):
     _fields_ = [("fields_num", C.c_uint32), ("tile_docs", C.c_uint32), ("n_docs", C.c_uint64),
                 ("n_terms", C.c_uint64), ("n_postings", C.c_uint64), ("n_pointers", C.c_uint64),
                 ("n_table_entries", C.c_uint64), ("device_bytes", C.c_uint64), ("device", C.c_int32),
-                ("max_layers", C.c_int32)]
+                ("max_layers", C.c_int32), ("n_ids", C.c_uint64), ("tiles_cap", C.c_uint32),
+                ("delta_layers", C.c_uint32), ("delta_postings", C.c_uint64)]
 
 
 class BatchStats(C.Structure):
@@ -97,7 +105,7 @@ class PlanEntry(C.Structure):
 class HostCsr(C.Structure):
     _fields_ = [("doc", C.POINTER(C.c_uint32)), ("tf", C.POINTER(C.c_uint32)), ("fl", C.POINTER(C.c_uint32)),
                 ("table", C.POINTER(C.c_uint32)), ("keys", C.POINTER(C.c_uint64)), ("avg", C.POINTER(C.c_double)),
-                ("plane_stride", C.c_uint64)]
+                ("plane_stride", C.c_uint64), ("alive", C.POINTER(C.c_uint32))]
 
 
 TOKENIZER_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -149,6 +157,8 @@ SYMBOLS = {
     "ps_snapshot_last_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "ps_snapshot_kernel_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "ps_snapshot_kernel_breakdown": (C.c_int, [_P, C.POINTER(KernelTimes), C.c_int]),
+    "ps_index_snapshot_ex": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "ps_snapshot_update": (C.c_int, [_P, _P, C.POINTER(UpdateStats)]),
     "ps_index_snapshot_multi": (C.c_int, [_P, C.POINTER(C.c_int), C.c_size_t, C.c_uint32, C.POINTER(_P)]),
     "ps_comm_get_unique_id": (C.c_int, [_P]),
     "ps_comm_init_rank": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

@@ -294,10 +294,68 @@ size_t ps_index_expand_term(const ps_index* idx, const char* term, size_t len, c
 }
 
 ps_status ps_index_snapshot(const ps_index* idx, int device, uint32_t tile_docs, ps_snapshot** out) {
+  return ps_index_snapshot_ex(idx, device, tile_docs, 0, out);
+}
+
+ps_status ps_snapshot_update(ps_snapshot* snap, const ps_index* idx, ps_update_stats* out) {
+  return guard([&]() -> ps_status {
+    if (!snap || !idx) return fail(PS_EINVAL, "null argument");
+    if (snap->snap.use_count() > 1) return fail(PS_EUNSUPPORTED, "replicas of ps_index_snapshot_multi share their host copy: re-create them");
+    ps_update_stats st;
+    memset(&st, 0, sizeof(st));
+    const double t0 = wall_ms();
+    if (snap->snap->src_epoch == idx->idx.epoch()) {
+      if (out) *out = st;
+      return PS_OK;
+    }
+    ps::DeltaRanges r;
+    if (snap->snap->apply_delta(idx->idx, r)) {
+      const double t1 = wall_ms();
+      std::vector<uint64_t> removed;
+      uint64_t bytes = 0;
+      if (snap->engine) snap->engine->apply_delta(r, removed, &bytes);
+      else removed = snap->snap->count_removed_df_host();
+      snap->snap->set_removed_df(removed);
+      st.mode = 1;
+      st.trie_refrozen = r.trie_refrozen ? 1 : 0;
+      st.docs_added = r.docs_added;
+      st.docs_removed = r.docs_removed;
+      st.postings_uploaded = r.plane_end - r.plane_begin;
+      st.bytes_uploaded = bytes;
+      st.host_ms = t1 - t0;
+      st.device_ms = wall_ms() - t1;
+    } else {
+      // not expressible as a delta: flatten again (same tile size and headroom) and swap
+      std::shared_ptr<ps::Snapshot> fresh(new ps::Snapshot(idx->idx, snap->tile_docs, snap->headroom_pct));
+      const double t1 = wall_ms();
+      std::unique_ptr<ps::Engine> eng;
+      if (snap->device >= 0) {
+        snap->engine.reset();  // free the old planes first
+        eng.reset(new ps::Engine(*fresh, snap->device));
+      }
+      snap->snap = fresh;
+      snap->engine = std::move(eng);
+      st.mode = 2;
+      st.postings_uploaded = fresh->n_postings;
+      st.bytes_uploaded = snap->engine ? snap->engine->device_bytes() : 0;
+      st.host_ms = t1 - t0;
+      st.device_ms = wall_ms() - t1;
+    }
+    st.delta_layers = snap->snap->n_delta_layers;
+    st.delta_postings = snap->snap->n_delta_postings;
+    if (out) *out = st;
+    return PS_OK;
+  });
+}
+
+ps_status ps_index_snapshot_ex(const ps_index* idx, int device, uint32_t tile_docs, uint32_t headroom_pct,
+                               ps_snapshot** out) {
   return guard([&]() -> ps_status {
     if (!idx || !out) return fail(PS_EINVAL, "null argument");
     std::unique_ptr<ps_snapshot> s(new ps_snapshot());
-    s->snap.reset(new ps::Snapshot(idx->idx, tile_docs));
+    s->snap.reset(new ps::Snapshot(idx->idx, tile_docs, headroom_pct));
+    s->tile_docs = tile_docs;
+    s->headroom_pct = headroom_pct;
     s->device = device;
     if (device >= 0) s->engine.reset(new ps::Engine(*s->snap, device));
     *out = s.release();
@@ -359,6 +417,10 @@ ps_status ps_snapshot_get_info(const ps_snapshot* snap, ps_snapshot_info* out) {
   out->device_bytes = snap->engine ? snap->engine->device_bytes() : 0;
   out->device = snap->device;
   out->max_layers = (int32_t)s.max_layers;
+  out->n_ids = s.n_ids;
+  out->tiles_cap = s.tiles_cap;
+  out->delta_layers = s.n_delta_layers;
+  out->delta_postings = s.n_delta_postings;
   return PS_OK;
 }
 
@@ -434,9 +496,12 @@ ps_status ps_index_query(ps_index* idx, const ps_scorer_desc* scorer, const char
       return PS_OK;
     });
   }
-  if (!idx->cached || idx->cached->snap->src_epoch != idx->idx.epoch()) {
-    if (idx->cached) { ps_snapshot_free(idx->cached); idx->cached = nullptr; }
-    ps_status st = ps_index_snapshot(idx, 0, 0, &idx->cached);
+  if (!idx->cached) {
+    // the lazily kept snapshot tracks the live index: room for 25 % more documents before a re-flatten
+    ps_status st = ps_index_snapshot_ex(idx, 0, 0, 25, &idx->cached);
+    if (st != PS_OK) return st;
+  } else if (idx->cached->snap->src_epoch != idx->idx.epoch()) {
+    ps_status st = ps_snapshot_update(idx->cached, idx, nullptr);  // delta if expressible, else full
     if (st != PS_OK) return st;
   }
   return ps_snapshot_query(idx->cached, scorer, query, query_len, fields_boost, n_boost, tokenizer, user, top_k, out,
@@ -519,6 +584,7 @@ ps_status ps_snapshot_host_csr(const ps_snapshot* snap, ps_host_csr* out) {
   out->keys = s.keys.data();
   out->avg = s.avg.data();
   out->plane_stride = s.P;
+  out->alive = s.alive.data();
   return PS_OK;
 }
 

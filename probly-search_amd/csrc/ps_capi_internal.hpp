@@ -13,6 +13,7 @@ struct ps_snapshot {
   std::shared_ptr<ps::Snapshot> snap;  // shared by the replicas of ps_index_snapshot_multi
   std::unique_ptr<ps::Engine> engine;  // null for host-only snapshots
   int device = -1;
+  uint32_t tile_docs = 0, headroom_pct = 0;  // as requested at creation (a full re-flatten reuses them)
   std::mutex stats_mu;
   ps_batch_stats last{};
   std::mutex pool_mu;

@@ -146,6 +146,8 @@ struct EngineImpl {
   uint32_t* d_fl = nullptr;
   uint32_t* d_table = nullptr;
   uint32_t* d_bits = nullptr;
+  uint32_t* d_alive = nullptr;  // one bit per doc id (delta removals)
+  DevBuf<unsigned long long> d_removed_df;  // per layer, scratch of count_removed_df
   uint64_t* d_keys = nullptr;
   double* d_lut = nullptr;
   uint32_t* d_work = nullptr;
@@ -167,7 +169,7 @@ struct EngineImpl {
   struct ListBounds {
     bool valid = false;
     double k1 = 0, b = 0;
-    std::vector<double> boosts, M, J;
+    std::vector<double> boosts, avg, M, J;
   } bounds;
   DevBuf<uint32_t> d_sort_doc, d_seg;  // K4 scratch
   DevBuf<uint64_t> d_sort_score, d_pack_off;
@@ -236,6 +238,8 @@ struct EngineImpl {
   }
 };
 
+namespace { void forget_rows(EngineImpl& m); }
+
 int device_count() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -273,7 +277,9 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     PS_HIP(hipMalloc((void**)&m.d_table, snap.table.size() * 4));
     PS_HIP(hipMalloc((void**)&m.d_bits, snap.bits.size() * 4));
     PS_HIP(hipMemcpy(m.d_bits, snap.bits.data(), snap.bits.size() * 4, hipMemcpyHostToDevice));
-    PS_HIP(hipMalloc((void**)&m.d_keys, std::max<size_t>(1, snap.keys.size()) * 8));
+    PS_HIP(hipMalloc((void**)&m.d_keys, std::max<size_t>(1, (size_t)snap.tiles_cap * snap.T) * 8));
+    PS_HIP(hipMalloc((void**)&m.d_alive, std::max<size_t>(1, snap.alive.size()) * 4));
+    if (!snap.alive.empty()) PS_HIP(hipMemcpy(m.d_alive, snap.alive.data(), snap.alive.size() * 4, hipMemcpyHostToDevice));
     PS_HIP(hipMalloc((void**)&m.d_lut, ((size_t)snap.lut_rows + 4) * LUT_TF * 8));
     PS_HIP(hipMemcpy(m.d_doc, snap.doc.data(), P * 4, hipMemcpyHostToDevice));
     PS_HIP(hipMemcpy(m.d_tf, snap.tf.data(), P * F * 4, hipMemcpyHostToDevice));
@@ -296,12 +302,12 @@ Engine::~Engine() {
   EngineImpl& m = *impl_;
   (void)hipSetDevice(m.device);
   (void)hipDeviceSynchronize();
-  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_bits, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work})
+  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_bits, (void*)m.d_alive, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work})
     if (p) (void)hipFree(p);
   m.d_stage.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
-  m.d_gthr.release(); m.d_rows.release(); m.d_cand_cnt.release();
+  m.d_gthr.release(); m.d_rows.release(); m.d_cand_cnt.release(); m.d_removed_df.release();
   free_daat_work(m.daat_work);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
   m.d_sort_tmp.release(); m.d_pack.release();
@@ -320,6 +326,76 @@ Engine::~Engine() {
   }
   if (m.stream) (void)hipStreamDestroy(m.stream);
   delete impl_;
+}
+
+// Per layer: sum of tf over the postings whose document a delta removed (Index::count_documents skips
+// removed documents, index.rs:287-293).  One workgroup-strided pass over the doc / tf planes.
+__global__ __launch_bounds__(256) void k_removed_df(const uint32_t* doc, const uint32_t* tf, const uint32_t* alive, uint64_t P,
+                                                     uint32_t F, const uint64_t* lay_off, const uint32_t* lay_len, uint32_t n_layers,
+                                                     unsigned long long* out) {
+  for (uint32_t l = blockIdx.x; l < n_layers; l += gridDim.x) {
+    unsigned long long acc = 0;
+    for (uint32_t i = threadIdx.x; i < lay_len[l]; i += blockDim.x) {
+      const uint64_t pi = lay_off[l] + i;
+      const uint32_t d = doc[pi];
+      if (!((alive[d >> 5] >> (d & 31u)) & 1u))
+        for (uint32_t x = 0; x < F; ++x) acc += tf[(uint64_t)x * P + pi];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&out[l], acc);
+  }
+}
+
+void Engine::apply_delta(const DeltaRanges& r, std::vector<uint64_t>& removed_df, uint64_t* bytes_uploaded) {
+  EngineImpl& m = *impl_;
+  const Snapshot& s = *m.snap;
+  std::lock_guard<std::mutex> lock(m.mu);
+  PS_HIP(hipSetDevice(m.device));
+  PS_HIP(hipDeviceSynchronize());  // no batch of this snapshot is in flight while its planes change
+  uint64_t up = 0;
+  auto put = [&](void* dst, const void* src, size_t bytes) {
+    if (!bytes) return;
+    PS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    up += bytes;
+  };
+  const size_t F = s.F, P = s.P;
+  if (r.plane_end > r.plane_begin) {
+    const size_t b = r.plane_begin, n = r.plane_end - r.plane_begin;
+    put(m.d_doc + b, s.doc.data() + b, n * 4);
+    for (size_t x = 0; x < F; ++x) {
+      put(m.d_tf + x * P + b, s.tf.data() + x * P + b, n * 4);
+      put(m.d_fl + x * P + b, s.fl.data() + x * P + b, n * 4);
+    }
+  }
+  if (r.table_end > r.table_begin) put(m.d_table + r.table_begin, s.table.data() + r.table_begin, (r.table_end - r.table_begin) * 4);
+  if (r.key_end > r.key_begin) put(m.d_keys + r.key_begin, s.keys.data() + r.key_begin, (r.key_end - r.key_begin) * 8);
+  if (r.alive_words.size() * 8 > s.alive.size()) {
+    put(m.d_alive, s.alive.data(), s.alive.size() * 4);
+  } else {
+    for (uint32_t w : r.alive_words) put(m.d_alive + w, s.alive.data() + w, 4);
+  }
+  // what depended on the old state: resident dense rows (doc range, avg), the saturated-tf LUT (avg)
+  forget_rows(m);
+  removed_df.assign(s.layers.size(), 0);
+  if (s.any_dead && !s.layers.empty()) {
+    const size_t nl = s.layers.size();
+    std::vector<uint64_t> off(nl);
+    std::vector<uint32_t> len(nl);
+    for (size_t l = 0; l < nl; ++l) { off[l] = s.layers[l].post_off; len[l] = s.layers[l].len; }
+    m.d_removed_df.ensure(nl * 3 + 8);
+    unsigned long long* d_out = m.d_removed_df.p;
+    uint64_t* d_off = reinterpret_cast<uint64_t*>(m.d_removed_df.p + nl);
+    uint32_t* d_len = reinterpret_cast<uint32_t*>(m.d_removed_df.p + 2 * nl);
+    PS_HIP(hipMemset(d_out, 0, nl * 8));
+    PS_HIP(hipMemcpy(d_off, off.data(), nl * 8, hipMemcpyHostToDevice));
+    PS_HIP(hipMemcpy(d_len, len.data(), nl * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_removed_df, dim3((uint32_t)std::min<size_t>(nl, 65535)), dim3(256), 0, m.stream, m.d_doc, m.d_tf, m.d_alive,
+                       (uint64_t)P, (uint32_t)F, d_off, d_len, (uint32_t)nl, d_out);
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipStreamSynchronize(m.stream));
+    PS_HIP(hipMemcpy(removed_df.data(), d_out, nl * 8, hipMemcpyDeviceToHost));
+  }
+  if (bytes_uploaded) *bytes_uploaded = up;
 }
 
 uint64_t Engine::device_bytes() const { return impl_->bytes; }
@@ -525,10 +601,15 @@ void compute_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   EngineImpl::ListBounds& lb = m.bounds;
   const uint32_t F = s.F;
   std::vector<double> bv(boosts, boosts + F);
-  if (lb.valid && lb.k1 == sc.bm25_k1 && lb.b == sc.bm25_b && lb.boosts == bv) return;
   const size_t nl = s.layers.size();
-  lb.M.assign(nl * F, 0.0);
-  lb.J.assign(nl, 0.0);
+  const bool same = lb.valid && lb.k1 == sc.bm25_k1 && lb.b == sc.bm25_b && lb.boosts == bv && lb.avg == std::vector<double>(s.avg.begin(), s.avg.end());
+  if (same && lb.J.size() == nl) return;
+  // (a delta snapshot only appends layers: with unchanged parameters only those are new)
+  const size_t l_first = same ? lb.J.size() : 0;
+  lb.M.resize(nl * F);
+  lb.J.resize(nl);
+  std::fill(lb.M.begin() + (long)(l_first * F), lb.M.end(), 0.0);
+  std::fill(lb.J.begin() + (long)l_first, lb.J.end(), 0.0);
   const double k1 = sc.bm25_k1, b = sc.bm25_b, k1p1 = sc.bm25_k1 + 1.0, omb = 1.0 - sc.bm25_b;
   auto tfn_of = [&](uint32_t x, uint32_t tfu, uint32_t flu) {
     const double tfd = (double)tfu, fld = (double)flu;
@@ -559,10 +640,10 @@ void compute_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* 
     lb.J[l] = J;
   };
   unsigned n_thr = s.n_postings > (1u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-  if (n_thr <= 1) {
-    for (size_t l = 0; l < nl; ++l) body(l);
+  if (n_thr <= 1 || nl - l_first < 1024) {
+    for (size_t l = l_first; l < nl; ++l) body(l);
   } else {
-    std::atomic<size_t> next{0};
+    std::atomic<size_t> next{l_first};
     auto worker = [&]() {
       for (;;) {
         const size_t b0 = next.fetch_add(64);
@@ -575,7 +656,7 @@ void compute_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* 
     worker();
     for (auto& t : th) t.join();
   }
-  lb.k1 = sc.bm25_k1; lb.b = sc.bm25_b; lb.boosts = bv; lb.valid = true;
+  lb.k1 = sc.bm25_k1; lb.b = sc.bm25_b; lb.boosts = bv; lb.avg.assign(s.avg.begin(), s.avg.end()); lb.valid = true;
 }
 
 // Upper bound of any posting score of plan entry `e` (list e.node), rounding included: the per-field
@@ -852,7 +933,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
       for (size_t q = 0; q < B; ++q) {
         if (z && !(qf[q] & 1u)) continue;  // zero_to_one: queries of the fast path only
         for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
-          if ((double)he[i].len < min_density * (double)s.n_docs) continue;
+          if ((double)he[i].len < min_density * (double)s.n_ids) continue;
           Agg& a = agg[key_of(he[i], q)];
           a.uses++;
           a.len = he[i].len;
@@ -864,11 +945,11 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
       for (auto& kv : agg)
         if (kv.second.uses >= min_uses) hot.emplace_back((uint64_t)kv.second.uses * kv.second.len, kv.first);
       std::sort(hot.begin(), hot.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-      const uint64_t row_bytes = (uint64_t)s.n_tiles * s.T * 8 * planes;
+      const uint64_t row_bytes = (uint64_t)s.tiles_cap * s.T * 8 * planes;
       const uint64_t mem_cap = (uint64_t)m.tune.dense_max_mb << 20;
       while (hot.size() > max_rows || hot.size() * row_bytes > mem_cap) hot.pop_back();
       // slab geometry: as many slots as the cache budget holds (at least one batch's worth)
-      const uint64_t row_elems = (uint64_t)s.n_tiles * s.T * planes;
+      const uint64_t row_elems = (uint64_t)s.tiles_cap * s.T * planes;
       size_t n_slots = std::max<size_t>(max_rows, std::min<size_t>(4096, ((uint64_t)m.tune.row_cache_mb << 20) / row_bytes));
       if (!hot.empty()) {
         // resident rows are only valid for the parameters they were scored with
@@ -970,7 +1051,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
 uint64_t layout_bytes_of(const EngineImpl& m, const BatchImage& img) {
   const Snapshot& s = *m.snap;
   const uint32_t planes = img.z ? s.F : 1u;
-  const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.n_tiles * s.T * 8 * planes;
+  const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.tiles_cap * s.T * 8 * planes;
   uint64_t lb = 0;
   for (size_t i = 0; i < img.ne; ++i) lb += (img.he[i].shift & DENSE_FLAG) ? row_bytes : (uint64_t)img.he[i].len * pb;
   const RowDesc* rd = reinterpret_cast<const RowDesc*>(img.h + img.off_r);
@@ -1096,6 +1177,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
 
   memset(&kp, 0, sizeof(kp));
   kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys; kp.bits = m.d_bits;
+  kp.alive = s.any_dead ? m.d_alive : nullptr;
   kp.plan = reinterpret_cast<const ps_plan_entry*>(dbase + off_e);
   kp.qbeg = reinterpret_cast<const uint32_t*>(dbase + off_q);
   kp.qterms_len = reinterpret_cast<const uint32_t*>(dbase + off_l);
@@ -1126,7 +1208,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   }
   kp.row_planes = z ? s.F : 1u;
   kp.row_mode = z ? 1u : 0u;
-  kp.row_stride = (uint64_t)s.n_tiles * s.T;
+  kp.row_stride = (uint64_t)s.tiles_cap * s.T;
   if (n_used) {
     kp.rows = m.d_rows.p;
   }
@@ -1153,7 +1235,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.P = s.P;
   kp.t_log2 = 0;
   while ((1u << kp.t_log2) < s.T) ++kp.t_log2;
-  kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_docs; kp.F = s.F;
+  kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_ids; kp.F = s.F;  // (id space: live + delta-removed documents)
   kp.max_qterms = std::max<uint32_t>(1, plan.max_qterms);
   kp.ablate = m.tune.ablate;
   kp.k1 = sc.bm25_k1; kp.b = sc.bm25_b;
@@ -1538,7 +1620,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   for (size_t q = 0; q < B; ++q) {
     uint64_t sum = 0;
     for (uint32_t e = plan.qbeg[q]; e < plan.qbeg[q + 1]; ++e) sum += plan.entries[e].len;
-    cap[q + 1] = cap[q] + std::min<uint64_t>(sum, s.n_docs);
+    cap[q + 1] = cap[q] + std::min<uint64_t>(sum, s.n_ids);
   }
   const uint64_t total_cap = cap[B];
   const uint64_t budget = (uint64_t)m.tune.full_budget_mb << 20;

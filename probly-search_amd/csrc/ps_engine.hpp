@@ -31,6 +31,10 @@ class Engine {
   // HIP-event durations summed over every batch since the last reset: the scoring kernel alone and
   // K0 / K0b in front of it (waits for outstanding launches).
   void kernel_times(ps_kernel_times& out, bool reset);
+  // Device side of Snapshot::apply_delta: uploads exactly the ranges it changed (appended postings,
+  // table entries, keys, alive words), drops what was derived from the old state and re-counts, on
+  // the device, the per-layer pointer count of delta-removed documents.  Call with no batch in flight.
+  void apply_delta(const DeltaRanges& r, std::vector<uint64_t>& removed_df, uint64_t* bytes_uploaded);
   uint64_t device_bytes() const;
   int device() const;
 

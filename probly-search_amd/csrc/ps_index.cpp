@@ -153,6 +153,17 @@ void Index::add_document(uint64_t key, const ps_str* values, const size_t* n_val
       field_length[i] = count;                                                // assignment (:114)
     }
   }
+  {
+    IndexChange c;
+    c.kind = IndexChange::ADD;
+    c.key = key;
+    c.was_present = docs_.count(key) != 0;
+    c.was_removed = has_removed_ && removed_.count(key) != 0;
+    c.nodes = doc_nodes_;
+    c.tf = doc_tf_;
+    c.field_length = field_length;
+    log_push(std::move(c));
+  }
   docs_[key] = DocDetails{std::move(field_length)};
   for (size_t k = 0; k < doc_nodes_.size(); ++k) {
     TrieNode& n = nodes_[(size_t)doc_nodes_[k]];
@@ -167,8 +178,37 @@ void Index::add_document(uint64_t key, const ps_str* values, const size_t* n_val
   ++epoch_;
 }
 
+void Index::log_push(IndexChange&& c) {
+  // bounded: a burst larger than this is cheaper to re-flatten than to replay
+  constexpr size_t MAX_ENTRIES = 1u << 20, MAX_POSTINGS = 16u << 20;
+  log_postings_ += c.nodes.size();
+  log_.push_back(std::move(c));
+  if (log_.size() > MAX_ENTRIES || log_postings_ > MAX_POSTINGS) {
+    log_base_ += log_.size();
+    log_.clear();
+    log_.shrink_to_fit();
+    log_postings_ = 0;
+  }
+}
+
+const IndexChange* Index::changes_since(uint64_t epoch, size_t* count) const {
+  *count = 0;
+  if (epoch < log_base_ || epoch > epoch_) return nullptr;
+  const size_t first = (size_t)(epoch - log_base_);
+  if (first > log_.size() || log_base_ + log_.size() != epoch_) return nullptr;
+  *count = log_.size() - first;
+  return log_.data() + first;
+}
+
 void Index::remove_document(uint64_t key) {
   has_removed_ = true;
+  {
+    IndexChange c;
+    c.kind = IndexChange::REMOVE;
+    c.key = key;
+    c.was_present = docs_.count(key) != 0;
+    log_push(std::move(c));
+  }
   auto it = docs_.find(key);
   if (it != docs_.end()) {
     removed_.insert(key);
@@ -231,6 +271,7 @@ size_t Index::vacuum_node(int32_t node) {
 }
 
 void Index::vacuum() {
+  log_push(IndexChange{});  // OTHER: lists are compacted and nodes recycled - snapshots re-flatten
   vacuum_node(0);
   removed_.clear();
   has_removed_ = false;

@@ -103,6 +103,18 @@ class TermCache {
   size_t used_ = 0, mask_ = 0;
 };
 
+// One logged mutation (the delta-snapshot path): enough to update a flattened snapshot
+// without walking the posting lists again.
+struct IndexChange {
+  enum Kind : uint8_t { ADD = 0, REMOVE = 1, OTHER = 2 } kind = OTHER;  // OTHER (vacuum) forces a full re-flatten
+  uint64_t key = 0;
+  bool was_present = false;   // ADD: the key was already a live document (re-add without removal); REMOVE: it existed
+  bool was_removed = false;   // ADD: the key sits in the lazily-removed set (it stays invisible until vacuum)
+  std::vector<int32_t> nodes;         // ADD: trie nodes of the document's distinct terms
+  std::vector<uint32_t> tf;           // ADD: F term frequencies per node
+  std::vector<uint32_t> field_length; // ADD: DocumentDetails::field_length
+};
+
 class Index {
  public:
   explicit Index(size_t fields_num, size_t expected_index_size = 1000, size_t expected_documents_count = 10000);
@@ -139,6 +151,10 @@ class Index {
   bool any_removed() const { return has_removed_ && !removed_.empty(); }
   int32_t root() const { return 0; }
   uint64_t epoch() const { return epoch_; }  // bumped by every mutation
+  // The mutations after `epoch`, oldest first, or nullptr if the log no longer reaches back that far
+  // (it is bounded; a snapshot that old re-flattens).  *count = number of entries.
+  const IndexChange* changes_since(uint64_t epoch, size_t* count) const;
+  uint32_t node_char(int32_t node) const { return nodes_[(size_t)node].ch; }
 
  private:
   int32_t new_node(uint32_t ch, int32_t parent);
@@ -159,6 +175,11 @@ class Index {
   // over linked sibling lists; dropped whenever vacuum prunes nodes.
   TermCache term_cache_;
   uint64_t epoch_ = 0;
+  // change log: entry i is the mutation that moved the epoch from log_base_ + i to log_base_ + i + 1
+  std::vector<IndexChange> log_;
+  uint64_t log_base_ = 0;
+  size_t log_postings_ = 0;
+  void log_push(IndexChange&& c);
   // add_document scratch
   std::vector<const char*> sp_;
   std::vector<size_t> sl_;

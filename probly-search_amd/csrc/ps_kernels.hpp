@@ -114,6 +114,7 @@ struct KParams {
   const uint32_t* qslot;        // [B+1] candidate slots (= items) of query q: [qslot[q], qslot[q+1])
   const uint32_t* rorder;       // [n_plan_entries] per query: its entries in rank order (highest bound first)
   const uint32_t* bits;         // membership bitmaps of the denser lists (ps_plan_entry::bm_off)
+  const uint32_t* alive;        // one bit per doc id, cleared by a delta removal; null = every document alive
   uint32_t n_ditems, t_log2;
   uint32_t item_base;           // first item of this launch (the batch may be split into two launches)
   uint32_t* cand_cnt;           // [n_ditems] candidates an item left in its slot
@@ -147,6 +148,11 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // (doc ids are assigned in ascending key order, so doc asc == key asc).
 __device__ __forceinline__ bool better(double as, uint32_t ad, double bs, uint32_t bd) {
   return as > bs || (as == bs && ad < bd);
+}
+
+// Documents removed by a delta snapshot keep their postings (tombstones): every emission site drops them.
+__device__ __forceinline__ bool doc_alive(const KParams& p, const uint32_t d) {
+  return p.alive == nullptr || ((p.alive[d >> 5] >> (d & 31u)) & 1u);
 }
 
 struct TopK {
@@ -800,8 +806,13 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
             if (zero_tile && (v.x > 0.0 || v.y > 0.0))
               *reinterpret_cast<double2*>(&acc[c + u * 2 * WAVE + 2 * lane]) = make_double2(0.0, 0.0);
             if (FUSED) { v.x += rv[u].x; v.y += rv[u].y; }  // the query's last entry, in plan order
-            const bool h0 = v.x > 0.0, h1 = v.y > 0.0;
             const uint32_t d = tile_base + c + u * 2 * WAVE + 2 * lane;
+            bool h0 = v.x > 0.0, h1 = v.y > 0.0;
+            if (p.alive != nullptr) {  // delta removals (wave-uniform branch; d is even: both bits sit in one word)
+              const uint32_t aw = p.alive[d >> 5] >> (d & 31u);
+              h0 = h0 && (aw & 1u);
+              h1 = h1 && (aw & 2u);
+            }
             if (FULL) {
               full_emit(p, q, lane, h0, v.x, d);
               full_emit(p, q, lane, h1, v.y, d + 1);
@@ -869,6 +880,11 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
               }
             }
             const uint32_t d = tile_base + c + u * 2 * WAVE + 2 * lane;
+            if (p.alive != nullptr) {  // delta removals
+              const uint32_t aw = p.alive[d >> 5] >> (d & 31u);
+              h0 = h0 && (aw & 1u);
+              h1 = h1 && (aw & 2u);
+            }
             if (FULL) {
               full_emit(p, q, lane, h0, b0, d);
               full_emit(p, q, lane, h1, b1, d + 1);
@@ -1010,6 +1026,7 @@ __global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
           if (has)
             for (uint32_t w = 0; w < stride; ++w) rec[local * stride + w] = 0;
           const uint32_t d = tile_base + local;
+          has = has && (d < p.n_docs) && doc_alive(p, d);
           if (FULL) full_emit(p, q, lane, has, best, d);
           else topk_offer(tk, p.K, lane, has, best, d);
         }
@@ -1290,6 +1307,10 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
         alive[u] = essential && i < end;
         pi[u] = own_off + (i < end ? i : end - 1);
         d[u] = p.doc[pi[u]];
+      }
+      if (p.alive != nullptr) {  // delta removals
+#pragma unroll
+        for (int u = 0; u < U; ++u) alive[u] = alive[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
       }
       posting_scores<F_, U>(p, lut, pi, alive, own_idf, own_eb, s_own);
       bool any_alive = false;

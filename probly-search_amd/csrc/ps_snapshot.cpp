@@ -54,16 +54,77 @@ struct SnapshotStorage {
   PlaneVec doc, tf, fl, table;
   std::vector<uint32_t> bits;
   std::vector<uint32_t> max_fl, lut_cap, lut_base;
+  std::vector<uint32_t> alive;
+  // delta bookkeeping (never saved): source trie node of every term ordinal, df_raw before the
+  // removed documents are subtracted
+  std::vector<int32_t> term_node;
+  std::vector<uint64_t> df_total;
 };
+
+namespace {
+// DFS pre-order over the index's trie, children newest-first (query.rs:130-147): frozen node ids,
+// term ordinals (a term = a node whose list holds a posting, query.rs:136-138), children sorted by
+// char for binary search.  No posting work: cheap enough to redo on every delta.
+struct FrozenTrie {
+  std::vector<FrozenNode> fnodes;
+  std::vector<uint32_t> fchar, fchild;
+  std::vector<int32_t> term_node;    // term ordinal -> source trie node
+  std::vector<uint32_t> term_bytes;  // byte length of the term
+  std::vector<uint32_t> term_fnode;
+};
+
+void freeze_trie(const Index& idx, FrozenTrie& ft) {
+  const std::vector<TrieNode>& nodes = idx.nodes();
+  const std::vector<PostingList>& lists = idx.lists();
+  std::vector<uint32_t> node_bytes;  // per frozen node: byte length of its path
+  std::vector<Frame> st;
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> kids;  // per frozen node: (char, fid)
+  auto enter = [&](int32_t node, uint32_t bytes) -> uint32_t {
+    uint32_t fid = (uint32_t)ft.fnodes.size();
+    ft.fnodes.push_back(FrozenNode{0, 0, (uint32_t)ft.term_node.size(), 0});
+    node_bytes.push_back(bytes);
+    kids.emplace_back();
+    int32_t li = nodes[(size_t)node].list;
+    if (li != NIL && !lists[(size_t)li].keys.empty()) {  // first_doc.is_some()  (query.rs:136-138)
+      ft.term_node.push_back(node);
+      ft.term_bytes.push_back(bytes);
+      ft.term_fnode.push_back(fid);
+    }
+    st.push_back(Frame{node, nodes[(size_t)node].first_child, fid});
+    return fid;
+  };
+  enter(idx.root(), 0);
+  while (!st.empty()) {
+    Frame& f = st.back();
+    if (f.child == NIL) {
+      ft.fnodes[f.fid].term_end = (uint32_t)ft.term_node.size();
+      st.pop_back();
+      continue;
+    }
+    int32_t c = f.child;
+    uint32_t parent_fid = f.fid;
+    f.child = nodes[(size_t)c].next;
+    uint32_t bytes = node_bytes[parent_fid] + utf8_len(nodes[(size_t)c].ch);
+    uint32_t cf = enter(c, bytes);  // invalidates f
+    kids[parent_fid].emplace_back(nodes[(size_t)c].ch, cf);
+  }
+  for (size_t n = 0; n < ft.fnodes.size(); ++n) {
+    std::sort(kids[n].begin(), kids[n].end());
+    ft.fnodes[n].child_begin = (uint32_t)ft.fchar.size();
+    ft.fnodes[n].child_count = (uint32_t)kids[n].size();
+    for (auto& kc : kids[n]) { ft.fchar.push_back(kc.first); ft.fchild.push_back(kc.second); }
+  }
+}
+}  // namespace
 
 void Snapshot::bind(const SnapshotStorage& st) {
   auto v = [](const auto& vec) { return View<typename std::decay_t<decltype(vec)>::value_type>{vec.data(), vec.size()}; };
   keys = v(st.keys); avg = v(st.avg); terms = v(st.terms); layers = v(st.layers); fnodes = v(st.fnodes);
   fchar = v(st.fchar); fchild = v(st.fchild); doc = v(st.doc); tf = v(st.tf); fl = v(st.fl); table = v(st.table); bits = v(st.bits);
-  max_fl = v(st.max_fl); lut_cap = v(st.lut_cap); lut_base = v(st.lut_base);
+  max_fl = v(st.max_fl); lut_cap = v(st.lut_cap); lut_base = v(st.lut_base); alive = v(st.alive);
 }
 
-Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
+Snapshot::Snapshot(const Index& idx, uint32_t tile_docs, uint32_t headroom_pct) {
   PhaseTimer pt;
   own_.reset(new SnapshotStorage());
   // the flattener fills the owned vectors (these references shadow the read-only views, which are
@@ -78,8 +139,13 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   src_epoch = idx.epoch();
   n_docs = idx.docs_len();
   if (n_docs >= 0xFFFFFFF0ull) throw std::length_error("more than 2^32-16 documents");
+  n_ids = n_docs;
   n_tiles = (uint32_t)((n_docs + T - 1) / T);
   if (n_tiles == 0) n_tiles = 1;
+  // headroom: tables, bitmaps and rows are laid out for tiles_cap tiles, the planes for extra postings
+  headroom_pct = std::min(headroom_pct, 400u);
+  tiles_cap = n_tiles;
+  if (headroom_pct) tiles_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull / T, n_tiles + std::max<uint64_t>(1, (uint64_t)n_tiles * headroom_pct / 100));
   avg.resize(F);
   for (uint32_t x = 0; x < F; ++x) avg[x] = idx.field(x).avg;
 
@@ -157,45 +223,16 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   // ---- DFS pre-order over the trie: frozen node ids + term ordinals ------------------------
   const std::vector<TrieNode>& nodes = idx.nodes();
   const std::vector<PostingList>& lists = idx.lists();
-  std::vector<int32_t> term_node;  // term ordinal -> source trie node
-  std::vector<uint32_t> node_bytes;  // per frozen node: byte length of its path
+  std::vector<int32_t>& term_node = own_->term_node;  // term ordinal -> source trie node
   {
-    std::vector<Frame> st;
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> kids;  // per frozen node: (char, fid)
-    auto enter = [&](int32_t node, uint32_t bytes) -> uint32_t {
-      uint32_t fid = (uint32_t)fnodes.size();
-      fnodes.push_back(FrozenNode{0, 0, (uint32_t)terms.size(), 0});
-      node_bytes.push_back(bytes);
-      kids.emplace_back();
-      int32_t li = nodes[(size_t)node].list;
-      if (li != NIL && !lists[(size_t)li].keys.empty()) {  // first_doc.is_some()  (query.rs:136-138)
-        terms.push_back(TermInfo{0, bytes, 0, 0, fid});
-        term_node.push_back(node);
-      }
-      st.push_back(Frame{node, nodes[(size_t)node].first_child, fid});
-      return fid;
-    };
-    enter(idx.root(), 0);
-    while (!st.empty()) {
-      Frame& f = st.back();
-      if (f.child == NIL) {
-        fnodes[f.fid].term_end = (uint32_t)terms.size();
-        st.pop_back();
-        continue;
-      }
-      int32_t c = f.child;
-      uint32_t parent_fid = f.fid;
-      f.child = nodes[(size_t)c].next;
-      uint32_t bytes = node_bytes[parent_fid] + utf8_len(nodes[(size_t)c].ch);
-      uint32_t cf = enter(c, bytes);  // invalidates f
-      kids[parent_fid].emplace_back(nodes[(size_t)c].ch, cf);
-    }
-    for (size_t n = 0; n < fnodes.size(); ++n) {
-      std::sort(kids[n].begin(), kids[n].end());
-      fnodes[n].child_begin = (uint32_t)fchar.size();
-      fnodes[n].child_count = (uint32_t)kids[n].size();
-      for (auto& kc : kids[n]) { fchar.push_back(kc.first); fchild.push_back(kc.second); }
-    }
+    FrozenTrie ft;
+    freeze_trie(idx, ft);
+    fnodes = std::move(ft.fnodes);
+    fchar = std::move(ft.fchar);
+    fchild = std::move(ft.fchild);
+    term_node = std::move(ft.term_node);
+    terms.resize(term_node.size());
+    for (size_t o = 0; o < terms.size(); ++o) terms[o] = TermInfo{0, ft.term_bytes[o], 0, 0, ft.term_fnode[o], NO_LAYER, 0};
   }
 
   pt.mark("trie");
@@ -268,7 +305,7 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
   // serial: place every layer (4-aligned starts, so 16-byte vector loads never straddle lists)
   // and its tile-offset table
   uint64_t cursor = 0, tcursor = 0, bcursor = 0;
-  const uint64_t bm_words = 2 * (((uint64_t)n_tiles * T + 31) / 32);  // {bits, postings before} per 32 documents
+  const uint64_t bm_words = 2 * (((uint64_t)tiles_cap * T + 31) / 32);  // {bits, postings before} per 32 documents
   for (size_t o = 0; o < terms.size(); ++o) {
     TermInfo& ti = terms[o];
     TermFlat& tfl = flat[o];
@@ -279,7 +316,7 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
     ti.n_layers = tfl.sorted_desc ? 1u : (uint32_t)tfl.lay.size();
     max_layers = std::max(max_layers, ti.n_layers);
     for (uint32_t l = 0; l < ti.n_layers; ++l) {
-      LayerInfo L{0, 0, 0, 0, NO_BITMAP};
+      LayerInfo L{0, 0, 0, 0, NO_BITMAP, NO_LAYER, 0};
       L.post_off = cursor;
       L.len = tfl.sorted_desc ? tfl.live : (uint32_t)tfl.lay[l].size();
       cursor = (cursor + L.len + 3) & ~(uint64_t)3;
@@ -287,8 +324,8 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
       // smallest shift with slots <= max(1, len/2): <= 2 table bytes per posting overall
       uint32_t shift = 0;
       const uint64_t want = std::max<uint64_t>(1, L.len / 2);
-      while ((((uint64_t)n_tiles - 1) >> shift) + 1 > want) ++shift;
-      const uint32_t slots = ((n_tiles - 1) >> shift) + 1;
+      while ((((uint64_t)tiles_cap - 1) >> shift) + 1 > want) ++shift;
+      const uint32_t slots = ((tiles_cap - 1) >> shift) + 1;
       L.shift = shift;
       if (tcursor + slots + 1 >= 0xFFFFFFFFull) throw std::length_error("tile-offset table exceeds 2^32 entries");
       L.tbl_off = (uint32_t)tcursor;
@@ -300,13 +337,28 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
       layers.push_back(L);
     }
   }
-  P = std::max<uint64_t>(cursor, 4);  // keep planes non-empty so device pointers are always valid
+  P_used = std::max<uint64_t>(cursor, 4);  // keep planes non-empty so device pointers are always valid
+  P = P_used;
+  if (headroom_pct) P = (P_used + std::max<uint64_t>(4096, P_used * headroom_pct / 100) + 3) & ~(uint64_t)3;
+  table_used = std::max<uint64_t>(tcursor, 1);
   doc.resize(P);
   tf.resize((size_t)P * F);
   fl.resize((size_t)P * F);
-  table.resize(std::max<uint64_t>(tcursor, 1));
+  table.resize(headroom_pct ? table_used + std::max<uint64_t>(65536, table_used * headroom_pct / 100) : table_used);
   if (tcursor == 0) table[0] = 0;
-  bits.assign(std::max<uint64_t>(bcursor, 1), 0u);
+  bits.assign(std::max<uint64_t>(bcursor, 2), 0u);
+  if (P > P_used) {  // the headroom is part of the saved file: keep it deterministic
+    std::fill(doc.begin() + (long)P_used, doc.end(), 0xFFFFFFFFu);
+    for (uint32_t x = 0; x < F; ++x) {
+      std::fill(tf.begin() + (long)((size_t)x * P + P_used), tf.begin() + (long)((size_t)(x + 1) * P), 0u);
+      std::fill(fl.begin() + (long)((size_t)x * P + P_used), fl.begin() + (long)((size_t)(x + 1) * P), 0u);
+    }
+  }
+  if (table.size() > table_used) std::fill(table.begin() + (long)table_used, table.end(), 0u);
+  keys.reserve((size_t)tiles_cap * T);
+  own_->alive.assign(((size_t)tiles_cap * T + 31) / 32, 0u);
+  for (uint64_t i = 0; i < n_ids; ++i) own_->alive[i >> 5] |= 1u << (i & 31u);
+  own_->df_total.assign(terms.size(), 0);
   if (cursor == 0) {
     std::fill(doc.begin(), doc.end(), 0xFFFFFFFFu);
     std::fill(tf.begin(), tf.end(), 0u);
@@ -347,7 +399,7 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
         for (uint32_t x = 0; x < F; ++x) { tf[(size_t)x * P + L.post_off + at] = 0; fl[(size_t)x * P + L.post_off + at] = 0; }
       }
       // tile-offset table: first posting of every (group of) tile(s), + the end
-      const uint32_t slots = ((n_tiles - 1) >> L.shift) + 1;
+      const uint32_t slots = ((tiles_cap - 1) >> L.shift) + 1;
       uint32_t pos = 0;
       for (uint32_t sl = 0; sl < slots; ++sl) {
         const uint64_t first_doc = ((uint64_t)sl << L.shift) * T;
@@ -363,25 +415,28 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs) {
       }
     }
   });
+  for (size_t o = 0; o < terms.size(); ++o) own_->df_total[o] = terms[o].df_raw;
+  removed_df.assign(layers.size(), 0);
   { std::vector<TermFlat>().swap(flat); }
   pt.mark("planes");
   bind(*own_);
 }
 
 // ---- on-disk snapshot ---------------------------------------------------------------------------
-// File = one 4096-byte header page + 15 sections, each starting on a 4096-byte boundary and holding
+// File = one 4096-byte header page + 16 sections, each starting on a 4096-byte boundary and holding
 // one array exactly as it lives in memory (little-endian, natural alignment):
-//   header: magic "PSNAP003" | u64 file_bytes | u64 scalars[10] | 14 x {u64 offset, u64 bytes, u64 checksum}
+//   header: magic "PSNAP004" | u64 file_bytes | u64 scalars[16] | 16 x {u64 offset, u64 bytes, u64 checksum}
 // Loading maps the file read-only and points the views at the sections; nothing is parsed or copied.
 namespace {
-constexpr char MAGIC[8] = {'P', 'S', 'N', 'A', 'P', '0', '0', '3'};
+constexpr char MAGIC[8] = {'P', 'S', 'N', 'A', 'P', '0', '0', '4'};
 constexpr size_t PAGE = 4096;
-constexpr int N_SECTIONS = 15;
+constexpr int N_SECTIONS = 16;
 struct SectionRef { uint64_t offset, bytes, checksum; };
 struct FileHeader {
   char magic[8];
   uint64_t file_bytes;
-  uint64_t scalars[10];  // F, T, n_tiles, n_docs, P, n_postings, n_pointers, n_live_terms, max_layers, lut_rows
+  uint64_t scalars[16];  // F, T, n_tiles, n_docs, P, n_postings, n_pointers, n_live_terms, max_layers, lut_rows,
+                         // n_ids, tiles_cap, P_used, table_used, any_dead, (reserved)
   SectionRef sec[N_SECTIONS];
 };
 static_assert(sizeof(FileHeader) <= PAGE, "header fits one page");
@@ -409,11 +464,12 @@ void Snapshot::save(const std::string& path) const {
       {layers.data(), layers.size() * sizeof(LayerInfo)}, {fnodes.data(), fnodes.size() * sizeof(FrozenNode)},
       {fchar.data(), fchar.size() * 4}, {fchild.data(), fchild.size() * 4}, {doc.data(), doc.size() * 4},
       {tf.data(), tf.size() * 4}, {fl.data(), fl.size() * 4}, {table.data(), table.size() * 4},
-      {max_fl.data(), max_fl.size() * 4}, {lut_cap.data(), lut_cap.size() * 4}, {lut_base.data(), lut_base.size() * 4}, {bits.data(), bits.size() * 4}};
+      {max_fl.data(), max_fl.size() * 4}, {lut_cap.data(), lut_cap.size() * 4}, {lut_base.data(), lut_base.size() * 4}, {bits.data(), bits.size() * 4}, {alive.data(), alive.size() * 4}};
   FileHeader h;
   memset(&h, 0, sizeof(h));
   memcpy(h.magic, MAGIC, 8);
-  const uint64_t sc[10] = {F, T, n_tiles, n_docs, P, n_postings, n_pointers, n_live_terms, max_layers, lut_rows};
+  const uint64_t sc[16] = {F, T, n_tiles, n_docs, P, n_postings, n_pointers, n_live_terms, max_layers, lut_rows,
+                           n_ids, tiles_cap, P_used, table_used, any_dead ? 1u : 0u, 0};
   memcpy(h.scalars, sc, sizeof(sc));
   uint64_t off = PAGE;
   for (int i = 0; i < N_SECTIONS; ++i) {
@@ -462,7 +518,9 @@ Snapshot::Snapshot(const std::string& path) {
   F = (uint32_t)h.scalars[0]; T = (uint32_t)h.scalars[1]; n_tiles = (uint32_t)h.scalars[2]; n_docs = h.scalars[3];
   P = h.scalars[4]; n_postings = h.scalars[5]; n_pointers = h.scalars[6]; n_live_terms = h.scalars[7];
   max_layers = (uint32_t)h.scalars[8]; lut_rows = (uint32_t)h.scalars[9];
-  const size_t elem[N_SECTIONS] = {8, 8, sizeof(TermInfo), sizeof(LayerInfo), sizeof(FrozenNode), 4, 4, 4, 4, 4, 4, 4, 4, 4, 4};
+  n_ids = h.scalars[10]; tiles_cap = (uint32_t)h.scalars[11]; P_used = h.scalars[12]; table_used = h.scalars[13];
+  any_dead = h.scalars[14] != 0;
+  const size_t elem[N_SECTIONS] = {8, 8, sizeof(TermInfo), sizeof(LayerInfo), sizeof(FrozenNode), 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4};
   for (int i = 0; i < N_SECTIONS; ++i) {
     const SectionRef& s = h.sec[i];
     if (s.offset % PAGE || s.offset < PAGE || s.offset > map_bytes_ || s.bytes > map_bytes_ - s.offset || s.bytes % elem[i])
@@ -477,8 +535,9 @@ Snapshot::Snapshot(const std::string& path) {
   layers = view(3, (LayerInfo*)nullptr); fnodes = view(4, (FrozenNode*)nullptr); fchar = view(5, (uint32_t*)nullptr);
   fchild = view(6, (uint32_t*)nullptr); doc = view(7, (uint32_t*)nullptr); tf = view(8, (uint32_t*)nullptr);
   fl = view(9, (uint32_t*)nullptr); table = view(10, (uint32_t*)nullptr); max_fl = view(11, (uint32_t*)nullptr);
-  lut_cap = view(12, (uint32_t*)nullptr); lut_base = view(13, (uint32_t*)nullptr); bits = view(14, (uint32_t*)nullptr);
+  lut_cap = view(12, (uint32_t*)nullptr); lut_base = view(13, (uint32_t*)nullptr); bits = view(14, (uint32_t*)nullptr); alive = view(15, (uint32_t*)nullptr);
   validate();
+  removed_df.assign(layers.size(), 0);
   src_epoch = ~0ull;
 }
 
@@ -488,12 +547,21 @@ void Snapshot::validate() const {
   auto bad = [](const char* what) { throw std::invalid_argument(std::string("snapshot file inconsistent: ") + what); };
   if (F > 8) bad("more than 8 fields");
   if (T < 256 || T > 4096 || (T & (T - 1))) bad("tile_docs");
-  if (n_docs >= 0xFFFFFFF0ull) bad("n_docs");
-  const uint64_t want_tiles = std::max<uint64_t>(1, (n_docs + T - 1) / T);
-  if (n_tiles != want_tiles) bad("n_tiles");
-  if (keys.size() != n_docs || avg.size() != F) bad("keys / avg size");
+  if (n_ids >= 0xFFFFFFF0ull || n_docs > n_ids) bad("n_docs / n_ids");
+  const uint64_t want_tiles = std::max<uint64_t>(1, (n_ids + T - 1) / T);
+  if (n_tiles != want_tiles || tiles_cap < n_tiles || (uint64_t)tiles_cap * T >= 0xFFFFFFF0ull + T) bad("n_tiles / tiles_cap");
+  if (keys.size() != n_ids || avg.size() != F) bad("keys / avg size");
   if (P < 4 || P % 4 || doc.size() != P || tf.size() != (size_t)P * F || fl.size() != (size_t)P * F) bad("plane sizes");
+  if (P_used > P || P_used % 4 || table_used > table.size()) bad("used sizes");
   if (table.empty() || bits.empty()) bad("empty table");
+  if (alive.size() != ((size_t)tiles_cap * T + 31) / 32) bad("alive bitmap size");
+  {
+    uint64_t live = 0;
+    for (size_t w = 0; w < alive.size(); ++w) live += (uint64_t)__builtin_popcount(alive[w]);
+    if (live > n_ids || (!any_dead && live != n_ids)) bad("alive bitmap population");
+    for (uint64_t i = n_ids; i < (uint64_t)alive.size() * 32; ++i)
+      if ((alive[i >> 5] >> (i & 31u)) & 1u) bad("alive bit beyond the id space");
+  }
   if (max_fl.size() != F || lut_cap.size() != F || lut_base.size() != F) bad("LUT vectors");
   uint64_t rows = 0;
   for (uint32_t x = 0; x < F; ++x) {
@@ -517,13 +585,17 @@ void Snapshot::validate() const {
     const TermInfo& t = terms[o];
     if (t.fnode >= fnodes.size()) bad("term fnode");
     if (t.n_layers && ((uint64_t)t.first_layer + t.n_layers > layers.size())) bad("term layer range");
+    uint32_t hops = 0;
+    for (uint32_t l = t.delta_head; l != NO_LAYER; l = layers[l].next)
+      if (l >= layers.size() || ++hops > layers.size()) bad("term delta chain");
   }
   for (size_t l = 0; l < layers.size(); ++l) {
     const LayerInfo& L = layers[l];
-    if (L.post_off % 4 || L.post_off > P || L.len > P - L.post_off) bad("layer posting range");
+    if (L.post_off % 4 || L.post_off > P_used || L.len > P_used - L.post_off) bad("layer posting range");
     if (L.shift > 31) bad("layer shift");
-    const uint64_t slots = (((uint64_t)n_tiles - 1) >> L.shift) + 1;
-    if ((uint64_t)L.tbl_off + slots + 1 > table.size()) bad("layer table range");
+    if (L.next != NO_LAYER && L.next >= layers.size()) bad("layer chain");
+    const uint64_t slots = (((uint64_t)tiles_cap - 1) >> L.shift) + 1;
+    if ((uint64_t)L.tbl_off + slots + 1 > table_used) bad("layer table range");
     uint32_t prev = 0;
     for (uint64_t sl = 0; sl <= slots; ++sl) {
       const uint32_t v = table[L.tbl_off + sl];
@@ -531,12 +603,12 @@ void Snapshot::validate() const {
       prev = v;
     }
     if (table[L.tbl_off + slots] != L.len) bad("table end");
-    const uint64_t bm_words = 2 * (((uint64_t)n_tiles * T + 31) / 32);
+    const uint64_t bm_words = 2 * (((uint64_t)tiles_cap * T + 31) / 32);
     if (L.bm_off != NO_BITMAP && ((L.bm_off & 1u) || (uint64_t)L.bm_off + bm_words > bits.size())) bad("layer bitmap range");
     uint64_t set = 0;
     for (uint32_t i = 0; i < L.len; ++i) {
       const uint32_t d = doc[L.post_off + i];
-      if (d >= n_docs || (i && doc[L.post_off + i - 1] >= d)) bad("posting doc ids");
+      if (d >= n_ids || (i && doc[L.post_off + i - 1] >= d)) bad("posting doc ids");
       if (L.bm_off != NO_BITMAP) {
         const uint32_t w = bits[(size_t)L.bm_off + 2 * (size_t)(d >> 5)], before = bits[(size_t)L.bm_off + 2 * (size_t)(d >> 5) + 1];
         if (!((w >> (d & 31u)) & 1u) || before + (uint32_t)__builtin_popcount(w & ((1u << (d & 31u)) - 1u)) != i)
@@ -548,6 +620,228 @@ void Snapshot::validate() const {
       if (set != L.len) bad("bitmap holds documents the list does not");
     }
   }
+}
+
+uint32_t Snapshot::chain_length(uint32_t head) const {
+  uint32_t n = 0;
+  for (uint32_t l = head; l != NO_LAYER; l = layers[l].next) ++n;
+  return n;
+}
+
+// ---- delta snapshot --------------------------------------------------------------
+bool Snapshot::apply_delta(const Index& idx, DeltaRanges& out) {
+  out = DeltaRanges{};
+  if (!own_ || src_epoch == ~0ull) return false;  // mapped from a file: no source bookkeeping
+  if (idx.epoch() == src_epoch) return true;
+  if (idx.fields_len() != F) return false;
+  size_t n_changes = 0;
+  const IndexChange* log = idx.changes_since(src_epoch, &n_changes);
+  if (!log) return false;
+  SnapshotStorage& st = *own_;
+  // ---- is the change set expressible? ----
+  std::vector<const IndexChange*> adds;
+  std::vector<uint32_t> removes;  // doc ids
+  bool have_key = !st.keys.empty();
+  uint64_t last_key = have_key ? st.keys.back() : 0;
+  size_t new_postings = 0;
+  for (size_t i = 0; i < n_changes; ++i) {
+    const IndexChange& c = log[i];
+    if (c.kind == IndexChange::OTHER) return false;
+    if (c.kind == IndexChange::ADD) {
+      // appended documents only: a key above every key the snapshot knows (doc ids stay key-ordered),
+      // not a re-add, not a lazily removed key (that one stays invisible until vacuum)
+      if (c.was_present || c.was_removed || (have_key && c.key <= last_key)) return false;
+      adds.push_back(&c);
+      last_key = c.key;
+      have_key = true;
+      new_postings += c.nodes.size();
+    } else if (c.was_present) {
+      auto it = std::lower_bound(st.keys.begin(), st.keys.end(), c.key);
+      if (it == st.keys.end() || *it != c.key) return false;  // a document added earlier in this very delta
+      removes.push_back((uint32_t)(it - st.keys.begin()));
+    }
+  }
+  if (n_ids + adds.size() > (uint64_t)tiles_cap * T) return false;
+  // room in the planes (4-aligned starts) and the table (<= len/2 + 2 slots per new layer, bounded below)
+  if (new_postings && P_used + 4 * new_postings > P) return false;  // (every touched term starts a 4-aligned run)
+  // ---- removals: clear the alive bit; df is re-counted by the caller (set_removed_df) ----
+  for (uint32_t id : removes) {
+    uint32_t& w = st.alive[id >> 5];
+    if (w & (1u << (id & 31u))) {
+      w &= ~(1u << (id & 31u));
+      out.alive_words.push_back(id >> 5);
+      ++out.docs_removed;
+      any_dead = true;
+    }
+  }
+  // ---- additions ----
+  out.key_begin = st.keys.size();
+  out.plane_begin = P_used;
+  out.table_begin = table_used;
+  if (!adds.empty()) {
+    // group the new postings by source trie node, in doc id order
+    struct NewPosting { uint32_t id; const IndexChange* c; uint32_t slot; };
+    std::unordered_map<int32_t, std::vector<NewPosting>> by_node;
+    for (const IndexChange* c : adds) {
+      const uint32_t id = (uint32_t)st.keys.size();
+      st.keys.push_back(c->key);
+      st.alive[id >> 5] |= 1u << (id & 31u);
+      out.alive_words.push_back(id >> 5);
+      for (uint32_t x = 0; x < F; ++x) st.max_fl[x] = std::max(st.max_fl[x], c->field_length[x]);
+      for (size_t k = 0; k < c->nodes.size(); ++k) by_node[c->nodes[k]].push_back(NewPosting{id, c, (uint32_t)k});
+    }
+    // table room: one slot table per new layer
+    uint64_t need_tbl = 0;
+    for (auto& kv : by_node) {
+      uint32_t shift = 0;
+      const uint64_t want = std::max<uint64_t>(1, kv.second.size() / 2);
+      while ((((uint64_t)tiles_cap - 1) >> shift) + 1 > want) ++shift;
+      need_tbl += (((uint64_t)tiles_cap - 1) >> shift) + 2;
+    }
+    if (table_used + need_tbl > st.table.size() || st.layers.size() + by_node.size() >= 0xFFFFFFF0ull) {
+      // undo the additions made so far (nothing else was touched)
+      for (size_t i = 0; i < adds.size(); ++i) {
+        const uint32_t id = (uint32_t)st.keys.size() - 1;
+        st.alive[id >> 5] &= ~(1u << (id & 31u));
+        st.keys.pop_back();
+      }
+      // (removals already applied stay: the caller re-flattens anyway)
+      bind(st);
+      return false;
+    }
+    // terms: does every touched node already have a term ordinal?
+    std::unordered_map<int32_t, uint32_t> ord_of;
+    ord_of.reserve(st.term_node.size() * 2);
+    for (size_t o = 0; o < st.term_node.size(); ++o) ord_of.emplace(st.term_node[o], (uint32_t)o);
+    bool new_terms = false;
+    for (auto& kv : by_node)
+      if (!ord_of.count(kv.first)) { new_terms = true; break; }
+    if (new_terms) {
+      // re-freeze the trie (no posting work) and carry every term's lists over by source node
+      FrozenTrie ft;
+      freeze_trie(idx, ft);
+      std::vector<TermInfo> nt(ft.term_node.size());
+      std::vector<uint64_t> ndf(ft.term_node.size(), 0);
+      for (size_t o = 0; o < nt.size(); ++o) {
+        auto it = ord_of.find(ft.term_node[o]);
+        if (it != ord_of.end()) {
+          nt[o] = st.terms[it->second];
+          ndf[o] = st.df_total[it->second];
+        } else {
+          nt[o] = TermInfo{0, ft.term_bytes[o], 0, 0, 0, NO_LAYER, 0};
+        }
+        nt[o].byte_len = ft.term_bytes[o];
+        nt[o].fnode = ft.term_fnode[o];
+      }
+      st.terms = std::move(nt);
+      st.df_total = std::move(ndf);
+      st.fnodes = std::move(ft.fnodes);
+      st.fchar = std::move(ft.fchar);
+      st.fchild = std::move(ft.fchild);
+      st.term_node = std::move(ft.term_node);
+      ord_of.clear();
+      for (size_t o = 0; o < st.term_node.size(); ++o) ord_of.emplace(st.term_node[o], (uint32_t)o);
+      out.trie_refrozen = true;
+    }
+    // one delta layer per touched term, appended to the planes / the table
+    std::vector<int32_t> touched;
+    touched.reserve(by_node.size());
+    for (auto& kv : by_node) touched.push_back(kv.first);
+    std::sort(touched.begin(), touched.end());  // deterministic layout
+    for (int32_t node : touched) {
+      const std::vector<NewPosting>& np = by_node[node];
+      auto it = ord_of.find(node);
+      if (it == ord_of.end()) throw std::logic_error("delta: a touched trie node has no term (index / log out of step)");
+      TermInfo& ti = st.terms[it->second];
+      LayerInfo L{P_used, (uint32_t)np.size(), (uint32_t)table_used, 0, NO_BITMAP, ti.delta_head, 0};
+      const uint64_t want = std::max<uint64_t>(1, L.len / 2);
+      while ((((uint64_t)tiles_cap - 1) >> L.shift) + 1 > want) ++L.shift;
+      const uint32_t slots = ((tiles_cap - 1) >> L.shift) + 1;
+      uint64_t added_df = 0;
+      for (size_t i = 0; i < np.size(); ++i) {
+        const uint64_t at = P_used + i;
+        st.doc[at] = np[i].id;
+        for (uint32_t x = 0; x < F; ++x) {
+          const uint32_t t = np[i].c->tf[(size_t)np[i].slot * F + x];
+          st.tf[(size_t)x * P + at] = t;
+          st.fl[(size_t)x * P + at] = np[i].c->field_length[x];
+          added_df += t;
+        }
+      }
+      const uint64_t padded = (L.len + 3) & ~(uint64_t)3;
+      for (uint64_t at = P_used + L.len; at < P_used + padded; ++at) {
+        st.doc[at] = 0xFFFFFFFFu;
+        for (uint32_t x = 0; x < F; ++x) { st.tf[(size_t)x * P + at] = 0; st.fl[(size_t)x * P + at] = 0; }
+      }
+      uint32_t pos = 0;
+      for (uint32_t sl = 0; sl < slots; ++sl) {
+        const uint64_t first_doc = ((uint64_t)sl << L.shift) * T;
+        while (pos < L.len && st.doc[P_used + pos] < first_doc) ++pos;
+        st.table[table_used + sl] = pos;
+      }
+      st.table[table_used + slots] = L.len;
+      P_used += padded;
+      table_used += slots + 1;
+      ti.delta_head = (uint32_t)st.layers.size();
+      st.layers.push_back(L);
+      st.df_total[it->second] += added_df;
+      ti.df_raw += added_df;
+      n_postings += L.len;
+      n_pointers += added_df;
+      n_delta_postings += L.len;
+      ++n_delta_layers;
+    }
+    removed_df.resize(st.layers.size(), 0);
+    n_ids = st.keys.size();
+    n_tiles = (uint32_t)std::max<uint64_t>(1, (n_ids + T - 1) / T);
+    out.docs_added = adds.size();
+  }
+  out.key_end = st.keys.size();
+  out.plane_end = P_used;
+  out.table_end = table_used;
+  std::sort(out.alive_words.begin(), out.alive_words.end());
+  out.alive_words.erase(std::unique(out.alive_words.begin(), out.alive_words.end()), out.alive_words.end());
+  // scalars the scorers read (index.rs:112-114, 176-186; bm25.rs:41): current as of this epoch
+  n_docs = idx.docs_len();
+  for (uint32_t x = 0; x < F; ++x) st.avg[x] = idx.field(x).avg;
+  n_live_terms = 0;
+  for (const TermInfo& t : st.terms)
+    if (t.n_layers || t.delta_head != NO_LAYER) ++n_live_terms;
+  src_epoch = idx.epoch();
+  bind(st);
+  return true;
+}
+
+// Per layer, the pointer count (sum of tf) of the postings whose document was removed by a delta:
+// Index::count_documents skips removed documents (index.rs:287-293), so df_raw shrinks by it.
+void Snapshot::set_removed_df(const std::vector<uint64_t>& removed_per_layer) {
+  if (!own_) return;
+  SnapshotStorage& st = *own_;
+  removed_df = removed_per_layer;
+  removed_df.resize(st.layers.size(), 0);
+  for (size_t o = 0; o < st.terms.size(); ++o) {
+    TermInfo& t = st.terms[o];
+    uint64_t gone = 0;
+    for (uint32_t l = 0; l < t.n_layers; ++l) gone += removed_df[t.first_layer + l];
+    for (uint32_t l = t.delta_head; l != NO_LAYER; l = st.layers[l].next) gone += removed_df[l];
+    t.df_raw = st.df_total[o] > gone ? st.df_total[o] - gone : 0;
+  }
+  bind(st);
+}
+
+// Host fallback of the same count (host-only snapshots; the engine does it on the device).
+std::vector<uint64_t> Snapshot::count_removed_df_host() const {
+  std::vector<uint64_t> r(layers.size(), 0);
+  if (!any_dead) return r;
+  for (size_t l = 0; l < layers.size(); ++l) {
+    const LayerInfo& L = layers[l];
+    for (uint32_t i = 0; i < L.len; ++i) {
+      const uint32_t d = doc[L.post_off + i];
+      if ((alive[d >> 5] >> (d & 31u)) & 1u) continue;
+      for (uint32_t x = 0; x < F; ++x) r[l] += tf[(size_t)x * P + L.post_off + i];
+    }
+  }
+  return r;
 }
 
 int64_t Snapshot::find_fnode(std::string_view term) const {
@@ -583,7 +877,7 @@ void Snapshot::plan_query(const ps_scorer_desc& sc, std::string_view q, ps_token
       const FrozenNode& node = fnodes[(size_t)fn];
       for (uint32_t o = node.term_begin; o < node.term_end; ++o) {  // == expand_term order
         const TermInfo& t = terms[o];
-        if (t.df_raw == 0 || t.n_layers == 0) continue;  // query.rs:47-48
+        if (t.df_raw == 0 || (t.n_layers == 0 && t.delta_head == NO_LAYER)) continue;  // query.rs:47-48
         ps_plan_entry e;
         memset(&e, 0, sizeof(e));
         e.qterm = qord;
@@ -606,14 +900,19 @@ void Snapshot::plan_query(const ps_scorer_desc& sc, std::string_view q, ps_token
           if (k == seen_nodes.size()) seen_nodes.push_back(t.fnode);
           e.node = (uint32_t)k;
         }
-        for (uint32_t l = 0; l < t.n_layers; ++l) {
-          const LayerInfo& L = layers[t.first_layer + l];
+        // base layers (newest version first), then the delta layers (documents added after the flatten:
+        // disjoint from the base documents, so "another entry of the same query term" is exact)
+        const uint32_t n_chain = t.n_layers + chain_length(t.delta_head);
+        for (uint32_t l = 0, dl = t.delta_head; l < n_chain; ++l) {
+          const uint32_t li = l < t.n_layers ? t.first_layer + l : dl;
+          const LayerInfo& L = layers[li];
+          if (l >= t.n_layers) dl = L.next;
           e.post_off = L.post_off;
           e.len = L.len;
           e.tbl_off = L.tbl_off;
           e.shift = L.shift | (l << 8);  // bits 8.. = version layer (0 = newest)
           if (sc.kind == PS_SCORER_BM25) {
-            e.node = t.first_layer + l;  // ordinal of the list (the engine's per-list bounds)
+            e.node = li;                 // ordinal of the list (the engine's per-list bounds)
             e.bm_off = L.bm_off;         // the list's membership bitmap (K1d lookups)
           }
           plan.entries.push_back(e);

@@ -30,9 +30,12 @@ struct TermInfo {
   uint64_t df_raw;       // live DocumentPointer count of the term
   uint32_t byte_len;     // str::len() of the term (bm25.rs:48-53, zero_to_one.rs:57-58)
   uint32_t first_layer;  // index into Snapshot::layers
-  uint32_t n_layers;     // 0 if no live posting
+  uint32_t n_layers;     // 0 if no live posting in the base lists
   uint32_t fnode;        // frozen node id (unique per term; zero_to_one's index_node_id)
+  uint32_t delta_head;   // first delta layer of the term (postings of documents added after the flatten), or NO_LAYER
+  uint32_t _pad;
 };
+constexpr uint32_t NO_LAYER = 0xFFFFFFFFu;
 
 struct LayerInfo {
   uint64_t post_off;  // multiple of 4 (16-byte aligned planes)
@@ -40,6 +43,8 @@ struct LayerInfo {
   uint32_t tbl_off;
   uint32_t shift;
   uint32_t bm_off;    // first word of the list's membership bitmap in Snapshot::bits, or NO_BITMAP
+  uint32_t next;      // delta layers: next (older) delta layer of the same term, or NO_LAYER
+  uint32_t _pad;
 };
 constexpr uint32_t NO_BITMAP = 0xFFFFFFFFu;
 
@@ -87,9 +92,28 @@ struct View {
 
 struct SnapshotStorage;  // the flattener's vectors (ps_snapshot.cpp)
 
+// What Snapshot::apply_delta changed, for the device side (Engine::apply_delta uploads exactly this).
+struct DeltaRanges {
+  uint64_t plane_begin = 0, plane_end = 0;  // postings appended to the planes
+  uint64_t table_begin = 0, table_end = 0;  // tile-offset table entries appended
+  uint64_t key_begin = 0, key_end = 0;      // doc ids appended
+  std::vector<uint32_t> alive_words;        // words of the alive bitmap that changed
+  uint64_t docs_added = 0, docs_removed = 0;
+  bool trie_refrozen = false;
+};
+
 class Snapshot {
  public:
-  Snapshot(const Index& idx, uint32_t tile_docs);
+  // headroom_pct > 0 reserves room (documents, postings, table entries) so that apply_delta can
+  // append documents in place; 0 = exact fit (removals can still be applied as a delta).
+  Snapshot(const Index& idx, uint32_t tile_docs, uint32_t headroom_pct = 0);
+  // Incremental re-flatten: brings the snapshot from the index epoch it was built at
+  // to the index's current one by (a) clearing the alive bit of removed documents and (b) appending
+  // the postings of added documents as delta layers of their terms, re-freezing the trie (cheap, no
+  // posting work) when they introduced new terms.  O(changes), not O(postings).  Returns false -
+  // nothing modified - when the change set cannot be expressed (vacuum, re-added or out-of-order
+  // keys, headroom exhausted, snapshot loaded from a file): the caller re-flattens.
+  bool apply_delta(const Index& idx, DeltaRanges& out);
   // On-disk form of the flattened snapshot (the reference has no persistence at
   // all): a versioned little-endian file whose page-aligned sections ARE the arrays below, so
   // loading is one read-only mmap (no parse, no copy; the planes go from the page cache straight
@@ -105,7 +129,22 @@ class Snapshot {
   void plan_query(const ps_scorer_desc& sc, std::string_view q, ps_tokenizer_fn tok, void* user, Plan& plan) const;
 
   uint32_t F, T, n_tiles;
-  uint64_t n_docs;  // docs.len()
+  uint32_t tiles_cap = 0;   // tiles every table / bitmap / row is laid out for (>= n_tiles; headroom)
+  uint64_t n_docs;  // docs.len(): LIVE documents (BM25's N)
+  uint64_t n_ids = 0;       // doc id space = keys.size(): live + removed-by-delta documents
+  uint64_t P_used = 0, table_used = 0;  // filled part of the planes / the table (the rest is headroom)
+  uint32_t n_delta_layers = 0;
+  uint64_t n_delta_postings = 0;
+  // one bit per doc id: cleared by a delta removal (the kernels drop such documents when they emit;
+  // null view = every document alive)
+  View<uint32_t> alive;
+  bool any_dead = false;
+  // df_raw of the documents removed by deltas, per layer, is subtracted from TermInfo::df_raw by the
+  // device side (Engine::apply_delta counts it with one pass over the planes and calls this)
+  void set_removed_df(const std::vector<uint64_t>& removed_per_layer);
+  std::vector<uint64_t> count_removed_df_host() const;
+  uint32_t chain_length(uint32_t head) const;
+  std::vector<uint64_t> removed_df;  // per layer
   View<uint64_t> keys;
   View<double> avg;
   View<TermInfo> terms;

@@ -199,6 +199,13 @@ class Snapshot:
         except Exception:
             pass
 
+    def update(self):
+        """ps_snapshot_update: bring the snapshot up to its Index's current state - a delta (alive bits,
+        appended postings; O(changes)) when expressible, a full re-flatten otherwise.  -> stats dict."""
+        st = _lib.UpdateStats()
+        _lib.check(self._L.ps_snapshot_update(self._h, self._owner._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
     def save(self, path):
         """Write the flattened snapshot to disk (versioned binary dump)."""
         _lib.check(self._L.ps_snapshot_save(self._h, os.fsencode(path)))
@@ -359,7 +366,8 @@ class Snapshot:
         return {"doc": arr(c.doc, shape=(P,)), "tf": arr(c.tf, shape=(max(F, 1), P))[:F],
                 "fl": arr(c.fl, shape=(max(F, 1), P))[:F],
                 "table": arr(c.table, shape=(max(1, inf["n_table_entries"]),)),
-                "keys": arr(c.keys, shape=(max(1, inf["n_docs"]),))[:inf["n_docs"]],
+                "keys": arr(c.keys, shape=(max(1, inf["n_ids"]),))[:inf["n_ids"]],
+                "alive": arr(c.alive, shape=(max(1, (inf["tiles_cap"] * inf["tile_docs"] + 31) // 32),)),
                 "avg": arr(c.avg, shape=(max(F, 1),))[:F].copy(), "tile_docs": inf["tile_docs"]}
 
 
@@ -459,10 +467,11 @@ class Index:
             raise keep[2][0]
         return _take_results(self._L, out, n.value)
 
-    def snapshot(self, device=0, tile_docs=0):
-        """Flatten to CSR planes and upload to `device` (-1: host-only, for inspection)."""
+    def snapshot(self, device=0, tile_docs=0, headroom_pct=0):
+        """Flatten to CSR planes and upload to `device` (-1: host-only, for inspection).
+        headroom_pct > 0 reserves room so that Snapshot.update can append documents in place."""
         h = C.c_void_p()
-        _lib.check(self._L.ps_index_snapshot(self._h, device, tile_docs, C.byref(h)))
+        _lib.check(self._L.ps_index_snapshot_ex(self._h, device, tile_docs, headroom_pct, C.byref(h)))
         return Snapshot(h, self)
 
     # ---- read-side state the reference's unit tests look at -----------------------------------

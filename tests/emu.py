@@ -30,7 +30,8 @@ def emulate(snap, scorer, query, boosts, tokenizer=None):
     info = snap.info()
     entries, qtl = snap.plan(query, scorer, tokenizer)
     F, T = info["fields_num"], info["tile_docs"]
-    n_tiles = max(1, (info["n_docs"] + T - 1) // T)
+    n_tiles = max(1, (info["n_ids"] + T - 1) // T)
+    alive = lambda d: bool((int(csr["alive"][d >> 5]) >> (d & 31)) & 1)  # delta removals: dropped when emitted
     seen = 0
     if scorer.kind == 1:
         k1, b = scorer.bm25k1, scorer.bm25b
@@ -58,7 +59,7 @@ def emulate(snap, scorer, query, boosts, tokenizer=None):
                     tag[d] = e["qterm"]
             assert n_seen == e["len"], "tile tables do not cover the list exactly once"
             seen += n_seen
-        res = [(int(csr["keys"][d]), s) for d, s in acc.items()]
+        res = [(int(csr["keys"][d]), s) for d, s in acc.items() if alive(d)]
     else:
         rec, fls = {}, {}
         for e in entries:
@@ -76,7 +77,7 @@ def emulate(snap, scorer, query, boosts, tokenizer=None):
                         fls[(d, x)] = int(csr["fl"][x][pi])
             assert n_seen == e["len"]
         order = sorted(range(len(entries)), key=lambda i: -entries[i]["boost"])  # stable
-        docs = sorted({k[0] for k in rec})
+        docs = sorted({k[0] for k in rec if alive(k[0])})
         res = []
         for d in docs:
             best = 0.0

@@ -155,9 +155,9 @@ def test_snapshot_load_rejects_damaged_files(tmp_path):
     path = str(tmp_path / "s.bin")
     snap.save(path)
     good = open(path, "rb").read()
-    assert len(good) % 4096 == 0 and good[:8] == b"PSNAP003"
+    assert len(good) % 4096 == 0 and good[:8] == b"PSNAP004"
     psa.Snapshot.load(path, device=-1)
-    hdr_secs = 8 + 8 + 80  # magic | file_bytes | scalars[10]
+    hdr_secs = 8 + 8 + 128  # magic | file_bytes | scalars[10]
 
     def section(i):
         return struct.unpack_from("<QQQ", good, hdr_secs + 24 * i)
