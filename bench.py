@@ -48,6 +48,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-queries", type=int, default=24, help="bounded CPU-baseline sample (queries, 1 thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scorer", default="", help="override: bm25 | zero_to_one")
+    ap.add_argument("--no-bulk-index", action="store_true",
+                    help="skip timing the GPU bulk indexer on the same corpus (reported beside index_build_s; N=1, <= 2M docs)")
     return ap.parse_args(argv)
 
 
@@ -129,15 +131,37 @@ def main():
 
     # ---- the index: built once per node, shared through the snapshot file --------------------------
     t_index = t_generate = t_snap = 0.0
+    bulk = None
     snap_path = "/dev/shm/ps_bench_%s_%s.snap" % (os.environ.get("MASTER_PORT", str(os.getpid())), args.config)
     if local_rank == 0:
         t0 = time.time()
         index = psa.Index(F)
+        keep = world == 1 and not args.no_bulk_index and cfg["n_docs"] <= 2_000_000
+        kept = []
         for keys, text, offsets in corpus.chunks(100_000):
             ta = time.time()
             index.add_documents_flat(keys, text, offsets)  # inside the library: tokenise + trie + postings
             t_index += time.time() - ta
+            if keep:
+                kept.append((keys, text, offsets))
         t_generate = time.time() - t0 - t_index  # synthetic text generation
+        bulk = None
+        if keep:
+            # the same corpus through the GPU bulk indexer (ps_index_add_documents_flat_gpu): identical index
+            base, ks, ts, os_ = 0, [], [], []
+            for keys, text, offsets in kept:
+                ks.append(keys); ts.append(text); os_.append(offsets[:-1] + np.uint64(base)); base += len(text)
+            ak, at = np.concatenate(ks), np.concatenate(ts)
+            ao = np.concatenate(os_ + [np.array([base], dtype=np.uint64)])
+            del kept, ks, ts, os_
+            gidx = psa.Index(F)
+            ta = time.time()
+            used = gidx.add_documents_flat_gpu(ak, at, ao, device=dev)
+            t_bulk = time.time() - ta
+            bulk = {"seconds": t_bulk, "docs_per_s": cfg["n_docs"] / t_bulk, "ran_on_gpu": bool(used),
+                    "host_seconds_same_corpus": t_index, "same_index": gidx.fields == index.fields and
+                    gidx.count_nodes() == index.count_nodes() and gidx.live_pointers() == index.live_pointers()}
+            del gidx, ak, at, ao
         t0 = time.time()
         snap = index.snapshot(device=dev, tile_docs=tile_docs)
         t_snap = time.time() - t0
@@ -262,7 +286,7 @@ def main():
             "p50_batch_submit_ms": float(np.median(lat) * 1e3),
             "host_plan_ms_per_step": plan_ms / steps,
             "postings_per_step": postings / steps,
-            "index_build_s": t_index, "corpus_generation_s": t_generate, "snapshot_s": t_snap,
+            "index_build_s": t_index, "gpu_bulk_index": bulk, "corpus_generation_s": t_generate, "snapshot_s": t_snap,
             "hbm_resident_bytes": info["device_bytes"],
             "roofline": roofline(args, cfg, kt["score_kernel"], k_avg_ms, rows_avg_ms, int(kt["launches"]),
                                  alg_bytes_launch, layout_bytes / max(1, steps), dense_rows / max(1, steps),

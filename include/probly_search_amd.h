@@ -154,6 +154,16 @@ ps_status ps_index_add_document(ps_index* idx, uint64_t key, const ps_str* value
  * text[offsets[d*F+f] .. offsets[d*F+f+1]).  Equivalent to n_docs add_document calls in order. */
 ps_status ps_index_add_documents_flat(ps_index* idx, size_t n_docs, const uint64_t* keys, const char* text,
                                       const uint64_t* offsets);
+/* GPU bulk indexing (the reference's own benchmark is exactly this loop,
+ * benches/test_benchmark.rs:37-63): the same result as ps_index_add_documents_flat on an EMPTY index
+ * with distinct keys, but the per-token work of add_document - tokenise, find the term, count its
+ * frequency per field - runs on `device` as tokenise -> hash -> stable radix sort by term ->
+ * segmented reduce; the host only interns the distinct terms (first-occurrence order, so the trie
+ * and its newest-first child lists come out identical) and copies the grouped postings into place.
+ * Falls back to the host indexer by itself if two terms collide in the 64-bit hash (checked byte by
+ * byte on the device).  *used_gpu (may be NULL) says which path ran. */
+ps_status ps_index_add_documents_flat_gpu(ps_index* idx, size_t n_docs, const uint64_t* keys, const char* text,
+                                          const uint64_t* offsets, int device, int* used_gpu);
 /* Index::remove_document (src/index.rs:161-191) — lazy delete, fixes field sums/averages. */
 ps_status ps_index_remove_document(ps_index* idx, uint64_t key);
 /* Index::vacuum (src/index.rs:194-241) — unlinks removed postings, prunes empty trie subtrees. */

@@ -122,6 +122,7 @@ SYMBOLS = {
     "ps_index_free": (None, [_P]),
     "ps_index_add_document": (C.c_int, [_P, C.c_uint64, C.POINTER(Str), C.POINTER(C.c_size_t), _P, _P]),
     "ps_index_add_documents_flat": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
+    "ps_index_add_documents_flat_gpu": (C.c_int, [_P, C.c_size_t, _P, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     "ps_index_remove_document": (C.c_int, [_P, C.c_uint64]),
     "ps_index_vacuum": (C.c_int, [_P]),
     "ps_index_fields_len": (C.c_size_t, [_P]),

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../include/probly_search_amd.h"
+#include "ps_build.hpp"
 #include "ps_capi_internal.hpp"
 #include "ps_engine.hpp"
 #include "ps_errors.hpp"
@@ -221,6 +222,23 @@ ps_status ps_index_add_documents_flat(ps_index* idx, size_t n_docs, const uint64
     }
     return PS_OK;
   });
+}
+
+ps_status ps_index_add_documents_flat_gpu(ps_index* idx, size_t n_docs, const uint64_t* keys, const char* text,
+                                          const uint64_t* offsets, int device, int* used_gpu) {
+  if (used_gpu) *used_gpu = 0;
+  ps_status st = guard([&]() -> ps_status {
+    if (!idx || (n_docs && (!keys || !text || !offsets))) return fail(PS_EINVAL, "null argument");
+    if (!idx->idx.pristine()) return fail(PS_EINVAL, "GPU bulk indexing fills an empty index (use ps_index_add_documents_flat to append)");
+    ps::GroupedCorpus g;
+    if (!ps::gpu_group_corpus(device, (uint32_t)idx->idx.fields_len(), n_docs, text, offsets, g)) return PS_EUNSUPPORTED;  // hash collision
+    idx->idx.bulk_load(g, n_docs, keys, text);
+    if (used_gpu) *used_gpu = 1;
+    return PS_OK;
+  });
+  if (st == PS_EUNSUPPORTED && idx && idx->idx.pristine())  // a detected 64-bit hash collision: same result, on the host
+    return ps_index_add_documents_flat(idx, n_docs, keys, text, offsets);
+  return st;
 }
 
 ps_status ps_index_remove_document(ps_index* idx, uint64_t key) {

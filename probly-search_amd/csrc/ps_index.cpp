@@ -1,6 +1,7 @@
 // ps_index.cpp — host-side mutable index.  See ps_index.hpp for the design notes and the
 // reference citations (src/index.rs of quantleaf/probly-search 2.0.1).
 #include "ps_index.hpp"
+#include "ps_build.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -175,6 +176,42 @@ void Index::add_document(uint64_t key, const ps_str* values, const size_t* n_val
     pl.keys.push_back(key);
     pl.tf.insert(pl.tf.end(), doc_tf_.begin() + (long)(k * F), doc_tf_.begin() + (long)((k + 1) * F));
   }
+  ++epoch_;
+}
+
+void Index::bulk_load(const GroupedCorpus& g, size_t n_docs, const uint64_t* keys, const char* text) {
+  if (!pristine()) throw std::invalid_argument("bulk_load needs an empty index");
+  const size_t F = fields_.size();
+  const size_t n_terms = g.term_pos.size();
+  // documents + field statistics: sum accumulates every field length; avg = sum / (docs.len() + 1) as
+  // of the LAST add_document (index.rs:112-114), i.e. sum / n for distinct keys
+  docs_.reserve(n_docs * 2);
+  for (size_t d = 0; d < n_docs; ++d) {
+    DocDetails dd;
+    dd.field_length.assign(g.field_length.begin() + (long)(d * F), g.field_length.begin() + (long)((d + 1) * F));
+    for (size_t x = 0; x < F; ++x) fields_[x].sum += dd.field_length[x];
+    docs_.emplace(keys[d], std::move(dd));
+  }
+  if (docs_.size() != n_docs) throw std::invalid_argument("bulk_load: duplicate keys (re-adding a key is add_document's job)");
+  if (n_docs)
+    for (size_t x = 0; x < F; ++x) fields_[x].avg = (double)fields_[x].sum / (double)n_docs;
+  // terms in first-occurrence order: the incremental build creates a term's missing trie nodes when it
+  // first meets the term, and prepends each new node to its parent's child list (index.rs:409-419)
+  std::vector<uint32_t> order(n_terms);
+  for (size_t t = 0; t < n_terms; ++t) order[t] = (uint32_t)t;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g.term_first_token[a] < g.term_first_token[b]; });
+  lists_.resize(n_terms);
+  for (size_t k = 0; k < n_terms; ++k) {
+    const uint32_t t = order[k];
+    const int32_t node = find_or_create(std::string_view(text + g.term_pos[t], g.term_len[t]));
+    nodes_[(size_t)node].list = (int32_t)k;
+    PostingList& pl = lists_[k];
+    const uint32_t b = g.term_post_begin[t], e = g.term_post_begin[t + 1];
+    pl.keys.resize(e - b);
+    for (uint32_t i = b; i < e; ++i) pl.keys[i - b] = keys[g.post_doc[i]];
+    pl.tf.assign(g.post_tf.begin() + (long)((size_t)b * F), g.post_tf.begin() + (long)((size_t)e * F));
+  }
+  log_push(IndexChange{});  // OTHER: not replayable as a delta
   ++epoch_;
 }
 

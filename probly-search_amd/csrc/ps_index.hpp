@@ -135,6 +135,14 @@ class Index {
   std::vector<std::string> expand_term(std::string_view term) const;
   std::vector<uint32_t> children(int32_t node) const;
 
+  // Bulk form of n add_document calls on an EMPTY index (single-valued fields, whitespace tokenizer,
+  // distinct keys) from a corpus the GPU already tokenised and grouped (ps_build.hip): the trie is
+  // built by interning the distinct terms in first-occurrence order (same nodes, same newest-first
+  // child lists as the incremental build), the posting lists are filled in document order.
+  // The resulting index is indistinguishable from the incrementally built one.
+  void bulk_load(const struct GroupedCorpus& g, size_t n_docs, const uint64_t* keys, const char* text);
+  bool pristine() const { return docs_.empty() && nodes_.size() == 1 && !has_removed_ && lists_.empty(); }
+
   // Index::query for a caller-supplied ScoreCalculator (PS_SCORER_HOST_CALLBACKS): the reference's
   // driver loop (src/query.rs:29-105) over this index's posting lists, calling the three
   // callbacks in the reference's order.  Results in canonical order (score desc, key asc).

@@ -435,6 +435,19 @@ class Index:
         _lib.check(self._L.ps_index_add_documents_flat(self._h, len(keys), keys.ctypes.data, text.ctypes.data,
                                                        offsets.ctypes.data))
 
+    def add_documents_flat_gpu(self, keys, text, offsets, device=0):
+        """GPU bulk indexing of an EMPTY index (ps_index_add_documents_flat_gpu): same result as
+        add_documents_flat, the per-token work runs on the device.  -> True if the GPU path ran."""
+        import numpy as np
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text)
+        used = C.c_int(0)
+        _lib.check(self._L.ps_index_add_documents_flat_gpu(self._h, len(keys), keys.ctypes.data, text.ctypes.data,
+                                                           offsets.ctypes.data, device, C.byref(used)))
+        return bool(used.value)
+
     def remove_document(self, key):
         _lib.check(self._L.ps_index_remove_document(self._h, key))
 
