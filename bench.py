@@ -345,6 +345,11 @@ def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layo
         out.update({"bound": bound, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"],
                     "unit": res[bound]["rate_unit"], "frac": res[bound]["frac"],
                     "traffic": drv.get("hbm_bytes_per_launch"), "resources": res,
+                    "wave_cycles_in_profiled_run": drv.get("wave_cycles"),
+                    "reading": "frac is the busiest unit's share of ITS peak (per-launch counter amount from the committed "
+                               "PMC passes / this run's kernel time).  With every unit far below its peak and most "
+                               "wave-cycles parked on s_waitcnt the kernel is bound by dependent memory latency "
+                               "(document-at-a-time lookups), not by a throughput roof",
                     "derivation": "profiles/roofline_%s.json (tools/derive_roofline.py over the rocprofv3 PMC passes "
                                   "of head %s)" % (args.config, drv.get("head"))})
     else:
