@@ -48,6 +48,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-queries", type=int, default=24, help="bounded CPU-baseline sample (queries, 1 thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scorer", default="", help="override: bm25 | zero_to_one")
+    ap.add_argument("--device-plan", action="store_true",
+                    help="plan the batches on the device too (ps_snapshot_query_batch_device_planned_flat: BM25, K1 k_score; "
+                         "N=1): the SURVEY 8f N2 path, not the headline")
     ap.add_argument("--no-bulk-index", action="store_true",
                     help="skip timing the GPU bulk indexer on the same corpus (reported beside index_build_s; N=1, <= 2M docs)")
     return ap.parse_args(argv)
@@ -205,6 +208,11 @@ def main():
     def step(batch, i):
         text, offsets = batch
         slot = i % n_blk
+        if args.device_plan and world == 1:
+            base = local[slot].data_ptr()
+            snap.query_batch_device_planned_flat(text, offsets, scorer, boosts, K, base, base + 8 * B * K, base + 16 * B * K,
+                                                 stream=streams[slot].cuda_stream)
+            return
         snap.query_batch_allgather_flat(comm, text, offsets, scorer, boosts, K, local[slot].data_ptr(),
                                         gathered[slot].data_ptr(), stream=streams[slot].cuda_stream)
 
@@ -281,7 +289,8 @@ def main():
                        "global_batch": world * B, "parallelism": "replicated corpus, query batch sharded x%d, "
                        "ncclAllGather of top-k blocks inside the library" % world if world > 1 else
                        "single GPU (no collective)",
-                       "tile_docs": info["tile_docs"], "postings": info["n_postings"], "pointers": info["n_pointers"]},
+                       "tile_docs": info["tile_docs"], "postings": info["n_postings"], "pointers": info["n_pointers"],
+                       "planner": "device (k_plan)" if args.device_plan else "host"},
             "p50_single_query_ms": float(np.median(single) * 1e3) if single else None,
             "p50_batch_submit_ms": float(np.median(lat) * 1e3),
             "host_plan_ms_per_step": plan_ms / steps,

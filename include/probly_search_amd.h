@@ -314,6 +314,16 @@ ps_status ps_snapshot_query_batch_allgather_flat(ps_snapshot* snap, ps_comm* com
                                                  void* user, size_t top_k, void* d_local_block, void* d_all_blocks,
                                                  void* hip_stream);
 
+/* SURVEY 8f N2 - the same batch call with the PLANNER on the device too: tokenising (split on ' '),
+ * term lookup in the frozen trie, prefix expansion in the reference's newest-first DFS order
+ * (src/query.rs:109-147, src/index.rs:300-337) and BM25's before_each (src/score/default/bm25.rs:35-58)
+ * run in a kernel over the trie kept in HBM; the plan never exists on the host (the host learns four
+ * totals to size the launch).  BM25 with the built-in tokenizer; scoring is K1 k_score (the exact
+ * pruning kernel needs host-built descriptors).  Same results as ps_snapshot_query_batch_device_flat. */
+ps_status ps_snapshot_query_batch_device_planned_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text,
+                                                      const uint64_t* offsets, size_t n_queries, const double* fields_boost,
+                                                      size_t n_boost, size_t top_k, void* d_keys, void* d_scores,
+                                                      void* d_counts, void* hip_stream);
 /* Timing / roofline accounting of the most recent batch executed on this snapshot. */
 typedef struct ps_batch_stats {
   uint64_t n_queries;
@@ -368,6 +378,13 @@ typedef struct ps_plan_entry {
 ps_status ps_snapshot_plan(const ps_snapshot* snap, const ps_scorer_desc* scorer, const char* query,
                            size_t query_len, ps_tokenizer_fn tokenizer, void* user, ps_plan_entry** out,
                            size_t* out_len, size_t* query_terms_len);
+/* The plan the device planner builds, copied back for inspection (entries of all queries, qbeg with
+ * n_queries + 1 entries, per-query query_terms_len; release each with ps_free).  Must equal what
+ * ps_snapshot_plan returns query by query. */
+ps_status ps_snapshot_plan_device(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text, const uint64_t* offsets,
+                                  size_t n_queries, ps_plan_entry** entries, size_t* n_entries, uint32_t** qbeg,
+                                  uint32_t** query_terms_len);
+
 /* Borrowed pointers into the host copy of the CSR planes (valid while the snapshot lives). */
 typedef struct ps_host_csr {
   const uint32_t* doc;       /* [n_postings_padded]                     */

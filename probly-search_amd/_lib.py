@@ -155,6 +155,12 @@ SYMBOLS = {
     "ps_snapshot_query_batch_device_flat": (C.c_int, [_P, C.POINTER(ScorerDesc), _P, _P, C.c_size_t,
                                                       C.POINTER(C.c_double), C.c_size_t, _P, _P, C.c_size_t, _P, _P,
                                                       _P, _P]),
+    "ps_snapshot_query_batch_device_planned_flat": (C.c_int, [_P, C.POINTER(ScorerDesc), _P, _P, C.c_size_t,
+                                                              C.POINTER(C.c_double), C.c_size_t, C.c_size_t, _P, _P,
+                                                              _P, _P]),
+    "ps_snapshot_plan_device": (C.c_int, [_P, C.POINTER(ScorerDesc), _P, _P, C.c_size_t,
+                                          C.POINTER(C.POINTER(PlanEntry)), C.POINTER(C.c_size_t),
+                                          C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32))]),
     "ps_snapshot_last_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "ps_snapshot_kernel_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "ps_snapshot_kernel_breakdown": (C.c_int, [_P, C.POINTER(KernelTimes), C.c_int]),

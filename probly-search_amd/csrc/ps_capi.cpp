@@ -545,6 +545,45 @@ ps_status ps_snapshot_query_batch_device_flat(ps_snapshot* snap, const ps_scorer
                              d_scores, d_counts, hip_stream);
 }
 
+ps_status ps_snapshot_query_batch_device_planned_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text,
+                                                      const uint64_t* offsets, size_t n_queries, const double* fields_boost,
+                                                      size_t n_boost, size_t top_k, void* d_keys, void* d_scores,
+                                                      void* d_counts, void* hip_stream) {
+  return guard([&]() -> ps_status {
+    ps_status st = check_query_args(snap, scorer, fields_boost, n_boost);
+    if (st != PS_OK) return st;
+    if (!d_keys || !d_scores || !d_counts || !offsets || (n_queries && !text)) return fail(PS_EINVAL, "null argument");
+    const double t0 = wall_ms();
+    ps_batch_stats stats;
+    snap->engine->run_device_planned(*scorer, fields_boost, text, offsets, n_queries, top_k, d_keys, d_scores, d_counts,
+                                     hip_stream, stats);
+    stats.total_ms = wall_ms() - t0;
+    set_stats(snap, stats);
+    return PS_OK;
+  });
+}
+
+ps_status ps_snapshot_plan_device(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text, const uint64_t* offsets,
+                                  size_t n_queries, ps_plan_entry** entries, size_t* n_entries, uint32_t** qbeg,
+                                  uint32_t** query_terms_len) {
+  return guard([&]() -> ps_status {
+    if (!snap || !scorer || !offsets || !entries || !n_entries || !qbeg || !query_terms_len) return fail(PS_EINVAL, "null argument");
+    if (scorer->kind != PS_SCORER_BM25) return fail(PS_EINVAL, "the device planner handles BM25");
+    if (!snap->engine) return fail(PS_ENODEVICE, "host-only snapshot");
+    ps::Plan plan;
+    snap->engine->plan_device(text, offsets, n_queries, plan);
+    ps_plan_entry* e = (ps_plan_entry*)malloc(sizeof(ps_plan_entry) * (plan.entries.size() ? plan.entries.size() : 1));
+    uint32_t* qb = (uint32_t*)malloc(4 * (n_queries + 1));
+    uint32_t* ql = (uint32_t*)malloc(4 * (n_queries ? n_queries : 1));
+    if (!e || !qb || !ql) { free(e); free(qb); free(ql); return fail(PS_ENOMEM, "out of memory"); }
+    if (!plan.entries.empty()) memcpy(e, plan.entries.data(), sizeof(ps_plan_entry) * plan.entries.size());
+    memcpy(qb, plan.qbeg.data(), 4 * (n_queries + 1));
+    if (n_queries) memcpy(ql, plan.qterms_len.data(), 4 * n_queries);
+    *entries = e; *n_entries = plan.entries.size(); *qbeg = qb; *query_terms_len = ql;
+    return PS_OK;
+  });
+}
+
 ps_status ps_snapshot_last_stats(const ps_snapshot* snap, ps_batch_stats* out) {
   if (!snap || !out) return fail(PS_EINVAL, "null argument");
   ps_snapshot* s = const_cast<ps_snapshot*>(snap);

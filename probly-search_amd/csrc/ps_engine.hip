@@ -184,6 +184,20 @@ struct EngineImpl {
   struct KTimer { hipEvent_t a = nullptr, m = nullptr, b = nullptr; bool pending = false; };
   KTimer kt[N_KTIMER];
   KTimer* last_kt = nullptr;
+  // N2 device-side planner: the frozen trie + per-term / per-layer tables in HBM (uploaded on first
+  // use, again after a delta changed them), per-batch scratch
+  bool dev_trie_valid = false;
+  DevBuf<uint4> d_fnodes, d_layer_a, d_layer_b;
+  DevBuf<uint32_t> d_fchar, d_fchild, d_term_meta, d_term_delta;
+  DevBuf<uint64_t> d_term_df;
+  DevBuf<double> d_term_idf, d_eb_table;
+  uint32_t eb_n = 0;
+  DevBuf<char> d_qtext;
+  DevBuf<uint64_t> d_qoff;
+  DevBuf<uint32_t> d_pl_cnt, d_pl_qtl, d_pl_nterms, d_pl_multi, d_pl_qbeg, d_pl_qorder;
+  DevBuf<unsigned long long> d_pl_post;
+  DevBuf<ps_plan_entry> d_pl_entries;
+  PlanTotals* h_totals = nullptr;  // pinned
   std::unique_ptr<Pool> pool;  // K1d descriptor building for large batches
   struct DaatWork* daat_work = nullptr;  // reused across batches (defined below)
   std::vector<uint32_t> daat_chunk_of, daat_nchunk_of, daat_entry_order, daat_first_slot;
@@ -309,6 +323,11 @@ Engine::~Engine() {
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
   m.d_gthr.release(); m.d_rows.release(); m.d_cand_cnt.release(); m.d_removed_df.release();
   free_daat_work(m.daat_work);
+  m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fchar.release(); m.d_fchild.release();
+  m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release();
+  m.d_qtext.release(); m.d_qoff.release(); m.d_pl_cnt.release(); m.d_pl_qtl.release(); m.d_pl_nterms.release();
+  m.d_pl_multi.release(); m.d_pl_qbeg.release(); m.d_pl_qorder.release(); m.d_pl_post.release(); m.d_pl_entries.release();
+  if (m.h_totals) (void)hipHostFree(m.h_totals);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
   m.d_sort_tmp.release(); m.d_pack.release();
   for (auto& sg : m.stage) {
@@ -374,8 +393,10 @@ void Engine::apply_delta(const DeltaRanges& r, std::vector<uint64_t>& removed_df
   } else {
     for (uint32_t w : r.alive_words) put(m.d_alive + w, s.alive.data() + w, 4);
   }
-  // what depended on the old state: resident dense rows (doc range, avg), the saturated-tf LUT (avg)
+  // what depended on the old state: resident dense rows (doc range, avg), the saturated-tf LUT (avg),
+  // the device copy of the trie / term tables
   forget_rows(m);
+  m.dev_trie_valid = false;
   removed_df.assign(s.layers.size(), 0);
   if (s.any_dead && !s.layers.empty()) {
     const size_t nl = s.layers.size();
@@ -1540,6 +1561,204 @@ Plan sub_plan(const Plan& plan, size_t b, size_t e) {
 }
 
 }  // namespace
+
+namespace {
+
+// Uploads the frozen trie, the per-term tables (df, idf, lengths, layer ranges) and the per-layer
+// tables for the device-side planner.  idf and the expansion-boost table are computed HERE with the
+// host's libm, by the very expressions of Snapshot::plan_query - the device never calls log.
+void ensure_dev_trie(EngineImpl& m) {
+  if (m.dev_trie_valid) return;
+  const Snapshot& s = *m.snap;
+  const size_t nn = s.fnodes.size(), nt = s.terms.size(), nl = s.layers.size();
+  std::vector<uint4> fn(nn), la(std::max<size_t>(nl, 1)), lb(std::max<size_t>(nl, 1));
+  for (size_t i = 0; i < nn; ++i) fn[i] = make_uint4(s.fnodes[i].child_begin, s.fnodes[i].child_count, s.fnodes[i].term_begin, s.fnodes[i].term_end);
+  for (size_t l = 0; l < nl; ++l) {
+    const LayerInfo& L = s.layers[l];
+    la[l] = make_uint4((uint32_t)L.post_off, (uint32_t)(L.post_off >> 32), L.len, L.tbl_off);
+    lb[l] = make_uint4(L.shift, L.bm_off, L.next, 0u);
+  }
+  std::vector<uint32_t> meta(std::max<size_t>(nt, 1) * 4), delta(std::max<size_t>(nt, 1));
+  std::vector<uint64_t> df(std::max<size_t>(nt, 1));
+  std::vector<double> idf(std::max<size_t>(nt, 1));
+  uint32_t max_len = 0;
+  for (size_t o = 0; o < nt; ++o) {
+    const TermInfo& t = s.terms[o];
+    meta[4 * o] = t.byte_len; meta[4 * o + 1] = t.first_layer; meta[4 * o + 2] = t.n_layers; meta[4 * o + 3] = t.fnode;
+    delta[o] = t.delta_head;
+    df[o] = t.df_raw;
+    // BM25::before_each, bm25.rs:41-56 (as in Snapshot::plan_query)
+    const uint64_t frequency = std::min<uint64_t>(s.n_docs, t.df_raw);
+    const uint64_t diff = s.n_docs - frequency;
+    idf[o] = std::log(1.0 + ((double)diff + 0.5) / ((double)frequency + 0.5));
+    max_len = std::max(max_len, t.byte_len);
+  }
+  m.eb_n = max_len + 2;
+  std::vector<double> eb(m.eb_n);
+  for (uint32_t d = 0; d < m.eb_n; ++d) eb[d] = std::log(1.0 + (1.0 / (1.0 + (double)d)));  // bm25.rs:48-53, (1 + len_exp) - len_q == 1 + d
+  auto up = [&](auto& buf, const auto& v) {
+    buf.ensure(v.size() + 1);
+    PS_HIP(hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+  };
+  up(m.d_fnodes, fn); up(m.d_layer_a, la); up(m.d_layer_b, lb); up(m.d_term_meta, meta); up(m.d_term_delta, delta);
+  up(m.d_term_df, df); up(m.d_term_idf, idf); up(m.d_eb_table, eb);
+  std::vector<uint32_t> fc(s.fchar.begin(), s.fchar.end()), fd(s.fchild.begin(), s.fchild.end());
+  if (fc.empty()) { fc.push_back(0); fd.push_back(0); }
+  up(m.d_fchar, fc); up(m.d_fchild, fd);
+  if (!m.h_totals) PS_HIP(hipHostMalloc((void**)&m.h_totals, sizeof(PlanTotals), hipHostMallocDefault));
+  m.dev_trie_valid = true;
+}
+
+// Plans a flat BM25 batch on the device (stream `st`); returns the totals (one small synchronisation).
+PlanTotals device_plan(EngineImpl& m, const char* text, const uint64_t* offsets, size_t B, hipStream_t st) {
+  ensure_dev_trie(m);
+  const size_t n_bytes = B ? (size_t)offsets[B] : 0;
+  if (n_bytes >= 0xFFFFFFF0ull) throw std::length_error("device planner: more than 4 GiB of query text");
+  m.d_qtext.ensure(n_bytes + 16);
+  m.d_qoff.ensure(B + 2);
+  PS_HIP(hipMemcpyAsync(m.d_qtext.p, text, n_bytes, hipMemcpyHostToDevice, st));
+  PS_HIP(hipMemcpyAsync(m.d_qoff.p, offsets, (B + 1) * 8, hipMemcpyHostToDevice, st));
+  m.d_pl_cnt.ensure(B + 1); m.d_pl_qtl.ensure(B + 1); m.d_pl_nterms.ensure(B + 1); m.d_pl_multi.ensure(B + 1);
+  m.d_pl_post.ensure(B + 1); m.d_pl_qbeg.ensure(B + 2); m.d_pl_qorder.ensure(B + 1);
+  DevTrie t{m.d_fnodes.p, m.d_fchar.p, m.d_fchild.p, m.d_term_df.p, m.d_term_meta.p, m.d_term_delta.p, m.d_term_idf.p,
+            m.d_layer_a.p, m.d_layer_b.p, m.d_eb_table.p, m.eb_n};
+  const uint32_t blocks = (uint32_t)((B + 63) / 64);
+  hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, m.d_qtext.p, m.d_qoff.p, (uint32_t)B, nullptr,
+                     nullptr, m.d_pl_cnt.p, m.d_pl_qtl.p, m.d_pl_nterms.p, m.d_pl_multi.p, m.d_pl_post.p, nullptr);
+  // totals land in a small device buffer, then in pinned memory
+  m.d_removed_df.ensure(8);
+  PlanTotals* d_tot = reinterpret_cast<PlanTotals*>(m.d_removed_df.p);
+  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, m.d_pl_cnt.p, m.d_pl_nterms.p, m.d_pl_multi.p, m.d_pl_post.p, (uint32_t)B,
+                     m.d_pl_qbeg.p, d_tot);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipMemcpyAsync(m.h_totals, d_tot, sizeof(PlanTotals), hipMemcpyDeviceToHost, st));
+  PS_HIP(hipStreamSynchronize(st));
+  const PlanTotals tot = *m.h_totals;
+  m.d_pl_entries.ensure((size_t)tot.n_entries + 1);
+  hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, m.d_qtext.p, m.d_qoff.p, (uint32_t)B, m.d_pl_qbeg.p,
+                     m.d_pl_entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, m.d_pl_qorder.p);
+  PS_HIP(hipGetLastError());
+  return tot;
+}
+
+}  // namespace
+
+// N2: the plan of a flat BM25 batch built on the device, copied back (inspection / parity tests).
+void Engine::plan_device(const char* text, const uint64_t* offsets, size_t B, Plan& out) {
+  EngineImpl& m = *impl_;
+  std::lock_guard<std::mutex> lock(m.mu);
+  PS_HIP(hipSetDevice(m.device));
+  const PlanTotals tot = device_plan(m, text, offsets, B, m.stream);
+  out = Plan{};
+  out.entries.resize(tot.n_entries);
+  out.qbeg.resize(B + 1);
+  out.qterms_len.resize(B);
+  out.n_nodes.assign(B, 0);
+  PS_HIP(hipStreamSynchronize(m.stream));
+  if (tot.n_entries) PS_HIP(hipMemcpy(out.entries.data(), m.d_pl_entries.p, (size_t)tot.n_entries * sizeof(ps_plan_entry), hipMemcpyDeviceToHost));
+  PS_HIP(hipMemcpy(out.qbeg.data(), m.d_pl_qbeg.p, (B + 1) * 4, hipMemcpyDeviceToHost));
+  if (B) PS_HIP(hipMemcpy(out.qterms_len.data(), m.d_pl_qtl.p, B * 4, hipMemcpyDeviceToHost));
+  out.postings = tot.postings;
+  out.max_entries = tot.max_entries;
+  out.max_qterms = tot.max_qterms;
+  out.multi_expansion = tot.multi != 0;
+}
+
+// N2: a BM25 top-k batch whose plan never exists on the host: query text -> k_plan (count, scan,
+// fill) -> K1 k_score -> K3 k_merge.  The host only learns four totals (entries, largest plan, most
+// query terms, whether any term has several expansions) to size the launch.
+void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, const char* text, const uint64_t* offsets,
+                                size_t B, size_t top_k, void* d_keys, void* d_scores, void* d_counts, void* stream,
+                                ps_batch_stats& stats) {
+  EngineImpl& m = *impl_;
+  const Snapshot& s = *m.snap;
+  if (sc.kind != PS_SCORER_BM25) throw std::invalid_argument("the device planner handles BM25 (zero_to_one classifies its queries on the host)");
+  if (s.F > (uint32_t)MAX_F) throw std::length_error("the GPU path supports at most 8 fields");
+  if (top_k < 1 || top_k > PS_MAX_DEVICE_TOPK) throw std::invalid_argument("top_k must be in [1, 64] for the device top-k path");
+  std::lock_guard<std::mutex> lock(m.mu);
+  PS_HIP(hipSetDevice(m.device));
+  const double t0 = now_ms();
+  hipStream_t st = stream ? (hipStream_t)stream : m.stream;
+  if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
+  m.tail_pending = false;
+  const PlanTotals tot = device_plan(m, text, offsets, B, st);
+  if (tot.max_qterms >= 0x7FFF) throw std::length_error("more than 32766 non-empty terms in one query");
+  const double t1 = now_ms();
+  Plan shape;  // the scalars the launch geometry needs; the entries stay on the device
+  shape.max_entries = tot.max_entries;
+  shape.max_qterms = tot.max_qterms;
+  shape.multi_expansion = tot.multi != 0;
+  shape.postings = tot.postings;
+  KParams kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys; kp.bits = m.d_bits;
+  kp.alive = s.any_dead ? m.d_alive : nullptr;
+  kp.plan = m.d_pl_entries.p;
+  kp.qbeg = m.d_pl_qbeg.p;
+  kp.qterms_len = m.d_pl_qtl.p;
+  kp.qorder = m.d_pl_qorder.p;
+  const size_t n_thr = B + 2;
+  const bool fresh = m.d_gthr.ensure(n_thr, true);
+  kp.work_counter = m.d_work;
+  kp.gthr = m.d_gthr.p;
+  if (!(m.ctl_clean && !fresh)) {
+    PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
+    PS_HIP(hipMemsetAsync(m.d_work, 0, 64, st));
+  }
+  m.ctl_clean = false;
+  kp.P = s.P;
+  while ((1u << kp.t_log2) < s.T) ++kp.t_log2;
+  kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_ids; kp.F = s.F;
+  kp.max_qterms = std::max<uint32_t>(1, shape.max_qterms);
+  kp.k1 = sc.bm25_k1; kp.b = sc.bm25_b; kp.k1p1 = sc.bm25_k1 + 1.0; kp.one_minus_b = 1.0 - sc.bm25_b;
+  for (uint32_t x = 0; x < s.F; ++x) { kp.avg[x] = s.avg[x]; kp.boost[x] = boosts[x]; }
+  if (m.tune.lut) {
+    kp.lut = m.d_lut;
+    kp.lut_rows = s.lut_rows;
+    kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;
+    for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
+  }
+  kp.row_stride = (uint64_t)s.tiles_cap * s.T;
+  BatchImage img;
+  img.B = B;
+  choose_run_length(m, sc, shape, img, true, kp);
+  kp.K = (uint32_t)top_k;
+  const size_t n_cand = (size_t)B * kp.n_super * top_k;
+  m.d_cand_score.ensure(n_cand + 1);
+  m.d_cand_doc.ensure(n_cand + 1);
+  kp.cand_score = m.d_cand_score.p;
+  kp.cand_doc = m.d_cand_doc.p;
+  kp.out_keys = (uint64_t*)d_keys; kp.out_scores = (double*)d_scores; kp.out_counts = (uint32_t*)d_counts;
+  EngineImpl::KTimer* kt = &m.kt[m.next_kt];
+  m.next_kt = (m.next_kt + 1) % N_KTIMER;
+  m.harvest(*kt, true);
+  PS_HIP(hipEventRecord(kt->a, st));
+  m.build_slots.clear();
+  launch_score<false>(m, sc, shape, kp, m.n_cu, st, kt->m);
+  PS_HIP(hipEventRecord(kt->b, st));
+  kt->pending = true;
+  m.last_kt = kt;
+  if (B) {
+    const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));
+    hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
+    PS_HIP(hipGetLastError());
+    m.ctl_clean = true;
+  }
+  PS_HIP(hipEventRecord(m.ev[0], st));
+  m.tail_stream = st;
+  m.tail_pending = true;
+  memset(&stats, 0, sizeof(stats));
+  stats.n_queries = B;
+  stats.n_plan_entries = tot.n_entries;
+  stats.postings_visited = tot.postings;
+  stats.algorithmic_bytes = tot.postings * (4 + 8 * (uint64_t)s.F) + (uint64_t)B * top_k * 16;
+  stats.plan_ms = t1 - t0;  // device planner incl. its one synchronisation
+  if (!stream) {
+    PS_HIP(hipStreamSynchronize(st));
+    read_kernel_times(m, stats);
+  }
+  stats.total_ms = now_ms() - t0;
+}
 
 void Engine::run_device(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,
                         void* d_scores, void* d_counts, void* stream, ps_batch_stats& stats) {

@@ -28,6 +28,14 @@ class Engine {
   void run_device(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,
                   void* d_scores, void* d_counts, void* stream, ps_batch_stats& stats);
 
+  // SURVEY 8f N2 - device-side planner (BM25, built-in tokenizer): tokenise, term lookup in the frozen
+  // trie, prefix expansion and before_each run on the GPU.  plan_device copies the plan back (tests);
+  // run_device_planned scores the batch without the plan ever existing on the host.
+  void plan_device(const char* text, const uint64_t* offsets, size_t n_queries, Plan& out);
+  void run_device_planned(const ps_scorer_desc& sc, const double* boosts, const char* text, const uint64_t* offsets,
+                          size_t n_queries, size_t top_k, void* d_keys, void* d_scores, void* d_counts, void* stream,
+                          ps_batch_stats& stats);
+
   // HIP-event durations summed over every batch since the last reset: the scoring kernel alone and
   // K0 / K0b in front of it (waits for outstanding launches).
   void kernel_times(ps_kernel_times& out, bool reset);

@@ -1502,6 +1502,164 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge_items(const KParam
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// N2: device-side query planner - tokenise, term lookup, prefix expansion, before_each
+//     (query.rs:29-60,109-147; index.rs:300-337; bm25.rs:35-58) for a whole batch, BM25.
+//
+// The frozen trie lives in HBM as it does on the host (nodes in DFS pre-order with children
+// newest-first, so expand_term(prefix) is the contiguous ordinal range [term_begin, term_end) of the
+// prefix's node; a node's children sorted by char for binary search).  `ln` never runs on the device:
+// idf depends on the term only and is tabulated per term by the host (same libm call as the host
+// planner), expansion_boost depends on the byte-length difference only and is tabulated per
+// difference.  One thread plans one query; pass 1 counts, a scan places, pass 2 writes - the entries
+// come out exactly as Snapshot::plan_query writes them (tests compare the bytes).
+// ------------------------------------------------------------------------------------------
+struct DevTrie {
+  const uint4* fnodes;       // {child_begin, child_count, term_begin, term_end}
+  const uint32_t* fchar;
+  const uint32_t* fchild;
+  const uint64_t* term_df;   // live df_raw per term ordinal
+  const uint32_t* term_meta; // [4 per term] byte_len, first_layer, n_layers, fnode
+  const uint32_t* term_delta;// delta_head per term
+  const double* term_idf;
+  const uint4* layer_a;      // {post_off lo, post_off hi, len, tbl_off}
+  const uint4* layer_b;      // {shift, bm_off, next, -}
+  const double* eb_table;    // [EB_TABLE] expansion_boost by (len_expanded - len_query)
+  uint32_t eb_n;
+};
+
+struct PlanTotals {  // written by k_plan_scan
+  uint32_t n_entries, max_entries, max_qterms, multi;
+  unsigned long long postings;
+};
+
+__device__ __forceinline__ uint32_t utf8_next(const char* s, uint32_t& i, const uint32_t end) {
+  const unsigned char c = (unsigned char)s[i++];
+  if (c < 0x80) return c;
+  const int extra = (c >> 5) == 0x6 ? 1 : (c >> 4) == 0xE ? 2 : 3;
+  uint32_t cp = extra == 1 ? (c & 0x1Fu) : extra == 2 ? (c & 0x0Fu) : (c & 0x07u);
+  for (int k = 0; k < extra && i < end; ++k) cp = (cp << 6) | ((unsigned char)s[i++] & 0x3Fu);
+  return cp;
+}
+
+// find_inverted_index_node (index.rs:300-337) on the frozen trie: -1 if the path does not exist
+__device__ __forceinline__ int64_t dev_find_node(const DevTrie& t, const char* s, uint32_t b, const uint32_t e) {
+  uint32_t n = 0;
+  while (b < e) {
+    const uint32_t ch = utf8_next(s, b, e);
+    const uint4 fn = t.fnodes[n];
+    uint32_t lo = 0, hi = fn.y;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (t.fchar[fn.x + mid] < ch) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= fn.y || t.fchar[fn.x + lo] != ch) return -1;
+    n = t.fchild[fn.x + lo];
+  }
+  return (int64_t)n;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_plan(const DevTrie t, const char* text, const uint64_t* offsets, const uint32_t B,
+                                             const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt, uint32_t* q_terms_len,
+                                             uint32_t* q_nterms, uint32_t* q_multi, unsigned long long* q_postings,
+                                             uint32_t* qorder) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= B) return;
+  const uint32_t qb = (uint32_t)offsets[q], qe = (uint32_t)offsets[q + 1];
+  const char* s = text;
+  uint32_t n_tokens = 0, qord = 0, n_ent = 0, multi = 0;
+  unsigned long long postings = 0;
+  uint32_t w = FILL ? qbeg[q] : 0u;
+  // s.split(' ') (lib.rs:42-44): k separators -> k + 1 tokens; empty ones are skipped but counted (query.rs:32-35)
+  uint32_t tb = qb;
+  for (uint32_t i = qb; i <= qe; ++i) {
+    if (i != qe && s[i] != ' ') continue;
+    const uint32_t te = i;
+    const uint32_t qi = n_tokens++;
+    if (te > tb) {
+      const int64_t fn = dev_find_node(t, s, tb, te);
+      uint32_t here = 0;
+      if (fn >= 0) {
+        const uint4 node = t.fnodes[fn];
+        for (uint32_t o = node.z; o < node.w; ++o) {  // == expand_term order (query.rs:130-147)
+          const uint64_t df = t.term_df[o];
+          const uint32_t byte_len = t.term_meta[4 * o], first_layer = t.term_meta[4 * o + 1], n_layers = t.term_meta[4 * o + 2];
+          const uint32_t delta_head = t.term_delta[o];
+          if (df == 0 || (n_layers == 0 && delta_head == 0xFFFFFFFFu)) continue;  // query.rs:47-48
+          uint32_t l = 0, li = n_layers ? first_layer : delta_head;
+          while (li != 0xFFFFFFFFu) {
+            const uint4 la = t.layer_a[li], lb = t.layer_b[li];
+            if (FILL) {
+              ps_plan_entry e;
+              e.post_off = (uint64_t)la.x | ((uint64_t)la.y << 32);
+              e.len = la.z;
+              e.tbl_off = la.w;
+              e.shift = lb.x | (l << 8);
+              e.qterm = qord;
+              e.idf = t.term_idf[o];
+              // bm25.rs:45-53: 1 for the query term itself, else ln(1 + 1/((1 + len_exp) - len_q)), tabulated
+              const uint32_t delta = byte_len - (te - tb);
+              e.boost = (t.term_meta[4 * o + 3] == (uint32_t)fn) ? 1.0 : t.eb_table[delta < t.eb_n ? delta : 0];
+              e.node = li;
+              e.qterm_index = qi;
+              e.bm_off = lb.y;
+              e._pad = 0;
+              entries[w++] = e;
+            }
+            postings += la.z;
+            ++here;
+            ++l;
+            // base layers are contiguous, then the delta chain
+            if (l < n_layers) li = first_layer + l;
+            else if (l == n_layers) li = delta_head;
+            else li = lb.z;
+          }
+        }
+      }
+      if (here > 1) multi = 1;
+      n_ent += here;
+      ++qord;
+    }
+    tb = i + 1;
+  }
+  if (!FILL) {
+    q_cnt[q] = n_ent;
+    q_terms_len[q] = n_tokens;
+    q_nterms[q] = qord;
+    q_multi[q] = multi;
+    q_postings[q] = postings;
+  } else {
+    qorder[q] = q;
+  }
+}
+
+// one workgroup: exclusive scan of the per-query entry counts + the batch totals
+__global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t* q_cnt, const uint32_t* q_nterms, const uint32_t* q_multi,
+                                                     const unsigned long long* q_postings, const uint32_t B, uint32_t* qbeg,
+                                                     PlanTotals* tot) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t mx_e[1024], mx_t[1024], any_m[1024];
+  __shared__ unsigned long long post[1024];
+  const uint32_t tid = threadIdx.x, per = (B + 1023) / 1024;
+  const uint32_t b = min(B, tid * per), e = min(B, b + per);
+  uint32_t sum = 0, me = 0, mt = 0, mm = 0;
+  unsigned long long ps = 0;
+  for (uint32_t i = b; i < e; ++i) { sum += q_cnt[i]; me = max(me, q_cnt[i]); mt = max(mt, q_nterms[i]); mm |= q_multi[i]; ps += q_postings[i]; }
+  part[tid] = sum; mx_e[tid] = me; mx_t[tid] = mt; any_m[tid] = mm; post[tid] = ps;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0, a = 0, c = 0, d = 0;
+    unsigned long long pp = 0;
+    for (uint32_t i = 0; i < 1024; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; a = max(a, mx_e[i]); c = max(c, mx_t[i]); d |= any_m[i]; pp += post[i]; }
+    tot->n_entries = run; tot->max_entries = a; tot->max_qterms = c; tot->multi = d; tot->postings = pp;
+    qbeg[B] = run;
+  }
+  __syncthreads();
+  uint32_t run = part[tid];
+  for (uint32_t i = b; i < e; ++i) { qbeg[i] = run; run += q_cnt[i]; }
+}
+
 // Plan upload without the copy engine: the staged batch is read from the pinned, device-mapped
 // slot with coalesced 16-byte loads.  (An SDMA copy between two kernels costs a 20-30 us hand-over
 // per batch; this is a few microseconds for the ~150 KB of a 1024-query plan.)

@@ -324,6 +324,37 @@ class Snapshot:
         except PsError as e:
             _raise(e)
 
+    def query_batch_device_planned_flat(self, text, offsets, score_calculator, fields_boost, top_k, d_keys, d_scores,
+                                        d_counts, stream=None):
+        """ps_snapshot_query_batch_device_planned_flat: like query_batch_device_flat, but the query planner
+        (tokenise, trie lookup, expansion, before_each) runs on the device as well (BM25)."""
+        desc = _scorer_desc(score_calculator)
+        b, nb = _boosts(fields_boost)
+        try:
+            _lib.check(self._L.ps_snapshot_query_batch_device_planned_flat(
+                self._h, C.byref(desc), text.ctypes.data, offsets.ctypes.data, len(offsets) - 1, b, nb, top_k, d_keys,
+                d_scores, d_counts, stream if stream else None))
+        except PsError as e:
+            _raise(e)
+
+    def plan_device(self, queries, score_calculator):
+        """The plans the DEVICE planner builds for `queries` -> list of (entries, query_terms_len), the
+        same shape Snapshot.plan returns per query."""
+        from . import synth
+        text, offsets = synth.pack_queries(list(queries))
+        desc = _scorer_desc(score_calculator)
+        ent, n = C.POINTER(_lib.PlanEntry)(), C.c_size_t()
+        qb, ql = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+        _lib.check(self._L.ps_snapshot_plan_device(self._h, C.byref(desc), text.ctypes.data, offsets.ctypes.data,
+                                                   len(queries), C.byref(ent), C.byref(n), C.byref(qb), C.byref(ql)))
+        out = []
+        for q in range(len(queries)):
+            es = [{k: getattr(ent[i], k) for k, _ in _lib.PlanEntry._fields_} for i in range(qb[q], qb[q + 1])]
+            out.append((es, ql[q]))
+        for p in (ent, qb, ql):
+            self._L.ps_free(p)
+        return out
+
     def last_stats(self):
         s = _lib.BatchStats()
         _lib.check(self._L.ps_snapshot_last_stats(self._h, C.byref(s)))
