@@ -128,7 +128,7 @@ struct Tuning {
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
   uint32_t daat_persistent = 0;  // PS_DAAT_PERSISTENT: persistent waves + item counter instead of one wave per item
   uint32_t daat_threads = 8;     // PS_DAAT_THREADS: host threads that build the K1d descriptors of a large batch
-  uint32_t daat_multi = 0;       // PS_DAAT_MULTI: also take batches with several expansions per query term (K1 is faster there today)
+  uint32_t daat_multi = 1;       // PS_DAAT_MULTI: also take batches with several expansions per query term (0: they stay on K1)
   uint32_t daat_split = 0;       // PS_DAAT_SPLIT: the queries' highest-bound lists in a launch of their own, first
   void load();
 };
@@ -551,7 +551,7 @@ struct BatchImage {
   uint32_t z_qterms = 0;  // most query terms with entries in one general zero_to_one query
   // K1d
   bool daat = false;
-  size_t off_d = 0, off_i = 0, off_s = 0, off_ro = 0, n_ditems = 0;
+  size_t off_d = 0, off_i = 0, off_s = 0, off_ro = 0, off_dg = 0, n_ditems = 0;
 };
 
 }  // namespace
@@ -559,6 +559,7 @@ struct DaatWork {
   std::vector<DEntry> dentry;
   std::vector<DItem> items;
   std::vector<uint32_t> qslot, rorder;
+  std::vector<DGroup> dgroup;  // multi-expansion batches only
 };
 void free_daat_work(DaatWork* w) { delete w; }
 namespace {
@@ -585,7 +586,8 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
     img.off_i = img.off_d + ne * sizeof(DEntry);
     img.off_s = img.off_i + img.n_ditems * sizeof(DItem);
     img.off_ro = img.off_s + (B + 1) * 4;
-    img.total = img.off_ro + ne * 4;
+    img.off_dg = (img.off_ro + ne * 4 + 15) & ~(size_t)15;
+    img.total = img.off_dg + (dw->dgroup.empty() ? 0 : ne * sizeof(DGroup));
   }
   Stage& sg = m.stage[m.next_stage];
   m.next_stage = (m.next_stage + 1) % N_STAGE;
@@ -601,6 +603,7 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
     if (img.n_ditems) memcpy(img.h + img.off_i, dw->items.data(), img.n_ditems * sizeof(DItem));
     memcpy(img.h + img.off_s, dw->qslot.data(), (B + 1) * 4);
     if (ne) memcpy(img.h + img.off_ro, dw->rorder.data(), ne * 4);
+    if (ne && !dw->dgroup.empty()) memcpy(img.h + img.off_dg, dw->dgroup.data(), ne * sizeof(DGroup));
   }
   return img;
 }
@@ -705,6 +708,7 @@ void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& 
   dw.dentry.resize(ne);
   dw.qslot.assign(B + 1, 0);
   dw.rorder.resize(ne);
+  if (plan.multi_expansion) dw.dgroup.assign(ne, DGroup{}); else dw.dgroup.clear();
   std::vector<uint32_t>& chunk = m.daat_chunk_of;
   std::vector<uint32_t>& nchunk = m.daat_nchunk_of;
   chunk.resize(ne);
@@ -746,6 +750,22 @@ void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& 
           if (g.first != qt) rest += g.second;
         d.others = (rest + alt) * SLACK;
         if (!(d.others >= 0.0)) d.others = INFINITY;
+      }
+      if (plan.multi_expansion) {
+        // per entry: the dense ordinal of its query term and the (inflated) bound of the next list of the
+        // same term in rank order - what k_daat's pass 1 falls back to once this list has been looked at
+        for (uint32_t r = 0; r < n; ++r) {
+          const uint32_t i = ord[r];
+          DGroup& dg = dw.dgroup[b + i];
+          const uint32_t qt = plan.entries[b + i].qterm;
+          uint32_t g = 0;
+          while (g < gmax.size() && gmax[g].first != qt) ++g;
+          dg.grp = gmax.size() <= 4 ? g : 0xFFFFFFFFu;
+          dg.ub_s = ub[i] * SLACK;
+          dg.nxt_s = 0.0;
+          for (uint32_t r2 = r + 1; r2 < n; ++r2)
+            if (plan.entries[b + ord[r2]].qterm == qt) { dg.nxt_s = ub[ord[r2]] * SLACK; break; }
+        }
       }
       // skip thresholds: entries in ascending bound order; a document that only occurs in the first k
       // of them scores at most sum over query terms of the largest bound among those of its lists
@@ -1214,6 +1234,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     kp.ditems = reinterpret_cast<const DItem*>(dbase + img.off_i);
     kp.qslot = reinterpret_cast<const uint32_t*>(dbase + img.off_s);
     kp.rorder = reinterpret_cast<const uint32_t*>(dbase + img.off_ro);
+    kp.dgroup = dw.dgroup.empty() ? nullptr : reinterpret_cast<const DGroup*>(dbase + img.off_dg);
     kp.n_ditems = (uint32_t)img.n_ditems;
     uint32_t max_slots = 0;
     for (size_t q = 0; q < B; ++q) max_slots = std::max(max_slots, dw.qslot[q + 1] - dw.qslot[q]);

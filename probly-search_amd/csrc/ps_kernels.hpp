@@ -64,6 +64,12 @@ struct DEntry {        // per plan entry
   uint32_t rank;       // position in the query's processing order (0 = highest upper bound); the dedupe order
   uint32_t q;          // query of the entry
 };
+struct DGroup {        // per plan entry, for queries with several expansions per query term
+  double ub_s;         // this entry's bound, inflated (1e-9)
+  double nxt_s;        // inflated bound of the next entry (rank order) of the SAME query term, 0 = none
+  uint32_t grp;        // dense ordinal of the entry's query term within the query; 0xFFFFFFFF = more than 4 terms
+  uint32_t _pad[3];
+};
 struct DItem {         // a chunk of one list
   uint32_t entry;      // plan entry
   uint32_t begin;      // first posting of the chunk within the list
@@ -113,6 +119,7 @@ struct KParams {
   const struct DItem* ditems;   // [n_ditems] in processing order (highest upper bound first)
   const uint32_t* qslot;        // [B+1] candidate slots (= items) of query q: [qslot[q], qslot[q+1])
   const uint32_t* rorder;       // [n_plan_entries] per query: its entries in rank order (highest bound first)
+  const struct DGroup* dgroup;  // [n_plan_entries] (multi-expansion batches)
   const uint32_t* bits;         // membership bitmaps of the denser lists (ps_plan_entry::bm_off)
   const uint32_t* alive;        // one bit per doc id, cleared by a delta removal; null = every document alive
   uint32_t n_ditems, t_log2;
@@ -1234,7 +1241,7 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
 template <int F_, bool MULTI>
 __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int U = F_ ? PS_DAAT_U : 2;  // postings per lane in flight
+  constexpr int U = (F_ && !MULTI) ? PS_DAAT_U : 2;  // postings per lane in flight (the multi-expansion arm keeps per-term maxima per posting)
   const int lane = threadIdx.x & (WAVE - 1);
   const double* lut = reinterpret_cast<const double*>(smem);
   // A grid that covers every item with its own wave assigns them by index (workgroups are dispatched
@@ -1284,6 +1291,23 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
     const uint64_t own_off = own.post_off;
     const uint32_t own_rank = de.rank;
     const double skip_thr = de.skip_thr, others = de.others;
+    // multi-expansion queries: the query term of this list, and per query term the bound of its best
+    // OTHER list (what pass 1 starts from)
+    uint32_t own_grp = 0xFFFFFFFFu;
+    double rem0[4] = {0.0, 0.0, 0.0, 0.0};
+    if (MULTI && p.dgroup != nullptr && e1 - e0 <= 64u) {
+      own_grp = p.dgroup[e_own].grp;
+      if (own_grp < 4u) {
+        for (uint32_t r = e1; r-- > e0;) {  // ascending bound: the last write per term is its best list
+          const uint32_t j = p.rorder[r];
+          if (j == e_own) continue;
+          const DGroup gj = p.dgroup[j];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if ((uint32_t)g == gj.grp) rem0[g] = gj.ub_s;
+        }
+      }
+    }
     TopK tk;
     tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
     double published = 0.0;
@@ -1376,6 +1400,87 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
 #pragma unroll
               for (int u = 0; u < U; ++u)
                 if (alive[u] && s[u] > 0.0) P[u] += s[u];
+            }
+          }
+        } else if (MULTI && ne <= 64u && own_grp < 4u) {
+          // Several expansions per query term: the expansions of one term merge by max
+          // (query.rs:150-164), so a document scores at most the sum over query terms of the best of
+          // its lists of that term.  Pass 1 (highest-bound lists first) keeps, per query term, the best
+          // contribution found so far (per posting) and the bound of the best list not looked at yet
+          // (wave-uniform); the posting is dropped when their sum cannot reach theta.
+          double act[U][4];
+          unsigned long long hits[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            hits[u] = 0ull;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) act[u][g] = (uint32_t)g == own_grp ? s_own[u] : 0.0;
+          }
+          double rem[4] = {rem0[0], rem0[1], rem0[2], rem0[3]};
+          for (uint32_t r = e0; r < e1 && any_alive; ++r) {
+            const uint32_t j = p.rorder[r];
+            if (j != e_own) {
+              const ps_plan_entry& en = p.plan[j];
+              const DGroup gj = p.dgroup[j];
+              const uint32_t j_rank = p.dentry[j].rank;
+              double s[U];
+              lookup_scores<F_, U>(p, lut, en, d, alive, s);
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                if ((uint32_t)g == gj.grp) rem[g] = gj.nxt_s;
+              bool any = false;
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                if (alive[u]) {
+                  if (s[u] > 0.0) {
+                    hits[u] |= 1ull << (j - e0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                      if ((uint32_t)g == gj.grp) act[u][g] = fmax(act[u][g], s[u]);
+                  }
+                  double bound = 0.0;
+#pragma unroll
+                  for (int g = 0; g < 4; ++g) bound += fmax(act[u][g], rem[g]);
+                  // (j_rank < own_rank: the document is evaluated from its highest-bound list only)
+                  if (bound < theta || (s[u] > 0.0 && j_rank < own_rank)) alive[u] = false;
+                }
+                any |= alive[u];
+              }
+              any_alive = __any(any);
+            }
+          }
+          // Pass 2, the survivors: the add / max state machine in PLAN order (query.rs:33-89,150-164)
+          if (any_alive) {
+            bool present[U], visited[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { present[u] = false; visited[u] = false; }
+            uint32_t cur_qterm = 0xFFFFFFFFu;
+            for (uint32_t j = e0; j < e1; ++j) {
+              const ps_plan_entry& en = p.plan[j];
+              if (en.qterm != cur_qterm) {  // query.rs:37
+                cur_qterm = en.qterm;
+#pragma unroll
+                for (int u = 0; u < U; ++u) visited[u] = false;
+              }
+              double s[U];
+              if (j == e_own) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) s[u] = s_own[u];
+              } else {
+                bool want[U];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u) { want[u] = alive[u] && ((hits[u] >> (j - e0)) & 1ull); any |= want[u]; s[u] = 0.0; }
+                if (__any(any)) lookup_scores<F_, U>(p, lut, en, d, want, s);
+              }
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                if (alive[u] && s[u] > 0.0) {
+                  P[u] = present[u] ? (visited[u] ? fmax(P[u], s[u]) : P[u] + s[u]) : s[u];
+                  visited[u] = true;
+                  present[u] = true;
+                }
+              }
             }
           }
         } else {
