@@ -34,6 +34,7 @@
 #include <map>
 #include <memory>
 #include <thread>
+#include <unordered_map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -128,6 +129,7 @@ struct Tuning {
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
   uint32_t daat_persistent = 0;  // PS_DAAT_PERSISTENT: persistent waves + item counter instead of one wave per item
   uint32_t daat_threads = 8;     // PS_DAAT_THREADS: host threads that build the K1d descriptors of a large batch
+  uint32_t daat_z21 = 0;         // PS_DAAT_Z21: zero_to_one top-k batches of simple queries take K1dz k_daat_z (off: K1 is 3x faster)
   uint32_t daat_multi = 1;       // PS_DAAT_MULTI: also take batches with several expansions per query term (0: they stay on K1)
   uint32_t daat_split = 0;       // PS_DAAT_SPLIT: the queries' highest-bound lists in a launch of their own, first
   void load();
@@ -171,6 +173,8 @@ struct EngineImpl {
     double k1 = 0, b = 0;
     std::vector<double> boosts, avg, M, J;
   } bounds;
+  std::vector<uint32_t> z_minfl;  // K1dz: [layer][field] shortest field length holding the term (compute_z_bounds)
+  std::unordered_map<uint64_t, uint32_t> z_layer_of;  // post_off -> layer (zero_to_one plan entries do not carry it)
   DevBuf<uint32_t> d_sort_doc, d_seg;  // K4 scratch
   DevBuf<uint64_t> d_sort_score, d_pack_off;
   DevBuf<unsigned char> d_sort_tmp;
@@ -481,6 +485,7 @@ void Tuning::load() {
     daat_persistent = env_u32("PS_DAAT_PERSISTENT", daat_persistent);
     daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
+    daat_z21 = env_u32("PS_DAAT_Z21", daat_z21);
     daat_threads = std::max(1u, std::min(env_u32("PS_DAAT_THREADS", daat_threads), std::max(1u, std::thread::hardware_concurrency())));
 }
 
@@ -608,8 +613,6 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
   return img;
 }
 
-inline bool sync_path_small(const Plan&) { return false; }
-
 // ---- K1d: bounds and work descriptors ------------------------------------------------------------
 bool bm25_params_sane(const Snapshot& s, const ps_scorer_desc& sc, const double* boosts) {
   bool sane = s.n_docs > 0 && std::isfinite(sc.bm25_k1) && sc.bm25_k1 >= 0.0 && sc.bm25_b >= 0.0 && sc.bm25_b <= 1.0;
@@ -683,6 +686,46 @@ void compute_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   lb.k1 = sc.bm25_k1; lb.b = sc.bm25_b; lb.boosts = bv; lb.avg.assign(s.avg.begin(), s.avg.end()); lb.valid = true;
 }
 
+// zero_to_one: per (layer, field) the shortest field length among the postings that hold the term in
+// that field (0xFFFFFFFF = none does).  A record contributes (min(score/tf, 1) * tf) / max(field_length,
+// query_terms_len) <= score * (1 + 1e-12) / max(that minimum, query_terms_len).  Scorer-independent:
+// computed once per snapshot (incrementally for the layers a delta appended).
+void compute_z_bounds(EngineImpl& m) {
+  const Snapshot& s = *m.snap;
+  const size_t nl = s.layers.size(), F = s.F;
+  const size_t first = m.z_minfl.size() / std::max<size_t>(F, 1);
+  if (first == nl) return;
+  m.z_minfl.resize(nl * F, 0xFFFFFFFFu);
+  auto body = [&](size_t l) {
+    const LayerInfo& L = s.layers[l];
+    for (size_t x = 0; x < F; ++x) {
+      uint32_t mn = 0xFFFFFFFFu;
+      const uint32_t* tf = s.tf.data() + x * s.P + L.post_off;
+      const uint32_t* fl = s.fl.data() + x * s.P + L.post_off;
+      for (uint32_t i = 0; i < L.len; ++i)
+        if (tf[i] && fl[i] < mn) mn = fl[i];
+      m.z_minfl[l * F + x] = mn;
+    }
+  };
+  const unsigned n_thr = s.n_postings > (1u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+  if (n_thr <= 1 || nl - first < 1024) {
+    for (size_t l = first; l < nl; ++l) body(l);
+  } else {
+    std::atomic<size_t> next{first};
+    auto worker = [&]() {
+      for (;;) {
+        const size_t b0 = next.fetch_add(64);
+        if (b0 >= nl) break;
+        for (size_t l = b0; l < std::min(nl, b0 + 64); ++l) body(l);
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < n_thr; ++i) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+  }
+}
+
 // Upper bound of any posting score of plan entry `e` (list e.node), rounding included: the per-field
 // form pushes the maxima through the kernels' own expression (every operation is monotone), the joint
 // form bounds the real-number value and is inflated past the few roundings between them.
@@ -702,13 +745,14 @@ double entry_upper_bound(const EngineImpl& m, const ps_plan_entry& e, const doub
 // items ordered highest-bound lists first (rank-major), candidate slots query-major.  The per-query
 // part runs on the engine's small thread pool for large batches (it sits on the host's critical path:
 // at ~0.7 ms of GPU time per 1024-query batch, 0.3 ms of serial descriptor building would show).
-void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& dw) {
+template <typename UbFn>
+void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const bool multi, UbFn&& ub_of, DaatWork& dw) {
   const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size();
   constexpr double SLACK = 1.0 + 1e-9;  // the bounds are summed in another order than the scores
   dw.dentry.resize(ne);
   dw.qslot.assign(B + 1, 0);
   dw.rorder.resize(ne);
-  if (plan.multi_expansion) dw.dgroup.assign(ne, DGroup{}); else dw.dgroup.clear();
+  if (multi) dw.dgroup.assign(ne, DGroup{}); else dw.dgroup.clear();
   std::vector<uint32_t>& chunk = m.daat_chunk_of;
   std::vector<uint32_t>& nchunk = m.daat_nchunk_of;
   chunk.resize(ne);
@@ -722,12 +766,16 @@ void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& 
       const uint32_t n = e - b;
       ord.resize(n);
       ub.resize(n);
-      for (uint32_t i = 0; i < n; ++i) { ord[i] = i; ub[i] = entry_upper_bound(m, plan.entries[b + i], boosts); }
-      std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) { return ub[a] > ub[c]; });
+      for (uint32_t i = 0; i < n; ++i) { ord[i] = i; ub[i] = ub_of(ents[b + i], q); }
+      // equal bounds (zero_to_one: every list that occurs in some shortest field has the same one): the
+      // LONGER list ranks lower, so it is the one that becomes non-essential
+      std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) {
+        return ub[a] > ub[c] || (ub[a] == ub[c] && ents[b + a].len < ents[b + c].len);
+      });
       // group maxima over ALL entries (what the other query terms can add to a candidate)
       gmax.clear();
       for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t qt = plan.entries[b + i].qterm;
+        const uint32_t qt = ents[b + i].qterm;
         bool found = false;
         for (auto& g : gmax)
           if (g.first == qt) { g.second = std::max(g.second, ub[i]); found = true; }
@@ -741,30 +789,30 @@ void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& 
         d.ub = ub[i];
         dw.rorder[b + r] = b + i;
         // what every other entry can add: the other groups' maxima + the best other entry of its own group
-        const uint32_t qt = plan.entries[b + i].qterm;
+        const uint32_t qt = ents[b + i].qterm;
         double alt = 0.0, rest = 0.0;
-        if (plan.multi_expansion)
+        if (multi)
           for (uint32_t j = 0; j < n; ++j)
-            if (j != i && plan.entries[b + j].qterm == qt) alt = std::max(alt, ub[j]);
+            if (j != i && ents[b + j].qterm == qt) alt = std::max(alt, ub[j]);
         for (auto& g : gmax)
           if (g.first != qt) rest += g.second;
         d.others = (rest + alt) * SLACK;
         if (!(d.others >= 0.0)) d.others = INFINITY;
       }
-      if (plan.multi_expansion) {
+      if (multi) {
         // per entry: the dense ordinal of its query term and the (inflated) bound of the next list of the
         // same term in rank order - what k_daat's pass 1 falls back to once this list has been looked at
         for (uint32_t r = 0; r < n; ++r) {
           const uint32_t i = ord[r];
           DGroup& dg = dw.dgroup[b + i];
-          const uint32_t qt = plan.entries[b + i].qterm;
+          const uint32_t qt = ents[b + i].qterm;
           uint32_t g = 0;
           while (g < gmax.size() && gmax[g].first != qt) ++g;
           dg.grp = gmax.size() <= 4 ? g : 0xFFFFFFFFu;
           dg.ub_s = ub[i] * SLACK;
           dg.nxt_s = 0.0;
           for (uint32_t r2 = r + 1; r2 < n; ++r2)
-            if (plan.entries[b + ord[r2]].qterm == qt) { dg.nxt_s = ub[ord[r2]] * SLACK; break; }
+            if (ents[b + ord[r2]].qterm == qt) { dg.nxt_s = ub[ord[r2]] * SLACK; break; }
         }
       }
       // skip thresholds: entries in ascending bound order; a document that only occurs in the first k
@@ -772,7 +820,7 @@ void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& 
       pm.clear();
       for (uint32_t r = n; r-- > 0;) {
         const uint32_t i = ord[r];
-        const uint32_t qt = plan.entries[b + i].qterm;
+        const uint32_t qt = ents[b + i].qterm;
         bool found = false;
         for (auto& g : pm)
           if (g.first == qt) { g.second = std::max(g.second, ub[i]); found = true; }
@@ -785,7 +833,7 @@ void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& 
       }
       uint32_t slots = 0;
       for (uint32_t i = b; i < e; ++i) {
-        const uint32_t len = plan.entries[i].len;
+        const uint32_t len = ents[i].len;
         // (a fixed chunk for every list measured slower: C2 0.563 vs 0.536 ms, C4 2.16 vs 1.90 ms - the
         // long low-bound lists are skipped whole, and fewer, larger skips are cheaper)
         const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + 63) / 64 + 255) & ~255u);
@@ -815,7 +863,7 @@ void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& 
     const uint32_t n0 = cnt[1];
     for (size_t i = 0; i < ne; ++i) eo[cnt[dw.dentry[i].rank]++] = (uint32_t)i;
     std::sort(eo.begin(), eo.begin() + n0, [&](uint32_t a, uint32_t c) {
-      if (plan.entries[a].len != plan.entries[c].len) return plan.entries[a].len > plan.entries[c].len;
+      if (ents[a].len != ents[c].len) return ents[a].len > ents[c].len;
       return a < c;
     });
   }
@@ -829,7 +877,7 @@ void plan_daat(EngineImpl& m, const double* boosts, const Plan& plan, DaatWork& 
   dw.items.resize(dw.qslot[B]);
   size_t at = 0;
   for (uint32_t i : eo) {
-    const uint32_t len = plan.entries[i].len;
+    const uint32_t len = ents[i].len;
     for (uint32_t k = 0; k < nchunk[i]; ++k)
       dw.items[at++] = DItem{i, k * chunk[i], std::min(chunk[i], len - k * chunk[i]), first_slot[i] + k};
   }
@@ -1163,20 +1211,65 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     fprintf(stderr, "[ps]   stage %-10s %.3f ms\n", what, n - tsp);
     tsp = n;
   };
-  if (topk_path && !sync_path_small(plan) && sc.kind == PS_SCORER_BM25 && m.tune.daat && m.tune.lut &&
-      plan.qbeg.size() - 1 >= m.tune.daat_min_batch && !plan.entries.empty() && bm25_params_sane(s, sc, boosts) &&
+  const bool daat_batch = topk_path && m.tune.daat && plan.qbeg.size() - 1 >= m.tune.daat_min_batch && !plan.entries.empty();
+  if (daat_batch && sc.kind == PS_SCORER_BM25 && m.tune.lut && bm25_params_sane(s, sc, boosts) &&
       (!plan.multi_expansion || m.tune.daat_multi)) {
     compute_list_bounds(m, sc, boosts);
-    plan_daat(m, boosts, plan, dw);
+    plan_daat(m, plan, plan.entries.data(), plan.multi_expansion,
+              [&](const ps_plan_entry& e, size_t) { return entry_upper_bound(m, e, boosts); }, dw);
     use_daat = !dw.items.empty();
   }
+  // zero_to_one: whether the batch qualifies is only known after the queries are classified, which
+  // needs the staged image; reserve the descriptors' space now (their sizes do not depend on it)
+  const bool z_daat_maybe = daat_batch && sc.kind == PS_SCORER_ZERO_TO_ONE && m.tune.daat_z21 && (s.F == 1 || s.F == 2) &&
+                            s.n_docs > 0 && !plan.multi_expansion && plan.max_entries <= 64;
+  if (z_daat_maybe) {
+    const size_t ne = plan.entries.size();
+    size_t n_items = 0;
+    for (size_t i = 0; i < ne; ++i) {
+      const uint32_t len = plan.entries[i].len;
+      const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + 63) / 64 + 255) & ~255u);
+      n_items += (len + c - 1) / c;
+    }
+    dw.dentry.resize(ne); dw.rorder.resize(ne); dw.qslot.resize(plan.qbeg.size()); dw.items.resize(n_items); dw.dgroup.clear();
+  }
   SP("daat");
-  BatchImage img = lay_out_batch(m, sc, plan, use_daat ? &dw : nullptr);
+  BatchImage img = lay_out_batch(m, sc, plan, (use_daat || z_daat_maybe) ? &dw : nullptr);
+  if (z_daat_maybe) img.daat = false;  // decided below
   SP("layout");
   const size_t B = img.B;
   const bool z = img.z;
   if (!img.daat) order_queries(m, plan, img);  // (K1d has its own item order)
   if (z) classify_zero_to_one(m, plan, img);
+  if (z_daat_maybe && img.n_general == 0 && img.z_masked == 0 && img.n_simple == B) {
+    // every query is "simple": K1dz.  Bounds from the entries as uploaded (record-sort order).
+    compute_z_bounds(m);
+    if (m.z_layer_of.size() != s.layers.size()) {
+      m.z_layer_of.clear();
+      for (size_t l = 0; l < s.layers.size(); ++l) m.z_layer_of.emplace(s.layers[l].post_off, (uint32_t)l);
+    }
+    const uint32_t F = s.F;
+    plan_daat(m, plan, img.he, false, [&](const ps_plan_entry& e, size_t q) {
+      const uint32_t l = m.z_layer_of.at(e.post_off);
+      const uint32_t qtl = plan.qterms_len[q];
+      double ub = 0.0;
+      for (uint32_t x = 0; x < F; ++x) {
+        const uint32_t mn = m.z_minfl[(size_t)l * F + x];
+        if (mn == 0xFFFFFFFFu) continue;
+        ub = std::max(ub, e.boost * (1.0 + 1e-12) / (double)std::max(mn, qtl));
+      }
+      return ub;
+    }, dw);
+    if (dw.items.size() == img.n_ditems && !dw.items.empty()) {
+      const size_t ne = plan.entries.size();
+      memcpy(img.h + img.off_d, dw.dentry.data(), ne * sizeof(DEntry));
+      memcpy(img.h + img.off_i, dw.items.data(), img.n_ditems * sizeof(DItem));
+      memcpy(img.h + img.off_s, dw.qslot.data(), (B + 1) * 4);
+      memcpy(img.h + img.off_ro, dw.rorder.data(), ne * 4);
+      img.daat = true;
+      use_daat = true;
+    }
+  }
   SP("order");
   select_dense_rows(m, sc, boosts, plan, img);
   SP("rows");
@@ -1414,6 +1507,14 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
   } else {
     launch_rows(kp, m.build_slots, st);
     if (mid) PS_HIP(hipEventRecord(mid, st));
+    if (!FULL && kp.n_ditems) {  // K1dz: every query of the batch is simple
+      const uint32_t n_wg = (kp.n_ditems + 7) / 8;
+      if (kp.F == 1) hipLaunchKernelGGL((k_daat_z<1>), dim3(n_wg), dim3(WAVE * 8), 0, st, kp);
+      else hipLaunchKernelGGL((k_daat_z<2>), dim3(n_wg), dim3(WAVE * 8), 0, st, kp);
+      m.score_kernel_name = kp.F == 1 ? "ps::k_daat_z<1>" : "ps::k_daat_z<2>";
+      PS_HIP(hipGetLastError());
+      return;
+    }
     if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(m, kp, kp.z_masked != 0, n_cu, st);
     if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget

@@ -1552,6 +1552,255 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// K1dz: k_daat_z - the same exact dynamic pruning for zero_to_one, "simple" queries (one entry per
+// query term, one version layer; a node repeated in the query is the tf >= k rule, as in
+// k_score<MODE_Z21S>).  A record contributes (min(score/tf, 1) * tf) / max(field_length, query_terms_len)
+// to the pool of its field (zero_to_one.rs:117-120), the pools are summed in the record-sort order
+// (the entries of such a query are uploaded in that order) and the document scores the best pool
+// (:122).  Bound of a list: score * (1 + 1e-12) / max(shortest field that holds the term, query terms);
+// a document scores at most the sum over its lists of their best field's contribution, which is what
+// pass 1 tracks.  Pass 2 rebuilds the per-field pools of the survivors in record-sort order.
+// ------------------------------------------------------------------------------------------
+template <int F_, int U>
+__device__ __forceinline__ void posting_contribs_z(const KParams& p, const uint64_t (&pi)[U], const bool (&on)[U], const double sc,
+                                                   const uint32_t need, const uint32_t qtl, double (&c)[U][F_]) {
+  uint32_t tfv[U][F_], flv[U][F_];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int x = 0; x < F_; ++x) {
+      tfv[u][x] = 0; flv[u][x] = 1;
+      if (on[u]) { tfv[u][x] = p.tf[(uint64_t)x * p.P + pi[u]]; flv[u][x] = p.fl[(uint64_t)x * p.P + pi[u]]; }
+    }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int x = 0; x < F_; ++x) {
+      const uint32_t tfu = tfv[u][x], flu = flv[u][x];
+      const double df = (double)tfu;
+      const uint32_t den = flu > qtl ? flu : qtl;
+      const double v = fmin(sc / df, 1.0) * df / (double)den;  // zero_to_one.rs:117-120, same association as k_score
+      c[u][x] = (on[u] && tfu >= need && tfu > 0) ? v : 0.0;
+    }
+}
+
+template <int F_, int U>
+__device__ __forceinline__ void lookup_contribs_z(const KParams& p, const ps_plan_entry& en, const uint32_t (&d)[U],
+                                                  const bool (&on)[U], const uint32_t qtl, double (&c)[U][F_]) {
+  if (en.shift & DENSE_FLAG) {  // one row plane per field, already the contribution (0.0 = none)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int x = 0; x < F_; ++x)
+        c[u][x] = on[u] ? p.rows[((uint64_t)en.node * F_ + x) * p.row_stride + d[u]] : 0.0;
+    return;
+  }
+  bool found[U];
+  uint64_t pi[U];
+  if (en.bm_off != 0xFFFFFFFFu) {
+    uint2 cell[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      cell[u] = on[u] ? *reinterpret_cast<const uint2*>(p.bits + (uint64_t)en.bm_off + 2 * (uint64_t)(d[u] >> 5)) : make_uint2(0u, 0u);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t bit = d[u] & 31u;
+      found[u] = on[u] && ((cell[u].x >> bit) & 1u);
+      pi[u] = en.post_off + cell[u].y + (uint32_t)__popc(cell[u].x & ((1u << bit) - 1u));
+    }
+  } else {
+    const uint32_t* docs = p.doc + en.post_off;
+    uint32_t lo[U], hi[U], end[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      lo[u] = 0; hi[u] = 0; end[u] = 0;
+      if (on[u]) {
+        const uint32_t slot = (d[u] >> p.t_log2) >> (en.shift & 0xFFu);
+        lo[u] = p.table[en.tbl_off + slot];
+        end[u] = p.table[en.tbl_off + slot + 1];
+        hi[u] = end[u];
+      }
+    }
+    bool more = true;  // wave-uniform
+    while (more) {
+      uint32_t v[U], mid[U];
+      bool act[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        act[u] = lo[u] < hi[u];
+        mid[u] = (lo[u] + hi[u]) >> 1;
+        v[u] = act[u] ? docs[mid[u]] : 0u;
+      }
+      bool any_act = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (act[u]) { if (v[u] < d[u]) lo[u] = mid[u] + 1; else hi[u] = mid[u]; }
+        any_act |= lo[u] < hi[u];
+      }
+      more = __any(any_act);
+    }
+    uint32_t chk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) chk[u] = (on[u] && lo[u] < end[u]) ? docs[lo[u]] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { found[u] = on[u] && lo[u] < end[u] && chk[u] == d[u]; pi[u] = en.post_off + (found[u] ? lo[u] : 0u); }
+  }
+  // en.boost = ScoreByTerm::score, en.qterm_index low 16 bits = occurrence rank of the node (the pool rule)
+  posting_contribs_z<F_, U>(p, pi, found, en.boost, en.qterm_index & 0xFFFFu, qtl, c);
+}
+
+template <int F_>
+__global__ __launch_bounds__(WAVE * 8) void k_daat_z(const KParams p) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t id = blockIdx.x * 8u + (uint32_t)wave;  // one wave per item (the grid covers every item)
+  if (id >= p.n_ditems) return;
+  const DItem it = p.ditems[p.item_base + id];
+  const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
+  const ps_plan_entry& own = p.plan[e_own];
+  const DEntry de = p.dentry[e_own];
+  const uint32_t q = __builtin_amdgcn_readfirstlane(de.q);
+  const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
+  const uint32_t qtl = p.qterms_len[q];
+  const double own_sc = own.boost;
+  const uint32_t own_need = own.qterm_index & 0xFFFFu;
+  const uint64_t own_off = own.post_off;
+  const uint32_t own_rank = de.rank;
+  const double skip_thr = de.skip_thr, others = de.others;
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+  double published = 0.0;
+  const uint32_t end = it.begin + it.count;
+  bool essential = true;  // wave-uniform
+  for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
+    const unsigned long long tbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)),
+                                          __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits));
+    essential = !(skip_thr < theta);
+    uint32_t d[U];
+    uint64_t pi[U];
+    bool alive[U];
+    double c_own[U][F_];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + u * WAVE + lane;
+      alive[u] = essential && i < end;
+      pi[u] = own_off + (i < end ? i : end - 1);
+      d[u] = p.doc[pi[u]];
+    }
+    if (p.alive != nullptr) {  // delta removals
+#pragma unroll
+      for (int u = 0; u < U; ++u) alive[u] = alive[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
+    }
+    posting_contribs_z<F_, U>(p, pi, alive, own_sc, own_need, qtl, c_own);
+    double bound[U];
+    bool any_alive = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double best = 0.0;
+#pragma unroll
+      for (int x = 0; x < F_; ++x) best = fmax(best, c_own[u][x]);
+      // a posting that adds nothing here (tf below the node's occurrence rank) is not this list's document
+      alive[u] = alive[u] && best > 0.0 && (best + others >= theta);
+      bound[u] = best + others;
+      any_alive |= alive[u];
+    }
+    any_alive = __any(any_alive);
+    double P[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) P[u] = 0.0;
+    if (any_alive) {
+      const uint32_t ne = e1 - e0;
+      unsigned long long hits[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) hits[u] = 0ull;
+      // pass 1: highest-bound lists first; a list's bound is replaced by its best field's real contribution
+      for (uint32_t r = e0; r < e1 && any_alive; ++r) {
+        const uint32_t j = p.rorder[r];
+        if (j != e_own) {
+          const ps_plan_entry& en = p.plan[j];
+          const DEntry dj = p.dentry[j];
+          double c[U][F_];
+          lookup_contribs_z<F_, U>(p, en, d, alive, qtl, c);
+          bool any = false;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (alive[u]) {
+              double sj = 0.0;
+#pragma unroll
+              for (int x = 0; x < F_; ++x) sj = fmax(sj, c[u][x]);
+              bound[u] = (bound[u] - dj.ub) + sj;
+              if (sj > 0.0 && ne <= 64u) hits[u] |= 1ull << (j - e0);
+              if (bound[u] < theta || (sj > 0.0 && dj.rank < own_rank)) alive[u] = false;
+            }
+            any |= alive[u];
+          }
+          any_alive = __any(any);
+        }
+      }
+      // pass 2: the per-field pools of the survivors, summed in record-sort order (= entry order)
+      if (any_alive) {
+        double pool[U][F_];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int x = 0; x < F_; ++x) pool[u][x] = 0.0;
+        for (uint32_t j = e0; j < e1; ++j) {
+          const ps_plan_entry& en = p.plan[j];
+          double c[U][F_];
+          if (j == e_own) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int x = 0; x < F_; ++x) c[u][x] = c_own[u][x];
+          } else {
+            bool want[U];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              want[u] = alive[u] && (ne > 64u || ((hits[u] >> (j - e0)) & 1ull));
+              any |= want[u];
+#pragma unroll
+              for (int x = 0; x < F_; ++x) c[u][x] = 0.0;
+            }
+            if (__any(any)) lookup_contribs_z<F_, U>(p, en, d, want, qtl, c);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int x = 0; x < F_; ++x)
+              if (alive[u] && c[u][x] > 0.0) pool[u][x] += c[u][x];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          double best = 0.0;  // result.score = max(score_by_pool, result.score) from the dummy 0. (zero_to_one.rs:81,122)
+#pragma unroll
+          for (int x = 0; x < F_; ++x) best = fmax(pool[u][x], best);
+          P[u] = best;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool offer = alive[u] && P[u] > 0.0 && P[u] >= theta;
+        if (__any(offer)) topk_offer(tk, p.K, lane, alive[u] && P[u] > 0.0, P[u], d[u], theta);
+      }
+      if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta) {
+        published = tk.thr_s;
+        if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+      }
+    }
+  }
+  if ((uint32_t)lane < p.K) {
+    const uint64_t o = (uint64_t)it.slot * p.K + lane;
+    const bool ok = (uint32_t)lane < tk.n;
+    p.cand_score[o] = ok ? tk.s : 0.0;
+    p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
+    if (lane == 0) p.cand_cnt[it.slot] = tk.n;
+  }
+}
+
 // K3d: merge of the items' candidate lists of a query -> final top-K, doc id -> key.  A document is
 // evaluated by exactly one item, so the lists are disjoint.  Leaves the control words zeroed.
 __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge_items(const KParams p) {

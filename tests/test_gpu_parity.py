@@ -23,7 +23,8 @@ def scoring_kernel(request, monkeypatch):
     K1 k_score (PS_DAAT=0; still the kernel of full-result mode, zero_to_one, small batches and
     non-positive boosts).  The knob is read when a snapshot's engine is created."""
     monkeypatch.setenv("PS_DAAT", "1" if request.param == "daat" else "0")
-    monkeypatch.setenv("PS_DAAT_MULTI", "1")  # K1d's multi-expansion arm is off by default (K1 is faster there): test it anyway
+    monkeypatch.setenv("PS_DAAT_MULTI", "1")
+    monkeypatch.setenv("PS_DAAT_Z21", "1" if request.param == "daat" else "0")  # K1dz is off by default (slower than K1): test it anyway
     return request.param
 
 
