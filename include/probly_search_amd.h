@@ -135,6 +135,12 @@ const char* ps_last_error(void);
 void ps_free(void* p);
 /* Number of visible HIP devices (0 if none / HIP unusable). */
 int ps_device_count(void);
+/* Tuning knobs by name - the PS_* names listed in DESIGN.md section 11 (e.g. "PS_DAAT", "PS_ROW_CACHE_MB",
+ * "PS_DENSE_MIN_USES").  A value set here wins over the environment variable of the same name; knobs are
+ * read when a snapshot's engine is created (ps_index_snapshot*, ps_snapshot_load), so set them before.
+ * ps_get_option returns 1 and the effective override / environment value, 0 if the knob is at its default. */
+ps_status ps_set_option(const char* name, uint32_t value);
+int ps_get_option(const char* name, uint32_t* value);
 
 /* ------------------------------------------------------------------ index build side -------- */
 /* Index::new(fields_num)  (src/index.rs:37-39) */

@@ -117,6 +117,8 @@ SYMBOLS = {
     "ps_last_error": (C.c_char_p, []),
     "ps_free": (None, [_P]),
     "ps_device_count": (C.c_int, []),
+    "ps_set_option": (C.c_int, [C.c_char_p, C.c_uint32]),
+    "ps_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32)]),
     "ps_index_new": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
     "ps_index_new_with_capacity": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
     "ps_index_free": (None, [_P]),

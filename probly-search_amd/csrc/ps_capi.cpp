@@ -173,6 +173,17 @@ extern "C" {
 const char* ps_last_error(void) { return g_err.c_str(); }
 void ps_free(void* p) { free(p); }
 int ps_device_count(void) { return ps::device_count(); }
+ps_status ps_set_option(const char* name, uint32_t value) {
+  if (!name || strncmp(name, "PS_", 3) != 0) return fail(PS_EINVAL, "option names are the PS_* knob names");
+  ps::set_option(name, value);
+  return PS_OK;
+}
+int ps_get_option(const char* name, uint32_t* value) {
+  uint32_t v = 0;
+  if (!name || !ps::get_option(name, &v)) return 0;
+  if (value) *value = v;
+  return 1;
+}
 
 ps_status ps_index_new(size_t fields_num, ps_index** out) {
   return guard([&]() -> ps_status {

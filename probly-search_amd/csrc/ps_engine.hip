@@ -126,6 +126,8 @@ struct Tuning {
   uint32_t daat = 1;             // PS_DAAT: BM25 top-k batches take K1d k_daat (exact dynamic pruning)
   uint32_t daat_min_batch = 8;   // PS_DAAT_MIN_BATCH: smaller batches keep the k_score latency path
   uint32_t daat_chunk = 4096;    // PS_DAAT_CHUNK: smallest chunk of a list one item covers
+  uint32_t daat_chunk0 = 0;      // PS_DAAT_CHUNK0: chunk of a query's highest-bound list (0 = same rule as the others)
+  uint32_t daat_split_div = 64;  // PS_DAAT_SPLIT_DIV: a list is cut into at most this many chunks
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
   uint32_t daat_persistent = 0;  // PS_DAAT_PERSISTENT: persistent waves + item counter instead of one wave per item
   uint32_t daat_threads = 8;     // PS_DAAT_THREADS: host threads that build the K1d descriptors of a large batch
@@ -451,12 +453,38 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+std::mutex g_opt_mu;
+std::map<std::string, uint32_t>& option_overrides() {
+  static std::map<std::string, uint32_t> m;
+  return m;
+}
+
+// A tuning knob: ps_set_option (the ABI) wins over the environment variable of the same name.
 uint32_t env_u32(const char* name, uint32_t dflt) {
+  {
+    std::lock_guard<std::mutex> l(g_opt_mu);
+    auto it = option_overrides().find(name);
+    if (it != option_overrides().end()) return it->second;
+  }
   const char* v = getenv(name);
   if (!v || !*v) return dflt;
   return (uint32_t)strtoul(v, nullptr, 10);
 }
 }  // namespace
+
+void set_option(const char* name, uint32_t value) {
+  std::lock_guard<std::mutex> l(g_opt_mu);
+  option_overrides()[name] = value;
+}
+bool get_option(const char* name, uint32_t* value) {
+  std::lock_guard<std::mutex> l(g_opt_mu);
+  auto it = option_overrides().find(name);
+  if (it != option_overrides().end()) { *value = it->second; return true; }
+  const char* v = getenv(name);
+  if (!v || !*v) return false;
+  *value = (uint32_t)strtoul(v, nullptr, 10);
+  return true;
+}
 
 void Tuning::load() {
     dense_max_rows = env_u32("PS_DENSE_MAX_ROWS", dense_max_rows);
@@ -482,6 +510,8 @@ void Tuning::load() {
     daat_min_batch = env_u32("PS_DAAT_MIN_BATCH", daat_min_batch);
     daat_chunk = std::max(256u, env_u32("PS_DAAT_CHUNK", daat_chunk));
     daat_rows = env_u32("PS_DAAT_ROWS", daat_rows);
+    daat_chunk0 = env_u32("PS_DAAT_CHUNK0", daat_chunk0);
+    daat_split_div = std::max(1u, env_u32("PS_DAAT_SPLIT_DIV", daat_split_div));
     daat_persistent = env_u32("PS_DAAT_PERSISTENT", daat_persistent);
     daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
@@ -836,7 +866,12 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
         const uint32_t len = ents[i].len;
         // (a fixed chunk for every list measured slower: C2 0.563 vs 0.536 ms, C4 2.16 vs 1.90 ms - the
         // long low-bound lists are skipped whole, and fewer, larger skips are cheaper)
-        const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + 63) / 64 + 255) & ~255u);
+        // (the query's highest-bound list is always scanned: short chunks keep the launch's critical path -
+        // one wave scans one chunk - short; the other lists are mostly skipped whole)
+        const uint32_t div = m.tune.daat_split_div;
+        const uint32_t c = (dw.dentry[i].rank == 0 && m.tune.daat_chunk0)
+                               ? m.tune.daat_chunk0
+                               : std::max<uint32_t>(m.tune.daat_chunk, ((len + div - 1) / div + 255) & ~255u);
         chunk[i] = c;
         nchunk[i] = (len + c - 1) / c;
         slots += nchunk[i];
@@ -844,12 +879,21 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
       dw.qslot[q + 1] = slots;  // turned into a prefix sum below
     }
   };
+  static const bool trace_pd = getenv("PS_TRACE") && *getenv("PS_TRACE") == '2';
+  double tpd = trace_pd ? now_ms() : 0.0;
+  auto PD = [&](const char* what) {
+    if (!trace_pd) return;
+    const double n = now_ms();
+    fprintf(stderr, "[ps]     daat %-10s %.3f ms\n", what, n - tpd);
+    tpd = n;
+  };
   if (B >= 256 && m.tune.daat_threads > 1) {
     if (!m.pool || m.pool->size() != m.tune.daat_threads) m.pool.reset(new Pool(m.tune.daat_threads - 1));
     m.pool->run([&](unsigned part, unsigned parts) { per_query(B * part / parts, B * (part + 1) / parts); });
   } else {
     per_query(0, B);
   }
+  PD("per-query");
   for (size_t q = 0; q < B; ++q) dw.qslot[q + 1] += dw.qslot[q];
   // processing order: rank-major (every query's highest-bound list first), longest lists first within
   // a rank, so thresholds exist before the long low-bound lists come up and the launch ends on skips
@@ -874,6 +918,7 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
     uint32_t sl = dw.qslot[q];
     for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) { first_slot[i] = sl; sl += nchunk[i]; }
   }
+  PD("order");
   dw.items.resize(dw.qslot[B]);
   size_t at = 0;
   for (uint32_t i : eo) {
@@ -881,6 +926,7 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
     for (uint32_t k = 0; k < nchunk[i]; ++k)
       dw.items[at++] = DItem{i, k * chunk[i], std::min(chunk[i], len - k * chunk[i]), first_slot[i] + k};
   }
+  PD("items");
 }
 
 // qorder: K1 hands out the items of a run heaviest query first (longest-processing-time order).
@@ -1228,7 +1274,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     size_t n_items = 0;
     for (size_t i = 0; i < ne; ++i) {
       const uint32_t len = plan.entries[i].len;
-      const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + 63) / 64 + 255) & ~255u);
+      const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + m.tune.daat_split_div - 1) / m.tune.daat_split_div + 255) & ~255u);
       n_items += (len + c - 1) / c;
     }
     dw.dentry.resize(ne); dw.rorder.resize(ne); dw.qslot.resize(plan.qbeg.size()); dw.items.resize(n_items); dw.dgroup.clear();
@@ -1448,10 +1494,10 @@ void launch_daat(EngineImpl& m, KParams& kp, bool multi, int n_cu, hipStream_t s
 #define PS_DAAT(FV, MU)                                                                                  \
   do {                                                                                                   \
     const void* fn = reinterpret_cast<const void*>(&k_daat<FV, MU>);                                     \
-    const uint32_t per_cu = (uint32_t)(k_score_waves_per_cu(m, fn, 8, lds) / 8);                         \
+    const uint32_t per_cu = (uint32_t)(k_score_waves_per_cu(m, fn, DAAT_WGW, lds) / DAAT_WGW);                         \
     const uint32_t n_wg = m.tune.daat_persistent                                                         \
-        ? std::min<uint32_t>((kp.n_ditems + 7) / 8, std::max(1u, per_cu) * (uint32_t)n_cu)                 \
-        : (kp.n_ditems + 7) / 8;                                                                         \
+        ? std::min<uint32_t>((kp.n_ditems + DAAT_WGW - 1) / DAAT_WGW, std::max(1u, per_cu) * (uint32_t)n_cu)                 \
+        : (kp.n_ditems + DAAT_WGW - 1) / DAAT_WGW;                                                                         \
     char nm[96];                                                                                         \
     snprintf(nm, sizeof(nm), "ps::k_daat<%d, %s>", (int)(FV), (MU) ? "true" : "false");                  \
     m.score_kernel_name = nm;                                                                            \
@@ -1461,10 +1507,10 @@ void launch_daat(EngineImpl& m, KParams& kp, bool multi, int n_cu, hipStream_t s
       a.n_ditems = m.daat_first_items;                                                                   \
       b.item_base = m.daat_first_items;                                                                  \
       b.n_ditems = kp.n_ditems - m.daat_first_items;                                                     \
-      hipLaunchKernelGGL((k_daat<FV, MU>), dim3((a.n_ditems + 7) / 8), dim3(WAVE * 8), lds, st, a);      \
-      hipLaunchKernelGGL((k_daat<FV, MU>), dim3((b.n_ditems + 7) / 8), dim3(WAVE * 8), lds, st, b);      \
+      hipLaunchKernelGGL((k_daat<FV, MU>), dim3((a.n_ditems + DAAT_WGW - 1) / DAAT_WGW), dim3(WAVE * DAAT_WGW), lds, st, a);      \
+      hipLaunchKernelGGL((k_daat<FV, MU>), dim3((b.n_ditems + DAAT_WGW - 1) / DAAT_WGW), dim3(WAVE * DAAT_WGW), lds, st, b);      \
     } else {                                                                                             \
-      hipLaunchKernelGGL((k_daat<FV, MU>), dim3(n_wg), dim3(WAVE * 8), lds, st, kp);                     \
+      hipLaunchKernelGGL((k_daat<FV, MU>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);                     \
     }                                                                                                    \
   } while (0)
   if (multi) {

@@ -51,5 +51,8 @@ class Engine {
 };
 
 int device_count();
+// Tuning knobs by name (the PS_* names of DESIGN.md section 11); read when a snapshot's engine is created.
+void set_option(const char* name, uint32_t value);
+bool get_option(const char* name, uint32_t* value);
 
 }  // namespace ps

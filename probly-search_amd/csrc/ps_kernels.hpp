@@ -38,9 +38,13 @@ constexpr int WAVE = 64;
 #ifndef PS_DAAT_U
 #define PS_DAAT_U 4          // K1d: postings per lane whose lookups are in flight together
 #endif
+#ifndef PS_DAAT_WGW
+#define PS_DAAT_WGW 2        // K1d: waves per workgroup (they share the LUT copy; 8 / 4 / 2 measured 0.51 / 0.46 / 0.44 ms on C2: a workgroup holds its slots until its slowest wave ends)
+#endif
 #ifndef PS_ABLATE_BUILD
 #define PS_ABLATE_BUILD 0    // profiling builds only: honour KParams::ablate in the hot loops
 #endif
+constexpr int DAAT_WGW = PS_DAAT_WGW;
 constexpr int UNROLL = PS_UNROLL;
 constexpr int WG_WAVES = PS_WG_WAVES;   // each wave owns its own LDS tile
 constexpr int MERGE_WAVES = 16;         // most waves per workgroup of K3 (the host sizes it to the candidates)
@@ -1239,7 +1243,7 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
 }
 
 template <int F_, bool MULTI>
-__global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
+__global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int U = (F_ && !MULTI) ? PS_DAAT_U : 2;  // postings per lane in flight (the multi-expansion arm keeps per-term maxima per posting)
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1248,11 +1252,11 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
   // in index order, so the processing order still holds approximately); otherwise the waves are
   // persistent and pull items from the device-scope counter.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const bool by_index = p.n_ditems <= gridDim.x * 8u;
+  const bool by_index = p.n_ditems <= gridDim.x * (uint32_t)DAAT_WGW;
   if (by_index) {
     // most workgroups of a launch only hold chunks of lists that are already non-essential: they
     // leave before they stage the LUT
-    const uint32_t id = blockIdx.x * 8u + (uint32_t)wave;
+    const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
     int need = 0;
     if (id < p.n_ditems) {
       const DEntry de = p.dentry[p.ditems[p.item_base + id].entry];
@@ -1266,7 +1270,7 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
   }
   {
     double* l = reinterpret_cast<double*>(smem);
-    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * 8) l[i] = p.lut[i];
+    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * DAAT_WGW) l[i] = p.lut[i];
     __syncthreads();  // the last workgroup-level synchronisation
   }
   bool first = true;
@@ -1275,7 +1279,7 @@ __global__ __launch_bounds__(WAVE * 8) void k_daat(const KParams p) {
     if (by_index) {
       if (!first) break;
       first = false;
-      id = blockIdx.x * 8u + (uint32_t)wave;
+      id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
     } else {
       if (lane == 0) id = atomicAdd(p.work_counter, 1u);
       id = __builtin_amdgcn_readfirstlane(id);
