@@ -88,7 +88,7 @@ def main():
         res["lds_issue"] = {"per_launch": g("SQ_ACTIVE_INST_LDS") * 4, "unit": "CU-cycles", "scale": 1e9,
                             "peak": N_CU * clock / 1e9, "rate_unit": "G CU-cycles/s"}
         notes.append("lds_issue = SQ_ACTIVE_INST_LDS x 4 against %d CUs" % N_CU)
-    if g("SQ_ACTIVE_INST_VMEM") is not None:
+    if g("SQ_ACTIVE_INST_VMEM"):  # (reads 0 on this rocprofv3 / gfx950: then it is left out)
         res["vmem_issue"] = {"per_launch": g("SQ_ACTIVE_INST_VMEM") * 4, "unit": "CU-cycles", "scale": 1e9,
                              "peak": N_CU * clock / 1e9, "rate_unit": "G CU-cycles/s"}
         notes.append("vmem_issue = SQ_ACTIVE_INST_VMEM x 4 against %d CUs (one vector-memory issue port per CU)" % N_CU)
