@@ -126,6 +126,7 @@ struct Tuning {
   uint32_t daat = 1;             // PS_DAAT: BM25 top-k batches take K1d k_daat (exact dynamic pruning)
   uint32_t daat_min_batch = 8;   // PS_DAAT_MIN_BATCH: smaller batches keep the k_score latency path
   uint32_t daat_chunk = 4096;    // PS_DAAT_CHUNK: smallest chunk of a list one item covers
+  uint32_t daat_dense_min_density_pct = 40;  // PS_DAAT_DENSE_MIN_DENSITY_PCT
   uint32_t daat_chunk0 = 0;      // PS_DAAT_CHUNK0: chunk of a query's highest-bound list (0 = same rule as the others)
   uint32_t daat_split_div = 64;  // PS_DAAT_SPLIT_DIV: a list is cut into at most this many chunks
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
@@ -206,7 +207,7 @@ struct EngineImpl {
   PlanTotals* h_totals = nullptr;  // pinned
   std::unique_ptr<Pool> pool;  // K1d descriptor building for large batches
   struct DaatWork* daat_work = nullptr;  // reused across batches (defined below)
-  std::vector<uint32_t> daat_chunk_of, daat_nchunk_of, daat_entry_order, daat_first_slot;
+  std::vector<uint32_t> daat_chunk_of, daat_nchunk_of, daat_entry_order, daat_first_slot, daat_item_at;
   uint32_t daat_max_slots = 0;
   uint32_t daat_first_items = 0;  // K1d: items of the queries' rank-0 lists (they lead the item order)  // K1d: most candidate slots of one query in the batch being enqueued
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
@@ -511,6 +512,7 @@ void Tuning::load() {
     daat_chunk = std::max(256u, env_u32("PS_DAAT_CHUNK", daat_chunk));
     daat_rows = env_u32("PS_DAAT_ROWS", daat_rows);
     daat_chunk0 = env_u32("PS_DAAT_CHUNK0", daat_chunk0);
+    daat_dense_min_density_pct = env_u32("PS_DAAT_DENSE_MIN_DENSITY_PCT", daat_dense_min_density_pct);
     daat_split_div = std::max(1u, env_u32("PS_DAAT_SPLIT_DIV", daat_split_div));
     daat_persistent = env_u32("PS_DAAT_PERSISTENT", daat_persistent);
     daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
@@ -920,12 +922,24 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
   }
   PD("order");
   dw.items.resize(dw.qslot[B]);
-  size_t at = 0;
-  for (uint32_t i : eo) {
-    const uint32_t len = ents[i].len;
-    for (uint32_t k = 0; k < nchunk[i]; ++k)
-      dw.items[at++] = DItem{i, k * chunk[i], std::min(chunk[i], len - k * chunk[i]), first_slot[i] + k};
+  // item ranges of the entries in processing order, then the (independent) fills - on the pool for large batches
+  std::vector<uint32_t>& item_at = m.daat_item_at;
+  item_at.resize(ne + 1);
+  {
+    uint32_t at = 0;
+    for (size_t k = 0; k < ne; ++k) { item_at[k] = at; at += nchunk[eo[k]]; }
+    item_at[ne] = at;
   }
+  auto fill = [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; ++k) {
+      const uint32_t i = eo[k];
+      const uint32_t len = ents[i].len, c = chunk[i], fs = first_slot[i];
+      DItem* out = dw.items.data() + item_at[k];
+      for (uint32_t j = 0; j < nchunk[i]; ++j) out[j] = DItem{i, j * c, std::min(c, len - j * c), fs + j};
+    }
+  };
+  if (B >= 256 && m.tune.daat_threads > 1 && m.pool) m.pool->run([&](unsigned part, unsigned parts) { fill(ne * part / parts, ne * (part + 1) / parts); });
+  else fill(0, ne);
   PD("items");
 }
 
@@ -1049,7 +1063,8 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
         sane = std::isfinite(boosts[x]) && boosts[x] > 0.0 && std::isfinite(s.avg[x]) && s.avg[x] > 0.0;
     }
     const uint32_t min_uses = m.tune.dense_min_uses;
-    const double min_density = m.tune.dense_min_density_pct / 100.0;
+    // (K1d only looks rows up: below ~40 % density the bitmap cell + posting is as good as the row costs to build)
+    const double min_density = (img.daat ? std::max(m.tune.dense_min_density_pct, m.tune.daat_dense_min_density_pct) : m.tune.dense_min_density_pct) / 100.0;
     const uint32_t planes = z ? s.F : 1u;
     if (sane && ne) {
       struct Key { uint64_t post_off, w, k3; };
@@ -1154,6 +1169,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
           if (z && !(qf[q] & 1u)) continue;
           const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
           for (uint32_t i = b; i < e; ++i) {
+            if ((double)he[i].len < min_density * (double)s.n_ids) continue;  // never a row candidate: no map lookup
             auto it = row_of.find(key_of(he[i], q));
             if (it != row_of.end()) { he[i].shift |= DENSE_FLAG; he[i].node = it->second; }
           }

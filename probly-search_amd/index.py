@@ -310,13 +310,22 @@ class Snapshot:
         except PsError as e:
             _raise(e)
 
+    def _cached_args(self, score_calculator, fields_boost):
+        """ctypes descriptor + boosts array for a serving loop that repeats the same scorer / boosts."""
+        key = (score_calculator.kind, float(score_calculator.bm25k1), float(score_calculator.bm25b), tuple(fields_boost))
+        hit = getattr(self, "_arg_cache", None)
+        if hit is None or hit[0] != key:
+            b, nb = _boosts(fields_boost)
+            hit = (key, _scorer_desc(score_calculator), b, nb)
+            self._arg_cache = hit
+        return hit[1], hit[2], hit[3]
+
     def query_batch_allgather_flat(self, comm, text, offsets, score_calculator, fields_boost, top_k, d_local_block,
                                    d_all_blocks, stream=None):
         """ps_snapshot_query_batch_allgather_flat: score this rank's shard into d_local_block and
         all-gather every rank's block into d_all_blocks (ncclAllGather inside the library, ordered on
         `stream`).  comm: dist.Comm or None (one rank: no collective)."""
-        desc = _scorer_desc(score_calculator)
-        b, nb = _boosts(fields_boost)
+        desc, b, nb = self._cached_args(score_calculator, fields_boost)
         try:
             _lib.check(self._L.ps_snapshot_query_batch_allgather_flat(
                 self._h, comm._h if comm is not None else None, C.byref(desc), text.ctypes.data, offsets.ctypes.data,
