@@ -132,6 +132,7 @@ struct Tuning {
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
   uint32_t daat_persistent = 0;  // PS_DAAT_PERSISTENT: persistent waves + item counter instead of one wave per item
   uint32_t daat_threads = 8;     // PS_DAAT_THREADS: host threads that build the K1d descriptors of a large batch
+  uint32_t z21_field_prune = 1;  // PS_Z21_FIELD_PRUNE: k_score<MODE_Z21S> drops fields whose pool bound fell below the query's threshold
   uint32_t daat_z21 = 0;         // PS_DAAT_Z21: zero_to_one top-k batches of simple queries take K1dz k_daat_z (off: K1 is 3x faster)
   uint32_t daat_multi = 1;       // PS_DAAT_MULTI: also take batches with several expansions per query term (0: they stay on K1)
   uint32_t daat_split = 0;       // PS_DAAT_SPLIT: the queries' highest-bound lists in a launch of their own, first
@@ -518,6 +519,7 @@ void Tuning::load() {
     daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
     daat_z21 = env_u32("PS_DAAT_Z21", daat_z21);
+    z21_field_prune = env_u32("PS_Z21_FIELD_PRUNE", z21_field_prune);
     daat_threads = std::max(1u, std::min(env_u32("PS_DAAT_THREADS", daat_threads), std::max(1u, std::thread::hardware_concurrency())));
 }
 
@@ -589,6 +591,7 @@ struct BatchImage {
   // K1d
   bool daat = false;
   size_t off_d = 0, off_i = 0, off_s = 0, off_ro = 0, off_dg = 0, n_ditems = 0;
+  size_t off_zf = 0;  // zero_to_one: per-query per-field pool bounds (k_score's field pruning)
 };
 
 }  // namespace
@@ -616,6 +619,10 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
   img.off_g = img.off_f + B * 4;
   img.off_r = (img.off_g + B * 4 + 15) & ~(size_t)15;
   img.total = img.off_r + (size_t)m.tune.dense_max_rows * sizeof(RowDesc);
+  if (img.z) {
+    img.off_zf = (img.total + 15) & ~(size_t)15;
+    img.total = img.off_zf + B * m.snap->F * sizeof(double);
+  }
   if (dw) {
     img.daat = true;
     img.n_ditems = dw->items.size();
@@ -1303,6 +1310,30 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const bool z = img.z;
   if (!img.daat) order_queries(m, plan, img);  // (K1d has its own item order)
   if (z) classify_zero_to_one(m, plan, img);
+  bool z_field_bounds = false;
+  if (z && topk_path && m.tune.z21_field_prune && img.n_simple && s.n_docs > 0 && !plan.entries.empty()) {
+    // per query and field: no document's pool of that field can exceed the sum over the query's lists of
+    // score / max(shortest such field holding the term, query terms)
+    compute_z_bounds(m);
+    if (m.z_layer_of.size() != s.layers.size()) {
+      m.z_layer_of.clear();
+      for (size_t l = 0; l < s.layers.size(); ++l) m.z_layer_of.emplace(s.layers[l].post_off, (uint32_t)l);
+    }
+    double* zf = reinterpret_cast<double*>(img.h + img.off_zf);
+    const uint32_t F = s.F;
+    for (size_t q = 0; q < img.B; ++q) {
+      for (uint32_t x = 0; x < F; ++x) {
+        double sum = 0.0;
+        for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
+          const ps_plan_entry& e = img.he[i];
+          const uint32_t mn = m.z_minfl[(size_t)m.z_layer_of.at(e.post_off) * F + x];
+          if (mn != 0xFFFFFFFFu) sum += e.boost * (1.0 + 1e-12) / (double)std::max(mn, plan.qterms_len[q]);
+        }
+        zf[q * F + x] = sum * (1.0 + 1e-9);
+      }
+    }
+    z_field_bounds = true;
+  }
   if (z_daat_maybe && img.n_general == 0 && img.z_masked == 0 && img.n_simple == B) {
     // every query is "simple": K1dz.  Bounds from the entries as uploaded (record-sort order).
     compute_z_bounds(m);
@@ -1354,7 +1385,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   } else {
     // one upload: the device image has the staging layout (entries | qbeg | qterms_len | qorder | zorder | qflags)
     m.d_stage.ensure(total + 64);
-    const size_t up_bytes = img.daat ? total : n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z);
+    const size_t up_bytes = (img.daat || z_field_bounds) ? total : n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z);
     if (m.tune.kernel_upload && up_bytes <= ((size_t)4 << 20)) {
       const size_t n16 = (up_bytes + 15) / 16;  // slot and device buffer are both padded past `total`
       const uint32_t blocks = (uint32_t)std::min<size_t>(256, (n16 + 255) / 256);
@@ -1384,6 +1415,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const uint64_t layout_bytes = layout_bytes_of(m, img);
   kp.row_desc = reinterpret_cast<const RowDesc*>(dbase + off_r);
   kp.n_rows = n_rows;
+  kp.zfub = z_field_bounds ? reinterpret_cast<const double*>(dbase + img.off_zf) : nullptr;
   if (img.daat) {
     kp.dentry = reinterpret_cast<const DEntry*>(dbase + img.off_d);
     kp.ditems = reinterpret_cast<const DItem*>(dbase + img.off_i);

@@ -99,6 +99,7 @@ struct KParams {
   const uint32_t* qflags;      // zero_to_one: bit 0 = "simple" query (k_score<MODE_Z21S> owns it)
   uint32_t slice_bytes;        // per-wave LDS for the table slices (0 = look ranges up in global memory)
   const uint32_t* zorder;      // zero_to_one: per query, entry indices sorted by (score desc, plan order)
+  const double* zfub;          // zero_to_one: [B][F] upper bound of any document's pool of field x for query q (null: none)
   uint64_t P;
   uint32_t B, n_tiles, T, S, n_super, K, n_docs, F, max_qterms, z_nodes, z_tile, z_qwords;
   double k1, k1p1, one_minus_b, b;
@@ -354,8 +355,10 @@ __device__ __forceinline__ void dense_chunk_z(const double* r, double* accx, uin
 
 template <bool MASKS, bool ASSIGN = false>
 __device__ __forceinline__ void dense_apply_z(const KParams& p, double* acc, uint32_t* zmask, const int lane,
-                                              const uint32_t row, const uint32_t tile_base, const uint32_t mask_bit) {
+                                              const uint32_t row, const uint32_t tile_base, const uint32_t mask_bit,
+                                              const uint32_t fmask = 0xFFFFFFFFu) {
   for (uint32_t x = 0; x < p.F; ++x) {
+    if (!((fmask >> x) & 1u)) continue;  // a field whose pool cannot reach the query's threshold any more
     const double* r = p.rows + ((uint64_t)row * p.F + x) * p.row_stride + tile_base;
     double* accx = acc + x * p.T;
     uint32_t* zmx = zmask + x * p.T;
@@ -435,12 +438,13 @@ struct EntryC {      // wave-uniform per-entry constants (SGPRs)
   uint32_t tag;      // BM25: visited tag of the entry's query term for the current tile
   double w0;         // BM25: idf              | Z21S: ScoreByTerm::score
   double w1;         // BM25: expansion_boost  | Z21S: unused
+  uint32_t fmask;    // Z21S: fields still worth accumulating for this item (bit x; see k_score)
 };
 
 template <int F_, int U>
 __device__ __forceinline__ void load_trip(const KParams& p, const int lane, const uint64_t post_off, const uint32_t i0,
                                           const uint32_t re, uint32_t (&dv)[U], uint32_t (&tfv)[U][F_ ? F_ : MAX_F],
-                                          uint32_t (&flv)[U][F_ ? F_ : MAX_F]) {
+                                          uint32_t (&flv)[U][F_ ? F_ : MAX_F], const uint32_t fmask = 0xFFFFFFFFu) {
   constexpr int FA = F_ ? F_ : MAX_F;
   const uint32_t F = F_ ? (uint32_t)F_ : p.F;
 #pragma unroll
@@ -451,8 +455,11 @@ __device__ __forceinline__ void load_trip(const KParams& p, const int lane, cons
 #pragma unroll
     for (int x = 0; x < FA; ++x) {
       if ((uint32_t)x < F) {
-        tfv[u][x] = p.tf[(uint64_t)x * p.P + pi];
-        flv[u][x] = p.fl[(uint64_t)x * p.P + pi];
+        // (a field that is out for this item - Z21S field pruning - re-reads plane 0: same cache lines,
+        // no branch in the load burst; score_trip ignores the values)
+        const uint64_t plane = ((fmask >> x) & 1u) ? (uint64_t)x * p.P : 0ull;
+        tfv[u][x] = p.tf[plane + pi];
+        flv[u][x] = p.fl[plane + pi];
       }
     }
   }
@@ -566,7 +573,7 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
           const uint32_t den = flu > qtl ? flu : qtl;
           const double c = fmin(ec.w0 / df, 1.0) * df / (double)den;
           // ec.tag = occurrence rank of the node (low 16 bits, >= 1: the pool rule) | query-term ordinal
-          bool take = ok[u] && tfu >= (ec.tag & 0xFFFFu);
+          bool take = ok[u] && tfu >= (ec.tag & 0xFFFFu) && ((ec.fmask >> x) & 1u);
           if (TAGS && (ec.tag >> 31)) {  // bit 31: this query has query terms with several expansions
             // consumed_index (zero_to_one.rs:101-103): the first record of a query term (in sorted
             // order, which is the order entries are processed in) that hits this (doc, field)
@@ -599,11 +606,11 @@ __device__ __forceinline__ void score_stream(const KParams& p, const double* lut
     // full trips, double-buffered
     uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
     uint32_t dn[UN], tfnx[UN][FA], flnx[UN][FA];
-    load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+    load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv, ec.fmask);
     while (re - i0 >= (uint32_t)(UN * WAVE)) {
       const uint32_t nx = i0 + UN * WAVE;
       const bool more = re - nx >= (uint32_t)(UN * WAVE);
-      if (more) load_trip<F_, UN>(p, lane, ec.post_off, nx, re, dn, tfnx, flnx);
+      if (more) load_trip<F_, UN>(p, lane, ec.post_off, nx, re, dn, tfnx, flnx, ec.fmask);
       score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
       if (more) {
 #pragma unroll
@@ -622,11 +629,11 @@ __device__ __forceinline__ void score_stream(const KParams& p, const double* lut
   if (i0 < re) {
     if (re - i0 > (uint32_t)WAVE) {
       uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
-      load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+      load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv, ec.fmask);
       score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
     } else {
       uint32_t dv[1], tfv[1][FA], flv[1][FA];
-      load_trip<F_, 1>(p, lane, ec.post_off, i0, re, dv, tfv, flv);
+      load_trip<F_, 1>(p, lane, ec.post_off, i0, re, dv, tfv, flv, ec.fmask);
       score_trip<MODE, F_, TAGS, 1>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
     }
   }
@@ -696,12 +703,26 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
   const bool mine = MODE == MODE_BM25 || (p.qflags[q] & 1u);  // Z21S: only "simple" queries
   if (MODE == MODE_Z21S && !mine) continue;                   // k_z21 owns this query's candidate slots
   const uint32_t qtl = MODE == MODE_Z21S ? p.qterms_len[q] : 0u;
+  // zero_to_one, top-k: a document scores the best of its per-field pools, and the pool of field x is at
+  // most zfub[q][x] (sum over the query's lists of score / max(shortest field x holding the term, query
+  // terms)).  Once the query's threshold - a lower bound of its final K-th best score, published by the
+  // runs that finished - exceeds that, field x cannot decide any top-K score: it is not accumulated,
+  // not loaded and not harvested for this item (exact: such pools lose the max against any score that
+  // can still be returned).  With every field out the item is skipped whole.
+  uint32_t fmask = 0xFFFFFFFFu;
+  if (MODE == MODE_Z21S && !FULL && p.zfub != nullptr) {
+    const double th = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const double thu = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(th)), __builtin_amdgcn_readfirstlane(__double2loint(th)));
+    for (uint32_t x = 0; x < F; ++x)
+      if (thu > p.zfub[(uint64_t)q * F + x]) fmask &= ~(1u << x);
+  }
+  const bool item_dead = MODE == MODE_Z21S && (fmask & ((1u << F) - 1u)) == 0u;
   const bool q_assign = !TAGS && ne != 0 && (p.plan[e0].shift & DENSE_ASSIGN_FLAG);
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
 
-  if (ne != 0) {
+  if (ne != 0 && !item_dead) {
     const uint32_t t_begin = sup * p.S;
     const uint32_t t_end = min(p.n_tiles, t_begin + p.S);
     // Table slices: the [rb, re) range of every (entry, tile of this run), fetched once with
@@ -736,6 +757,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         ec[g].shift = en.shift & 0xFFu;                                                                         \
         ec[g].w0 = MODE == MODE_BM25 ? en.idf : en.boost;                                                       \
         ec[g].w1 = en.boost;                                                                                    \
+        ec[g].fmask = fmask;                                                                                    \
         ec_qterm[g] = MODE == MODE_Z21S ? en.qterm_index : en.qterm;                                            \
         ec_tbl[g] = en.tbl_off;                                                                                 \
         ec_row[g] = (en.shift & DENSE_FLAG) ? en.node : 0xFFFFFFFFu;                                            \
@@ -750,7 +772,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         rb[g] = p.table[ec_tbl[g] + slot];                                                                      \
         re[g] = p.table[ec_tbl[g] + slot + 1];                                                                  \
       }                                                                                                         \
-      if (rb[g] < re[g]) load_trip<F_, FU>(p, lane, ec[g].post_off, rb[g], re[g], dv[g], tfv[g], flv[g]);       \
+      if (rb[g] < re[g]) load_trip<F_, FU>(p, lane, ec[g].post_off, rb[g], re[g], dv[g], tfv[g], flv[g], fmask);\
     }                                                                                                           \
   }
     PS_PHASE1(t_begin, 0u, true)
@@ -769,9 +791,9 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
           else if (MODE == MODE_BM25) dense_apply<TAGS>(p, acc, tag, lane, ec_row[g], tile_base, (uint16_t)(tagbase + ec_qterm[g]));
           else if (!TAGS && F_ != 0 && (ec_flags[g] & DENSE_FUSE_FLAG)) fuse_row = ec_row[g];
           else if (!TAGS && F_ != 0 && (ec_flags[g] & DENSE_ASSIGN_FLAG))
-            dense_apply_z<false, true>(p, acc, reinterpret_cast<uint32_t*>(tag), lane, ec_row[g], tile_base, 0u);
+            dense_apply_z<false, true>(p, acc, reinterpret_cast<uint32_t*>(tag), lane, ec_row[g], tile_base, 0u, fmask);
           else dense_apply_z<TAGS>(p, acc, reinterpret_cast<uint32_t*>(tag), lane, ec_row[g], tile_base,
-                                   (ec_qterm[g] >> 31) ? (1u << ((ec_qterm[g] >> 16) & 31u)) : 0u);
+                                   (ec_qterm[g] >> 31) ? (1u << ((ec_qterm[g] >> 16) & 31u)) : 0u, fmask);
         } else if (rb[g] < re[g]) {
           dirty = true;
           ec[g].tag = MODE == MODE_Z21S ? ec_qterm[g] : tagbase + ec_qterm[g];
@@ -861,15 +883,18 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
 #pragma unroll
             for (int u = 0; u < ZU; ++u)
 #pragma unroll
-              for (int x = 0; x < (F_ ? FA : 1); ++x)
-                rv[u][x] = *reinterpret_cast<const double2*>(p.rows + ((uint64_t)fuse_row * F + x) * p.row_stride + tile_base +
+              for (int x = 0; x < (F_ ? FA : 1); ++x) {
+                // (a field that is out re-reads plane 0 of the row - same lines - and its value is dropped below)
+                const uint32_t xs = ((fmask >> x) & 1u) ? (uint32_t)x : 0u;
+                rv[u][x] = *reinterpret_cast<const double2*>(p.rows + ((uint64_t)fuse_row * F + xs) * p.row_stride + tile_base +
                                                              c + u * 2 * WAVE + 2 * lane);
+              }
           }
 #pragma unroll
           for (int u = 0; u < ZU; ++u)
 #pragma unroll
             for (int x = 0; x < FA; ++x)
-              if (F_ && (uint32_t)x < F) vv[u][x] = *reinterpret_cast<double2*>(&acc[(uint32_t)x * T + c + u * 2 * WAVE + 2 * lane]);
+              if (F_ && (uint32_t)x < F) vv[u][x] = *reinterpret_cast<double2*>(&acc[(uint32_t)x * T + c + u * 2 * WAVE + 2 * lane]);  // (a field that is out is never written: its plane reads zero)
 #pragma unroll
           for (int u = 0; u < ZU; ++u) {
             // result.score = max(score_by_pool, result.score) over fields, from the dummy 0. (zero_to_one.rs:81,122)
@@ -885,7 +910,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
                   *reinterpret_cast<double2*>(&acc[at]) = make_double2(0.0, 0.0);
                   if (TAGS) *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(tag) + at) = make_uint2(0u, 0u);
                 }
-                if (F_ != 0 && fused) { v.x += rv[u][F_ ? x : 0].x; v.y += rv[u][F_ ? x : 0].y; }  // last record, in sorted order
+                if (F_ != 0 && fused && ((fmask >> x) & 1u)) { v.x += rv[u][F_ ? x : 0].x; v.y += rv[u][F_ ? x : 0].y; }  // last record, in sorted order
                 h0 |= v.x > 0.0; h1 |= v.y > 0.0;
                 b0 = fmax(v.x, b0); b1 = fmax(v.y, b1);
               }

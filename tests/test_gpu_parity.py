@@ -339,6 +339,7 @@ def test_dense_rows_path_forced(seed, monkeypatch):
     must stay bit-identical, single- and multi-expansion (visited tags) queries alike."""
     monkeypatch.setenv("PS_DENSE_MIN_USES", "1")
     monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "0")
+    monkeypatch.setenv("PS_DAAT_DENSE_MIN_DENSITY_PCT", "0")
     F, steps, vocab = build_script(300 + seed, n_docs=400, fields=1 + seed % 2, vocab_size=25, shuffle_keys=seed % 2 == 1)
     o, p = orc.Index(F), ProductIndex(F)
     replay(steps, F, o, p)
@@ -394,6 +395,7 @@ def test_dense_rows_first_written_last_fused(fuse, fields, monkeypatch):
     terms included, non-unit boosts, tiles of 256 and 1024 documents."""
     monkeypatch.setenv("PS_DENSE_MIN_USES", "1")
     monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "30")  # only the head lists become rows: mixed plans
+    monkeypatch.setenv("PS_DAAT_DENSE_MIN_DENSITY_PCT", "30")
     monkeypatch.setenv("PS_DENSE_FUSE", fuse)
     cfg = dict(synth.CONFIGS["C2" if fields == 2 else "C1"], n_docs=6_000, vocab=300)
     corpus = synth.Corpus(**cfg)
@@ -423,6 +425,7 @@ def test_resident_rows_reuse_eviction_and_invalidation(monkeypatch):
     batches; changing k1 / b / the boosts / the scorer drops them.  Every answer bit-exact."""
     monkeypatch.setenv("PS_DENSE_MIN_USES", "1")
     monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "0")
+    monkeypatch.setenv("PS_DAAT_DENSE_MIN_DENSITY_PCT", "0")
     monkeypatch.setenv("PS_DENSE_MAX_ROWS", "6")
     monkeypatch.setenv("PS_ROW_CACHE_MB", "1")
     cfg = dict(synth.CONFIGS["C2"], n_docs=30_000, vocab=400)   # 240 KB per row: 6 slots (the per-batch minimum)

@@ -83,6 +83,7 @@ def test_mixed_sign_and_zero_field_boosts(boosts, force_rows, monkeypatch):
     if force_rows:
         monkeypatch.setenv("PS_DENSE_MIN_USES", "1")
         monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "0")
+        monkeypatch.setenv("PS_DAAT_DENSE_MIN_DENSITY_PCT", "0")
     cfg = dict(synth.CONFIGS["C5"], n_docs=6000, vocab=60)
     corpus = synth.Corpus(**cfg)
     p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
