@@ -333,7 +333,7 @@ ps_status ps_snapshot_update(ps_snapshot* snap, const ps_index* idx, ps_update_s
     ps_update_stats st;
     memset(&st, 0, sizeof(st));
     const double t0 = wall_ms();
-    if (snap->snap->src_epoch == idx->idx.epoch()) {
+    if (snap->snap->src_uid == idx->idx.uid() && snap->snap->src_epoch == idx->idx.epoch()) {
       if (out) *out = st;
       return PS_OK;
     }
@@ -401,6 +401,7 @@ ps_status ps_index_snapshot_multi(const ps_index* idx, const int* devices, size_
     for (size_t i = 0; i < n_devices; ++i) {
       std::unique_ptr<ps_snapshot> s(new ps_snapshot());
       s->snap = host;
+      s->tile_docs = tile_docs;
       s->device = devices[i];
       if (devices[i] >= 0) s->engine.reset(new ps::Engine(*host, devices[i]));
       reps.push_back(std::move(s));
@@ -425,6 +426,7 @@ ps_status ps_snapshot_load(const char* path, int device, ps_snapshot** out) {
     if (!path || !out) return fail(PS_EINVAL, "null argument");
     std::unique_ptr<ps_snapshot> s(new ps_snapshot());
     s->snap.reset(new ps::Snapshot(std::string(path)));
+    s->tile_docs = s->snap->T;  // (a later ps_snapshot_update re-flattens with the same tile size)
     s->device = device;
     if (device >= 0) s->engine.reset(new ps::Engine(*s->snap, device));
     *out = s.release();
@@ -529,7 +531,7 @@ ps_status ps_index_query(ps_index* idx, const ps_scorer_desc* scorer, const char
     // the lazily kept snapshot tracks the live index: room for 25 % more documents before a re-flatten
     ps_status st = ps_index_snapshot_ex(idx, 0, 0, 25, &idx->cached);
     if (st != PS_OK) return st;
-  } else if (idx->cached->snap->src_epoch != idx->idx.epoch()) {
+  } else if (idx->cached->snap->src_epoch != idx->idx.epoch() || idx->cached->snap->src_uid != idx->idx.uid()) {
     ps_status st = ps_snapshot_update(idx->cached, idx, nullptr);  // delta if expressible, else full
     if (st != PS_OK) return st;
   }

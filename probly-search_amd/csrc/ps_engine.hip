@@ -127,6 +127,7 @@ struct Tuning {
   uint32_t daat_min_batch = 8;   // PS_DAAT_MIN_BATCH: smaller batches keep the k_score latency path
   uint32_t daat_chunk = 4096;    // PS_DAAT_CHUNK: smallest chunk of a list one item covers
   uint32_t daat_dense_min_density_pct = 40;  // PS_DAAT_DENSE_MIN_DENSITY_PCT
+  uint32_t daat_merge_waves = 4;   // PS_DAAT_MERGE_WAVES: most waves per query in K3d (16 / 4 / 2 measured 30 / 24 / 31 us on C2)
   uint32_t daat_chunk0 = 0;      // PS_DAAT_CHUNK0: chunk of a query's highest-bound list (0 = same rule as the others)
   uint32_t daat_split_div = 64;  // PS_DAAT_SPLIT_DIV: a list is cut into at most this many chunks
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
@@ -513,6 +514,7 @@ void Tuning::load() {
     daat_chunk = std::max(256u, env_u32("PS_DAAT_CHUNK", daat_chunk));
     daat_rows = env_u32("PS_DAAT_ROWS", daat_rows);
     daat_chunk0 = env_u32("PS_DAAT_CHUNK0", daat_chunk0);
+    daat_merge_waves = std::max(1u, std::min((uint32_t)MERGE_WAVES, env_u32("PS_DAAT_MERGE_WAVES", daat_merge_waves)));
     daat_dense_min_density_pct = env_u32("PS_DAAT_DENSE_MIN_DENSITY_PCT", daat_dense_min_density_pct);
     daat_split_div = std::max(1u, env_u32("PS_DAAT_SPLIT_DIV", daat_split_div));
     daat_persistent = env_u32("PS_DAAT_PERSISTENT", daat_persistent);
@@ -1714,7 +1716,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   if (B) {
     // one wave per ~4 wave-wide candidate loads, at most MERGE_WAVES
     if (kp.n_ditems) {
-      const uint32_t mw = std::min<uint32_t>(MERGE_WAVES, std::max<uint32_t>(1, (m.daat_max_slots + 7) / 8));
+      const uint32_t mw = std::min<uint32_t>(m.tune.daat_merge_waves, std::max<uint32_t>(1, (m.daat_max_slots + 7) / 8));
       hipLaunchKernelGGL(k_merge_items, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
     } else {
     const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));

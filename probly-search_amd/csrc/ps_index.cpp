@@ -4,6 +4,7 @@
 #include "ps_build.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <stdexcept>
 
@@ -63,7 +64,12 @@ void append_utf8(std::string& s, uint32_t cp) {
   }
 }
 
+namespace {
+std::atomic<uint64_t> g_next_uid{1};
+}
+
 Index::Index(size_t fields_num, size_t expected_index_size, size_t expected_documents_count) {
+  uid_ = g_next_uid.fetch_add(1);
   fields_.assign(fields_num, FieldDetails{});
   nodes_.reserve(std::max<size_t>(expected_index_size, 16));
   docs_.reserve(expected_documents_count);

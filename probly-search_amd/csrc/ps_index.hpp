@@ -159,6 +159,7 @@ class Index {
   bool any_removed() const { return has_removed_ && !removed_.empty(); }
   int32_t root() const { return 0; }
   uint64_t epoch() const { return epoch_; }  // bumped by every mutation
+  uint64_t uid() const { return uid_; }      // identity of this index object (a snapshot only takes deltas from its own source)
   // The mutations after `epoch`, oldest first, or nullptr if the log no longer reaches back that far
   // (it is bounded; a snapshot that old re-flattens).  *count = number of entries.
   const IndexChange* changes_since(uint64_t epoch, size_t* count) const;
@@ -183,6 +184,7 @@ class Index {
   // over linked sibling lists; dropped whenever vacuum prunes nodes.
   TermCache term_cache_;
   uint64_t epoch_ = 0;
+  uint64_t uid_ = 0;
   // change log: entry i is the mutation that moved the epoch from log_base_ + i to log_base_ + i + 1
   std::vector<IndexChange> log_;
   uint64_t log_base_ = 0;

@@ -137,6 +137,7 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs, uint32_t headroom_pct) 
   T = tile_docs ? tile_docs : 1024;
   if (T < 256 || T > 4096 || (T & (T - 1))) throw std::invalid_argument("tile_docs must be a power of two in [256, 4096]");
   src_epoch = idx.epoch();
+  src_uid = idx.uid();
   n_docs = idx.docs_len();
   if (n_docs >= 0xFFFFFFF0ull) throw std::length_error("more than 2^32-16 documents");
   n_ids = n_docs;
@@ -631,7 +632,7 @@ uint32_t Snapshot::chain_length(uint32_t head) const {
 // ---- delta snapshot --------------------------------------------------------------
 bool Snapshot::apply_delta(const Index& idx, DeltaRanges& out) {
   out = DeltaRanges{};
-  if (!own_ || src_epoch == ~0ull) return false;  // mapped from a file: no source bookkeeping
+  if (!own_ || src_epoch == ~0ull || src_uid != idx.uid()) return false;  // mapped from a file / another index: no source bookkeeping
   if (idx.epoch() == src_epoch) return true;
   if (idx.fields_len() != F) return false;
   size_t n_changes = 0;

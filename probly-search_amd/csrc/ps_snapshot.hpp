@@ -161,6 +161,7 @@ class Snapshot {
   uint64_t n_postings = 0, n_pointers = 0, n_live_terms = 0;
   uint32_t max_layers = 1;
   uint64_t src_epoch = 0;
+  uint64_t src_uid = 0;  // Index::uid() of the source index (0: loaded from a file)
   // geometry of the BM25 saturated-tf LUT the engine builds per batch (rows of 16 doubles):
   // field x owns rows [lut_base[x], lut_base[x] + lut_cap[x]), one per field length < lut_cap[x]
   View<uint32_t> max_fl, lut_cap, lut_base;

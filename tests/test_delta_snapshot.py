@@ -129,6 +129,21 @@ def test_delta_fallbacks_and_removal_without_headroom(tmp_path):
     _check_host(back, o, queries + ["abd", "new"], "loaded delta")
 
 
+def test_update_from_another_index_reflattens():
+    """A snapshot only takes deltas from the index it was flattened from; handed another index (even one
+    at a later epoch) it re-flattens and then answers for THAT index."""
+    rng, vocab, o1, p1 = _build(5, n=40)
+    _r, _v, o2, p2 = _build(6, n=60)
+    snap = p1.idx.snapshot(device=-1, tile_docs=256, headroom_pct=50)
+    import ctypes as C
+    from probly_search_amd import _lib
+    st = _lib.UpdateStats()
+    _lib.check(_lib.load().ps_snapshot_update(snap._h, p2.idx._h, C.byref(st)))
+    assert st.mode == 2
+    snap._owner = p2.idx
+    _check_host(snap, o2, _queries(rng, _v, 6), "other index")
+
+
 def test_index_query_keeps_one_snapshot_through_mutations_host_log():
     """The change log reaches back exactly to the epoch a snapshot was made at; older -> None path is
     exercised through a host-only snapshot made before a vacuum."""
