@@ -170,6 +170,7 @@ struct EngineImpl {
   DevBuf<unsigned long long> d_gthr;
   DevBuf<double> d_rows;  // dense per-document score rows of the batch's hot lists
   DevBuf<uint32_t> d_cand_cnt;  // K1d: candidates per item
+  DevBuf<DItem> d_ditems;       // K1d: work items (k_make_items)
   // K1d: per list (layer) upper bounds of the saturated term frequency, exact for the current
   // (k1, b): M[l*F+x] = max tfn_x over the list's postings, J[l] = max over postings of
   // sum_x boost_x * tfn_x.  Host pass over the planes, once per (k1, b, boosts).
@@ -330,7 +331,7 @@ Engine::~Engine() {
   m.d_stage.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
-  m.d_gthr.release(); m.d_rows.release(); m.d_cand_cnt.release(); m.d_removed_df.release();
+  m.d_gthr.release(); m.d_rows.release(); m.d_cand_cnt.release(); m.d_ditems.release(); m.d_removed_df.release();
   free_daat_work(m.daat_work);
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fchar.release(); m.d_fchild.release();
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release();
@@ -599,7 +600,8 @@ struct BatchImage {
 }  // namespace
 struct DaatWork {
   std::vector<DEntry> dentry;
-  std::vector<DItem> items;
+  std::vector<DItemGen> gen;  // per list in processing order; the device expands them into DItems
+  size_t n_items = 0, first_items = 0;  // items in all / of the queries' rank-0 lists (they lead the order)
   std::vector<uint32_t> qslot, rorder;
   std::vector<DGroup> dgroup;  // multi-expansion batches only
 };
@@ -627,10 +629,10 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
   }
   if (dw) {
     img.daat = true;
-    img.n_ditems = dw->items.size();
+    img.n_ditems = dw->n_items;
     img.off_d = (img.total + 15) & ~(size_t)15;
     img.off_i = img.off_d + ne * sizeof(DEntry);
-    img.off_s = img.off_i + img.n_ditems * sizeof(DItem);
+    img.off_s = img.off_i + ne * sizeof(DItemGen);
     img.off_ro = img.off_s + (B + 1) * 4;
     img.off_dg = (img.off_ro + ne * 4 + 15) & ~(size_t)15;
     img.total = img.off_dg + (dw->dgroup.empty() ? 0 : ne * sizeof(DGroup));
@@ -646,7 +648,7 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
   if (B) memcpy(img.h + img.off_l, plan.qterms_len.data(), B * 4);
   if (dw) {
     if (ne) memcpy(img.h + img.off_d, dw->dentry.data(), ne * sizeof(DEntry));
-    if (img.n_ditems) memcpy(img.h + img.off_i, dw->items.data(), img.n_ditems * sizeof(DItem));
+    if (ne) memcpy(img.h + img.off_i, dw->gen.data(), ne * sizeof(DItemGen));
     memcpy(img.h + img.off_s, dw->qslot.data(), (B + 1) * 4);
     if (ne) memcpy(img.h + img.off_ro, dw->rorder.data(), ne * 4);
     if (ne && !dw->dgroup.empty()) memcpy(img.h + img.off_dg, dw->dgroup.data(), ne * sizeof(DGroup));
@@ -930,25 +932,19 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
     for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) { first_slot[i] = sl; sl += nchunk[i]; }
   }
   PD("order");
-  dw.items.resize(dw.qslot[B]);
-  // item ranges of the entries in processing order, then the (independent) fills - on the pool for large batches
-  std::vector<uint32_t>& item_at = m.daat_item_at;
-  item_at.resize(ne + 1);
+  // the lists in processing order with their item ranges; k_make_items expands them on the device
+  dw.gen.resize(ne);
   {
     uint32_t at = 0;
-    for (size_t k = 0; k < ne; ++k) { item_at[k] = at; at += nchunk[eo[k]]; }
-    item_at[ne] = at;
-  }
-  auto fill = [&](size_t k0, size_t k1) {
-    for (size_t k = k0; k < k1; ++k) {
+    dw.first_items = 0;
+    for (size_t k = 0; k < ne; ++k) {
       const uint32_t i = eo[k];
-      const uint32_t len = ents[i].len, c = chunk[i], fs = first_slot[i];
-      DItem* out = dw.items.data() + item_at[k];
-      for (uint32_t j = 0; j < nchunk[i]; ++j) out[j] = DItem{i, j * c, std::min(c, len - j * c), fs + j};
+      dw.gen[k] = DItemGen{i, at, chunk[i], first_slot[i]};
+      at += nchunk[i];
+      if (dw.dentry[i].rank == 0) dw.first_items = at;
     }
-  };
-  if (B >= 256 && m.tune.daat_threads > 1 && m.pool) m.pool->run([&](unsigned part, unsigned parts) { fill(ne * part / parts, ne * (part + 1) / parts); });
-  else fill(0, ne);
+    dw.n_items = at;
+  }
   PD("items");
 }
 
@@ -1288,7 +1284,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     compute_list_bounds(m, sc, boosts);
     plan_daat(m, plan, plan.entries.data(), plan.multi_expansion,
               [&](const ps_plan_entry& e, size_t) { return entry_upper_bound(m, e, boosts); }, dw);
-    use_daat = !dw.items.empty();
+    use_daat = dw.n_items != 0;
   }
   // zero_to_one: whether the batch qualifies is only known after the queries are classified, which
   // needs the staged image; reserve the descriptors' space now (their sizes do not depend on it)
@@ -1302,7 +1298,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + m.tune.daat_split_div - 1) / m.tune.daat_split_div + 255) & ~255u);
       n_items += (len + c - 1) / c;
     }
-    dw.dentry.resize(ne); dw.rorder.resize(ne); dw.qslot.resize(plan.qbeg.size()); dw.items.resize(n_items); dw.dgroup.clear();
+    dw.dentry.resize(ne); dw.rorder.resize(ne); dw.qslot.resize(plan.qbeg.size()); dw.gen.resize(ne); dw.n_items = n_items; dw.dgroup.clear();
   }
   SP("daat");
   BatchImage img = lay_out_batch(m, sc, plan, (use_daat || z_daat_maybe) ? &dw : nullptr);
@@ -1355,10 +1351,10 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
       }
       return ub;
     }, dw);
-    if (dw.items.size() == img.n_ditems && !dw.items.empty()) {
+    if (dw.n_items == img.n_ditems && dw.n_items) {
       const size_t ne = plan.entries.size();
       memcpy(img.h + img.off_d, dw.dentry.data(), ne * sizeof(DEntry));
-      memcpy(img.h + img.off_i, dw.items.data(), img.n_ditems * sizeof(DItem));
+      memcpy(img.h + img.off_i, dw.gen.data(), ne * sizeof(DItemGen));
       memcpy(img.h + img.off_s, dw.qslot.data(), (B + 1) * 4);
       memcpy(img.h + img.off_ro, dw.rorder.data(), ne * 4);
       img.daat = true;
@@ -1420,7 +1416,14 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.zfub = z_field_bounds ? reinterpret_cast<const double*>(dbase + img.off_zf) : nullptr;
   if (img.daat) {
     kp.dentry = reinterpret_cast<const DEntry*>(dbase + img.off_d);
-    kp.ditems = reinterpret_cast<const DItem*>(dbase + img.off_i);
+    m.d_ditems.ensure(img.n_ditems + 1);
+    kp.ditems = m.d_ditems.p;
+    {
+      const uint32_t ne32 = (uint32_t)img.ne;
+      hipLaunchKernelGGL(k_make_items, dim3((ne32 + 3) / 4), dim3(256), 0, st, reinterpret_cast<const DItemGen*>(dbase + img.off_i),
+                         reinterpret_cast<const ps_plan_entry*>(dbase + off_e), ne32, m.d_ditems.p);
+      PS_HIP(hipGetLastError());
+    }
     kp.qslot = reinterpret_cast<const uint32_t*>(dbase + img.off_s);
     kp.rorder = reinterpret_cast<const uint32_t*>(dbase + img.off_ro);
     kp.dgroup = dw.dgroup.empty() ? nullptr : reinterpret_cast<const DGroup*>(dbase + img.off_dg);
@@ -1428,9 +1431,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     uint32_t max_slots = 0;
     for (size_t q = 0; q < B; ++q) max_slots = std::max(max_slots, dw.qslot[q + 1] - dw.qslot[q]);
     m.daat_max_slots = max_slots;
-    uint32_t first = 0;
-    while (first < dw.items.size() && dw.dentry[dw.items[first].entry].rank == 0) ++first;
-    m.daat_first_items = first;
+    m.daat_first_items = (uint32_t)dw.first_items;
   }
   m.build_slots.clear();  // rows the host has to zero-fill for K0b
   for (uint32_t r = 0; r < n_rows; ++r) {

@@ -81,6 +81,13 @@ struct DItem {         // a chunk of one list
   uint32_t slot;       // candidate slot (query-major)
 };
 
+struct DItemGen {      // one list in processing order: k_make_items expands it into its DItems on the device
+  uint32_t entry;      // plan entry
+  uint32_t item_at;    // its first item
+  uint32_t chunk;      // postings per item
+  uint32_t first_slot; // candidate slot of its first item
+};
+
 constexpr uint32_t DENSE_FLAG = 0x80000000u;  // ps_plan_entry::shift bit 31: entry reads dense row `node`
 constexpr uint32_t DENSE_ASSIGN_FLAG = 0x40000000u;  // ... as the tile's first contribution: written, not added
 constexpr uint32_t DENSE_FUSE_FLAG = 0x20000000u;    // ... as the query's last one: added while harvesting
@@ -2048,6 +2055,21 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t* q_cnt, const
 // per batch; this is a few microseconds for the ~150 KB of a 1024-query plan.)
 __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ src, uint4* __restrict__ dst, const size_t n16) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// K1d work items from the per-list records: one wave per list, one lane per chunk.  (The items are
+// ~16 B per 4096 postings - 1 MB for a 1024-query batch; built here they never cross PCIe.)
+__global__ __launch_bounds__(256) void k_make_items(const DItemGen* __restrict__ gen, const ps_plan_entry* __restrict__ plan,
+                                                    const uint32_t ne, DItem* __restrict__ out) {
+  const uint32_t k = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  if (k >= ne) return;
+  const DItemGen g = gen[k];
+  const uint32_t len = plan[g.entry].len;
+  const uint32_t n = (len + g.chunk - 1) / g.chunk;
+  for (uint32_t j = threadIdx.x % WAVE; j < n; j += WAVE) {
+    const uint32_t b = j * g.chunk;
+    out[g.item_at + j] = DItem{g.entry, b, min(g.chunk, len - b), g.first_slot + j};
+  }
 }
 
 // Full-result mode: the first (out_off[q+1] - out_off[q]) sorted results of run q -> {key, score}.
