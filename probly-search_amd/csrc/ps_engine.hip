@@ -133,6 +133,7 @@ struct Tuning {
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
   uint32_t daat_persistent = 0;  // PS_DAAT_PERSISTENT: persistent waves + item counter instead of one wave per item
   uint32_t daat_threads = 8;     // PS_DAAT_THREADS: host threads that build the K1d descriptors of a large batch
+  uint32_t z21_exact_numerator = 1;  // PS_Z21_EXACT_NUMERATOR: k_score<MODE_Z21S> one-division arm for small term frequencies (score_trip)
   uint32_t z21_field_prune = 1;  // PS_Z21_FIELD_PRUNE: k_score<MODE_Z21S> drops fields whose pool bound fell below the query's threshold
   uint32_t daat_z21 = 0;         // PS_DAAT_Z21: zero_to_one top-k batches of simple queries take K1dz k_daat_z (off: K1 is 3x faster)
   uint32_t daat_multi = 1;       // PS_DAAT_MULTI: also take batches with several expansions per query term (0: they stay on K1)
@@ -151,6 +152,7 @@ struct EngineImpl {
   uint32_t* d_doc = nullptr;
   uint32_t* d_tf = nullptr;
   uint32_t* d_fl = nullptr;
+  uint32_t* d_tfl = nullptr;  // packed {tf, field length} words, [P][F] (k_pack_tfl): what K1 / K1d stream
   uint32_t* d_table = nullptr;
   uint32_t* d_bits = nullptr;
   uint32_t* d_alive = nullptr;  // one bit per doc id (delta removals)
@@ -298,6 +300,7 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     PS_HIP(hipMalloc((void**)&m.d_doc, P * 4));
     PS_HIP(hipMalloc((void**)&m.d_tf, P * F * 4));
     PS_HIP(hipMalloc((void**)&m.d_fl, P * F * 4));
+    PS_HIP(hipMalloc((void**)&m.d_tfl, std::max<size_t>(1, P * F) * 4));
     PS_HIP(hipMalloc((void**)&m.d_table, snap.table.size() * 4));
     PS_HIP(hipMalloc((void**)&m.d_bits, snap.bits.size() * 4));
     PS_HIP(hipMemcpy(m.d_bits, snap.bits.data(), snap.bits.size() * 4, hipMemcpyHostToDevice));
@@ -308,10 +311,15 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     PS_HIP(hipMemcpy(m.d_doc, snap.doc.data(), P * 4, hipMemcpyHostToDevice));
     PS_HIP(hipMemcpy(m.d_tf, snap.tf.data(), P * F * 4, hipMemcpyHostToDevice));
     PS_HIP(hipMemcpy(m.d_fl, snap.fl.data(), P * F * 4, hipMemcpyHostToDevice));
+    if (P * F) {
+      hipLaunchKernelGGL(k_pack_tfl, dim3(2048), dim3(256), 0, m.stream, m.d_tf, m.d_fl, m.d_tfl, (uint64_t)P, (uint32_t)F, (uint64_t)0, (uint64_t)P);
+      PS_HIP(hipGetLastError());
+      PS_HIP(hipStreamSynchronize(m.stream));
+    }
     PS_HIP(hipMemcpy(m.d_table, snap.table.data(), snap.table.size() * 4, hipMemcpyHostToDevice));
     if (!snap.keys.empty())
       PS_HIP(hipMemcpy(m.d_keys, snap.keys.data(), snap.keys.size() * 8, hipMemcpyHostToDevice));
-    m.bytes = P * 4 + 2 * P * F * 4 + snap.table.size() * 4 + snap.keys.size() * 8 + snap.bits.size() * 4;
+    m.bytes = P * 4 + 3 * P * F * 4 + snap.table.size() * 4 + snap.keys.size() * 8 + snap.bits.size() * 4;
   } catch (...) {
     delete impl_;
     impl_ = nullptr;
@@ -326,7 +334,7 @@ Engine::~Engine() {
   EngineImpl& m = *impl_;
   (void)hipSetDevice(m.device);
   (void)hipDeviceSynchronize();
-  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_table, (void*)m.d_bits, (void*)m.d_alive, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work})
+  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_tfl, (void*)m.d_table, (void*)m.d_bits, (void*)m.d_alive, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work})
     if (p) (void)hipFree(p);
   m.d_stage.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
@@ -395,6 +403,10 @@ void Engine::apply_delta(const DeltaRanges& r, std::vector<uint64_t>& removed_df
       put(m.d_tf + x * P + b, s.tf.data() + x * P + b, n * 4);
       put(m.d_fl + x * P + b, s.fl.data() + x * P + b, n * 4);
     }
+    hipLaunchKernelGGL(k_pack_tfl, dim3((uint32_t)std::min<size_t>(2048, (n * F + 255) / 256)), dim3(256), 0, m.stream, m.d_tf, m.d_fl,
+                       m.d_tfl, (uint64_t)P, (uint32_t)F, (uint64_t)b, (uint64_t)(b + n));
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipStreamSynchronize(m.stream));
   }
   if (r.table_end > r.table_begin) put(m.d_table + r.table_begin, s.table.data() + r.table_begin, (r.table_end - r.table_begin) * 4);
   if (r.key_end > r.key_begin) put(m.d_keys + r.key_begin, s.keys.data() + r.key_begin, (r.key_end - r.key_begin) * 8);
@@ -523,6 +535,7 @@ void Tuning::load() {
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
     daat_z21 = env_u32("PS_DAAT_Z21", daat_z21);
     z21_field_prune = env_u32("PS_Z21_FIELD_PRUNE", z21_field_prune);
+    z21_exact_numerator = env_u32("PS_Z21_EXACT_NUMERATOR", z21_exact_numerator);
     daat_threads = std::max(1u, std::min(env_u32("PS_DAAT_THREADS", daat_threads), std::max(1u, std::thread::hardware_concurrency())));
 }
 
@@ -1207,7 +1220,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
 uint64_t layout_bytes_of(const EngineImpl& m, const BatchImage& img) {
   const Snapshot& s = *m.snap;
   const uint32_t planes = img.z ? s.F : 1u;
-  const uint64_t pb = 4 + 8 * (uint64_t)s.F, row_bytes = (uint64_t)s.tiles_cap * s.T * 8 * planes;
+  const uint64_t pb = 4 + 4 * (uint64_t)s.F, row_bytes = (uint64_t)s.tiles_cap * s.T * 8 * planes;
   uint64_t lb = 0;
   for (size_t i = 0; i < img.ne; ++i) lb += (img.he[i].shift & DENSE_FLAG) ? row_bytes : (uint64_t)img.he[i].len * pb;
   const RowDesc* rd = reinterpret_cast<const RowDesc*>(img.h + img.off_r);
@@ -1308,6 +1321,26 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const bool z = img.z;
   if (!img.daat) order_queries(m, plan, img);  // (K1d has its own item order)
   if (z) classify_zero_to_one(m, plan, img);
+  if (z && m.tune.z21_exact_numerator) {
+    // k_score's one-division arm (score_trip): per entry the largest L with fmin(score / t, 1.) * t == score
+    // for every term frequency t <= L, evaluated here in the same IEEE f64 arithmetic; it rides in the
+    // entry's idf word, which zero_to_one does not use
+    double last = -1.0;
+    uint64_t last_l = 0;
+    for (size_t i = 0; i < img.ne; ++i) {
+      const double w = img.he[i].boost;
+      if (!(w == last)) {
+        last = w;
+        last_l = 0;
+        for (uint32_t t = 1; t <= 254; ++t) {  // (255 is the packed words' "see the tf plane" value)
+          const double df = (double)t;
+          if (!(std::fmin(w / df, 1.0) * df == w)) break;
+          last_l = t;
+        }
+      }
+      memcpy(&img.he[i].idf, &last_l, 8);
+    }
+  }
   bool z_field_bounds = false;
   if (z && topk_path && m.tune.z21_field_prune && img.n_simple && s.n_docs > 0 && !plan.entries.empty()) {
     // per query and field: no document's pool of that field can exceed the sum over the query's lists of
@@ -1401,7 +1434,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   }
 
   memset(&kp, 0, sizeof(kp));
-  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys; kp.bits = m.d_bits;
+  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.tfl = m.d_tfl; kp.table = m.d_table; kp.keys = m.d_keys; kp.bits = m.d_bits;
   kp.alive = s.any_dead ? m.d_alive : nullptr;
   kp.plan = reinterpret_cast<const ps_plan_entry*>(dbase + off_e);
   kp.qbeg = reinterpret_cast<const uint32_t*>(dbase + off_q);
@@ -1910,7 +1943,7 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   shape.postings = tot.postings;
   KParams kp;
   memset(&kp, 0, sizeof(kp));
-  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.table = m.d_table; kp.keys = m.d_keys; kp.bits = m.d_bits;
+  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.tfl = m.d_tfl; kp.table = m.d_table; kp.keys = m.d_keys; kp.bits = m.d_bits;
   kp.alive = s.any_dead ? m.d_alive : nullptr;
   kp.plan = m.d_pl_entries.p;
   kp.qbeg = m.d_pl_qbeg.p;

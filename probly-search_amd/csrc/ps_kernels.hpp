@@ -132,6 +132,7 @@ struct KParams {
   const uint32_t* qslot;        // [B+1] candidate slots (= items) of query q: [qslot[q], qslot[q+1])
   const uint32_t* rorder;       // [n_plan_entries] per query: its entries in rank order (highest bound first)
   const struct DGroup* dgroup;  // [n_plan_entries] (multi-expansion batches)
+  const uint32_t* tfl;          // [P][F] packed {tf (8 bits, 255 = see the tf plane), field length (24 bits, all ones = see the fl plane)}: what the hot loops read
   const uint32_t* bits;         // membership bitmaps of the denser lists (ps_plan_entry::bm_off)
   const uint32_t* alive;        // one bit per doc id, cleared by a delta removal; null = every document alive
   uint32_t n_ditems, t_log2;
@@ -306,9 +307,11 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
       const uint32_t d = p.doc[pi];
       const uint32_t qtl = rd._pad & 0xFFFFu, need = rd._pad >> 16;
       for (uint32_t x = 0; x < p.F; ++x) {
-        const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
+        const uint32_t w = p.tfl[pi * p.F + x];  // packed {tf, field length} (tfl_pack); saturated sub-fields -> the exact planes
+        uint32_t tfu = w >> 24, flu = w & 0xFFFFFFu;
+        if (tfu == 255u) tfu = p.tf[(uint64_t)x * p.P + pi];
         if (tfu >= need) {
-          const uint32_t flu = p.fl[(uint64_t)x * p.P + pi];
+          if (flu == 0xFFFFFFu) flu = p.fl[(uint64_t)x * p.P + pi];
           const double df = (double)tfu;
           row[(uint64_t)x * p.row_stride + d] = fmin(rd.idf / df, 1.0) * df / (double)(flu > qtl ? flu : qtl);
         }
@@ -320,8 +323,11 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
     const uint64_t pi = rd.post_off + i;
     double s = 0.0;
     for (uint32_t x = 0; x < p.F; ++x) {
-      const uint32_t tfu = p.tf[(uint64_t)x * p.P + pi];
-      if (tfu > 0) s += bm25_tfn(p, x, tfu, p.fl[(uint64_t)x * p.P + pi]) * rd.idf * p.boost[x] * rd.eb;
+      const uint32_t w = p.tfl[pi * p.F + x];
+      uint32_t tfu = w >> 24, flu = w & 0xFFFFFFu;
+      if (tfu == 255u) tfu = p.tf[(uint64_t)x * p.P + pi];
+      if (flu == 0xFFFFFFu) flu = p.fl[(uint64_t)x * p.P + pi];
+      if (tfu > 0) s += bm25_tfn(p, x, tfu, flu) * rd.idf * p.boost[x] * rd.eb;
     }
     row[p.doc[pi]] = s;
   }
@@ -448,27 +454,60 @@ struct EntryC {      // wave-uniform per-entry constants (SGPRs)
   uint32_t fmask;    // Z21S: fields still worth accumulating for this item (bit x; see k_score)
 };
 
+// The packed posting words: tf and field length of one (posting, field) in one u32, the fields of a
+// posting next to each other - a posting costs one 4*F-byte load next to its doc id instead of 2F
+// four-byte ones from 2F planes (12 instead of 20 bytes for two fields).  Saturated sub-fields (tf >= 255,
+// field length >= 2^24 - 1) send the reader to the exact planes; k_pack_tfl builds the words.
+constexpr uint32_t TFL_TF_ESC = 255u, TFL_FL_ESC = 0xFFFFFFu;
+__device__ __forceinline__ uint32_t tfl_pack(const uint32_t tf, const uint32_t fl) {
+  return (min(tf, TFL_TF_ESC) << 24) | min(fl, TFL_FL_ESC);
+}
+template <int F_>
+__device__ __forceinline__ void tfl_load(const KParams& p, const uint64_t pi, uint32_t (&w)[F_ ? F_ : MAX_F]) {
+  if (F_ == 1) {
+    w[0] = p.tfl[pi];
+  } else if (F_ == 2) {
+    const uint2 v = reinterpret_cast<const uint2*>(p.tfl)[pi];
+    w[0] = v.x; w[1] = v.y;
+  } else {
+#pragma unroll
+    for (int x = 0; x < (F_ ? F_ : MAX_F); ++x)
+      if ((uint32_t)x < p.F) w[x] = p.tfl[pi * p.F + x];
+  }
+}
+// Unpacks U postings per lane.  Saturated sub-fields stay saturated: every reader already has a cold arm
+// that such a value falls into (tf 255 is off the saturated-tf table and above any exact-numerator limit,
+// a field length of 2^24 - 1 is past any table), and fetches the exact value there with tfl_exact.
 template <int F_, int U>
-__device__ __forceinline__ void load_trip(const KParams& p, const int lane, const uint64_t post_off, const uint32_t i0,
-                                          const uint32_t re, uint32_t (&dv)[U], uint32_t (&tfv)[U][F_ ? F_ : MAX_F],
-                                          uint32_t (&flv)[U][F_ ? F_ : MAX_F], const uint32_t fmask = 0xFFFFFFFFu) {
+__device__ __forceinline__ void tfl_unpack(const KParams& p, const uint32_t (&w)[U][F_ ? F_ : MAX_F],
+                                           uint32_t (&tfv)[U][F_ ? F_ : MAX_F], uint32_t (&flv)[U][F_ ? F_ : MAX_F]) {
   constexpr int FA = F_ ? F_ : MAX_F;
   const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int x = 0; x < FA; ++x) {
+      tfv[u][x] = 0; flv[u][x] = 0;
+      if ((uint32_t)x < F) {
+        tfv[u][x] = w[u][x] >> 24;
+        flv[u][x] = w[u][x] & TFL_FL_ESC;
+      }
+    }
+}
+__device__ __forceinline__ void tfl_exact(const KParams& p, const uint32_t x, const uint64_t pi, uint32_t& tf, uint32_t& fl) {
+  if (tf == TFL_TF_ESC) tf = p.tf[(uint64_t)x * p.P + pi];
+  if (fl == TFL_FL_ESC) fl = p.fl[(uint64_t)x * p.P + pi];
+}
+
+template <int F_, int U>
+__device__ __forceinline__ void load_trip(const KParams& p, const int lane, const uint64_t post_off, const uint32_t i0,
+                                          const uint32_t re, uint32_t (&dv)[U], uint32_t (&wv)[U][F_ ? F_ : MAX_F]) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t i = i0 + u * WAVE + lane;
     const uint64_t pi = post_off + (i < re ? i : re - 1);  // clamp: always a valid posting
     dv[u] = p.doc[pi];
-#pragma unroll
-    for (int x = 0; x < FA; ++x) {
-      if ((uint32_t)x < F) {
-        // (a field that is out for this item - Z21S field pruning - re-reads plane 0: same cache lines,
-        // no branch in the load burst; score_trip ignores the values)
-        const uint64_t plane = ((fmask >> x) & 1u) ? (uint64_t)x * p.P : 0ull;
-        tfv[u][x] = p.tf[plane + pi];
-        flv[u][x] = p.fl[plane + pi];
-      }
-    }
+    tfl_load<F_>(p, pi, wv[u]);
   }
 }
 
@@ -480,17 +519,22 @@ template <int MODE, int F_, bool TAGS, int U>
 __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, double* acc, uint16_t* tag,
                                            const int lane, const uint32_t tile_base, const uint32_t i0,
                                            const uint32_t re, const uint32_t (&dv)[U],
-                                           const uint32_t (&tfv)[U][F_ ? F_ : MAX_F],
-                                           const uint32_t (&flv)[U][F_ ? F_ : MAX_F], const EntryC& ec,
+                                           const uint32_t (&wv)[U][F_ ? F_ : MAX_F], const EntryC& ec,
                                            const uint32_t qtl) {
   constexpr int FA = F_ ? F_ : MAX_F;
   const uint32_t F = F_ ? (uint32_t)F_ : p.F;
   if (PS_ABLATE_BUILD && (p.ablate & 2u)) {  // profiling only: loads stay alive, no scoring
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if ((dv[u] ^ tfv[u][0] ^ flv[u][0]) == 0xFFFFFFF1u) acc[0] = 1.0;
+      if ((dv[u] ^ wv[u][0]) == 0xFFFFFFF1u) acc[0] = 1.0;
     return;
   }
+  uint32_t tfv[U][FA], flv[U][FA];
+  tfl_unpack<F_, U>(p, wv, tfv, flv);
+  auto posting_of = [&](int u) {  // cold arms only: the posting slot u was loaded from (load_trip's clamp)
+    const uint32_t i = i0 + u * WAVE + lane;
+    return ec.post_off + (i < re ? i : re - 1);
+  };
   bool ok[U];
   uint32_t local[U];
 #pragma unroll
@@ -523,9 +567,11 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
 #pragma unroll
         for (int x = 0; x < FA; ++x) {
           if ((uint32_t)x < F) {
-            const uint32_t tfu = tfv[u][x], flu = flv[u][x];
-            if (!(tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x]))
+            uint32_t tfu = tfv[u][x], flu = flv[u][x];
+            if (!(tfu < (uint32_t)LUT_TF && flu < p.lut_cap[x])) {
+              tfl_exact(p, (uint32_t)x, posting_of(u), tfu, flu);
               tfn[u][x] = bm25_tfn_cold(p.k1, p.k1p1, p.one_minus_b, p.b, p.avg[x], tfu, flu);
+            }
           }
         }
       }
@@ -570,15 +616,33 @@ __device__ __forceinline__ void score_trip(const KParams& p, const double* lut, 
     }
   } else {
     // zero_to_one.rs:117-120: (min(score / tf, 1.) * tf) / max(field_length, all_query_terms_len)
+    // The numerator only depends on (score, tf), and for small tf it is the score itself - exactly, in
+    // f64: the host found the largest L with fmin(score / t, 1.) * t == score for every t <= L (48 for
+    // score 1.0, the exact-match expansion) and left it in the entry (ec.w1's bit pattern).  A trip whose
+    // term frequencies are all <= L - nearly every trip - takes one f64 division per (posting, field)
+    // instead of two; otherwise the whole wave evaluates the full expression.
+    const uint32_t tf_exact = (uint32_t)__double2loint(ec.w1);
+    bool wide = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int x = 0; x < FA; ++x)
+        if ((uint32_t)x < F) wide = wide || (ok[u] && (tfv[u][x] > tf_exact || flv[u][x] == TFL_FL_ESC));  // (tf_exact <= 254)
+    const bool full_expr = __builtin_amdgcn_ballot_w64(wide) != 0ull;  // wave-uniform
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int x = 0; x < FA; ++x) {
         if ((uint32_t)x < F) {
-          const uint32_t tfu = tfv[u][x], flu = flv[u][x];
-          const double df = (double)tfu;
+          uint32_t tfu = tfv[u][x], flu = flv[u][x];
+          double num = ec.w0;
+          if (full_expr) {
+            tfl_exact(p, (uint32_t)x, posting_of(u), tfu, flu);
+            const double df = (double)tfu;
+            num = fmin(ec.w0 / df, 1.0) * df;
+          }
           const uint32_t den = flu > qtl ? flu : qtl;
-          const double c = fmin(ec.w0 / df, 1.0) * df / (double)den;
+          const double c = num / (double)den;
           // ec.tag = occurrence rank of the node (low 16 bits, >= 1: the pool rule) | query-term ordinal
           bool take = ok[u] && tfu >= (ec.tag & 0xFFFFu) && ((ec.fmask >> x) & 1u);
           if (TAGS && (ec.tag >> 31)) {  // bit 31: this query has query terms with several expansions
@@ -611,21 +675,21 @@ __device__ __forceinline__ void score_stream(const KParams& p, const double* lut
   uint32_t i0 = rb;
   if (re - i0 >= (uint32_t)(UN * WAVE)) {
     // full trips, double-buffered
-    uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
-    uint32_t dn[UN], tfnx[UN][FA], flnx[UN][FA];
-    load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv, ec.fmask);
+    uint32_t dv[UN], wv[UN][FA];
+    uint32_t dn[UN], wnx[UN][FA];
+    load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, wv);
     while (re - i0 >= (uint32_t)(UN * WAVE)) {
       const uint32_t nx = i0 + UN * WAVE;
       const bool more = re - nx >= (uint32_t)(UN * WAVE);
-      if (more) load_trip<F_, UN>(p, lane, ec.post_off, nx, re, dn, tfnx, flnx, ec.fmask);
-      score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+      if (more) load_trip<F_, UN>(p, lane, ec.post_off, nx, re, dn, wnx);
+      score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, wv, ec, qtl);
       if (more) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
           dv[u] = dn[u];
 #pragma unroll
           for (int x = 0; x < FA; ++x)
-            if ((uint32_t)x < F) { tfv[u][x] = tfnx[u][x]; flv[u][x] = flnx[u][x]; }
+            if ((uint32_t)x < F) wv[u][x] = wnx[u][x];
         }
       }
       i0 = nx;
@@ -635,13 +699,13 @@ __device__ __forceinline__ void score_stream(const KParams& p, const double* lut
   // 64-wide trip when it is short (no empty lane slots to pay for)
   if (i0 < re) {
     if (re - i0 > (uint32_t)WAVE) {
-      uint32_t dv[UN], tfv[UN][FA], flv[UN][FA];
-      load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, tfv, flv, ec.fmask);
-      score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+      uint32_t dv[UN], wv[UN][FA];
+      load_trip<F_, UN>(p, lane, ec.post_off, i0, re, dv, wv);
+      score_trip<MODE, F_, TAGS, UN>(p, lut, acc, tag, lane, tile_base, i0, re, dv, wv, ec, qtl);
     } else {
-      uint32_t dv[1], tfv[1][FA], flv[1][FA];
-      load_trip<F_, 1>(p, lane, ec.post_off, i0, re, dv, tfv, flv, ec.fmask);
-      score_trip<MODE, F_, TAGS, 1>(p, lut, acc, tag, lane, tile_base, i0, re, dv, tfv, flv, ec, qtl);
+      uint32_t dv[1], wv[1][FA];
+      load_trip<F_, 1>(p, lane, ec.post_off, i0, re, dv, wv);
+      score_trip<MODE, F_, TAGS, 1>(p, lut, acc, tag, lane, tile_base, i0, re, dv, wv, ec, qtl);
     }
   }
 }
@@ -752,7 +816,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
     uint32_t ec_qterm[G], ec_tbl[G], ec_row[G], ec_flags[G];
     uint32_t fuse_row = 0xFFFFFFFFu;  // dense row of the query's last entry, added during the harvest
     uint32_t rb[G], re[G];
-    uint32_t dv[G][FU], tfv[G][FU][FA], flv[G][FU][FA];
+    uint32_t dv[G][FU], wv[G][FU][FA];
     // phase 1 of a visit (tile VT, entries EG..EG+G): ranges + first trips, all loads in flight together
 #define PS_PHASE1(VT, EG, FIRST)                                                                                \
   _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                               \
@@ -763,7 +827,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         ec[g].post_off = en.post_off;                                                                           \
         ec[g].shift = en.shift & 0xFFu;                                                                         \
         ec[g].w0 = MODE == MODE_BM25 ? en.idf : en.boost;                                                       \
-        ec[g].w1 = en.boost;                                                                                    \
+        ec[g].w1 = MODE == MODE_BM25 ? en.boost : en.idf; /* Z21S: bits = exact-numerator tf limit */           \
         ec[g].fmask = fmask;                                                                                    \
         ec_qterm[g] = MODE == MODE_Z21S ? en.qterm_index : en.qterm;                                            \
         ec_tbl[g] = en.tbl_off;                                                                                 \
@@ -779,9 +843,16 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         rb[g] = p.table[ec_tbl[g] + slot];                                                                      \
         re[g] = p.table[ec_tbl[g] + slot + 1];                                                                  \
       }                                                                                                         \
-      if (rb[g] < re[g]) load_trip<F_, FU>(p, lane, ec[g].post_off, rb[g], re[g], dv[g], tfv[g], flv[g], fmask);\
+      if (rb[g] < re[g]) load_trip<F_, FU>(p, lane, ec[g].post_off, rb[g], re[g], dv[g], wv[g]);                 \
     }                                                                                                           \
-  }
+  }                                                                                                             \
+  if (!FULL) gt_req = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The query's threshold for a tile's harvest is requested with that tile's postings (the last load of
+    // the visit) and moved to SGPRs before the next visit's loads are issued: a vector-memory load issued
+    // after them would only return behind them (loads return in order), and the harvest - which is meant
+    // to run while they fly - would start by waiting for all of them.  A slightly stale threshold is still a
+    // lower bound of the final K-th best.
+    unsigned long long gt_req = 0ull;
     PS_PHASE1(t_begin, 0u, true)
     uint32_t t = t_begin, eg = 0;
     bool dirty = false;
@@ -804,7 +875,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
         } else if (rb[g] < re[g]) {
           dirty = true;
           ec[g].tag = MODE == MODE_Z21S ? ec_qterm[g] : tagbase + ec_qterm[g];
-          score_trip<MODE, F_, TAGS, FU>(p, lut, acc, tag, lane, tile_base, rb[g], re[g], dv[g], tfv[g], flv[g], ec[g], qtl);
+          score_trip<MODE, F_, TAGS, FU>(p, lut, acc, tag, lane, tile_base, rb[g], re[g], dv[g], wv[g], ec[g], qtl);
           if (rb[g] + FU * WAVE < re[g])
             score_stream<MODE, F_, TAGS>(p, lut, acc, tag, lane, tile_base, rb[g] + FU * WAVE, re[g], ec[g], qtl);
         }
@@ -815,14 +886,15 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       bool last = false;
       if (neg >= ne) { neg = 0; nt = t + 1; last = true; }
       const bool more = nt < t_end;
+      const double gt_tile = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(gt_req >> 32)),
+                                              __builtin_amdgcn_readfirstlane((int)(uint32_t)gt_req));
       if (more) { PS_PHASE1(nt, neg, false) }
       const bool harvest = last && dirty && !(PS_ABLATE_BUILD && (p.ablate & 4u));
       if (last) dirty = false;
       t = nt; eg = neg;
       if (harvest) {
       // tile epilogue: harvest + reset (two f64 per lane per LDS access where the layout allows)
-      double gt = 0.0;
-      if (!FULL) gt = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const double gt = FULL ? 0.0 : gt_tile;
       const bool zero_tile = TAGS || !q_assign || !more;
       if (MODE == MODE_BM25) {
         // several 16-byte LDS reads in flight per lane: chunks of PS_HARVEST_UNROLL x 128 documents,
@@ -1176,13 +1248,27 @@ __device__ __forceinline__ void posting_scores(const KParams& p, const double* l
                                                const double idf, const double eb, double (&s)[U]) {
   constexpr int FA = F_ ? F_ : MAX_F;
   const uint32_t F = F_ ? (uint32_t)F_ : p.F;
-  uint32_t tfv[U][FA], flv[U][FA];
+  uint32_t wv[U][FA], tfv[U][FA], flv[U][FA];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
 #pragma unroll
-    for (int x = 0; x < FA; ++x) {
-      tfv[u][x] = 0; flv[u][x] = 0;
-      if ((uint32_t)x < F && on[u]) { tfv[u][x] = p.tf[(uint64_t)x * p.P + pi[u]]; flv[u][x] = p.fl[(uint64_t)x * p.P + pi[u]]; }
+    for (int x = 0; x < FA; ++x) wv[u][x] = 0;
+    if (on[u]) tfl_load<F_>(p, pi[u], wv[u]);
+  }
+  tfl_unpack<F_, U>(p, wv, tfv, flv);
+  {  // saturated sub-fields: fetch the exact values now, while the posting indices are still live (rare; the whole wave goes)
+    bool esc = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int x = 0; x < FA; ++x)
+        if ((uint32_t)x < F) esc = esc || tfv[u][x] == TFL_TF_ESC || flv[u][x] == TFL_FL_ESC;
+    if (__any(esc)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int x = 0; x < FA; ++x)
+          if ((uint32_t)x < F && on[u]) tfl_exact(p, (uint32_t)x, pi[u], tfv[u][x], flv[u][x]);
     }
   }
 #pragma unroll
@@ -2055,6 +2141,19 @@ __global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t* q_cnt, const
 // per batch; this is a few microseconds for the ~150 KB of a 1024-query plan.)
 __global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ src, uint4* __restrict__ dst, const size_t n16) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// The packed {tf, field length} words of postings [begin, end) from the exact planes (engine creation,
+// and the appended range after a delta).
+__global__ __launch_bounds__(256) void k_pack_tfl(const uint32_t* __restrict__ tf, const uint32_t* __restrict__ fl,
+                                                  uint32_t* __restrict__ tfl, const uint64_t P, const uint32_t F,
+                                                  const uint64_t begin, const uint64_t end) {
+  const uint64_t n = (end - begin) * F;
+  for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = begin + k / F;
+    const uint32_t x = (uint32_t)(k % F);
+    tfl[i * F + x] = tfl_pack(tf[(uint64_t)x * P + i], fl[(uint64_t)x * P + i]);
+  }
 }
 
 // K1d work items from the per-list records: one wave per list, one lane per chunk.  (The items are

@@ -527,3 +527,54 @@ def test_snapshot_loaded_from_disk_scores_identically(tmp_path):
     for sc in (psa.bm25.new(), psa.zero_to_one.new()):
         assert snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=10) == back.query_batch(queries, sc, None, [1.0, 1.0], top_k=10)
         assert snap.query(queries[0], sc, None, [1.0, 1.0]) == back.query(queries[0], sc, None, [1.0, 1.0])
+
+
+def test_zero_to_one_large_term_frequencies():
+    """k_score's zero_to_one arm divides once per (posting, field) while every term frequency of the trip
+    is <= the entry's exact-numerator limit (48 for an exact-match expansion) and evaluates the full
+    zero_to_one.rs:117-120 expression otherwise: documents on both sides of the limit, exact terms and
+    prefix expansions, top-k and full results."""
+    F = 2
+    o, p = orc.Index(F), ProductIndex(F)
+    tfs = [1, 2, 3, 7, 47, 48, 49, 50, 63, 64, 65, 98, 120, 255, 256, 300]
+    for k, tf in enumerate(tfs * 3):
+        a = " ".join(["alpha"] * tf + ["beta"] * (k % 5) + ["alphabet"] * (k % 3))
+        b = " ".join(["beta"] * (tf // 2 + 1) + ["alpha"] * (k % 4) + ["gamma"])
+        for ix in (o, p):
+            ix.add_document(1000 + k, [a, b])
+    snap = p.idx.snapshot(device=0, tile_docs=256)
+    queries = ["alpha", "alpha beta", "alph", "beta gamma alpha", "alphabet alpha", "a b g"] * 3
+    # (bm25 too: term frequencies >= 255 do not fit the packed {tf, field length} posting words the
+    # kernels stream and are fetched from the exact planes)
+    for name in ("zero_to_one", "bm25"):
+        sc = product_scorer(name)
+        for boosts in ([1.0, 1.0], [2.0, 0.5]):
+            full = snap.query_batch(queries, sc, None, boosts, top_k=0)
+            top5 = snap.query_batch(queries, sc, None, boosts, top_k=5)
+            for q, f, t5 in zip(queries, full, top5):
+                exp = o.query(q, oracle_scorer(name), boosts)
+                assert_same([tuple(r) for r in f], exp, (name, q, boosts))
+                assert_same([tuple(r) for r in t5], exp[:5], (name, q, boosts, "top5"))
+
+
+def test_field_longer_than_the_packed_posting_word_holds():
+    """A field of 2^24 + 50 tokens: its length (and the term frequency) saturate the packed posting word
+    (8-bit tf, 24-bit field length) and every kernel has to fetch the exact values from the planes."""
+    F = 2
+    n = (1 << 24) + 50
+    o, p = orc.Index(F), ProductIndex(F)
+    big = "x " * (n - 3) + "rare y x"
+    docs = [(1, [big, "x y"]), (2, ["x y rare", "y"]), (3, ["y y", "rare x x"]), (4, ["z", big[: 2 * 300]])]
+    for key, fields in docs:
+        for ix in (o, p):
+            ix.add_document(key, fields)
+    snap = p.idx.snapshot(device=0, tile_docs=256)
+    queries = ["x", "rare", "x rare y", "y z", "ra"] * 2
+    for name in ("bm25", "zero_to_one"):
+        sc = product_scorer(name)
+        full = snap.query_batch(queries, sc, None, [1.0, 1.5], top_k=0)
+        top2 = snap.query_batch(queries, sc, None, [1.0, 1.5], top_k=2)
+        for q, f, t2 in zip(queries, full, top2):
+            exp = o.query(q, oracle_scorer(name), [1.0, 1.5])
+            assert_same([tuple(r) for r in f], exp, (name, q))
+            assert_same([tuple(r) for r in t2], exp[:2], (name, q, "top2"))
