@@ -29,6 +29,9 @@ constexpr int WAVE = 64;
 #ifndef PS_FU
 #define PS_FU 1              // postings per lane in a prefetched first trip
 #endif
+#ifndef PS_Z21_HARVEST_UNROLL_1F
+#define PS_Z21_HARVEST_UNROLL_1F 4  // zero_to_one harvest with one live field: 16-byte LDS reads in flight per lane
+#endif
 #ifndef PS_HARVEST_UNROLL
 #define PS_HARVEST_UNROLL 8  // 16-byte LDS reads in flight per lane while a tile is harvested
 #endif
@@ -954,64 +957,79 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       } else {
         // accumulators are planar ([field][T]); two documents per lane per 16-byte LDS access, the
         // reads of all fields of ZU chunks in flight together
-        constexpr int ZU = F_ ? 2 : 1;
-        for (uint32_t c = 0; c < T; c += 2 * WAVE * ZU) {
-          double2 vv[ZU][FA], rv[ZU][F_ ? FA : 1];
-          const bool fused = !TAGS && F_ != 0 && fuse_row != 0xFFFFFFFFu;  // the query's last entry is a dense row
-          if (fused) {
+        // FM: compile-time copy of the item's field mask (F_ == 2: one loop body per mask, so a pruned field
+        // costs no LDS read, no row fetch and no compare), or all ones = test the run-time mask per field
+        auto harvest_z = [&](auto fm_tag, auto zu_tag) {
+          constexpr uint32_t FM = decltype(fm_tag)::value;
+          constexpr int ZU = decltype(zu_tag)::value;  // chunks of 128 documents whose LDS reads are in flight together
+          auto live = [&](const int x) { return FM != 0xFFFFFFFFu ? ((FM >> x) & 1u) != 0u : ((fmask >> x) & 1u) != 0u; };
+          for (uint32_t c = 0; c < T; c += 2 * WAVE * ZU) {
+            double2 vv[ZU][FA], rv[ZU][F_ ? FA : 1];
+            const bool fused = !TAGS && F_ != 0 && fuse_row != 0xFFFFFFFFu;  // the query's last entry is a dense row
+            if (fused) {
+#pragma unroll
+              for (int u = 0; u < ZU; ++u)
+#pragma unroll
+                for (int x = 0; x < (F_ ? FA : 1); ++x) {
+                  // (run-time mask: a field that is out re-reads plane 0 of the row - same lines, no branch in
+                  // the load burst - and its value is dropped below)
+                  const uint32_t xs = live(x) ? (uint32_t)x : 0u;
+                  if (FM == 0xFFFFFFFFu || ((FM >> x) & 1u))
+                    rv[u][x] = *reinterpret_cast<const double2*>(p.rows + ((uint64_t)fuse_row * F + xs) * p.row_stride + tile_base +
+                                                                 c + u * 2 * WAVE + 2 * lane);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < ZU; ++u)
 #pragma unroll
-              for (int x = 0; x < (F_ ? FA : 1); ++x) {
-                // (a field that is out re-reads plane 0 of the row - same lines - and its value is dropped below)
-                const uint32_t xs = ((fmask >> x) & 1u) ? (uint32_t)x : 0u;
-                rv[u][x] = *reinterpret_cast<const double2*>(p.rows + ((uint64_t)fuse_row * F + xs) * p.row_stride + tile_base +
-                                                             c + u * 2 * WAVE + 2 * lane);
-              }
-          }
+              for (int x = 0; x < FA; ++x)
+                if (F_ && (uint32_t)x < F && (FM == 0xFFFFFFFFu || ((FM >> x) & 1u)))  // (a field that is out is never written: its plane reads zero)
+                  vv[u][x] = *reinterpret_cast<double2*>(&acc[(uint32_t)x * T + c + u * 2 * WAVE + 2 * lane]);
 #pragma unroll
-          for (int u = 0; u < ZU; ++u)
+            for (int u = 0; u < ZU; ++u) {
+              // result.score = max(score_by_pool, result.score) over fields, from the dummy 0. (zero_to_one.rs:81,122)
+              double b0 = 0.0, b1 = 0.0;
+              bool h0 = false, h1 = false;
 #pragma unroll
-            for (int x = 0; x < FA; ++x)
-              if (F_ && (uint32_t)x < F) vv[u][x] = *reinterpret_cast<double2*>(&acc[(uint32_t)x * T + c + u * 2 * WAVE + 2 * lane]);  // (a field that is out is never written: its plane reads zero)
-#pragma unroll
-          for (int u = 0; u < ZU; ++u) {
-            // result.score = max(score_by_pool, result.score) over fields, from the dummy 0. (zero_to_one.rs:81,122)
-            double b0 = 0.0, b1 = 0.0;
-            bool h0 = false, h1 = false;
-#pragma unroll
-            for (int x = 0; x < FA; ++x) {
-              if ((uint32_t)x < F) {
-                const uint32_t at = (uint32_t)x * T + c + u * 2 * WAVE + 2 * lane;
-                // (any number of fields: one plane at a time, 8 preloaded planes would cost 32 VGPRs)
-                double2 v = F_ ? vv[u][x] : *reinterpret_cast<double2*>(&acc[at]);
-                if (zero_tile && (v.x > 0.0 || v.y > 0.0)) {
-                  *reinterpret_cast<double2*>(&acc[at]) = make_double2(0.0, 0.0);
-                  if (TAGS) *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(tag) + at) = make_uint2(0u, 0u);
+              for (int x = 0; x < FA; ++x) {
+                if ((uint32_t)x < F && (FM == 0xFFFFFFFFu || ((FM >> x) & 1u))) {
+                  const uint32_t at = (uint32_t)x * T + c + u * 2 * WAVE + 2 * lane;
+                  // (any number of fields: one plane at a time, 8 preloaded planes would cost 32 VGPRs)
+                  double2 v = F_ ? vv[u][x] : *reinterpret_cast<double2*>(&acc[at]);
+                  if (zero_tile && (v.x > 0.0 || v.y > 0.0)) {
+                    *reinterpret_cast<double2*>(&acc[at]) = make_double2(0.0, 0.0);
+                    if (TAGS) *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(tag) + at) = make_uint2(0u, 0u);
+                  }
+                  if (F_ != 0 && fused && live(x)) { v.x += rv[u][F_ ? x : 0].x; v.y += rv[u][F_ ? x : 0].y; }  // last record, in sorted order
+                  h0 |= v.x > 0.0; h1 |= v.y > 0.0;
+                  b0 = fmax(v.x, b0); b1 = fmax(v.y, b1);
                 }
-                if (F_ != 0 && fused && ((fmask >> x) & 1u)) { v.x += rv[u][F_ ? x : 0].x; v.y += rv[u][F_ ? x : 0].y; }  // last record, in sorted order
-                h0 |= v.x > 0.0; h1 |= v.y > 0.0;
-                b0 = fmax(v.x, b0); b1 = fmax(v.y, b1);
               }
-            }
-            const uint32_t d = tile_base + c + u * 2 * WAVE + 2 * lane;
-            if (p.alive != nullptr) {  // delta removals
-              const uint32_t aw = p.alive[d >> 5] >> (d & 31u);
-              h0 = h0 && (aw & 1u);
-              h1 = h1 && (aw & 2u);
-            }
-            if (FULL) {
-              full_emit(p, q, lane, h0, b0, d);
-              full_emit(p, q, lane, h1, b1, d + 1);
-            } else {
-              const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
-              if (__any((h0 && b0 >= lo) || (h1 && b1 >= lo))) {
-                topk_offer(tk, p.K, lane, h0, b0, d, gt);
-                topk_offer(tk, p.K, lane, h1, b1, d + 1, gt);
+              const uint32_t d = tile_base + c + u * 2 * WAVE + 2 * lane;
+              if (p.alive != nullptr) {  // delta removals
+                const uint32_t aw = p.alive[d >> 5] >> (d & 31u);
+                h0 = h0 && (aw & 1u);
+                h1 = h1 && (aw & 2u);
+              }
+              if (FULL) {
+                full_emit(p, q, lane, h0, b0, d);
+                full_emit(p, q, lane, h1, b1, d + 1);
+              } else {
+                const double lo = (tk.n == p.K && tk.thr_s > gt) ? tk.thr_s : gt;
+                if (__any((h0 && b0 >= lo) || (h1 && b1 >= lo))) {
+                  topk_offer(tk, p.K, lane, h0, b0, d, gt);
+                  topk_offer(tk, p.K, lane, h1, b1, d + 1, gt);
+                }
               }
             }
           }
-        }
+        };
+        const uint32_t fm2 = fmask & 3u;  // wave-uniform
+        constexpr int ZU1 = PS_Z21_HARVEST_UNROLL_1F;  // one live field: half the registers per chunk
+        const bool wide_ok = (T % (2 * WAVE * ZU1)) == 0u;
+        if (F_ == 2 && !FULL && !TAGS && fm2 == 1u && wide_ok) harvest_z(std::integral_constant<uint32_t, 1u>{}, std::integral_constant<int, ZU1>{});
+        else if (F_ == 2 && !FULL && !TAGS && fm2 == 2u && wide_ok) harvest_z(std::integral_constant<uint32_t, 2u>{}, std::integral_constant<int, ZU1>{});
+        else harvest_z(std::integral_constant<uint32_t, 0xFFFFFFFFu>{}, std::integral_constant<int, (F_ ? 2 : 1)>{});
       }
       fuse_row = 0xFFFFFFFFu;
       if (!FULL && tk.n == p.K && tk.thr_s > gt) {
