@@ -77,6 +77,12 @@ void set_stats(ps_snapshot* s, const ps_batch_stats& st) {
   s->last = st;
 }
 
+double wall_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 // Host planner for a whole batch.  Queries are independent (each owns its scores / visited maps
 // in the reference, src/query.rs:31,37), so with the built-in tokenizer the batch is planned by a
 // small persistent thread pool, each thread producing a private Plan that is then concatenated
@@ -96,15 +102,19 @@ void plan_batch(ps_snapshot* snap, const ps_scorer_desc& sc, const std::vector<s
     for (size_t i = 0; i < n; ++i) snap->snap->plan_query(sc, qs[i], tok, user, plan);
     return;
   }
+  static const bool trace = getenv("PS_TRACE") && *getenv("PS_TRACE") == '2';
+  const double tp0 = trace ? wall_ms() : 0.0;
   std::lock_guard<std::mutex> l(snap->pool_mu);
   if (!snap->pool || snap->pool->size() != want) snap->pool.reset(new ps::Pool(want - 1));
   std::vector<ps::Plan> parts(want);
+  const double tp1 = trace ? wall_ms() : 0.0;
   snap->pool->run([&](unsigned part, unsigned nparts) {
     size_t b = n * part / nparts, e = n * (part + 1) / nparts;
     ps::Plan& pl = parts[part];
     pl.qbeg.assign(1, 0);
     for (size_t i = b; i < e; ++i) snap->snap->plan_query(sc, qs[i], nullptr, nullptr, pl);
   });
+  const double tp2 = trace ? wall_ms() : 0.0;
   for (ps::Plan& pl : parts) {
     const uint32_t base = (uint32_t)plan.entries.size();
     plan.entries.insert(plan.entries.end(), pl.entries.begin(), pl.entries.end());
@@ -117,6 +127,7 @@ void plan_batch(ps_snapshot* snap, const ps_scorer_desc& sc, const std::vector<s
     plan.max_nodes = std::max(plan.max_nodes, pl.max_nodes);
     plan.multi_expansion = plan.multi_expansion || pl.multi_expansion;
   }
+  if (trace) fprintf(stderr, "[ps] plan_batch   setup %.3f  run %.3f  merge %.3f ms (%u threads)\n", tp1 - tp0, tp2 - tp1, wall_ms() - tp2, want);
 }
 
 std::vector<std::string_view> views_of(const ps_str* queries, size_t n) {
@@ -125,11 +136,6 @@ std::vector<std::string_view> views_of(const ps_str* queries, size_t n) {
   return v;
 }
 
-double wall_ms() {
-  timespec ts;
-  clock_gettime(CLOCK_MONOTONIC, &ts);
-  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-}
 
 }  // namespace
 
