@@ -1574,7 +1574,9 @@ void launch_k_score(EngineImpl& m, KParams& kp, bool tags, int n_cu, hipStream_t
 
 // K1d: persistent 8-wave workgroups (the LUT is the only LDS), items from the device-scope counter
 void launch_daat(EngineImpl& m, KParams& kp, bool multi, int n_cu, hipStream_t st) {
-  const size_t lds = (size_t)kp.lut_stride * LUT_TF * 8;
+  // (PS_DAAT_PAD_LDS: extra dynamic LDS per workgroup - an occupancy cap for experiments; 24000 = 3 waves per SIMD)
+  static const size_t pad_lds = env_u32("PS_DAAT_PAD_LDS", 0);
+  const size_t lds = std::max((size_t)kp.lut_stride * LUT_TF * 8, pad_lds);
 #define PS_DAAT(FV, MU)                                                                                  \
   do {                                                                                                   \
     const void* fn = reinterpret_cast<const void*>(&k_daat<FV, MU>);                                     \
