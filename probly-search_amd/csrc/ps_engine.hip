@@ -7,7 +7,9 @@
 // (src/score/default/zero_to_one.rs:44-126), max_score_merger (src/query.rs:150-164) and the
 // result materialisation + sort (src/query.rs:97-105) with:
 //
+//       k_pack_tfl   per snapshot (and per delta): the packed {tf, field length} posting words the hot kernels stream
 //       k_upload     per batch: the staged plan, read from the device-mapped pinned slot
+//       k_make_items per K1d batch: the work items, expanded on the device from one record per list
 //   K0  k_bm25_lut   per (k1, b): saturated-tf table tfn(field, tf < 16, field length), same f64 expression
 //   K0b k_dense_rows per-document score rows of the hot (list, idf, boost) combinations not yet resident
 //   K1  k_score      persistent waves, one (query, run of S doc tiles) item at a time; wave-private
@@ -18,6 +20,8 @@
 //                    tags; per tile harvest into a register-resident wave top-K with a per-query
 //                    threshold shared through one device-scope word.  No barriers after the LUT
 //                    load, no inter-wave atomics on scores: bit-reproducible.
+//   K1d k_daat       BM25 top-k batches: exact dynamic pruning (per-list upper bounds, essential lists,
+//                    document-at-a-time lookups), one wave per chunk of a list; K3d k_merge_items behind it
 //   K2  k_z21        zero_to_one general case (same node under two query terms, version layers)
 //   K3  k_merge      per query: merge of the per-run top-K lists, doc id -> key
 //   K4  ps_sort.hip  full-result mode: canonical (score desc, key asc) order on the device

@@ -1,6 +1,6 @@
 // ps_kernels.hpp — device code of the query-scoring path (gfx950 / CDNA4): kernel parameter
-// block, wave-level top-K, K0 k_bm25_lut, K0b k_dense_rows, K1 k_score, K2 k_z21, K3 k_merge,
-// k_upload, k_pack_results.  Included by ps_engine.hip only (one translation unit); see that file's header
+// block, wave-level top-K, K0 k_bm25_lut, K0b k_dense_rows, K1 k_score, K1d k_daat (+ k_daat_z), K2 k_z21,
+// K3 k_merge / K3d k_merge_items, the device planner k_plan, k_pack_tfl, k_make_items, k_upload, k_pack_results.  Included by ps_engine.hip only (one translation unit); see that file's header
 // comment for the kernel overview and DESIGN.md section 3 for the design.
 #pragma once
 #include <hip/hip_runtime.h>
