@@ -32,6 +32,9 @@ constexpr int WAVE = 64;
 #ifndef PS_Z21_HARVEST_UNROLL_1F
 #define PS_Z21_HARVEST_UNROLL_1F 4  // zero_to_one harvest with one live field: 16-byte LDS reads in flight per lane
 #endif
+#ifndef PS_DAAT_UM
+#define PS_DAAT_UM 2             // K1d, multi-expansion arm: postings per lane in flight
+#endif
 #ifndef PS_HARVEST_UNROLL
 #define PS_HARVEST_UNROLL 8  // 16-byte LDS reads in flight per lane while a tile is harvested
 #endif
@@ -1381,7 +1384,7 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
 template <int F_, bool MULTI>
 __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int U = (F_ && !MULTI) ? PS_DAAT_U : 2;  // postings per lane in flight (the multi-expansion arm keeps per-term maxima per posting)
+  constexpr int U = (F_ && !MULTI) ? PS_DAAT_U : (F_ ? PS_DAAT_UM : 2);  // postings per lane in flight (the multi-expansion arm keeps per-term maxima per posting)
   const int lane = threadIdx.x & (WAVE - 1);
   const double* lut = reinterpret_cast<const double*>(smem);
   // A grid that covers every item with its own wave assigns them by index (workgroups are dispatched
