@@ -216,7 +216,9 @@ struct EngineImpl {
   PlanTotals* h_totals = nullptr;  // pinned
   std::unique_ptr<Pool> pool;  // K1d descriptor building for large batches
   struct DaatWork* daat_work = nullptr;  // reused across batches (defined below)
-  std::vector<uint32_t> daat_chunk_of, daat_nchunk_of, daat_entry_order, daat_first_slot, daat_item_at;
+  std::vector<uint32_t> daat_chunk_of, daat_nchunk_of, daat_entry_order, daat_first_slot;
+  std::vector<uint64_t> daat_sort_keys;
+  std::vector<uint16_t> daat_rank16;
   uint32_t daat_max_slots = 0;
   uint32_t daat_first_items = 0;  // K1d: items of the queries' rank-0 lists (they lead the item order)  // K1d: most candidate slots of one query in the batch being enqueued
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
@@ -817,6 +819,11 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
   std::vector<uint32_t>& nchunk = m.daat_nchunk_of;
   chunk.resize(ne);
   nchunk.resize(ne);
+  // ranks again as a compact array: the serial ordering pass below then pulls 2 bytes per entry out of the
+  // pool threads' caches instead of a 32-byte DEntry (the pass was bound by those cache-line transfers)
+  std::vector<uint16_t>& rk = m.daat_rank16;
+  rk.resize(ne);
+  auto rank_of = [&](size_t i) { return rk[i] != 0xFFFFu ? (uint32_t)rk[i] : dw.dentry[i].rank; };
   auto per_query = [&](size_t q0, size_t q1) {
     std::vector<uint32_t> ord;
     std::vector<double> ub;
@@ -845,6 +852,7 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
         const uint32_t i = ord[r];
         DEntry& d = dw.dentry[b + i];
         d.rank = r;
+        rk[b + i] = (uint16_t)std::min<uint32_t>(r, 0xFFFFu);
         d.q = (uint32_t)q;
         d.ub = ub[i];
         dw.rorder[b + r] = b + i;
@@ -915,7 +923,7 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
     if (!trace_pd) return;
     const double n = now_ms();
     fprintf(stderr, "[ps]     daat %-10s %.3f ms\n", what, n - tpd);
-    tpd = n;
+    tpd = now_ms();  // (after the print: its time is not the next stage's)
   };
   if (B >= 256 && m.tune.daat_threads > 1) {
     if (!m.pool || m.pool->size() != m.tune.daat_threads) m.pool.reset(new Pool(m.tune.daat_threads - 1));
@@ -932,14 +940,24 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
   for (size_t i = 0; i < ne; ++i) eo[i] = (uint32_t)i;
   {  // counting sort by rank, then the rank-0 bucket (the lists that set the thresholds) longest first
     std::vector<uint32_t> cnt(plan.max_entries + 2, 0);
-    for (size_t i = 0; i < ne; ++i) cnt[dw.dentry[i].rank + 1]++;
+    for (size_t i = 0; i < ne; ++i) cnt[rank_of(i) + 1]++;
     for (size_t r = 1; r < cnt.size(); ++r) cnt[r] += cnt[r - 1];
     const uint32_t n0 = cnt[1];
-    for (size_t i = 0; i < ne; ++i) eo[cnt[dw.dentry[i].rank]++] = (uint32_t)i;
-    std::sort(eo.begin(), eo.begin() + n0, [&](uint32_t a, uint32_t c) {
-      if (ents[a].len != ents[c].len) return ents[a].len > ents[c].len;
-      return a < c;
-    });
+    for (size_t i = 0; i < ne; ++i) eo[cnt[rank_of(i)]++] = (uint32_t)i;
+    // (a scheduling order, not a result order: a stable counting sort into 64 length classes - log2 with
+    // one fractional bit, longest first - costs 3 us per 1024 queries where the exact sort cost 30)
+    auto cls = [&](uint32_t e) {
+      const uint32_t len = std::max(1u, ents[e].len);
+      const uint32_t lg = 31u - (uint32_t)__builtin_clz(len);
+      return 63u - (2u * lg + (lg ? ((len >> (lg - 1)) & 1u) : 0u));
+    };
+    uint32_t cc[65] = {0};
+    for (uint32_t k = 0; k < n0; ++k) cc[cls(eo[k]) + 1]++;
+    for (uint32_t c = 1; c <= 64; ++c) cc[c] += cc[c - 1];
+    std::vector<uint64_t>& keys = m.daat_sort_keys;  // (scratch: the rank-0 entries in their new order)
+    keys.resize(n0);
+    for (uint32_t k = 0; k < n0; ++k) keys[cc[cls(eo[k])]++] = eo[k];
+    for (uint32_t k = 0; k < n0; ++k) eo[k] = (uint32_t)keys[k];
   }
   // candidate slots are query-major: slot of (entry, chunk) = qslot[q] + chunks of the query's earlier entries + chunk
   std::vector<uint32_t>& first_slot = m.daat_first_slot;
@@ -958,7 +976,7 @@ void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const
       const uint32_t i = eo[k];
       dw.gen[k] = DItemGen{i, at, chunk[i], first_slot[i]};
       at += nchunk[i];
-      if (dw.dentry[i].rank == 0) dw.first_items = at;
+      if (rk[i] == 0) dw.first_items = at;
     }
     dw.n_items = at;
   }
@@ -1293,7 +1311,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     if (!trace_sp) return;
     const double n = now_ms();
     fprintf(stderr, "[ps]   stage %-10s %.3f ms\n", what, n - tsp);
-    tsp = n;
+    tsp = now_ms();
   };
   const bool daat_batch = topk_path && m.tune.daat && plan.qbeg.size() - 1 >= m.tune.daat_min_batch && !plan.entries.empty();
   if (daat_batch && sc.kind == PS_SCORER_BM25 && m.tune.lut && bm25_params_sane(s, sc, boosts) &&
@@ -1711,7 +1729,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     if (!trace) return;
     double n = now_ms();
     fprintf(stderr, "[ps] %-12s %.3f ms\n", what, n - tt);
-    tt = n;
+    tt = now_ms();
   };
   if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
   m.tail_pending = false;
