@@ -51,6 +51,8 @@ def parse_args(argv=None):
     ap.add_argument("--device-plan", action="store_true",
                     help="plan the batches on the device too (ps_snapshot_query_batch_device_planned_flat: BM25, K1 k_score; "
                          "N=1): the SURVEY 8f N2 path, not the headline")
+    ap.add_argument("--no-streaming-leg", action="store_true",
+                    help="skip the untimed-for-headline K1 k_score leg (PS_DAAT=0) reported under roofline.streaming_kernel_leg")
     ap.add_argument("--no-bulk-index", action="store_true",
                     help="skip timing the GPU bulk indexer on the same corpus (reported beside index_build_s; N=1, <= 2M docs)")
     return ap.parse_args(argv)
@@ -227,6 +229,7 @@ def main():
         step(packed[s], s)
     fence()
     snap.kernel_breakdown(reset=True)
+    snap.work_counters(reset=True)
     postings = 0
     layout_bytes = 0
     dense_rows = 0
@@ -247,6 +250,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     kt = snap.kernel_breakdown(reset=False)
+    wc = snap.work_counters(reset=True)  # what the kernels of the timed steps counted themselves
     if world > 1:
         # the exchange really happened: this rank's slice of the last gathered buffer is its own block
         # (compare the key/score area; the counts area carries uninitialised padding)
@@ -299,8 +303,13 @@ def main():
             "hbm_resident_bytes": info["device_bytes"],
             "roofline": roofline(args, cfg, kt["score_kernel"], k_avg_ms, rows_avg_ms, int(kt["launches"]),
                                  alg_bytes_launch, layout_bytes / max(1, steps), dense_rows / max(1, steps),
-                                 dense_built / max(1, steps)),
+                                 dense_built / max(1, steps), wc, F),
         }
+        if world == 1 and cfg["scorer"] == "bm25" and not args.device_plan and not args.no_streaming_leg \
+                and kt["score_kernel"].startswith("ps::k_daat"):
+            # the streaming kernel the north star describes (K1 k_score: every posting of every list through
+            # the LDS tiles), on the same batches, outside the timed region of the headline
+            result["roofline"]["streaming_kernel_leg"] = streaming_leg(args, cfg, snap, step, fence, packed, F, B, K)
         if world == 1 and not args.no_cpu_baseline:
             sample = [q for b in batches[args.warmup:] for q in b]
             result["cpu_baseline"] = cpu_baseline(args, cfg, corpus, sample, boosts, snap, scorer, K, B)
@@ -313,17 +322,75 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layout_bytes, rows_used, rows_built):
-    """`achieved` / `frac` are priced against the resource that BINDS the dominant kernel, taken from
-    the committed PMC derivation (tools/derive_roofline.py -> profiles/roofline_<config>.json) when it
-    was made for this kernel symbol and config; its per-launch resource amounts are divided by the
-    kernel time measured LIVE in this run.  Without a matching derivation nothing counter-based is
-    printed (`traffic` null) and the bound falls back to the contract's algorithmic-bytes figure.
-    The algorithmic figure is always labelled for what it is: work the REFERENCE algorithm would
-    stream, not bytes this kernel moved (it prunes, and list slices are shared out of L2)."""
+def per_launch_work(wc):
+    n = max(1, wc["launches"])
+    return {k: (v / n) for k, v in wc.items() if k != "launches"}
+
+
+def streaming_leg(args, cfg, snap, step, fence, packed, F, B, K):
+    """K1 k_score on the same batches (PS_DAAT=0 through ps_set_option; the engine re-reads its knobs at
+    the next batch), timed alone with the library's HIP events; its own HBM fraction from its own counters."""
+    import probly_search_amd as psa
+    L = psa.load()
+    L.ps_set_option(b"PS_DAAT", 0)
+    try:
+        n = min(len(packed), max(3, min(args.steps, 10)))
+        step(packed[0], 0)
+        fence()
+        snap.kernel_breakdown(reset=True)
+        snap.work_counters(reset=True)
+        t0 = time.perf_counter()
+        for s in range(n):
+            step(packed[-1 - s], s)
+        fence()
+        wall = time.perf_counter() - t0
+        kt = snap.kernel_breakdown(reset=True)
+        wc = snap.work_counters(reset=True)
+    finally:
+        L.ps_set_option(b"PS_DAAT", 1)
+    launches = max(1, kt["launches"])
+    t = kt["score_ms"] / launches * 1e-3
+    w = per_launch_work(wc)
+    rate = w["bytes_touched"] / t / 1e9 if t > 0 else 0.0
+    return {"kernel": kt["score_kernel"], "kernel_avg_ms": t * 1e3, "rows_kernels_avg_ms": kt["rows_ms"] / launches,
+            "launches": int(launches), "ms_per_step": wall / n * 1e3, "queries_per_s": B * n / wall,
+            "units_processed": {"postings_streamed": w["k1_postings"], "dense_row_tile_slices": w["k1_row_slices"],
+                                "items": w["k1_items"]},
+            "bytes_touched": w["bytes_touched"], "achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": rate / HBM_PEAK_GBS,
+            "note": "every posting of every (query, list) streamed by its own wave: (4+4F) B per posting of the packed layout, "
+                    "8 B per document of a dense-row tile slice; queries that share a list re-read it through L2 / Infinity "
+                    "Cache (SURVEY 8d counts each visit), so this is a rate of bytes delivered to the CUs, not of HBM traffic"}
+
+
+def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layout_bytes, rows_used, rows_built, wc, F):
+    """`bound` is hbm; `achieved` = bytes the dominant kernel REALLY touched per launch - computed from the
+    work counters the kernel keeps itself (ps_snapshot_work_counters: postings scanned, lookups by kind,
+    hits, candidate slots, results), read live in this run - / its live HIP-event duration; `frac` =
+    achieved / 8 TB/s.  `units_processed` are those counts per launch, so the figure can be recomputed by
+    hand.  Beside it: the contract's algorithmic figure (work the REFERENCE walks: K1d prunes 97 % of it, so
+    that ratio exceeds 1 and is labelled, not claimed), and - when profiles/roofline_<config>.json was
+    derived for this kernel and setup - the PMC view of the same launch (`traffic` = 2 x FETCH_SIZE +
+    WRITE_SIZE per launch from the committed rocprofv3 passes; per-resource fractions in `pmc`)."""
     t = k_avg_ms * 1e-3
     alg_rate = alg_bytes / t / 1e9 if t > 0 else 0.0
-    out = {"kernel": kernel, "kernel_avg_ms": k_avg_ms, "rows_kernels_avg_ms": rows_avg_ms, "launches": launches,
+    w = per_launch_work(wc)
+    touched = w["bytes_touched"]
+    rate = touched / t / 1e9 if t > 0 else 0.0
+    daat = kernel.startswith("ps::k_daat")
+    units = ({"items": w["items"], "items_run": w["items_run"], "postings_scanned": w["postings_scanned"],
+              "postings_reached_lookups": w["postings_reached_lookups"], "lookups_row_8B": w["lookups_row"],
+              "lookups_bitmap_cell_8B": w["lookups_cell"], "lookups_binary_search_probe_4B": w["lookups_probe"],
+              "lookup_hits": w["lookup_hits"], "offers_to_topk": w["offers"], "results": w["results"]} if daat else
+             {"items": w["k1_items"], "postings_streamed": w["k1_postings"], "dense_row_tile_slices": w["k1_row_slices"],
+              "results": w["results"]})
+    out = {"bound": "hbm", "achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS,
+           "bytes_touched": touched, "units_processed": units, "counted_launches": int(wc["launches"]),
+           "bytes_touched_formula": "scanned x (4+4F) + row lookups x 8 + bitmap-cell lookups x 8 + search probes x 4 + "
+                                    "lookup hits x 4F + candidate slots written x 12 + results x 16  (F = %d; K1: postings "
+                                    "streamed x (4+4F) + row tile slices x tile_docs x 8)" % F,
+           "fraction_of_reference_postings_scanned": (w["postings_scanned"] * (4 + 8 * F) / alg_bytes) if daat and alg_bytes else None,
+           "kernel": kernel, "kernel_avg_ms": k_avg_ms, "rows_kernels_avg_ms": rows_avg_ms, "launches": launches,
            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_rate_GBps": alg_rate,
            "algorithmic_rate_over_hbm_peak": alg_rate / HBM_PEAK_GBS,
            "algorithmic_note": "SURVEY 8d formula: (4+8F) B x postings the reference walks + 16 B x results, / live kernel "
@@ -344,28 +411,32 @@ def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layo
                     args.config, d.get("kernel"))
         except Exception as e:  # noqa: BLE001
             out["derivation_skipped"] = "unreadable: %s" % e
+    # Little's law for the latency bound: bytes in flight = rate x latency.  An 8-byte lookup that misses L2
+    # returns after ~900 cycles (MI355X_MICROARCH.md: global_load HBM-miss latency; ~200 on an L2 hit).
+    clk_ghz = 2.4
+    lat_s = 900 / (clk_ghz * 1e9)
+    out["littles_law"] = {"assumed_load_latency_ns": lat_s * 1e9, "bytes_in_flight_at_achieved_rate": rate * 1e9 * lat_s,
+                          "bytes_in_flight_if_every_lane_of_4_waves_per_simd_kept_4_8B_loads_outstanding":
+                              1024 * 4 * 64 * 4 * 8,
+                          "reading": "the kernel keeps a few percent of the loads in flight that its occupancy would allow: "
+                                     "its lookups hang on each other (threshold -> own posting -> other lists -> hits), so "
+                                     "the bound is dependent latency, not HBM throughput"}
+    out["traffic"] = None
     if drv and t > 0:
         res = {}
         for name, r in drv["resources"].items():  # per-launch amount of each resource, its peak rate
-            rate = r["per_launch"] / t
-            res[name] = {"per_launch": r["per_launch"], "unit": r["unit"], "achieved": rate / r["scale"],
-                         "peak": r["peak"], "rate_unit": r["rate_unit"], "frac": rate / r["scale"] / r["peak"]}
-        bound = max(res, key=lambda k: res[k]["frac"])
-        out.update({"bound": bound, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"],
-                    "unit": res[bound]["rate_unit"], "frac": res[bound]["frac"],
-                    "traffic": drv.get("hbm_bytes_per_launch"), "resources": res,
-                    "wave_cycles_in_profiled_run": drv.get("wave_cycles"),
-                    "reading": "frac is the busiest unit's share of ITS peak (per-launch counter amount from the committed "
-                               "PMC passes / this run's kernel time).  With every unit far below its peak and most "
-                               "wave-cycles parked on s_waitcnt the kernel is bound by dependent memory latency "
-                               "(document-at-a-time lookups), not by a throughput roof",
-                    "derivation": "profiles/roofline_%s.json (tools/derive_roofline.py over the rocprofv3 PMC passes "
-                                  "of head %s)" % (args.config, drv.get("head"))})
-    else:
-        out.update({"bound": "hbm", "achieved": alg_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": alg_rate / HBM_PEAK_GBS, "traffic": None,
-                    "basis": "no PMC derivation for this kernel/config in profiles/: the contract's algorithmic-bytes "
-                             "figure (see algorithmic_note; not a measured HBM fraction)"})
+            rr = r["per_launch"] / t
+            res[name] = {"per_launch": r["per_launch"], "unit": r["unit"], "achieved": rr / r["scale"],
+                         "peak": r["peak"], "rate_unit": r["rate_unit"], "frac": rr / r["scale"] / r["peak"]}
+        traffic = drv.get("hbm_bytes_per_launch")
+        out.update({"traffic": traffic,
+                    "bytes_touched_over_traffic": (touched / traffic) if traffic else None,
+                    "pmc": {"resources": res, "wave_cycles_in_profiled_run": drv.get("wave_cycles"),
+                            "work_counters_in_profiled_run": drv.get("work_counters"),
+                            "note": "per-launch counter amounts of the committed rocprofv3 PMC passes (same kernel symbol, "
+                                    "config, scorer, row mode) / this run's kernel time; traffic = 2 x FETCH_SIZE + WRITE_SIZE",
+                            "derivation": "profiles/roofline_%s.json (tools/derive_roofline.py, head %s)" % (
+                                args.config, drv.get("head"))}})
     return out
 
 

@@ -364,6 +364,38 @@ typedef struct ps_kernel_times {
   char score_kernel[96];
 } ps_kernel_times;
 ps_status ps_snapshot_kernel_breakdown(ps_snapshot* snap, ps_kernel_times* out, int reset);
+/* Work the scoring kernels really did, counted BY THE KERNELS (always on): every wave adds its counts
+ * to device words when it finishes a work item, so the figures belong to the launches that ran, not to
+ * a model of them.  Summed over every batch of this snapshot since the last reset; the call waits for
+ * outstanding work.  This is what bench.py's roofline (`bytes_touched`) is computed from: the exact
+ * pruning kernel K1d k_daat skips most of the postings the reference walks (src/query.rs:61-89), so
+ * the bytes it moves have to be counted, not derived from the plan.
+ *   K1d k_daat: a posting of the item's own list is "scanned" (doc id + packed {tf, field length} words:
+ *   4 + 4F bytes); one that passes the first bound test "reaches the lookups"; a lookup into another
+ *   list is one 8-byte dense-row read, one 8-byte {bits, rank} bitmap-cell read, or 4-byte probes of a
+ *   binary search (two table words, the probed doc ids, the final check); a lookup that finds the
+ *   document reads its packed words (4F bytes).
+ *   K1 k_score: every posting of every (query, list) is streamed (4 + 4F bytes), a dense-row use reads
+ *   8 bytes per document and plane of the tile slice. */
+typedef struct ps_work_counters {
+  uint64_t launches;            /* scoring-kernel launches counted                                   */
+  uint64_t items;               /* K1d: work items (chunks of lists) handed to the launches          */
+  uint64_t items_run;           /* K1d: items that scanned at least one trip (the rest were skipped whole) */
+  uint64_t postings_scanned;    /* K1d: postings of the items' own lists read                        */
+  uint64_t postings_reached_lookups; /* K1d: ... that survived the first bound test                  */
+  uint64_t lookups_row;         /* K1d: 8-byte dense-row reads                                       */
+  uint64_t lookups_cell;        /* K1d: 8-byte bitmap-cell reads                                     */
+  uint64_t lookups_probe;       /* K1d: 4-byte binary-search probes                                  */
+  uint64_t lookup_hits;         /* K1d: lookups that found the document and scored its posting       */
+  uint64_t offers;              /* K1d: documents offered to a wave's top-K                          */
+  uint64_t k1_items;            /* K1: (query, run) items processed                                  */
+  uint64_t k1_postings;         /* K1: postings streamed through the LDS tiles                       */
+  uint64_t k1_row_slices;       /* K1: tile slices of dense rows read (tile_docs x 8 bytes x planes) */
+  uint64_t results;             /* results written (top-k slots filled)                              */
+  uint64_t bytes_touched;       /* the formula above applied to these counts, + 12 bytes per candidate
+                                   slot written and 16 bytes per result                              */
+} ps_work_counters;
+ps_status ps_snapshot_work_counters(ps_snapshot* snap, ps_work_counters* out, int reset);
 
 /* ------------------------------------------------------------------ host-side inspection ---- */
 /* The query plan the host hands to the kernels (tokenise -> expand_term -> before_each), one

@@ -80,6 +80,12 @@ class KernelTimes(C.Structure):
                 ("score_kernel", C.c_char * 96)]
 
 
+class WorkCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "launches", "items", "items_run", "postings_scanned", "postings_reached_lookups", "lookups_row", "lookups_cell",
+        "lookups_probe", "lookup_hits", "offers", "k1_items", "k1_postings", "k1_row_slices", "results", "bytes_touched")]
+
+
 class SnapshotInfo(C.Structure):
     _fields_ = [("fields_num", C.c_uint32), ("tile_docs", C.c_uint32), ("n_docs", C.c_uint64),
                 ("n_terms", C.c_uint64), ("n_postings", C.c_uint64), ("n_pointers", C.c_uint64),
@@ -166,6 +172,7 @@ SYMBOLS = {
     "ps_snapshot_last_stats": (C.c_int, [_P, C.POINTER(BatchStats)]),
     "ps_snapshot_kernel_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "ps_snapshot_kernel_breakdown": (C.c_int, [_P, C.POINTER(KernelTimes), C.c_int]),
+    "ps_snapshot_work_counters": (C.c_int, [_P, C.POINTER(WorkCounters), C.c_int]),
     "ps_index_snapshot_ex": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "ps_snapshot_update": (C.c_int, [_P, _P, C.POINTER(UpdateStats)]),
     "ps_index_snapshot_multi": (C.c_int, [_P, C.POINTER(C.c_int), C.c_size_t, C.c_uint32, C.POINTER(_P)]),

@@ -150,6 +150,10 @@ bool gpu_group_corpus(int device, uint32_t F, size_t n_docs, const char* text, c
   const uint64_t n_seg64 = (uint64_t)n_docs * F;
   if (n_seg64 >= 0xFFFFFFF0ull) throw std::length_error("GPU bulk indexing: more than 2^32 (document, field) segments");
   const uint32_t n_seg = (uint32_t)n_seg64;
+  // the kernels follow offsets[] without further checks: it has to start at 0 and never decrease
+  if (n_seg && offsets[0] != 0) throw std::invalid_argument("GPU bulk indexing: offsets[0] must be 0");
+  for (uint32_t i = 0; i < n_seg; ++i)
+    if (offsets[i + 1] < offsets[i]) throw std::invalid_argument("GPU bulk indexing: offsets must be non-decreasing");
   const uint64_t n = n_seg ? offsets[n_seg] : 0;  // bytes of text
   if (n >= 0xFFFFFFF0ull) throw std::length_error("GPU bulk indexing: more than 4 GiB of text in one call (split the corpus)");
   out = GroupedCorpus{};

@@ -363,13 +363,22 @@ ps_status ps_snapshot_update(ps_snapshot* snap, const ps_index* idx, ps_update_s
       // not expressible as a delta: flatten again (same tile size and headroom) and swap
       std::shared_ptr<ps::Snapshot> fresh(new ps::Snapshot(idx->idx, snap->tile_docs, snap->headroom_pct));
       const double t1 = wall_ms();
+      // The new engine is built while the old one still serves the handle: if that fails for lack of HBM the
+      // old planes are released and it is tried once more; a second failure leaves a consistent host-only
+      // handle (the fresh flatten, no engine) - never the old engine over a host copy a half-applied
+      // delta already changed.
       std::unique_ptr<ps::Engine> eng;
       if (snap->device >= 0) {
-        snap->engine.reset();  // free the old planes first
-        eng.reset(new ps::Engine(*fresh, snap->device));
+        try {
+          eng.reset(new ps::Engine(*fresh, snap->device));
+        } catch (const std::exception&) {
+          snap->engine.reset();
+          snap->snap = fresh;
+          eng.reset(new ps::Engine(*fresh, snap->device));
+        }
       }
+      snap->engine = std::move(eng);  // (the old engine still reads the old host arrays while it is torn down)
       snap->snap = fresh;
-      snap->engine = std::move(eng);
       st.mode = 2;
       st.postings_uploaded = fresh->n_postings;
       st.bytes_uploaded = snap->engine ? snap->engine->device_bytes() : 0;
@@ -628,6 +637,15 @@ ps_status ps_snapshot_kernel_breakdown(ps_snapshot* snap, ps_kernel_times* out, 
     if (!snap || !out) return fail(PS_EINVAL, "null argument");
     if (!snap->engine) return fail(PS_ENODEVICE, "host-only snapshot");
     snap->engine->kernel_times(*out, reset != 0);
+    return PS_OK;
+  });
+}
+
+ps_status ps_snapshot_work_counters(ps_snapshot* snap, ps_work_counters* out, int reset) {
+  return guard([&]() -> ps_status {
+    if (!snap || !out) return fail(PS_EINVAL, "null argument");
+    if (!snap->engine) return fail(PS_ENODEVICE, "host-only snapshot");
+    snap->engine->work_counters(*out, reset != 0);
     return PS_OK;
   });
 }

@@ -113,6 +113,9 @@ struct ps_comm {
   std::string shm_name;
   unsigned char* shm_base = nullptr;
   size_t shm_bytes = 0;
+  ~ps_comm() {  // (also the clean-up of an init that failed half way)
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
 };
 
 namespace {
@@ -244,8 +247,7 @@ void ps_comm_free(ps_comm* c) {
     munmap(c->shm_base, c->shm_bytes);
     if (c->rank == 0) shm_unlink(c->shm_name.c_str());
   }
-  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-  delete c;
+  delete c;  // (destroys own_stream)
 }
 
 int ps_comm_world_size(const ps_comm* c) { return c ? c->world : 1; }

@@ -61,6 +61,7 @@ namespace ps {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+static std::atomic<uint64_t> g_opt_gen{1};  // bumped by every ps_set_option: engines re-read their knobs at the next batch
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -164,8 +165,11 @@ struct EngineImpl {
   uint64_t* d_keys = nullptr;
   double* d_lut = nullptr;
   uint32_t* d_work = nullptr;
+  unsigned long long* d_wstats = nullptr;  // work counters the scoring kernels add to (ps_work_counters)
+  uint64_t wc_launches = 0, wc_items = 0, wc_results = 0, wc_cand_slots = 0, wc_k = 0;  // host-side part of the same accounting
   int n_cu = 256;
   Tuning tune;
+  uint64_t tune_gen = 0;  // g_opt_gen the knobs were read at
   uint64_t bytes = 0;
   std::mutex mu;
   // per-batch device buffers (grow-only; reuse is ordered by the stream)
@@ -295,8 +299,11 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
       throw std::runtime_error(std::string("built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
     m.n_cu = prop.multiProcessorCount;
     m.tune.load();
+    m.tune_gen = g_opt_gen.load();
     PS_HIP(hipMalloc((void**)&m.d_work, 256));
     PS_HIP(hipMemset(m.d_work, 0, 256));
+    PS_HIP(hipMalloc((void**)&m.d_wstats, (size_t)WS_SLOTS * WS_WORDS * 8));
+    PS_HIP(hipMemset(m.d_wstats, 0, (size_t)WS_SLOTS * WS_WORDS * 8));
     PS_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     for (auto& ev : m.ev) PS_HIP(hipEventCreate(&ev));
     for (auto& sg : m.stage) PS_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
@@ -340,7 +347,7 @@ Engine::~Engine() {
   EngineImpl& m = *impl_;
   (void)hipSetDevice(m.device);
   (void)hipDeviceSynchronize();
-  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_tfl, (void*)m.d_table, (void*)m.d_bits, (void*)m.d_alive, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work})
+  for (void* p : {(void*)m.d_doc, (void*)m.d_tf, (void*)m.d_fl, (void*)m.d_tfl, (void*)m.d_table, (void*)m.d_bits, (void*)m.d_alive, (void*)m.d_keys, (void*)m.d_lut, (void*)m.d_work, (void*)m.d_wstats})
     if (p) (void)hipFree(p);
   m.d_stage.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
@@ -453,13 +460,6 @@ void Engine::kernel_times(ps_kernel_times& out, bool reset) {
   std::lock_guard<std::mutex> lock(m.mu);
   (void)hipSetDevice(m.device);
   for (auto& t : m.kt) m.harvest(t, true);
-  if (m.tune.ablate & 64u) {  // PS_ABLATE=64: K1d statistics since the last call
-    uint32_t w[32];
-    (void)hipMemcpy(w, m.d_work, 128, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[ps] k_daat stats: items=%u skipped_whole=%u trips=%u (postings<=%llu) reached_lookups=%u offers=%u\n", w[20],
-            w[19], w[16], (unsigned long long)w[16] * 64ull, w[17], w[18]);
-    (void)hipMemset(m.d_work + 16, 0, 64);
-  }
   memset(&out, 0, sizeof(out));
   out.score_ms = m.kt_total_ms;
   out.rows_ms = m.kt_rows_ms;
@@ -468,6 +468,42 @@ void Engine::kernel_times(ps_kernel_times& out, bool reset) {
   if (reset) { m.kt_total_ms = 0.0; m.kt_rows_ms = 0.0; m.kt_launches = 0; }
 }
 int Engine::device() const { return impl_->device; }
+
+// The kernels' own work counts (see ps_work_counters) since the last reset; waits for outstanding work.
+void Engine::work_counters(ps_work_counters& out, bool reset) {
+  EngineImpl& m = *impl_;
+  std::lock_guard<std::mutex> lock(m.mu);
+  PS_HIP(hipSetDevice(m.device));
+  PS_HIP(hipDeviceSynchronize());
+  std::vector<unsigned long long> w((size_t)WS_SLOTS * WS_WORDS);
+  PS_HIP(hipMemcpy(w.data(), m.d_wstats, w.size() * 8, hipMemcpyDeviceToHost));
+  unsigned long long sum[WS_WORDS] = {};
+  for (uint32_t sl = 0; sl < WS_SLOTS; ++sl)
+    for (uint32_t k = 0; k < WS_WORDS; ++k) sum[k] += w[(size_t)sl * WS_WORDS + k];
+  memset(&out, 0, sizeof(out));
+  out.launches = m.wc_launches;
+  out.items = m.wc_items;
+  out.items_run = sum[WS_ITEMS_RUN];
+  out.postings_scanned = sum[WS_SCANNED];
+  out.postings_reached_lookups = sum[WS_REACHED];
+  out.lookups_row = sum[WS_ROW];
+  out.lookups_cell = sum[WS_CELL];
+  out.lookups_probe = sum[WS_PROBE];
+  out.lookup_hits = sum[WS_HIT];
+  out.offers = sum[WS_OFFER];
+  out.k1_items = sum[WS_K1_ITEMS];
+  out.k1_postings = sum[WS_K1_POSTINGS];
+  out.k1_row_slices = sum[WS_K1_ROWSLICES];
+  out.results = m.wc_results;
+  const uint64_t F = m.snap->F, pw = 4 + 4 * F;
+  out.bytes_touched = out.postings_scanned * pw + out.lookups_row * 8 + out.lookups_cell * 8 + out.lookups_probe * 4 +
+                      out.lookup_hits * 4 * F + out.k1_postings * pw + out.k1_row_slices * (uint64_t)m.snap->T * 8 +
+                      (m.wc_cand_slots + out.items_run * m.wc_k) * 12 + out.results * 16;
+  if (reset) {
+    PS_HIP(hipMemset(m.d_wstats, 0, w.size() * 8));
+    m.wc_launches = m.wc_items = m.wc_results = m.wc_cand_slots = 0;
+  }
+}
 
 namespace {
 
@@ -497,6 +533,7 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 void set_option(const char* name, uint32_t value) {
   std::lock_guard<std::mutex> l(g_opt_mu);
   option_overrides()[name] = value;
+  g_opt_gen.fetch_add(1);
 }
 bool get_option(const char* name, uint32_t* value) {
   std::lock_guard<std::mutex> l(g_opt_mu);
@@ -546,6 +583,14 @@ void Tuning::load() {
 }
 
 namespace {
+
+// Knobs changed through ps_set_option since this engine last read them take effect at the next batch.
+void refresh_tuning(EngineImpl& m) {
+  const uint64_t g = g_opt_gen.load(std::memory_order_relaxed);
+  if (m.tune_gen == g) return;
+  m.tune.load();
+  m.tune_gen = g;
+}
 
 void validate(const Snapshot& s, const ps_scorer_desc& sc, const Plan& plan) {
   if (s.F > (uint32_t)MAX_F) throw std::length_error("the GPU path supports at most 8 fields");
@@ -1300,6 +1345,7 @@ void choose_run_length(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan
 void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, hipStream_t st,
                 KParams& kp, bool topk_path, bool sync_path) {
   const Snapshot& s = *m.snap;
+  refresh_tuning(m);
   // K1d (exact dynamic pruning) takes BM25 top-k batches whose parameters make every score a
   // positive, monotone function of the saturated term frequency; everything else stays on K1
   if (!m.daat_work) m.daat_work = new DaatWork();
@@ -1507,6 +1553,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const size_t n_thr = B + 2;
   const bool fresh = m.d_gthr.ensure(n_thr, true);
   kp.work_counter = m.d_work;
+  kp.wstats = m.d_wstats;
   kp.gthr = m.d_gthr.p;
   if (!(m.ctl_clean && topk_path && !fresh)) {
     PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
@@ -1650,6 +1697,13 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
   if (n_items == 0) {
     if (mid) PS_HIP(hipEventRecord(mid, st));
     return;
+  }
+  // host-side part of ps_work_counters (the rest is counted by the kernels)
+  m.wc_launches++;
+  if (!FULL) {
+    m.wc_k = kp.K;
+    m.wc_results += (uint64_t)kp.B * kp.K;
+    if (kp.n_ditems) m.wc_items += kp.n_ditems; else m.wc_cand_slots += (uint64_t)n_items * kp.K;
   }
   if (sc.kind == PS_SCORER_BM25) {
     // K0 runs when (k1, b) change (or the stream does: no cross-stream ordering is assumed)
@@ -1980,6 +2034,7 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   const size_t n_thr = B + 2;
   const bool fresh = m.d_gthr.ensure(n_thr, true);
   kp.work_counter = m.d_work;
+  kp.wstats = m.d_wstats;
   kp.gthr = m.d_gthr.p;
   if (!(m.ctl_clean && !fresh)) {
     PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
@@ -2237,6 +2292,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
     sync_stream(st);
     memcpy(out.data(), m.result.p, total * sizeof(ps_result));
   }
+  m.wc_results += total;
   fill_stats(m, stats, s, plan, total);
   stats.total_ms = now_ms() - t0;
 }

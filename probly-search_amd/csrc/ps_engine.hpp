@@ -39,6 +39,8 @@ class Engine {
   // HIP-event durations summed over every batch since the last reset: the scoring kernel alone and
   // K0 / K0b in front of it (waits for outstanding launches).
   void kernel_times(ps_kernel_times& out, bool reset);
+  // What the scoring kernels counted themselves (postings scanned, lookups by kind, ...) since the last reset.
+  void work_counters(ps_work_counters& out, bool reset);
   // Device side of Snapshot::apply_delta: uploads exactly the ranges it changed (appended postings,
   // table entries, keys, alive words), drops what was derived from the old state and re-counts, on
   // the device, the per-layer pointer count of delta-removed documents.  Call with no batch in flight.

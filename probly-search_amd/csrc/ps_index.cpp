@@ -160,7 +160,7 @@ void Index::add_document(uint64_t key, const ps_str* values, const size_t* n_val
       field_length[i] = count;                                                // assignment (:114)
     }
   }
-  {
+  if (log_enabled_) {
     IndexChange c;
     c.kind = IndexChange::ADD;
     c.key = key;
@@ -170,6 +170,8 @@ void Index::add_document(uint64_t key, const ps_str* values, const size_t* n_val
     c.tf = doc_tf_;
     c.field_length = field_length;
     log_push(std::move(c));
+  } else {
+    log_base_ = epoch_ + 1;  // nothing recorded: no snapshot exists that could replay it
   }
   docs_[key] = DocDetails{std::move(field_length)};
   for (size_t k = 0; k < doc_nodes_.size(); ++k) {
@@ -187,6 +189,15 @@ void Index::add_document(uint64_t key, const ps_str* values, const size_t* n_val
 
 void Index::bulk_load(const GroupedCorpus& g, size_t n_docs, const uint64_t* keys, const char* text) {
   if (!pristine()) throw std::invalid_argument("bulk_load needs an empty index");
+  {
+    // duplicate keys are add_document's job (a re-add keeps both versions' pointers, index.rs:119-157):
+    // found BEFORE anything is touched, and reported as "not expressible here" (PS_EUNSUPPORTED), so that
+    // ps_index_add_documents_flat_gpu falls back to the incremental host path on a still-empty index
+    std::vector<uint64_t> sorted(keys, keys + n_docs);
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+      throw std::length_error("bulk_load: duplicate keys (re-adding a key is add_document's job)");
+  }
   const size_t F = fields_.size();
   const size_t n_terms = g.term_pos.size();
   // documents + field statistics: sum accumulates every field length; avg = sum / (docs.len() + 1) as
@@ -198,7 +209,6 @@ void Index::bulk_load(const GroupedCorpus& g, size_t n_docs, const uint64_t* key
     for (size_t x = 0; x < F; ++x) fields_[x].sum += dd.field_length[x];
     docs_.emplace(keys[d], std::move(dd));
   }
-  if (docs_.size() != n_docs) throw std::invalid_argument("bulk_load: duplicate keys (re-adding a key is add_document's job)");
   if (n_docs)
     for (size_t x = 0; x < F; ++x) fields_[x].avg = (double)fields_[x].sum / (double)n_docs;
   // terms in first-occurrence order: the incremental build creates a term's missing trie nodes when it
@@ -222,6 +232,10 @@ void Index::bulk_load(const GroupedCorpus& g, size_t n_docs, const uint64_t* key
 }
 
 void Index::log_push(IndexChange&& c) {
+  if (!log_enabled_) {  // the epoch is bumped right after this call: keep log_base_ + log_.size() == epoch_
+    log_base_ = epoch_ + 1;
+    return;
+  }
   // bounded: a burst larger than this is cheaper to re-flatten than to replay
   constexpr size_t MAX_ENTRIES = 1u << 20, MAX_POSTINGS = 16u << 20;
   log_postings_ += c.nodes.size();

@@ -159,6 +159,14 @@ class Index {
   bool any_removed() const { return has_removed_ && !removed_.empty(); }
   int32_t root() const { return 0; }
   uint64_t epoch() const { return epoch_; }  // bumped by every mutation
+  // Starts the change log at the current epoch (called by the flattener: a snapshot exists that can replay it).
+  void enable_change_log() const {
+    if (log_enabled_) return;
+    log_enabled_ = true;
+    log_.clear();
+    log_base_ = epoch_;
+    log_postings_ = 0;
+  }
   uint64_t uid() const { return uid_; }      // identity of this index object (a snapshot only takes deltas from its own source)
   // The mutations after `epoch`, oldest first, or nullptr if the log no longer reaches back that far
   // (it is bounded; a snapshot that old re-flattens).  *count = number of entries.
@@ -186,9 +194,12 @@ class Index {
   uint64_t epoch_ = 0;
   uint64_t uid_ = 0;
   // change log: entry i is the mutation that moved the epoch from log_base_ + i to log_base_ + i + 1
-  std::vector<IndexChange> log_;
-  uint64_t log_base_ = 0;
-  size_t log_postings_ = 0;
+  // The log is kept only once somebody can replay it: the first snapshot taken of this index switches
+  // it on (enable_change_log); until then a mutation costs no copy of the document's postings.
+  mutable std::vector<IndexChange> log_;
+  mutable uint64_t log_base_ = 0;
+  mutable size_t log_postings_ = 0;
+  mutable bool log_enabled_ = false;
   void log_push(IndexChange&& c);
   // add_document scratch
   std::vector<const char*> sp_;

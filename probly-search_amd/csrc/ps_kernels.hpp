@@ -145,6 +145,7 @@ struct KParams {
   uint32_t item_base;           // first item of this launch (the batch may be split into two launches)
   uint32_t* cand_cnt;           // [n_ditems] candidates an item left in its slot
   uint32_t* work_counter;    // next (query, run) item for the persistent waves of k_score
+  unsigned long long* wstats;  // [WS_SLOTS][WS_WORDS] work counters (always on; see WorkStats)
   unsigned long long* gthr;  // [B] bits of the best published local K-th score per query (0 = none)
   double* cand_score;  // [B * n_super * K]
   uint32_t* cand_doc;
@@ -158,6 +159,24 @@ struct KParams {
   double* out_scores;
   uint32_t* out_counts;
 };
+
+// ------------------------------------------------------------------------------------------
+// Work counters (ps_work_counters): what the scoring kernels really read, counted by the kernels.
+// A wave keeps wave-uniform counts in scalar registers (ballot + s_bcnt1, no vector registers) and
+// lane 0 adds them to one of WS_SLOTS cache lines when the item ends; the host sums the slots.
+// ------------------------------------------------------------------------------------------
+#ifndef PS_WORK_COUNTERS
+#define PS_WORK_COUNTERS 1   // 0: a build without the counters (A/B of their cost only)
+#endif
+constexpr uint32_t WS_SLOTS = 64, WS_WORDS = 16;  // one 128-byte line per slot
+enum { WS_ITEMS_RUN = 0, WS_SCANNED, WS_REACHED, WS_ROW, WS_CELL, WS_PROBE, WS_HIT, WS_OFFER, WS_K1_ITEMS, WS_K1_POSTINGS,
+       WS_K1_ROWSLICES };
+struct WorkStats {  // K1d, per item
+  uint32_t scanned = 0, reached = 0, row = 0, cell = 0, probe = 0, hit = 0, offer = 0;
+};
+__device__ __forceinline__ uint32_t lanes_on(const bool b) {  // wave-uniform count of lanes where b holds
+  return PS_WORK_COUNTERS ? (uint32_t)__popcll(__ballot(b)) : 0u;
+}
 
 // ------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -798,6 +817,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+  uint32_t ws_post = 0, ws_rows = 0;  // work counters (wave-uniform): postings streamed, dense-row tile slices read
 
   if (ne != 0 && !item_dead) {
     const uint32_t t_begin = sup * p.S;
@@ -869,6 +889,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
       for (int g = 0; g < G; ++g) {
         if (eg + g < ne && ec_row[g] != 0xFFFFFFFFu) {
           dirty = true;
+          if (PS_WORK_COUNTERS) ws_rows += MODE == MODE_Z21S ? (uint32_t)__popc(fmask & ((1u << F) - 1u)) : 1u;
           if (PS_ABLATE_BUILD && (p.ablate & 8u)) {
           } else if (MODE == MODE_BM25 && !TAGS && (ec_flags[g] & DENSE_FUSE_FLAG)) fuse_row = ec_row[g];
           else if (MODE == MODE_BM25 && !TAGS && (ec_flags[g] & DENSE_ASSIGN_FLAG)) dense_apply<false, true>(p, acc, tag, lane, ec_row[g], tile_base, 0);
@@ -880,6 +901,7 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
                                    (ec_qterm[g] >> 31) ? (1u << ((ec_qterm[g] >> 16) & 31u)) : 0u, fmask);
         } else if (rb[g] < re[g]) {
           dirty = true;
+          if (PS_WORK_COUNTERS) ws_post += re[g] - rb[g];
           ec[g].tag = MODE == MODE_Z21S ? ec_qterm[g] : tagbase + ec_qterm[g];
           score_trip<MODE, F_, TAGS, FU>(p, lut, acc, tag, lane, tile_base, rb[g], re[g], dv[g], wv[g], ec[g], qtl);
           if (rb[g] + FU * WAVE < re[g])
@@ -1057,6 +1079,12 @@ __global__ __launch_bounds__(WAVE * WGW) void k_score(const KParams p) {
     p.cand_score[o] = ok ? tk.s : 0.0;
     p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
   }
+  if (PS_WORK_COUNTERS && lane == 0) {
+    unsigned long long* w = p.wstats + (size_t)(blockIdx.x & (WS_SLOTS - 1u)) * WS_WORDS;
+    atomicAdd(&w[WS_K1_ITEMS], 1ull);
+    if (ws_post) atomicAdd(&w[WS_K1_POSTINGS], (unsigned long long)ws_post);
+    if (ws_rows) atomicAdd(&w[WS_K1_ROWSLICES], (unsigned long long)ws_rows);
+  }
   }  // item loop
 }
 
@@ -1092,6 +1120,7 @@ __global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
 
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+  uint32_t ws_post = 0;  // work counter: postings streamed (exact planes: 4 + 8F bytes each here)
 
   if (e0 != e1) {
     for (uint32_t i = lane; i < ZT * stride; i += WAVE) rec[i] = 0;
@@ -1112,6 +1141,7 @@ __global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
           const uint32_t slot = t >> shift;
           const uint32_t rb = p.table[tbl_off + slot];
           const uint32_t re = p.table[tbl_off + slot + 1];
+          if (PS_WORK_COUNTERS) ws_post += __builtin_amdgcn_readfirstlane(re - rb);
           for (uint32_t i = rb + lane; i < re; i += WAVE) {
             const uint64_t pi = post_off + i;
             const uint32_t local = p.doc[pi] - tile_base;
@@ -1174,6 +1204,11 @@ __global__ __launch_bounds__(WAVE) void k_z21(const KParams p) {
     const bool ok = (uint32_t)lane < tk.n;
     p.cand_score[o] = ok ? tk.s : 0.0;
     p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
+  }
+  if (PS_WORK_COUNTERS && lane == 0) {
+    unsigned long long* w = p.wstats + (size_t)(blockIdx.x & (WS_SLOTS - 1u)) * WS_WORDS;
+    atomicAdd(&w[WS_K1_ITEMS], 1ull);
+    if (ws_post) atomicAdd(&w[WS_K1_POSTINGS], (unsigned long long)ws_post);
   }
 }
 
@@ -1314,10 +1349,10 @@ __device__ __forceinline__ void posting_scores(const KParams& p, const double* l
 // The U lookups advance together: every step issues U independent loads.
 template <int F_, int U>
 __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lut, const ps_plan_entry& en, const uint32_t (&d)[U],
-                                              const bool (&on)[U], double (&s)[U]) {
+                                              const bool (&on)[U], double (&s)[U], WorkStats& ws) {
   if (en.shift & DENSE_FLAG) {  // a dense score row: the value itself
 #pragma unroll
-    for (int u = 0; u < U; ++u) s[u] = on[u] ? p.rows[(uint64_t)en.node * p.row_stride + d[u]] : 0.0;
+    for (int u = 0; u < U; ++u) { s[u] = on[u] ? p.rows[(uint64_t)en.node * p.row_stride + d[u]] : 0.0; ws.row += lanes_on(on[u]); }
     return;
   }
   bool found[U];
@@ -1333,6 +1368,7 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
       cell[u] = on[u] ? *reinterpret_cast<const uint2*>(p.bits + (uint64_t)en.bm_off + 2 * (uint64_t)(d[u] >> 5)) : make_uint2(0u, 0u);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      ws.cell += lanes_on(on[u]);
       const uint32_t bit = d[u] & 31u;
       found[u] = on[u] && ((cell[u].x >> bit) & 1u);
       pi[u] = en.post_off + cell[u].y + (uint32_t)__popc(cell[u].x & ((1u << bit) - 1u));
@@ -1350,6 +1386,7 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
         end[u] = p.table[en.tbl_off + slot + 1];
         hi[u] = end[u];
       }
+      ws.probe += 2u * lanes_on(on[u]);
     }
     bool more = true;  // wave-uniform
     while (more) {
@@ -1360,6 +1397,7 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
         act[u] = lo[u] < hi[u];
         mid[u] = (lo[u] + hi[u]) >> 1;
         v[u] = act[u] ? docs[mid[u]] : 0u;
+        ws.probe += lanes_on(act[u]);
       }
       bool any_act = false;
 #pragma unroll
@@ -1371,13 +1409,13 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
     }
     uint32_t chk[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) chk[u] = (on[u] && lo[u] < end[u]) ? docs[lo[u]] : 0xFFFFFFFFu;
+    for (int u = 0; u < U; ++u) { chk[u] = (on[u] && lo[u] < end[u]) ? docs[lo[u]] : 0xFFFFFFFFu; ws.probe += lanes_on(on[u] && lo[u] < end[u]); }
 #pragma unroll
     for (int u = 0; u < U; ++u) { found[u] = on[u] && lo[u] < end[u] && chk[u] == d[u]; pi[u] = en.post_off + (found[u] ? lo[u] : 0u); }
   }
   bool any_found = false;
 #pragma unroll
-  for (int u = 0; u < U; ++u) any_found |= found[u];
+  for (int u = 0; u < U; ++u) { any_found |= found[u]; ws.hit += lanes_on(found[u]); }
   if (__any(any_found)) posting_scores<F_, U>(p, lut, pi, found, en.idf, en.boost, s);
 }
 
@@ -1456,7 +1494,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
     double published = 0.0;
     const uint32_t end = (p.ablate & 16u) ? it.begin : it.begin + it.count;  // (debug: 16 = no postings)
     bool essential = true;  // wave-uniform
-    uint32_t st_trips = 0, st_alive = 0, st_offers = 0;  // PS_ABLATE=64 statistics
+    WorkStats ws;
     for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
       // the query's current threshold: a lower bound of its final K-th best score (0 = none yet).
       // One load instruction returns one value to the whole wave; readfirstlane tells the compiler.
@@ -1486,9 +1524,11 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
         // everything the other entries could add, at most: below theta the document is out
         alive[u] = alive[u] && (s_own[u] + others >= theta) && !(p.ablate & 32u);  // (debug: 32 = no lookups)
         any_alive |= alive[u];
-        st_alive += (uint32_t)__popcll(__ballot(alive[u]));
+        ws.reached += lanes_on(alive[u]);
       }
-      if (essential) ++st_trips;
+      // (the doc ids of a trip are requested together with the threshold: a trip that finds its list
+      // non-essential has read them - 4 bytes each, booked as probes - but not the packed words)
+      if (essential) ws.scanned += min(end - i0, (uint32_t)(WAVE * U)); else ws.probe += min(end - i0, (uint32_t)(WAVE * U));
       any_alive = __any(any_alive);
       double P[U];
 #pragma unroll
@@ -1509,7 +1549,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
               const ps_plan_entry& en = p.plan[j];
               const DEntry dj = p.dentry[j];
               double s[U];
-              lookup_scores<F_, U>(p, lut, en, d, alive, s);
+              lookup_scores<F_, U>(p, lut, en, d, alive, s, ws);
               bool any = false;
 #pragma unroll
               for (int u = 0; u < U; ++u) {
@@ -1538,7 +1578,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
                 bool any = false;
 #pragma unroll
                 for (int u = 0; u < U; ++u) { want[u] = alive[u] && ((hits[u] >> (j - e0)) & 1ull); any |= want[u]; s[u] = 0.0; }
-                if (__any(any)) lookup_scores<F_, U>(p, lut, en, d, want, s);
+                if (__any(any)) lookup_scores<F_, U>(p, lut, en, d, want, s, ws);
               }
 #pragma unroll
               for (int u = 0; u < U; ++u)
@@ -1567,7 +1607,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
               const DGroup gj = p.dgroup[j];
               const uint32_t j_rank = p.dentry[j].rank;
               double s[U];
-              lookup_scores<F_, U>(p, lut, en, d, alive, s);
+              lookup_scores<F_, U>(p, lut, en, d, alive, s, ws);
 #pragma unroll
               for (int g = 0; g < 4; ++g)
                 if ((uint32_t)g == gj.grp) rem[g] = gj.nxt_s;
@@ -1614,7 +1654,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
                 bool any = false;
 #pragma unroll
                 for (int u = 0; u < U; ++u) { want[u] = alive[u] && ((hits[u] >> (j - e0)) & 1ull); any |= want[u]; s[u] = 0.0; }
-                if (__any(any)) lookup_scores<F_, U>(p, lut, en, d, want, s);
+                if (__any(any)) lookup_scores<F_, U>(p, lut, en, d, want, s, ws);
               }
 #pragma unroll
               for (int u = 0; u < U; ++u) {
@@ -1643,7 +1683,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
 #pragma unroll
               for (int u = 0; u < U; ++u) s[u] = s_own[u];
             } else {
-              lookup_scores<F_, U>(p, lut, en, d, alive, s);
+              lookup_scores<F_, U>(p, lut, en, d, alive, s, ws);
             }
             const uint32_t j_rank = p.dentry[j].rank;
 #pragma unroll
@@ -1668,7 +1708,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bool offer = alive[u] && P[u] >= theta;
-          st_offers += (uint32_t)__popcll(__ballot(offer));
+          ws.offer += lanes_on(offer);
           if (__any(offer)) topk_offer(tk, p.K, lane, alive[u], P[u], d[u], theta);
         }
         if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta) {
@@ -1685,12 +1725,16 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
       p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
       if (lane == 0) p.cand_cnt[it.slot] = tk.n;
     }
-    if ((p.ablate & 64u) && lane == 0) {  // PS_ABLATE=64 (debug): trips scanned, postings that reached the lookups, offers
-      atomicAdd(&p.work_counter[16], st_trips);
-      atomicAdd(&p.work_counter[17], st_alive);
-      atomicAdd(&p.work_counter[18], st_offers);
-      atomicAdd(&p.work_counter[19], st_trips ? 0u : 1u);
-      atomicAdd(&p.work_counter[20], 1u);
+    if (PS_WORK_COUNTERS && lane == 0) {  // (an item skipped whole by its workgroup never gets here: it read nothing)
+      unsigned long long* w = p.wstats + (size_t)(blockIdx.x & (WS_SLOTS - 1u)) * WS_WORDS;
+      atomicAdd(&w[WS_ITEMS_RUN], 1ull);
+      if (ws.scanned) atomicAdd(&w[WS_SCANNED], (unsigned long long)ws.scanned);
+      if (ws.reached) atomicAdd(&w[WS_REACHED], (unsigned long long)ws.reached);
+      if (ws.row) atomicAdd(&w[WS_ROW], (unsigned long long)ws.row);
+      if (ws.cell) atomicAdd(&w[WS_CELL], (unsigned long long)ws.cell);
+      if (ws.probe) atomicAdd(&w[WS_PROBE], (unsigned long long)ws.probe);
+      if (ws.hit) atomicAdd(&w[WS_HIT], (unsigned long long)ws.hit);
+      if (ws.offer) atomicAdd(&w[WS_OFFER], (unsigned long long)ws.offer);
     }
   }
 }

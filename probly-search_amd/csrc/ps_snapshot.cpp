@@ -59,6 +59,11 @@ struct SnapshotStorage {
   // removed documents are subtracted
   std::vector<int32_t> term_node;
   std::vector<uint64_t> df_total;
+  // doc ids for which the flattener folded a duplicate record (a key re-added without removal whose
+  // term frequencies did not change): df_raw counts that record (index.rs:282-297 counts every
+  // pointer), but no posting stands for it, so the per-posting re-count of a delta removal would
+  // leave df too high.  Removing such a document is "not expressible": apply_delta re-flattens.
+  std::vector<uint32_t> folded_ids;  // sorted, unique
 };
 
 namespace {
@@ -126,6 +131,7 @@ void Snapshot::bind(const SnapshotStorage& st) {
 
 Snapshot::Snapshot(const Index& idx, uint32_t tile_docs, uint32_t headroom_pct) {
   PhaseTimer pt;
+  idx.enable_change_log();  // from here on this snapshot can be brought up to date by replaying the index's log
   own_.reset(new SnapshotStorage());
   // the flattener fills the owned vectors (these references shadow the read-only views, which are
   // bound to the finished vectors at the end)
@@ -248,6 +254,7 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs, uint32_t headroom_pct) 
     uint32_t live = 0;
     bool sorted_desc = true;
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> lay;  // general case: (doc id, record) per layer
+    std::vector<uint32_t> folded;  // doc ids with a duplicate record that became no posting
   };
   std::vector<TermFlat> flat(terms.size());
   auto for_terms = [&](const std::function<void(size_t)>& body) { for_range(terms.size(), terms.size() < 256, body); };
@@ -295,12 +302,17 @@ Snapshot::Snapshot(const Index& idx, uint32_t tile_docs, uint32_t headroom_pct) 
           if (tfl.lay.size() <= v) tfl.lay.emplace_back();
           tfl.lay[v].push_back(tmp[j]);
           ++v;
+        } else {
+          tfl.folded.push_back(tmp[j].first);
         }
         ++j;
       }
       i = j;
     }
   });
+  for (const TermFlat& tf_ : flat) own_->folded_ids.insert(own_->folded_ids.end(), tf_.folded.begin(), tf_.folded.end());
+  std::sort(own_->folded_ids.begin(), own_->folded_ids.end());
+  own_->folded_ids.erase(std::unique(own_->folded_ids.begin(), own_->folded_ids.end()), own_->folded_ids.end());
   pt.mark("count");
 
   // serial: place every layer (4-aligned starts, so 16-byte vector loads never straddle lists)
@@ -510,7 +522,11 @@ Snapshot::Snapshot(const std::string& path) {
   void* m = mmap(nullptr, map_bytes_, PROT_READ, MAP_PRIVATE, fd, 0);
   close(fd);
   if (m == MAP_FAILED) throw std::invalid_argument("cannot map snapshot file: " + path);
-  map_base_ = m;
+  // (a constructor that throws runs no destructor: the mapping is released here until the file is accepted)
+  struct MapGuard {
+    void* p; size_t n;
+    ~MapGuard() { if (p) munmap(p, n); }
+  } guard{m, map_bytes_};
   const unsigned char* base = static_cast<const unsigned char*>(m);
   FileHeader h;
   memcpy(&h, base, sizeof(h));
@@ -540,6 +556,8 @@ Snapshot::Snapshot(const std::string& path) {
   validate();
   removed_df.assign(layers.size(), 0);
   src_epoch = ~0ull;
+  map_base_ = m;
+  guard.p = nullptr;
 }
 
 // Every index the planner or the kernels follow is checked against the array it points into, so a
@@ -659,7 +677,10 @@ bool Snapshot::apply_delta(const Index& idx, DeltaRanges& out) {
     } else if (c.was_present) {
       auto it = std::lower_bound(st.keys.begin(), st.keys.end(), c.key);
       if (it == st.keys.end() || *it != c.key) return false;  // a document added earlier in this very delta
-      removes.push_back((uint32_t)(it - st.keys.begin()));
+      const uint32_t rid = (uint32_t)(it - st.keys.begin());
+      // (a duplicate record of this document was folded at flatten time: its df share has no posting)
+      if (std::binary_search(st.folded_ids.begin(), st.folded_ids.end(), rid)) return false;
+      removes.push_back(rid);
     }
   }
   if (n_ids + adds.size() > (uint64_t)tiles_cap * T) return false;

@@ -383,6 +383,13 @@ class Snapshot:
         return {"score_ms": kt.score_ms, "rows_ms": kt.rows_ms, "launches": kt.launches,
                 "score_kernel": kt.score_kernel.decode("utf-8", "replace")}
 
+    def work_counters(self, reset=False):
+        """What the scoring kernels counted themselves since the last reset (ps_snapshot_work_counters):
+        postings scanned, lookups by kind, offers, bytes touched.  Waits for outstanding work."""
+        w = _lib.WorkCounters()
+        _lib.check(self._L.ps_snapshot_work_counters(self._h, C.byref(w), 1 if reset else 0))
+        return {k: getattr(w, k) for k, _ in w._fields_}
+
     def plan(self, query, score_calculator, tokenizer=None):
         """Host query plan (tokenise -> expand_term -> before_each): (entries, query_terms_len)."""
         qb = query.encode("utf-8")

@@ -18,14 +18,18 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["daat", "k_score"])
-def scoring_kernel(request, monkeypatch):
+def scoring_kernel(request):
     """Every test of this module runs twice: BM25 top-k batches on K1d k_daat (the default) and on
     K1 k_score (PS_DAAT=0; still the kernel of full-result mode, zero_to_one, small batches and
-    non-positive boosts).  The knob is read when a snapshot's engine is created."""
-    monkeypatch.setenv("PS_DAAT", "1" if request.param == "daat" else "0")
-    monkeypatch.setenv("PS_DAAT_MULTI", "1")
-    monkeypatch.setenv("PS_DAAT_Z21", "1" if request.param == "daat" else "0")  # K1dz is off by default (slower than K1): test it anyway
-    return request.param
+    non-positive boosts).  The knobs go through ps_set_option: engines re-read them at the next batch,
+    so module-scoped snapshots (the full-size fixtures) really run under both settings."""
+    L = psa.load()
+    L.ps_set_option(b"PS_DAAT", 1 if request.param == "daat" else 0)
+    L.ps_set_option(b"PS_DAAT_MULTI", 1)
+    L.ps_set_option(b"PS_DAAT_Z21", 1 if request.param == "daat" else 0)  # K1dz is off by default (slower than K1): test it anyway
+    yield request.param
+    L.ps_set_option(b"PS_DAAT", 1)
+    L.ps_set_option(b"PS_DAAT_Z21", 0)
 
 
 def assert_same(got, exp, ctx):
@@ -269,7 +273,7 @@ def c2_full():
     return corpus, snap
 
 
-def test_full_size_c2_properties(c2_full):
+def test_full_size_c2_properties(c2_full, scoring_kernel):
     """Full BASELINE size, no oracle (it would take minutes): properties that hold at any size.
     (a) the batched top-10 (dense rows, fused / written row uses, LPT order) is the prefix of the
     full sorted list of the same query asked alone; (b) the 3-term score is ((s1 + s2) + s3) of the
@@ -281,6 +285,7 @@ def test_full_size_c2_properties(c2_full):
     queries = corpus.queries(1024, 3)
     top = snap.query_batch(queries, sc, None, b1, top_k=10)
     assert snap.last_stats()["dense_rows"] > 0
+    assert snap.kernel_breakdown(reset=True)["score_kernel"].startswith("ps::k_daat" if scoring_kernel == "daat" else "ps::k_score")
     for qi in (0, 17, 333, 1023):
         full = snap.query(queries[qi], sc, None, b1)
         assert top[qi] == full[:10], qi

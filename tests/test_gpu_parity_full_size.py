@@ -21,33 +21,86 @@ def assert_same(got, exp, ctx):
         assert bits(a) == bits(b), (ctx, k, a.hex(), b.hex())
 
 
-def _full_size(config, n_oracle_queries, batch):
+def _set(name, value):
+    """A tuning knob through the ABI: engines re-read their knobs at the next batch, so one snapshot
+    serves every kernel of a test (a PS_* environment variable is only read when an engine is created)."""
+    psa.load().ps_set_option(name.encode(), value)
+
+
+@pytest.fixture(autouse=True)
+def _default_kernels():
+    yield
+    _set("PS_DAAT", 1)
+    _set("PS_DAAT_MULTI", 1)
+
+
+def _tuples(results):
+    return [[(r.key, bits(r.score)) for r in rs] for rs in results]
+
+
+def _full_size(config, n_full_lists, batch, n_oracle_topk=64):
+    """One BASELINE config at its full size, pruning kernel (K1d k_daat) under test:
+      * whole batch: K1d top-k == K1 k_score top-k (the streaming kernel that prunes nothing), every query;
+      * the same batch five times: bit-identical (K1d's thresholds race between waves; results must not);
+      * `n_oracle_topk` queries of the batch against the ORACLE's top-k (threads: one query each), and
+        `n_full_lists` whole-list oracle comparisons (every match, every score bit);
+      * fields_boost changed between consecutive batches of one snapshot (src/query.rs:26 takes it per call):
+        each batch against K1 and, for the odd boosts, 8 queries against the oracle."""
     cfg = dict(synth.CONFIGS[config])
     corpus = synth.Corpus(**cfg)
-    F = cfg["fields"]
+    F, K = cfg["fields"], cfg["top_k"]
     boosts = [1.0] * F
     p = synth.fill(psa.Index(F), corpus)
     snap = p.snapshot(device=0, tile_docs=512 if cfg["scorer"] == "zero_to_one" else 0)
     del p
     o = synth.fill(orc.Index(F), corpus)
-    ps_sc = psa.bm25.new() if cfg["scorer"] == "bm25" else psa.zero_to_one.new()
-    or_sc = orc.bm25() if cfg["scorer"] == "bm25" else orc.zero_to_one()
+    bm25 = cfg["scorer"] == "bm25"
+    ps_sc = psa.bm25.new() if bm25 else psa.zero_to_one.new()
+    or_sc = orc.bm25() if bm25 else orc.zero_to_one()
     queries = corpus.queries(batch, cfg["q_terms"])
-    top = snap.query_batch(queries, ps_sc, None, boosts, top_k=cfg["top_k"])
-    # the heaviest and the lightest queries of the batch plus fixed positions
+    _set("PS_DAAT", 1)
+    top = snap.query_batch(queries, ps_sc, None, boosts, top_k=K)
+    kernel = snap.kernel_breakdown(reset=True)["score_kernel"]
+    if bm25:
+        assert kernel.startswith("ps::k_daat"), kernel
+        for rep in range(4):
+            assert _tuples(snap.query_batch(queries, ps_sc, None, boosts, top_k=K)) == _tuples(top), ("repeat", rep)
+        _set("PS_DAAT", 0)
+        top_k1 = snap.query_batch(queries, ps_sc, None, boosts, top_k=K)
+        assert snap.kernel_breakdown(reset=True)["score_kernel"].startswith("ps::k_score")
+        assert _tuples(top_k1) == _tuples(top), (config, "K1d batch != K1 batch")
+        # boosts change between consecutive batches of the same snapshot (bounds, dense rows, LUT follow)
+        for bs in ([2.0, 0.5][:F], [1.0] * F, [0.25, 3.0][:F]):
+            _set("PS_DAAT", 1)
+            a = snap.query_batch(queries[:512], ps_sc, None, bs, top_k=K)
+            _set("PS_DAAT", 0)
+            b = snap.query_batch(queries[:512], ps_sc, None, bs, top_k=K)
+            assert _tuples(a) == _tuples(b), (config, "boosts", bs)
+            if bs != boosts:
+                _, _, _, exp = o.bench_queries(queries[:8], or_sc, bs, threads=8, top_k=K)
+                for qi in range(8):
+                    assert_same([tuple(r) for r in a[qi]], exp[qi], (config, qi, "boosts", bs))
+        _set("PS_DAAT", 1)
+    # oracle top-k for many queries (one per host thread), whole lists for a few
+    import os
+    nq = min(n_oracle_topk, batch)
+    step = max(1, batch // nq)
+    picks = list(range(0, batch, step))[:nq]
+    _, _, _, exp_top = o.bench_queries([queries[i] for i in picks], or_sc, boosts, threads=min(len(picks), os.cpu_count() or 1), top_k=K)
+    for qi, exp in zip(picks, exp_top):
+        assert_same([tuple(r) for r in top[qi]], exp, (config, qi, "batched top-k vs oracle"))
     cost = [sum(e["len"] for e in snap.plan(q, ps_sc)[0]) for q in queries[:256]]
-    picks = sorted({cost.index(max(cost)), cost.index(min(cost)), 0, 7, 100, 255})[:n_oracle_queries]
-    for qi in picks:
+    for qi in sorted({cost.index(max(cost)), cost.index(min(cost)), 7, 100})[:n_full_lists]:
         exp = o.query(queries[qi], or_sc, boosts)
         full = [tuple(r) for r in snap.query(queries[qi], ps_sc, None, boosts)]
         assert_same(full, exp, (config, qi, "full list"))
-        assert_same([tuple(r) for r in top[qi]], exp[:cfg["top_k"]], (config, qi, "batched top-k"))
+        assert_same([tuple(r) for r in top[qi]], exp[:K], (config, qi, "batched top-k"))
     # size-independent properties over the whole batch: sorted, unique, prefix of the single query
     for qi in range(0, batch, max(1, batch // 16)):
         keys = [(-r.score, r.key) for r in top[qi]]
         assert keys == sorted(keys) and len({r.key for r in top[qi]}) == len(top[qi])
-        assert top[qi] == snap.query(queries[qi], ps_sc, None, boosts, top_k=cfg["top_k"]), (config, qi)
-    return snap, corpus, queries, top
+        assert top[qi] == snap.query(queries[qi], ps_sc, None, boosts, top_k=K), (config, qi)
+    return snap, corpus, queries, top, o
 
 
 def test_c2_full_size_against_oracle():
@@ -59,13 +112,34 @@ def test_c3_full_size_against_oracle():
 
 
 def test_c5_full_size_against_oracle():
-    _full_size("C5", 4, 1024)
+    """C5 + queries that leave K1d's register arm: more than 4 query terms and more than 64 expanded
+    lists per query (short prefixes expand to hundreds of terms), at C5's full scale."""
+    snap, corpus, queries, top, o = _full_size("C5", 4, 1024)
+    sc, osc = psa.bm25.new(), orc.bm25()
+    stems = [q.split(" ")[0] for q in queries[:64]]
+    wide = []
+    for i in range(16):
+        t = [stems[(5 * i + j) % 64] for j in range(5)]        # 5 query terms x 4 variants = 20 lists
+        t[i % 5] = t[i % 5][:2]                                   # one 2-letter prefix: hundreds of lists
+        if i % 3 == 0:
+            t.append(t[0][:3])                                    # a 6th term, 3-letter prefix
+        wide.append(" ".join(t))
+    assert max(len(snap.plan(q, sc)[0]) for q in wide) > 64
+    _set("PS_DAAT", 1)
+    a = snap.query_batch(wide, sc, None, [1.0, 1.0], top_k=10)
+    assert snap.kernel_breakdown(reset=True)["score_kernel"].startswith("ps::k_daat")
+    _set("PS_DAAT", 0)
+    b = snap.query_batch(wide, sc, None, [1.0, 1.0], top_k=10)
+    assert _tuples(a) == _tuples(b)
+    _, _, _, exp = o.bench_queries(wide, osc, [1.0, 1.0], threads=16, top_k=10)
+    for qi in range(len(wide)):
+        assert_same([tuple(r) for r in a[qi]], exp[qi], ("C5 wide", qi))
 
 
 def test_c4_full_size_against_oracle():
     """BASELINE configs[3]: 5M documents, 2 fields, BM25, 1024-query shard of the 8192-query batch
-    (what one GPU of the 8 scores), 4 whole-list oracle queries + batch split invariance."""
-    snap, corpus, queries, top = _full_size("C4", 4, 1024)
+    (what one GPU of the 8 scores) + batch split invariance."""
+    snap, corpus, queries, top, o = _full_size("C4", 4, 1024)
     sc = psa.bm25.new()
     halves = snap.query_batch(queries[:400], sc, None, [1.0, 1.0], top_k=10) + snap.query_batch(queries[400:], sc, None, [1.0, 1.0], top_k=10)
     assert halves == top
