@@ -392,6 +392,8 @@ typedef struct ps_work_counters {
   uint64_t k1_postings;         /* K1: postings streamed through the LDS tiles                       */
   uint64_t k1_row_slices;       /* K1: tile slices of dense rows read (tile_docs x 8 bytes x planes) */
   uint64_t results;             /* results written (top-k slots filled)                              */
+  uint64_t rows_built;          /* K1d: dense score rows scored by K0b (k_prep_finish's choice)      */
+  uint64_t rows_used;           /* K1d: dense score rows read by the batches (resident ones included) */
   uint64_t bytes_touched;       /* the formula above applied to these counts, + 12 bytes per candidate
                                    slot written and 16 bytes per result                              */
 } ps_work_counters;

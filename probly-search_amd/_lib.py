@@ -83,7 +83,8 @@ class KernelTimes(C.Structure):
 class WorkCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "launches", "items", "items_run", "postings_scanned", "postings_reached_lookups", "lookups_row", "lookups_cell",
-        "lookups_probe", "lookup_hits", "offers", "k1_items", "k1_postings", "k1_row_slices", "results", "bytes_touched")]
+        "lookups_probe", "lookup_hits", "offers", "k1_items", "k1_postings", "k1_row_slices", "results", "rows_built", "rows_used",
+        "bytes_touched")]
 
 
 class SnapshotInfo(C.Structure):

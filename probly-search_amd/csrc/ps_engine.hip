@@ -9,7 +9,8 @@
 //
 //       k_pack_tfl   per snapshot (and per delta): the packed {tf, field length} posting words the hot kernels stream
 //       k_upload     per batch: the staged plan, read from the device-mapped pinned slot
-//       k_make_items per K1d batch: the work items, expanded on the device from one record per list
+//       k_list_bounds / k_prep_query / k_prep_finish / k_prep_items  per K1d batch (ps_prep_kernels.hpp): per-list score
+//                    bounds, work descriptors, item order, candidate slots and dense-row choice, all on the device
 //   K0  k_bm25_lut   per (k1, b): saturated-tf table tfn(field, tf < 16, field length), same f64 expression
 //   K0b k_dense_rows per-document score rows of the hot (list, idf, boost) combinations not yet resident
 //   K1  k_score      persistent waves, one (query, run of S doc tiles) item at a time; wave-private
@@ -46,6 +47,7 @@
 #include "ps_engine.hpp"
 #include "ps_errors.hpp"
 #include "ps_kernels.hpp"
+#include "ps_prep_kernels.hpp"
 #include "ps_pool.hpp"
 #include "ps_sort.hpp"
 
@@ -133,16 +135,13 @@ struct Tuning {
   uint32_t daat_chunk = 4096;    // PS_DAAT_CHUNK: smallest chunk of a list one item covers
   uint32_t daat_dense_min_density_pct = 40;  // PS_DAAT_DENSE_MIN_DENSITY_PCT
   uint32_t daat_merge_waves = 4;   // PS_DAAT_MERGE_WAVES: most waves per query in K3d (16 / 4 / 2 measured 30 / 24 / 31 us on C2)
-  uint32_t daat_chunk0 = 0;      // PS_DAAT_CHUNK0: chunk of a query's highest-bound list (0 = same rule as the others)
   uint32_t daat_split_div = 64;  // PS_DAAT_SPLIT_DIV: a list is cut into at most this many chunks
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
   uint32_t daat_persistent = 0;  // PS_DAAT_PERSISTENT: persistent waves + item counter instead of one wave per item
-  uint32_t daat_threads = 8;     // PS_DAAT_THREADS: host threads that build the K1d descriptors of a large batch
   uint32_t z21_exact_numerator = 1;  // PS_Z21_EXACT_NUMERATOR: k_score<MODE_Z21S> one-division arm for small term frequencies (score_trip)
   uint32_t z21_field_prune = 1;  // PS_Z21_FIELD_PRUNE: k_score<MODE_Z21S> drops fields whose pool bound fell below the query's threshold
-  uint32_t daat_z21 = 0;         // PS_DAAT_Z21: zero_to_one top-k batches of simple queries take K1dz k_daat_z (off: K1 is 3x faster)
   uint32_t daat_multi = 1;       // PS_DAAT_MULTI: also take batches with several expansions per query term (0: they stay on K1)
-  uint32_t daat_split = 0;       // PS_DAAT_SPLIT: the queries' highest-bound lists in a launch of their own, first
+  uint32_t device_plan = 1;      // PS_DEVICE_PLAN: flat BM25 top-k batches (built-in tokenizer) are planned by k_plan on the device
   void load();
 };
 
@@ -180,16 +179,46 @@ struct EngineImpl {
   DevBuf<unsigned long long> d_gthr;
   DevBuf<double> d_rows;  // dense per-document score rows of the batch's hot lists
   DevBuf<uint32_t> d_cand_cnt;  // K1d: candidates per item
-  DevBuf<DItem> d_ditems;       // K1d: work items (k_make_items)
+  DevBuf<DItem> d_ditems;       // K1d: work items (k_prep_items)
+  // K1d batch preparation on the device (ps_prep_kernels.hpp): descriptors, order, candidate slots
+  DevBuf<DEntry> d_dentry;
+  DevBuf<DGroup> d_dgroup;
+  DevBuf<DItemGen> d_gen;
+  DevBuf<uint32_t> d_rorder, d_qslot, d_qslot_n;
+  DevBuf<uint8_t> d_gord;
+  PrepCtl* d_prep_ctl = nullptr;
+  RowState* d_row_state = nullptr;
+  RowDesc* d_row_desc = nullptr;
   // K1d: per list (layer) upper bounds of the saturated term frequency, exact for the current
-  // (k1, b): M[l*F+x] = max tfn_x over the list's postings, J[l] = max over postings of
-  // sum_x boost_x * tfn_x.  Host pass over the planes, once per (k1, b, boosts).
+  // (k1, b, avg): M[l*F+x] = max tfn_x over the list's postings, J[l] = max over postings of
+  // sum_x boost_x * tfn_x (k_list_bounds).  M does not depend on the boosts; J does, and a few J
+  // arrays stay resident (LRU by boost vector): a caller that alternates fields_boost between batches
+  // (src/query.rs:26 takes it per call) recomputes nothing.
   struct ListBounds {
-    bool valid = false;
+    bool m_valid = false;
     double k1 = 0, b = 0;
-    std::vector<double> boosts, avg, M, J;
+    std::vector<double> avg;
+    size_t n_layers = 0;
+    DevBuf<unsigned long long> M;
+    struct JSet { std::vector<double> boosts; DevBuf<unsigned long long> J; uint64_t last_use = 0; bool valid = false; };
+    JSet j[4];
+    uint64_t epoch = 0;
+    DevBuf<BoundUnit> units;
+    uint32_t n_units = 0;
+    double last_ms = 0.0;  // host wall time of the most recent (re)computation's enqueue
+    uint64_t recomputed = 0;
   } bounds;
-  std::vector<uint32_t> z_minfl;  // K1dz: [layer][field] shortest field length holding the term (compute_z_bounds)
+  // K1d dense-row candidates: the densest lists of the snapshot (static slots), chosen on the host per
+  // snapshot state / knobs; which of them a batch reads is decided on the device (k_prep_finish)
+  struct RowCands {
+    bool valid = false;
+    uint32_t n = 0;
+    std::vector<double> sig;  // knobs the choice was made with
+    DevBuf<uint8_t> of_layer;
+    DevBuf<double> rows;
+    std::vector<double> row_sig;  // scorer parameters + boosts the resident rows were scored with
+  } cands;
+  std::vector<uint32_t> z_minfl;  // zero_to_one field pruning: [layer][field] shortest field length holding the term (compute_z_bounds)
   std::unordered_map<uint64_t, uint32_t> z_layer_of;  // post_off -> layer (zero_to_one plan entries do not carry it)
   DevBuf<uint32_t> d_sort_doc, d_seg;  // K4 scratch
   DevBuf<uint64_t> d_sort_score, d_pack_off;
@@ -218,13 +247,7 @@ struct EngineImpl {
   DevBuf<unsigned long long> d_pl_post;
   DevBuf<ps_plan_entry> d_pl_entries;
   PlanTotals* h_totals = nullptr;  // pinned
-  std::unique_ptr<Pool> pool;  // K1d descriptor building for large batches
-  struct DaatWork* daat_work = nullptr;  // reused across batches (defined below)
-  std::vector<uint32_t> daat_chunk_of, daat_nchunk_of, daat_entry_order, daat_first_slot;
-  std::vector<uint64_t> daat_sort_keys;
-  std::vector<uint16_t> daat_rank16;
-  uint32_t daat_max_slots = 0;
-  uint32_t daat_first_items = 0;  // K1d: items of the queries' rank-0 lists (they lead the item order)  // K1d: most candidate slots of one query in the batch being enqueued
+  uint32_t daat_max_slots = 0;  // K1d: most candidate slots of one query in the batch being enqueued (0 = unknown: device-built plan)
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0, last_rows_built = 0;
@@ -302,6 +325,11 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     m.tune_gen = g_opt_gen.load();
     PS_HIP(hipMalloc((void**)&m.d_work, 256));
     PS_HIP(hipMemset(m.d_work, 0, 256));
+    PS_HIP(hipMalloc((void**)&m.d_prep_ctl, sizeof(PrepCtl)));
+    PS_HIP(hipMemset(m.d_prep_ctl, 0, sizeof(PrepCtl)));
+    PS_HIP(hipMalloc((void**)&m.d_row_state, sizeof(RowState) * PREP_MAX_ROWS));
+    PS_HIP(hipMemset(m.d_row_state, 0, sizeof(RowState) * PREP_MAX_ROWS));
+    PS_HIP(hipMalloc((void**)&m.d_row_desc, sizeof(RowDesc) * PREP_MAX_ROWS));
     PS_HIP(hipMalloc((void**)&m.d_wstats, (size_t)WS_SLOTS * WS_WORDS * 8));
     PS_HIP(hipMemset(m.d_wstats, 0, (size_t)WS_SLOTS * WS_WORDS * 8));
     PS_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
@@ -340,8 +368,6 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
   }
 }
 
-void free_daat_work(struct DaatWork* w);
-
 Engine::~Engine() {
   if (!impl_) return;
   EngineImpl& m = *impl_;
@@ -353,7 +379,12 @@ Engine::~Engine() {
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
   m.d_gthr.release(); m.d_rows.release(); m.d_cand_cnt.release(); m.d_ditems.release(); m.d_removed_df.release();
-  free_daat_work(m.daat_work);
+  m.d_dentry.release(); m.d_dgroup.release(); m.d_gen.release(); m.d_rorder.release(); m.d_qslot.release(); m.d_qslot_n.release();
+  m.d_gord.release(); m.bounds.M.release(); m.bounds.units.release();
+  for (auto& js : m.bounds.j) js.J.release();
+  m.cands.of_layer.release(); m.cands.rows.release();
+  for (void* p : {(void*)m.d_prep_ctl, (void*)m.d_row_state, (void*)m.d_row_desc})
+    if (p) (void)hipFree(p);
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fchar.release(); m.d_fchild.release();
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release();
   m.d_qtext.release(); m.d_qoff.release(); m.d_pl_cnt.release(); m.d_pl_qtl.release(); m.d_pl_nterms.release();
@@ -495,6 +526,8 @@ void Engine::work_counters(ps_work_counters& out, bool reset) {
   out.k1_postings = sum[WS_K1_POSTINGS];
   out.k1_row_slices = sum[WS_K1_ROWSLICES];
   out.results = m.wc_results;
+  out.rows_built = sum[WS_ROWS_BUILT];
+  out.rows_used = sum[WS_ROWS_USED];
   const uint64_t F = m.snap->F, pw = 4 + 4 * F;
   out.bytes_touched = out.postings_scanned * pw + out.lookups_row * 8 + out.lookups_cell * 8 + out.lookups_probe * 4 +
                       out.lookup_hits * 4 * F + out.k1_postings * pw + out.k1_row_slices * (uint64_t)m.snap->T * 8 +
@@ -569,17 +602,14 @@ void Tuning::load() {
     daat_min_batch = env_u32("PS_DAAT_MIN_BATCH", daat_min_batch);
     daat_chunk = std::max(256u, env_u32("PS_DAAT_CHUNK", daat_chunk));
     daat_rows = env_u32("PS_DAAT_ROWS", daat_rows);
-    daat_chunk0 = env_u32("PS_DAAT_CHUNK0", daat_chunk0);
     daat_merge_waves = std::max(1u, std::min((uint32_t)MERGE_WAVES, env_u32("PS_DAAT_MERGE_WAVES", daat_merge_waves)));
     daat_dense_min_density_pct = env_u32("PS_DAAT_DENSE_MIN_DENSITY_PCT", daat_dense_min_density_pct);
     daat_split_div = std::max(1u, env_u32("PS_DAAT_SPLIT_DIV", daat_split_div));
     daat_persistent = env_u32("PS_DAAT_PERSISTENT", daat_persistent);
-    daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
+    device_plan = env_u32("PS_DEVICE_PLAN", device_plan);
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
-    daat_z21 = env_u32("PS_DAAT_Z21", daat_z21);
     z21_field_prune = env_u32("PS_Z21_FIELD_PRUNE", z21_field_prune);
     z21_exact_numerator = env_u32("PS_Z21_EXACT_NUMERATOR", z21_exact_numerator);
-    daat_threads = std::max(1u, std::min(env_u32("PS_DAAT_THREADS", daat_threads), std::max(1u, std::thread::hardware_concurrency())));
 }
 
 namespace {
@@ -655,25 +685,16 @@ struct BatchImage {
   uint32_t n_used = 0;           // rows the batch reads (resident ones included)
   uint32_t n_simple = 0, n_general = 0, z_masked = 0;
   uint32_t z_qterms = 0;  // most query terms with entries in one general zero_to_one query
-  // K1d
-  bool daat = false;
-  size_t off_d = 0, off_i = 0, off_s = 0, off_ro = 0, off_dg = 0, n_ditems = 0;
+  bool daat = false;  // K1d: descriptors, items and dense-row flags are built on the device from the uploaded plan
+  size_t n_ditems = 0;  // its work items (exact: the host knows the list lengths)
   size_t off_zf = 0;  // zero_to_one: per-query per-field pool bounds (k_score's field pruning)
 };
 
 }  // namespace
-struct DaatWork {
-  std::vector<DEntry> dentry;
-  std::vector<DItemGen> gen;  // per list in processing order; the device expands them into DItems
-  size_t n_items = 0, first_items = 0;  // items in all / of the queries' rank-0 lists (they lead the order)
-  std::vector<uint32_t> qslot, rorder;
-  std::vector<DGroup> dgroup;  // multi-expansion batches only
-};
-void free_daat_work(DaatWork* w) { delete w; }
 namespace {
 
 // Claims the next pinned slot and copies the plan's arrays into it.
-BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, const DaatWork* dw) {
+BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan) {
   BatchImage img;
   const size_t B = img.B = plan.qbeg.size() - 1;
   const size_t ne = img.ne = plan.entries.size();
@@ -691,16 +712,6 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
     img.off_zf = (img.total + 15) & ~(size_t)15;
     img.total = img.off_zf + B * m.snap->F * sizeof(double);
   }
-  if (dw) {
-    img.daat = true;
-    img.n_ditems = dw->n_items;
-    img.off_d = (img.total + 15) & ~(size_t)15;
-    img.off_i = img.off_d + ne * sizeof(DEntry);
-    img.off_s = img.off_i + ne * sizeof(DItemGen);
-    img.off_ro = img.off_s + (B + 1) * 4;
-    img.off_dg = (img.off_ro + ne * 4 + 15) & ~(size_t)15;
-    img.total = img.off_dg + (dw->dgroup.empty() ? 0 : ne * sizeof(DGroup));
-  }
   Stage& sg = m.stage[m.next_stage];
   m.next_stage = (m.next_stage + 1) % N_STAGE;
   sg.ensure(img.total + 16);
@@ -710,13 +721,6 @@ BatchImage lay_out_batch(EngineImpl& m, const ps_scorer_desc& sc, const Plan& pl
   if (ne) memcpy(img.he, plan.entries.data(), ne * sizeof(ps_plan_entry));
   memcpy(img.h + img.off_q, plan.qbeg.data(), (B + 1) * 4);
   if (B) memcpy(img.h + img.off_l, plan.qterms_len.data(), B * 4);
-  if (dw) {
-    if (ne) memcpy(img.h + img.off_d, dw->dentry.data(), ne * sizeof(DEntry));
-    if (ne) memcpy(img.h + img.off_i, dw->gen.data(), ne * sizeof(DItemGen));
-    memcpy(img.h + img.off_s, dw->qslot.data(), (B + 1) * 4);
-    if (ne) memcpy(img.h + img.off_ro, dw->rorder.data(), ne * 4);
-    if (ne && !dw->dgroup.empty()) memcpy(img.h + img.off_dg, dw->dgroup.data(), ne * sizeof(DGroup));
-  }
   return img;
 }
 
@@ -728,69 +732,168 @@ bool bm25_params_sane(const Snapshot& s, const ps_scorer_desc& sc, const double*
   return sane;
 }
 
-// Exact per-list maxima of the saturated term frequency (the same f64 expression the kernels
-// evaluate: bm25.rs:78-82) and of the boosted per-posting sum.  One pass over the host planes.
-void compute_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts) {
+void ensure_dev_trie(EngineImpl& m);  // (defined with the device planner below)
+
+// Per-list score bounds on the device (k_list_bounds) for the current (k1, b, avg) and boosts; see
+// EngineImpl::ListBounds.  Enqueued on `st` in front of the batch that needs them; nothing is recomputed
+// while the parameters stay what they were, and a boost vector seen recently finds its J array resident.
+struct BoundsRef { const double* M; const double* J; };
+BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const KParams& kp, hipStream_t st) {
   const Snapshot& s = *m.snap;
   EngineImpl::ListBounds& lb = m.bounds;
-  const uint32_t F = s.F;
-  std::vector<double> bv(boosts, boosts + F);
-  const size_t nl = s.layers.size();
-  const bool same = lb.valid && lb.k1 == sc.bm25_k1 && lb.b == sc.bm25_b && lb.boosts == bv && lb.avg == std::vector<double>(s.avg.begin(), s.avg.end());
-  if (same && lb.J.size() == nl) return;
-  // (a delta snapshot only appends layers: with unchanged parameters only those are new)
-  const size_t l_first = same ? lb.J.size() : 0;
-  lb.M.resize(nl * F);
-  lb.J.resize(nl);
-  std::fill(lb.M.begin() + (long)(l_first * F), lb.M.end(), 0.0);
-  std::fill(lb.J.begin() + (long)l_first, lb.J.end(), 0.0);
-  const double k1 = sc.bm25_k1, b = sc.bm25_b, k1p1 = sc.bm25_k1 + 1.0, omb = 1.0 - sc.bm25_b;
-  auto tfn_of = [&](uint32_t x, uint32_t tfu, uint32_t flu) {
-    const double tfd = (double)tfu, fld = (double)flu;
-    return (k1p1 * tfd) / (k1 * (omb + b * (fld / s.avg[x])) + tfd);
-  };
-  // memo for the common small (tf, fl) pairs
-  constexpr uint32_t MT = 16, ML = 128;
-  std::vector<double> memo((size_t)F * MT * ML);
-  for (uint32_t x = 0; x < F; ++x)
-    for (uint32_t t = 0; t < MT; ++t)
-      for (uint32_t l = 0; l < ML; ++l) memo[((size_t)x * MT + t) * ML + l] = t ? tfn_of(x, t, l) : 0.0;
-  auto body = [&](size_t l) {
-    const LayerInfo& L = s.layers[l];
-    double J = 0.0;
-    for (uint32_t i = 0; i < L.len; ++i) {
-      const uint64_t pi = L.post_off + i;
-      double sum = 0.0;
-      for (uint32_t x = 0; x < F; ++x) {
-        const uint32_t tfu = s.tf[(size_t)x * s.P + pi];
-        if (!tfu) continue;
-        const uint32_t flu = s.fl[(size_t)x * s.P + pi];
-        const double t = (tfu < MT && flu < ML) ? memo[((size_t)x * MT + tfu) * ML + flu] : tfn_of(x, tfu, flu);
-        if (t > lb.M[l * F + x]) lb.M[l * F + x] = t;
-        sum += boosts[x] * t;
-      }
-      if (sum > J) J = sum;
-    }
-    lb.J[l] = J;
-  };
-  unsigned n_thr = s.n_postings > (1u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-  if (n_thr <= 1 || nl - l_first < 1024) {
-    for (size_t l = l_first; l < nl; ++l) body(l);
-  } else {
-    std::atomic<size_t> next{l_first};
-    auto worker = [&]() {
-      for (;;) {
-        const size_t b0 = next.fetch_add(64);
-        if (b0 >= nl) break;
-        for (size_t l = b0; l < std::min(nl, b0 + 64); ++l) body(l);
-      }
-    };
-    std::vector<std::thread> th;
-    for (unsigned i = 1; i < n_thr; ++i) th.emplace_back(worker);
-    worker();
-    for (auto& t : th) t.join();
+  ensure_dev_trie(m);  // the per-layer table (post_off, len) lives with the device planner's tables
+  const size_t nl = s.layers.size(), F = s.F;
+  const std::vector<double> avg(s.avg.begin(), s.avg.end()), bv(boosts, boosts + F);
+  const bool m_ok = lb.m_valid && lb.k1 == sc.bm25_k1 && lb.b == sc.bm25_b && lb.avg == avg && lb.n_layers == nl;
+  if (!m_ok)
+    for (auto& js : lb.j) js.valid = false;
+  ++lb.epoch;
+  EngineImpl::ListBounds::JSet* tgt = nullptr;
+  for (auto& js : lb.j)
+    if (js.valid && js.boosts == bv) tgt = &js;
+  if (m_ok && tgt) {
+    tgt->last_use = lb.epoch;
+    return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p)};
   }
-  lb.k1 = sc.bm25_k1; lb.b = sc.bm25_b; lb.boosts = bv; lb.avg.assign(s.avg.begin(), s.avg.end()); lb.valid = true;
+  const double t0 = now_ms();
+  if (lb.n_layers != nl || lb.n_units == 0) {  // the work list: one wave per list, long lists in 16 Ki-posting segments
+    std::vector<BoundUnit> units;
+    units.reserve(nl + s.n_postings / 16384 + 1);
+    for (size_t l = 0; l < nl; ++l)
+      for (uint32_t b0 = 0; b0 < s.layers[l].len; b0 += 16384u)
+        units.push_back(BoundUnit{(uint32_t)l, b0, std::min<uint32_t>(16384u, s.layers[l].len - b0)});
+    // longest segments first, so the launch ends on its cheapest waves
+    std::stable_sort(units.begin(), units.end(), [](const BoundUnit& a, const BoundUnit& b) { return a.count > b.count; });
+    lb.units.ensure(units.size() + 1);
+    if (!units.empty()) PS_HIP(hipMemcpy(lb.units.p, units.data(), units.size() * sizeof(BoundUnit), hipMemcpyHostToDevice));
+    lb.n_units = (uint32_t)units.size();
+  }
+  if (!tgt) {  // an invalid slot, else the least recently used one
+    for (auto& js : lb.j)
+      if (!tgt || (!js.valid && tgt->valid) || (js.valid == tgt->valid && js.last_use < tgt->last_use)) tgt = &js;
+  }
+  lb.M.ensure(nl * F + 1);
+  tgt->J.ensure(nl + 1);
+  if (!m_ok) PS_HIP(hipMemsetAsync(lb.M.p, 0, (nl * F + 1) * 8, st));
+  PS_HIP(hipMemsetAsync(tgt->J.p, 0, (nl + 1) * 8, st));
+  if (lb.n_units) {
+    hipLaunchKernelGGL(k_list_bounds, dim3((lb.n_units + 3) / 4), dim3(256), 0, st, kp, lb.units.p, lb.n_units, m.d_layer_a.p, lb.M.p,
+                       tgt->J.p, m_ok ? 0 : 1);
+    PS_HIP(hipGetLastError());
+  }
+  lb.m_valid = true; lb.k1 = sc.bm25_k1; lb.b = sc.bm25_b; lb.avg = avg; lb.n_layers = nl;
+  tgt->valid = true; tgt->boosts = bv; tgt->last_use = lb.epoch;
+  lb.last_ms = now_ms() - t0;
+  ++lb.recomputed;
+  return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p)};
+}
+
+// K1d dense-row candidates: the snapshot's densest lists with one table slot per tile, longest first,
+// each with a fixed row slot.  Chosen on the host when the snapshot's layers or the knobs change; which
+// candidates a batch reads, and with which weights, is decided on the device (k_prep_finish).
+void ensure_row_candidates(EngineImpl& m, hipStream_t st) {
+  const Snapshot& s = *m.snap;
+  EngineImpl::RowCands& rc = m.cands;
+  const uint32_t pct = std::max(m.tune.dense_min_density_pct, m.tune.daat_dense_min_density_pct);
+  const std::vector<double> sig{(double)m.tune.daat_rows, (double)pct, (double)m.tune.dense_max_rows, (double)m.tune.dense_max_mb,
+                                (double)s.layers.size(), (double)s.n_ids, (double)s.tiles_cap, (double)s.n_postings};
+  if (rc.valid && rc.sig == sig) return;
+  const size_t nl = s.layers.size();
+  std::vector<std::pair<uint32_t, uint32_t>> c;  // (len, layer)
+  if (m.tune.daat_rows && m.tune.dense_max_rows && s.n_ids > 0)
+    for (size_t l = 0; l < nl; ++l) {
+      const LayerInfo& L = s.layers[l];
+      if (L.shift == 0 && L.len && (double)L.len >= (pct / 100.0) * (double)s.n_ids) c.emplace_back(L.len, (uint32_t)l);
+    }
+  std::stable_sort(c.begin(), c.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+  const uint64_t row_bytes = (uint64_t)s.tiles_cap * s.T * 8;
+  size_t cap = std::min<size_t>(std::min<uint32_t>(m.tune.dense_max_rows, PREP_MAX_ROWS), c.size());
+  while (cap && cap * row_bytes > ((uint64_t)m.tune.dense_max_mb << 20)) --cap;
+  c.resize(cap);
+  std::vector<uint8_t> of(std::max<size_t>(nl, 1), (uint8_t)NO_CAND);
+  for (size_t k = 0; k < c.size(); ++k) of[c[k].second] = (uint8_t)k;
+  rc.of_layer.ensure(of.size() + 1);
+  PS_HIP(hipMemcpyAsync(rc.of_layer.p, of.data(), of.size(), hipMemcpyHostToDevice, st));
+  PS_HIP(hipStreamSynchronize(st));  // (`of` is pageable and leaves scope; this happens once per snapshot state)
+  rc.rows.ensure(std::max<size_t>(1, c.size()) * (size_t)s.tiles_cap * s.T + 16);
+  PS_HIP(hipMemsetAsync(m.d_row_state, 0, sizeof(RowState) * PREP_MAX_ROWS, st));
+  rc.n = (uint32_t)c.size();
+  rc.sig = sig;
+  rc.row_sig.clear();
+  rc.valid = true;
+}
+
+// The device-side preparation of a K1d batch (ps_prep_kernels.hpp) over a plan that already lives in
+// HBM - uploaded by the host planner or written by the device planner: bounds -> descriptors / order /
+// candidate slots -> items and dense-row flags.  `items_bound` >= the batch's item count (exact when the
+// host knows the list lengths).  Fills the K1d members of `kp`.
+void launch_prep(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, KParams& kp, hipStream_t st, ps_plan_entry* d_plan,
+                 const uint32_t* d_qbeg, size_t B, size_t ne, bool multi, size_t items_bound) {
+  const Snapshot& s = *m.snap;
+  const BoundsRef br = ensure_list_bounds(m, sc, boosts, kp, st);
+  ensure_row_candidates(m, st);
+  // resident rows are only valid for the parameters they were scored with
+  {
+    std::vector<double> sig{sc.bm25_k1, sc.bm25_b};
+    for (uint32_t x = 0; x < s.F; ++x) { sig.push_back(boosts[x]); sig.push_back(s.avg[x]); }
+    if (sig != m.cands.row_sig) {
+      PS_HIP(hipMemsetAsync(m.d_row_state, 0, sizeof(RowState) * PREP_MAX_ROWS, st));
+      m.cands.row_sig = sig;
+    }
+  }
+  m.d_dentry.ensure(ne + 1); m.d_rorder.ensure(ne + 1); m.d_gord.ensure(ne + 16); m.d_gen.ensure(ne + 1);
+  if (multi) m.d_dgroup.ensure(ne + 1);
+  m.d_qslot.ensure(B + 1); m.d_qslot_n.ensure(B + 1);
+  m.d_ditems.ensure(items_bound + 1);
+  m.d_cand_cnt.ensure(items_bound + 1);
+  PrepParams pp;
+  memset(&pp, 0, sizeof(pp));
+  pp.plan = d_plan; pp.qbeg = d_qbeg;
+  pp.B = (uint32_t)B; pp.ne = (uint32_t)ne; pp.F = s.F; pp.multi = multi ? 1u : 0u;
+  pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div;
+  for (uint32_t x = 0; x < s.F; ++x) pp.boost[x] = boosts[x];
+  pp.bound_m = br.M; pp.bound_j = br.J;
+  pp.dentry = m.d_dentry.p; pp.rorder = m.d_rorder.p; pp.dgroup = multi ? m.d_dgroup.p : nullptr; pp.gord = m.d_gord.p;
+  pp.gen = m.d_gen.p; pp.qslot = m.d_qslot.p; pp.qslot_n = m.d_qslot_n.p;
+  pp.items = m.d_ditems.p; pp.items_cap = (uint32_t)items_bound;
+  pp.ctl = m.d_prep_ctl;
+  pp.cand_of_layer = m.cands.of_layer.p; pp.n_cand = m.cands.n; pp.min_uses = std::max(1u, m.tune.dense_min_uses);
+  pp.rows_resident = m.tune.row_cache_mb != 0;
+  pp.layer_a = m.d_layer_a.p; pp.row_state = m.d_row_state; pp.row_desc = m.d_row_desc; pp.wstats = m.d_wstats;
+  if (B) {
+    hipLaunchKernelGGL(k_prep_query, dim3((uint32_t)((B + 63) / 64)), dim3(64), 0, st, pp);
+    hipLaunchKernelGGL(k_prep_finish, dim3(1), dim3(64), 0, st, pp);
+    if (ne) hipLaunchKernelGGL(k_prep_items, dim3((uint32_t)((ne + 3) / 4)), dim3(256), 0, st, pp);
+    PS_HIP(hipGetLastError());
+  }
+  kp.dentry = m.d_dentry.p; kp.ditems = m.d_ditems.p; kp.qslot = m.d_qslot.p; kp.qslot_n = m.d_qslot_n.p;
+  kp.rorder = m.d_rorder.p; kp.dgroup = multi ? m.d_dgroup.p : nullptr;
+  kp.n_ditems = (uint32_t)items_bound;
+  kp.n_ditems_dev = &m.d_prep_ctl->n_items;
+  kp.prep_ctl = reinterpret_cast<uint32_t*>(m.d_prep_ctl);
+  kp.prep_ctl_words = (uint32_t)(sizeof(PrepCtl) / 4);
+  kp.cand_cnt = m.d_cand_cnt.p;
+  kp.rows = m.cands.rows.p; kp.row_desc = m.d_row_desc; kp.n_rows = 0;
+  kp.row_planes = 1; kp.row_mode = 0; kp.row_stride = (uint64_t)s.tiles_cap * s.T;
+}
+
+// Items a batch has under the chunking rule of k_prep_query (host-planned batches: exact).
+size_t count_daat_items(const EngineImpl& m, const Plan& plan, uint32_t* max_slots) {
+  size_t n = 0;
+  uint32_t mx = 0;
+  const size_t B = plan.qbeg.size() - 1;
+  for (size_t q = 0; q < B; ++q) {
+    uint32_t sl = 0;
+    for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
+      const uint32_t len = plan.entries[i].len;
+      const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + m.tune.daat_split_div - 1) / m.tune.daat_split_div + 255) & ~255u);
+      sl += (len + c - 1) / c;
+    }
+    n += sl;
+    mx = std::max(mx, sl);
+  }
+  if (max_slots) *max_slots = mx;
+  return n;
 }
 
 // zero_to_one: per (layer, field) the shortest field length among the postings that hold the term in
@@ -831,201 +934,6 @@ void compute_z_bounds(EngineImpl& m) {
     worker();
     for (auto& t : th) t.join();
   }
-}
-
-// Upper bound of any posting score of plan entry `e` (list e.node), rounding included: the per-field
-// form pushes the maxima through the kernels' own expression (every operation is monotone), the joint
-// form bounds the real-number value and is inflated past the few roundings between them.
-double entry_upper_bound(const EngineImpl& m, const ps_plan_entry& e, const double* boosts) {
-  const uint32_t F = m.snap->F;
-  const EngineImpl::ListBounds& lb = m.bounds;
-  double ub_m = 0.0;
-  for (uint32_t x = 0; x < F; ++x) {
-    const double t = lb.M[(size_t)e.node * F + x];
-    if (t > 0.0) ub_m += t * e.idf * boosts[x] * e.boost;
-  }
-  const double ub_j = (e.idf * e.boost) * lb.J[e.node] * (1.0 + 1e-12);
-  return std::min(ub_m, ub_j);
-}
-
-// Work descriptors of a BM25 top-k batch: per entry its bounds and rank, per (entry, chunk) one item,
-// items ordered highest-bound lists first (rank-major), candidate slots query-major.  The per-query
-// part runs on the engine's small thread pool for large batches (it sits on the host's critical path:
-// at ~0.7 ms of GPU time per 1024-query batch, 0.3 ms of serial descriptor building would show).
-template <typename UbFn>
-void plan_daat(EngineImpl& m, const Plan& plan, const ps_plan_entry* ents, const bool multi, UbFn&& ub_of, DaatWork& dw) {
-  const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size();
-  constexpr double SLACK = 1.0 + 1e-9;  // the bounds are summed in another order than the scores
-  dw.dentry.resize(ne);
-  dw.qslot.assign(B + 1, 0);
-  dw.rorder.resize(ne);
-  if (multi) dw.dgroup.assign(ne, DGroup{}); else dw.dgroup.clear();
-  std::vector<uint32_t>& chunk = m.daat_chunk_of;
-  std::vector<uint32_t>& nchunk = m.daat_nchunk_of;
-  chunk.resize(ne);
-  nchunk.resize(ne);
-  // ranks again as a compact array: the serial ordering pass below then pulls 2 bytes per entry out of the
-  // pool threads' caches instead of a 32-byte DEntry (the pass was bound by those cache-line transfers)
-  std::vector<uint16_t>& rk = m.daat_rank16;
-  rk.resize(ne);
-  auto rank_of = [&](size_t i) { return rk[i] != 0xFFFFu ? (uint32_t)rk[i] : dw.dentry[i].rank; };
-  auto per_query = [&](size_t q0, size_t q1) {
-    std::vector<uint32_t> ord;
-    std::vector<double> ub;
-    std::vector<std::pair<uint32_t, double>> gmax, pm;  // (query term, max bound)
-    for (size_t q = q0; q < q1; ++q) {
-      const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1];
-      const uint32_t n = e - b;
-      ord.resize(n);
-      ub.resize(n);
-      for (uint32_t i = 0; i < n; ++i) { ord[i] = i; ub[i] = ub_of(ents[b + i], q); }
-      // equal bounds (zero_to_one: every list that occurs in some shortest field has the same one): the
-      // LONGER list ranks lower, so it is the one that becomes non-essential
-      std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) {
-        return ub[a] > ub[c] || (ub[a] == ub[c] && ents[b + a].len < ents[b + c].len);
-      });
-      // group maxima over ALL entries (what the other query terms can add to a candidate)
-      gmax.clear();
-      for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t qt = ents[b + i].qterm;
-        bool found = false;
-        for (auto& g : gmax)
-          if (g.first == qt) { g.second = std::max(g.second, ub[i]); found = true; }
-        if (!found) gmax.emplace_back(qt, ub[i]);
-      }
-      for (uint32_t r = 0; r < n; ++r) {
-        const uint32_t i = ord[r];
-        DEntry& d = dw.dentry[b + i];
-        d.rank = r;
-        rk[b + i] = (uint16_t)std::min<uint32_t>(r, 0xFFFFu);
-        d.q = (uint32_t)q;
-        d.ub = ub[i];
-        dw.rorder[b + r] = b + i;
-        // what every other entry can add: the other groups' maxima + the best other entry of its own group
-        const uint32_t qt = ents[b + i].qterm;
-        double alt = 0.0, rest = 0.0;
-        if (multi)
-          for (uint32_t j = 0; j < n; ++j)
-            if (j != i && ents[b + j].qterm == qt) alt = std::max(alt, ub[j]);
-        for (auto& g : gmax)
-          if (g.first != qt) rest += g.second;
-        d.others = (rest + alt) * SLACK;
-        if (!(d.others >= 0.0)) d.others = INFINITY;
-      }
-      if (multi) {
-        // per entry: the dense ordinal of its query term and the (inflated) bound of the next list of the
-        // same term in rank order - what k_daat's pass 1 falls back to once this list has been looked at
-        for (uint32_t r = 0; r < n; ++r) {
-          const uint32_t i = ord[r];
-          DGroup& dg = dw.dgroup[b + i];
-          const uint32_t qt = ents[b + i].qterm;
-          uint32_t g = 0;
-          while (g < gmax.size() && gmax[g].first != qt) ++g;
-          dg.grp = gmax.size() <= 4 ? g : 0xFFFFFFFFu;
-          dg.ub_s = ub[i] * SLACK;
-          dg.nxt_s = 0.0;
-          for (uint32_t r2 = r + 1; r2 < n; ++r2)
-            if (ents[b + ord[r2]].qterm == qt) { dg.nxt_s = ub[ord[r2]] * SLACK; break; }
-        }
-      }
-      // skip thresholds: entries in ascending bound order; a document that only occurs in the first k
-      // of them scores at most sum over query terms of the largest bound among those of its lists
-      pm.clear();
-      for (uint32_t r = n; r-- > 0;) {
-        const uint32_t i = ord[r];
-        const uint32_t qt = ents[b + i].qterm;
-        bool found = false;
-        for (auto& g : pm)
-          if (g.first == qt) { g.second = std::max(g.second, ub[i]); found = true; }
-        if (!found) pm.emplace_back(qt, ub[i]);
-        double bound = 0.0;
-        for (auto& g : pm) bound += g.second;
-        DEntry& d = dw.dentry[b + i];
-        d.skip_thr = bound * SLACK;
-        if (!(d.skip_thr >= 0.0)) d.skip_thr = INFINITY;
-      }
-      uint32_t slots = 0;
-      for (uint32_t i = b; i < e; ++i) {
-        const uint32_t len = ents[i].len;
-        // (a fixed chunk for every list measured slower: C2 0.563 vs 0.536 ms, C4 2.16 vs 1.90 ms - the
-        // long low-bound lists are skipped whole, and fewer, larger skips are cheaper)
-        // (the query's highest-bound list is always scanned: short chunks keep the launch's critical path -
-        // one wave scans one chunk - short; the other lists are mostly skipped whole)
-        const uint32_t div = m.tune.daat_split_div;
-        const uint32_t c = (dw.dentry[i].rank == 0 && m.tune.daat_chunk0)
-                               ? m.tune.daat_chunk0
-                               : std::max<uint32_t>(m.tune.daat_chunk, ((len + div - 1) / div + 255) & ~255u);
-        chunk[i] = c;
-        nchunk[i] = (len + c - 1) / c;
-        slots += nchunk[i];
-      }
-      dw.qslot[q + 1] = slots;  // turned into a prefix sum below
-    }
-  };
-  static const bool trace_pd = getenv("PS_TRACE") && *getenv("PS_TRACE") == '2';
-  double tpd = trace_pd ? now_ms() : 0.0;
-  auto PD = [&](const char* what) {
-    if (!trace_pd) return;
-    const double n = now_ms();
-    fprintf(stderr, "[ps]     daat %-10s %.3f ms\n", what, n - tpd);
-    tpd = now_ms();  // (after the print: its time is not the next stage's)
-  };
-  if (B >= 256 && m.tune.daat_threads > 1) {
-    if (!m.pool || m.pool->size() != m.tune.daat_threads) m.pool.reset(new Pool(m.tune.daat_threads - 1));
-    m.pool->run([&](unsigned part, unsigned parts) { per_query(B * part / parts, B * (part + 1) / parts); });
-  } else {
-    per_query(0, B);
-  }
-  PD("per-query");
-  for (size_t q = 0; q < B; ++q) dw.qslot[q + 1] += dw.qslot[q];
-  // processing order: rank-major (every query's highest-bound list first), longest lists first within
-  // a rank, so thresholds exist before the long low-bound lists come up and the launch ends on skips
-  std::vector<uint32_t>& eo = m.daat_entry_order;
-  eo.resize(ne);
-  for (size_t i = 0; i < ne; ++i) eo[i] = (uint32_t)i;
-  {  // counting sort by rank, then the rank-0 bucket (the lists that set the thresholds) longest first
-    std::vector<uint32_t> cnt(plan.max_entries + 2, 0);
-    for (size_t i = 0; i < ne; ++i) cnt[rank_of(i) + 1]++;
-    for (size_t r = 1; r < cnt.size(); ++r) cnt[r] += cnt[r - 1];
-    const uint32_t n0 = cnt[1];
-    for (size_t i = 0; i < ne; ++i) eo[cnt[rank_of(i)]++] = (uint32_t)i;
-    // (a scheduling order, not a result order: a stable counting sort into 64 length classes - log2 with
-    // one fractional bit, longest first - costs 3 us per 1024 queries where the exact sort cost 30)
-    auto cls = [&](uint32_t e) {
-      const uint32_t len = std::max(1u, ents[e].len);
-      const uint32_t lg = 31u - (uint32_t)__builtin_clz(len);
-      return 63u - (2u * lg + (lg ? ((len >> (lg - 1)) & 1u) : 0u));
-    };
-    uint32_t cc[65] = {0};
-    for (uint32_t k = 0; k < n0; ++k) cc[cls(eo[k]) + 1]++;
-    for (uint32_t c = 1; c <= 64; ++c) cc[c] += cc[c - 1];
-    std::vector<uint64_t>& keys = m.daat_sort_keys;  // (scratch: the rank-0 entries in their new order)
-    keys.resize(n0);
-    for (uint32_t k = 0; k < n0; ++k) keys[cc[cls(eo[k])]++] = eo[k];
-    for (uint32_t k = 0; k < n0; ++k) eo[k] = (uint32_t)keys[k];
-  }
-  // candidate slots are query-major: slot of (entry, chunk) = qslot[q] + chunks of the query's earlier entries + chunk
-  std::vector<uint32_t>& first_slot = m.daat_first_slot;
-  first_slot.resize(ne);
-  for (size_t q = 0; q < B; ++q) {
-    uint32_t sl = dw.qslot[q];
-    for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) { first_slot[i] = sl; sl += nchunk[i]; }
-  }
-  PD("order");
-  // the lists in processing order with their item ranges; k_make_items expands them on the device
-  dw.gen.resize(ne);
-  {
-    uint32_t at = 0;
-    dw.first_items = 0;
-    for (size_t k = 0; k < ne; ++k) {
-      const uint32_t i = eo[k];
-      dw.gen[k] = DItemGen{i, at, chunk[i], first_slot[i]};
-      at += nchunk[i];
-      if (rk[i] == 0) dw.first_items = at;
-    }
-    dw.n_items = at;
-  }
-  PD("items");
 }
 
 // qorder: K1 hands out the items of a run heaviest query first (longest-processing-time order).
@@ -1139,7 +1047,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
   uint32_t& n_rows = img.n_rows;
   uint32_t& n_used = img.n_used;
   const uint32_t z_masked = img.z_masked;
-  if (img.daat && !m.tune.daat_rows) return;  // K1d without rows: every lookup is a binary search
+  if (img.daat) return;  // K1d: which dense rows the batch reads is decided on the device (k_prep_finish)
   {
     bool sane = max_rows > 0 && s.n_docs > 0;
     if (!z) {
@@ -1347,10 +1255,8 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const Snapshot& s = *m.snap;
   refresh_tuning(m);
   // K1d (exact dynamic pruning) takes BM25 top-k batches whose parameters make every score a
-  // positive, monotone function of the saturated term frequency; everything else stays on K1
-  if (!m.daat_work) m.daat_work = new DaatWork();
-  DaatWork& dw = *m.daat_work;
-  bool use_daat = false;
+  // positive, monotone function of the saturated term frequency and whose plans have at most 64
+  // entries per query; everything else stays on K1.  Its descriptors are built on the device.
   static const bool trace_sp = env_u32("PS_TRACE", 0) != 0;
   double tsp = now_ms();
   auto SP = [&](const char* what) {
@@ -1360,30 +1266,15 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     tsp = now_ms();
   };
   const bool daat_batch = topk_path && m.tune.daat && plan.qbeg.size() - 1 >= m.tune.daat_min_batch && !plan.entries.empty();
-  if (daat_batch && sc.kind == PS_SCORER_BM25 && m.tune.lut && bm25_params_sane(s, sc, boosts) &&
-      (!plan.multi_expansion || m.tune.daat_multi)) {
-    compute_list_bounds(m, sc, boosts);
-    plan_daat(m, plan, plan.entries.data(), plan.multi_expansion,
-              [&](const ps_plan_entry& e, size_t) { return entry_upper_bound(m, e, boosts); }, dw);
-    use_daat = dw.n_items != 0;
-  }
-  // zero_to_one: whether the batch qualifies is only known after the queries are classified, which
-  // needs the staged image; reserve the descriptors' space now (their sizes do not depend on it)
-  const bool z_daat_maybe = daat_batch && sc.kind == PS_SCORER_ZERO_TO_ONE && m.tune.daat_z21 && (s.F == 1 || s.F == 2) &&
-                            s.n_docs > 0 && !plan.multi_expansion && plan.max_entries <= 64;
-  if (z_daat_maybe) {
-    const size_t ne = plan.entries.size();
-    size_t n_items = 0;
-    for (size_t i = 0; i < ne; ++i) {
-      const uint32_t len = plan.entries[i].len;
-      const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + m.tune.daat_split_div - 1) / m.tune.daat_split_div + 255) & ~255u);
-      n_items += (len + c - 1) / c;
-    }
-    dw.dentry.resize(ne); dw.rorder.resize(ne); dw.qslot.resize(plan.qbeg.size()); dw.gen.resize(ne); dw.n_items = n_items; dw.dgroup.clear();
-  }
+  size_t n_ditems = 0;
+  uint32_t max_slots = 0;
+  if (daat_batch && sc.kind == PS_SCORER_BM25 && m.tune.lut && bm25_params_sane(s, sc, boosts) && plan.max_entries <= 64 &&
+      (!plan.multi_expansion || m.tune.daat_multi))
+    n_ditems = count_daat_items(m, plan, &max_slots);
   SP("daat");
-  BatchImage img = lay_out_batch(m, sc, plan, (use_daat || z_daat_maybe) ? &dw : nullptr);
-  if (z_daat_maybe) img.daat = false;  // decided below
+  BatchImage img = lay_out_batch(m, sc, plan);
+  img.daat = n_ditems != 0;
+  img.n_ditems = n_ditems;
   SP("layout");
   const size_t B = img.B;
   const bool z = img.z;
@@ -1433,35 +1324,6 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     }
     z_field_bounds = true;
   }
-  if (z_daat_maybe && img.n_general == 0 && img.z_masked == 0 && img.n_simple == B) {
-    // every query is "simple": K1dz.  Bounds from the entries as uploaded (record-sort order).
-    compute_z_bounds(m);
-    if (m.z_layer_of.size() != s.layers.size()) {
-      m.z_layer_of.clear();
-      for (size_t l = 0; l < s.layers.size(); ++l) m.z_layer_of.emplace(s.layers[l].post_off, (uint32_t)l);
-    }
-    const uint32_t F = s.F;
-    plan_daat(m, plan, img.he, false, [&](const ps_plan_entry& e, size_t q) {
-      const uint32_t l = m.z_layer_of.at(e.post_off);
-      const uint32_t qtl = plan.qterms_len[q];
-      double ub = 0.0;
-      for (uint32_t x = 0; x < F; ++x) {
-        const uint32_t mn = m.z_minfl[(size_t)l * F + x];
-        if (mn == 0xFFFFFFFFu) continue;
-        ub = std::max(ub, e.boost * (1.0 + 1e-12) / (double)std::max(mn, qtl));
-      }
-      return ub;
-    }, dw);
-    if (dw.n_items == img.n_ditems && dw.n_items) {
-      const size_t ne = plan.entries.size();
-      memcpy(img.h + img.off_d, dw.dentry.data(), ne * sizeof(DEntry));
-      memcpy(img.h + img.off_i, dw.gen.data(), ne * sizeof(DItemGen));
-      memcpy(img.h + img.off_s, dw.qslot.data(), (B + 1) * 4);
-      memcpy(img.h + img.off_ro, dw.rorder.data(), ne * 4);
-      img.daat = true;
-      use_daat = true;
-    }
-  }
   SP("order");
   select_dense_rows(m, sc, boosts, plan, img);
   SP("rows");
@@ -1484,7 +1346,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   } else {
     // one upload: the device image has the staging layout (entries | qbeg | qterms_len | qorder | zorder | qflags)
     m.d_stage.ensure(total + 64);
-    const size_t up_bytes = (img.daat || z_field_bounds) ? total : n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z);
+    const size_t up_bytes = z_field_bounds ? total : n_rows ? off_r + n_rows * sizeof(RowDesc) : (z ? off_r : off_z);
     if (m.tune.kernel_upload && up_bytes <= ((size_t)4 << 20)) {
       const size_t n16 = (up_bytes + 15) / 16;  // slot and device buffer are both padded past `total`
       const uint32_t blocks = (uint32_t)std::min<size_t>(256, (n16 + 255) / 256);
@@ -1515,25 +1377,6 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   kp.row_desc = reinterpret_cast<const RowDesc*>(dbase + off_r);
   kp.n_rows = n_rows;
   kp.zfub = z_field_bounds ? reinterpret_cast<const double*>(dbase + img.off_zf) : nullptr;
-  if (img.daat) {
-    kp.dentry = reinterpret_cast<const DEntry*>(dbase + img.off_d);
-    m.d_ditems.ensure(img.n_ditems + 1);
-    kp.ditems = m.d_ditems.p;
-    {
-      const uint32_t ne32 = (uint32_t)img.ne;
-      hipLaunchKernelGGL(k_make_items, dim3((ne32 + 3) / 4), dim3(256), 0, st, reinterpret_cast<const DItemGen*>(dbase + img.off_i),
-                         reinterpret_cast<const ps_plan_entry*>(dbase + off_e), ne32, m.d_ditems.p);
-      PS_HIP(hipGetLastError());
-    }
-    kp.qslot = reinterpret_cast<const uint32_t*>(dbase + img.off_s);
-    kp.rorder = reinterpret_cast<const uint32_t*>(dbase + img.off_ro);
-    kp.dgroup = dw.dgroup.empty() ? nullptr : reinterpret_cast<const DGroup*>(dbase + img.off_dg);
-    kp.n_ditems = (uint32_t)img.n_ditems;
-    uint32_t max_slots = 0;
-    for (size_t q = 0; q < B; ++q) max_slots = std::max(max_slots, dw.qslot[q + 1] - dw.qslot[q]);
-    m.daat_max_slots = max_slots;
-    m.daat_first_items = (uint32_t)dw.first_items;
-  }
   m.build_slots.clear();  // rows the host has to zero-fill for K0b
   for (uint32_t r = 0; r < n_rows; ++r) {
     const RowDesc& d = reinterpret_cast<const RowDesc*>(h + off_r)[r];
@@ -1558,6 +1401,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (!(m.ctl_clean && topk_path && !fresh)) {
     PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
     PS_HIP(hipMemsetAsync(m.d_work, 0, 256, st));
+    PS_HIP(hipMemsetAsync(m.d_prep_ctl, 0, sizeof(PrepCtl), st));
   }
   m.ctl_clean = false;  // enqueue_topk sets it once k_merge is in the stream
   kp.n_simple = img.n_simple; kp.n_general = n_general; kp.z_masked = img.z_masked;
@@ -1582,8 +1426,15 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;  // odd stride; LUT bytes = stride*128, so tiles stay 16-B aligned
     for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
   }
-  if (!img.daat) choose_run_length(m, sc, plan, img, topk_path, kp);
-  else { kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0; }
+  if (!img.daat) {
+    choose_run_length(m, sc, plan, img, topk_path, kp);
+  } else {
+    kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0;
+    if (zero_copy) throw std::logic_error("K1d batches upload their plan");  // (B >= daat_min_batch > 4: never zero-copy)
+    launch_prep(m, sc, boosts, kp, st, reinterpret_cast<ps_plan_entry*>(m.d_stage.p + off_e),
+                reinterpret_cast<const uint32_t*>(m.d_stage.p + off_q), B, img.ne, plan.multi_expansion, img.n_ditems);
+    m.daat_max_slots = max_slots;
+  }
   SP("rest");
   static const bool trace = env_u32("PS_TRACE", 0) != 0;
   if (trace && B > 1)
@@ -1656,17 +1507,7 @@ void launch_daat(EngineImpl& m, KParams& kp, bool multi, int n_cu, hipStream_t s
     char nm[96];                                                                                         \
     snprintf(nm, sizeof(nm), "ps::k_daat<%d, %s>", (int)(FV), (MU) ? "true" : "false");                  \
     m.score_kernel_name = nm;                                                                            \
-    if (m.tune.daat_split && !m.tune.daat_persistent && m.daat_first_items && m.daat_first_items < kp.n_ditems) { \
-      /* thresholds first: every query's highest-bound list, then (stream order) everything else */    \
-      KParams a = kp, b = kp;                                                                            \
-      a.n_ditems = m.daat_first_items;                                                                   \
-      b.item_base = m.daat_first_items;                                                                  \
-      b.n_ditems = kp.n_ditems - m.daat_first_items;                                                     \
-      hipLaunchKernelGGL((k_daat<FV, MU>), dim3((a.n_ditems + DAAT_WGW - 1) / DAAT_WGW), dim3(WAVE * DAAT_WGW), lds, st, a);      \
-      hipLaunchKernelGGL((k_daat<FV, MU>), dim3((b.n_ditems + DAAT_WGW - 1) / DAAT_WGW), dim3(WAVE * DAAT_WGW), lds, st, b);      \
-    } else {                                                                                             \
-      hipLaunchKernelGGL((k_daat<FV, MU>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);                     \
-    }                                                                                                    \
+    hipLaunchKernelGGL((k_daat<FV, MU>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);                       \
   } while (0)
   if (multi) {
     if (kp.F == 1) PS_DAAT(1, true); else if (kp.F == 2) PS_DAAT(2, true); else PS_DAAT(0, true);
@@ -1712,21 +1553,23 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
       hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
       m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = st;
     }
-    launch_rows(kp, m.build_slots, st);
-    if (mid) PS_HIP(hipEventRecord(mid, st));
-    if (!FULL && kp.n_ditems) launch_daat(m, kp, plan.multi_expansion, n_cu, st);
-    else launch_k_score<MODE_BM25, FULL>(m, kp, plan.multi_expansion, n_cu, st);
+    if (!FULL && kp.n_ditems) {
+      // K1d: the rows to score were listed on the device (k_prep_finish); a fixed grid takes (row, tile range) units
+      if (m.cands.n) {
+        const uint32_t per_row = std::min(2048u, std::max(256u, kp.n_tiles));
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_row * m.cands.n, 4096);
+        hipLaunchKernelGGL(k_dense_rows_dyn, dim3(grid), dim3(256), 0, st, kp, m.cands.rows.p, m.d_prep_ctl, per_row);
+      }
+      if (mid) PS_HIP(hipEventRecord(mid, st));
+      launch_daat(m, kp, plan.multi_expansion, n_cu, st);
+    } else {
+      launch_rows(kp, m.build_slots, st);
+      if (mid) PS_HIP(hipEventRecord(mid, st));
+      launch_k_score<MODE_BM25, FULL>(m, kp, plan.multi_expansion, n_cu, st);
+    }
   } else {
     launch_rows(kp, m.build_slots, st);
     if (mid) PS_HIP(hipEventRecord(mid, st));
-    if (!FULL && kp.n_ditems) {  // K1dz: every query of the batch is simple
-      const uint32_t n_wg = (kp.n_ditems + 7) / 8;
-      if (kp.F == 1) hipLaunchKernelGGL((k_daat_z<1>), dim3(n_wg), dim3(WAVE * 8), 0, st, kp);
-      else hipLaunchKernelGGL((k_daat_z<2>), dim3(n_wg), dim3(WAVE * 8), 0, st, kp);
-      m.score_kernel_name = kp.F == 1 ? "ps::k_daat_z<1>" : "ps::k_daat_z<2>";
-      PS_HIP(hipGetLastError());
-      return;
-    }
     if (kp.n_simple) launch_k_score<MODE_Z21S, FULL>(m, kp, kp.z_masked != 0, n_cu, st);
     if (kp.n_general) {
       // general zero_to_one: the LDS sub-tile shrinks with (distinct nodes x fields) to fit the budget
@@ -1760,6 +1603,11 @@ void forget_rows(EngineImpl& m) {
   for (auto& sl : m.row_slots) sl = EngineImpl::RowSlot{};
   m.ctl_clean = false;
   m.lut_valid = false;
+  // K1d: bounds, row candidates and resident rows are re-derived from the snapshot's current state
+  m.bounds.m_valid = false;
+  m.bounds.n_units = 0;
+  for (auto& js : m.bounds.j) js.valid = false;
+  m.cands.valid = false;
 }
 
 void fill_stats(const EngineImpl& m, ps_batch_stats& st, const Snapshot& s, const Plan& plan, uint64_t emitted) {
@@ -1832,7 +1680,8 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   if (B) {
     // one wave per ~4 wave-wide candidate loads, at most MERGE_WAVES
     if (kp.n_ditems) {
-      const uint32_t mw = std::min<uint32_t>(m.tune.daat_merge_waves, std::max<uint32_t>(1, (m.daat_max_slots + 7) / 8));
+      const uint32_t mw = m.daat_max_slots ? std::min<uint32_t>(m.tune.daat_merge_waves, std::max<uint32_t>(1, (m.daat_max_slots + 7) / 8))
+                                           : m.tune.daat_merge_waves;
       hipLaunchKernelGGL(k_merge_items, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
     } else {
     const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));

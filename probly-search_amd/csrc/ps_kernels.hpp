@@ -1,6 +1,7 @@
 // ps_kernels.hpp — device code of the query-scoring path (gfx950 / CDNA4): kernel parameter
-// block, wave-level top-K, K0 k_bm25_lut, K0b k_dense_rows, K1 k_score, K1d k_daat (+ k_daat_z), K2 k_z21,
-// K3 k_merge / K3d k_merge_items, the device planner k_plan, k_pack_tfl, k_make_items, k_upload, k_pack_results.  Included by ps_engine.hip only (one translation unit); see that file's header
+// block, wave-level top-K, K0 k_bm25_lut, K0b k_dense_rows, K1 k_score, K1d k_daat, K2 k_z21,
+// K3 k_merge / K3d k_merge_items, the device planner k_plan, k_pack_tfl, k_upload, k_pack_results (the device-side
+// preparation of a K1d batch: ps_prep_kernels.hpp).  Included by ps_engine.hip only (one translation unit); see that file's header
 // comment for the kernel overview and DESIGN.md section 3 for the design.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -66,7 +67,7 @@ struct RowDesc {  // one hot (list, idf, expansion_boost) combination K0b has to
 };
 constexpr uint32_t NO_TABLE = 0xFFFFFFFFu;
 
-// K1d work descriptors (host: stage_daat in ps_engine.hip)
+// K1d work descriptors (built on the device: ps_prep_kernels.hpp)
 struct DEntry {        // per plan entry
   double skip_thr;     // upper bound of any document that only occurs in this list and lists with lower bounds
   double others;       // upper bound of what every OTHER entry of the query can add to a document of this list
@@ -87,7 +88,7 @@ struct DItem {         // a chunk of one list
   uint32_t slot;       // candidate slot (query-major)
 };
 
-struct DItemGen {      // one list in processing order: k_make_items expands it into its DItems on the device
+struct DItemGen {      // per plan entry: k_prep_items expands it into its DItems on the device
   uint32_t entry;      // plan entry
   uint32_t item_at;    // its first item
   uint32_t chunk;      // postings per item
@@ -135,7 +136,11 @@ struct KParams {
   // K1d k_daat (exact dynamic pruning, see there)
   const struct DEntry* dentry;  // [n_plan_entries], parallel to plan[]
   const struct DItem* ditems;   // [n_ditems] in processing order (highest upper bound first)
-  const uint32_t* qslot;        // [B+1] candidate slots (= items) of query q: [qslot[q], qslot[q+1])
+  const uint32_t* qslot;        // [B] first candidate slot (= item) of query q
+  const uint32_t* qslot_n;      // [B] its candidate slots
+  const uint32_t* n_ditems_dev; // the batch's item count as k_prep_finish wrote it (n_ditems below is the host's upper bound = the grid)
+  uint32_t* prep_ctl;           // the preparation's control words (ps_prep_kernels.hpp: PrepCtl), zeroed behind k_merge_items
+  uint32_t prep_ctl_words;
   const uint32_t* rorder;       // [n_plan_entries] per query: its entries in rank order (highest bound first)
   const struct DGroup* dgroup;  // [n_plan_entries] (multi-expansion batches)
   const uint32_t* tfl;          // [P][F] packed {tf (8 bits, 255 = see the tf plane), field length (24 bits, all ones = see the fl plane)}: what the hot loops read
@@ -170,7 +175,7 @@ struct KParams {
 #endif
 constexpr uint32_t WS_SLOTS = 64, WS_WORDS = 16;  // one 128-byte line per slot
 enum { WS_ITEMS_RUN = 0, WS_SCANNED, WS_REACHED, WS_ROW, WS_CELL, WS_PROBE, WS_HIT, WS_OFFER, WS_K1_ITEMS, WS_K1_POSTINGS,
-       WS_K1_ROWSLICES };
+       WS_K1_ROWSLICES, WS_ROWS_BUILT, WS_ROWS_USED, WS_ITEMS };
 struct WorkStats {  // K1d, per item
   uint32_t scanned = 0, reached = 0, row = 0, cell = 0, probe = 0, hit = 0, offer = 0;
 };
@@ -301,8 +306,8 @@ __global__ __launch_bounds__(256) void k_bm25_lut(const KParams p, double* out) 
 // into a dense per-document row (0.0 = no posting).  K1 then adds row values in plan order
 // instead of re-streaming 20-byte postings and re-deriving the score per query.  Runs inside the
 // timed step, once per batch.
-__global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* rows) {
-  const RowDesc rd = p.row_desc[blockIdx.y];
+// (one workgroup's share of one row: block `blk` of `nblk`)
+__device__ __forceinline__ void dense_row_block(const KParams& p, double* rows, const RowDesc rd, const uint32_t blk, const uint32_t nblk) {
   double* row = rows + (uint64_t)rd.slot * p.row_planes * p.row_stride;
   // Each workgroup owns a range of tiles of the row: it zero-fills that range (coalesced 16-byte
   // stores), then scatters the scores of the postings that fall into it - found through the list's
@@ -310,8 +315,8 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
   // it is still in L2.  (A list without a per-tile table is zero-filled by the host instead.)
   uint32_t pb = 0, pe = rd.len;
   if (rd.tbl_off != NO_TABLE) {
-    const uint32_t tpb = (p.n_tiles + gridDim.x - 1) / gridDim.x;
-    const uint32_t t0 = min(p.n_tiles, blockIdx.x * tpb), t1 = min(p.n_tiles, t0 + tpb);
+    const uint32_t tpb = (p.n_tiles + nblk - 1) / nblk;
+    const uint32_t t0 = min(p.n_tiles, blk * tpb), t1 = min(p.n_tiles, t0 + tpb);
     if (t0 == t1) return;
     for (uint32_t x = 0; x < p.row_planes; ++x) {
       double2* z = reinterpret_cast<double2*>(row + (uint64_t)x * p.row_stride + (uint64_t)t0 * p.T);
@@ -321,8 +326,8 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
     pe = p.table[rd.tbl_off + t1];
     __syncthreads();  // the zeros are in place before any score of this range is stored
   } else {
-    const uint32_t per = (rd.len + gridDim.x - 1) / gridDim.x;
-    pb = min(rd.len, blockIdx.x * per);
+    const uint32_t per = (rd.len + nblk - 1) / nblk;
+    pb = min(rd.len, blk * per);
     pe = min(rd.len, pb + per);
   }
   if (p.row_mode != 0) {
@@ -356,6 +361,9 @@ __global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* row
     }
     row[p.doc[pi]] = s;
   }
+}
+__global__ __launch_bounds__(256) void k_dense_rows(const KParams p, double* rows) {
+  dense_row_block(p, rows, p.row_desc[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // zero_to_one rows: plane x of the row goes to accumulator plane x of the tile ([F][T] in LDS).
@@ -1429,19 +1437,21 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
   // in index order, so the processing order still holds approximately); otherwise the waves are
   // persistent and pull items from the device-scope counter.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // (the grid is sized by the host's upper bound of the item count; the device-built count is exact)
+  const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
   const bool by_index = p.n_ditems <= gridDim.x * (uint32_t)DAAT_WGW;
   if (by_index) {
     // most workgroups of a launch only hold chunks of lists that are already non-essential: they
     // leave before they stage the LUT
     const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
     int need = 0;
-    if (id < p.n_ditems) {
+    if (id < n_ditems) {
       const DEntry de = p.dentry[p.ditems[p.item_base + id].entry];
       const double theta = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       need = !(de.skip_thr < theta);
     }
     if (!__syncthreads_or(need)) {
-      if (id < p.n_ditems && lane == 0) p.cand_cnt[p.ditems[p.item_base + id].slot] = 0u;
+      if (id < n_ditems && lane == 0) p.cand_cnt[p.ditems[p.item_base + id].slot] = 0u;
       return;
     }
   }
@@ -1461,7 +1471,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
       if (lane == 0) id = atomicAdd(p.work_counter, 1u);
       id = __builtin_amdgcn_readfirstlane(id);
     }
-    if (id >= p.n_ditems) break;
+    if (id >= n_ditems) break;
     const DItem it = p.ditems[p.item_base + id];
     const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
     const ps_plan_entry& own = p.plan[e_own];
@@ -1739,255 +1749,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// K1dz: k_daat_z - the same exact dynamic pruning for zero_to_one, "simple" queries (one entry per
-// query term, one version layer; a node repeated in the query is the tf >= k rule, as in
-// k_score<MODE_Z21S>).  A record contributes (min(score/tf, 1) * tf) / max(field_length, query_terms_len)
-// to the pool of its field (zero_to_one.rs:117-120), the pools are summed in the record-sort order
-// (the entries of such a query are uploaded in that order) and the document scores the best pool
-// (:122).  Bound of a list: score * (1 + 1e-12) / max(shortest field that holds the term, query terms);
-// a document scores at most the sum over its lists of their best field's contribution, which is what
-// pass 1 tracks.  Pass 2 rebuilds the per-field pools of the survivors in record-sort order.
-// ------------------------------------------------------------------------------------------
-template <int F_, int U>
-__device__ __forceinline__ void posting_contribs_z(const KParams& p, const uint64_t (&pi)[U], const bool (&on)[U], const double sc,
-                                                   const uint32_t need, const uint32_t qtl, double (&c)[U][F_]) {
-  uint32_t tfv[U][F_], flv[U][F_];
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-#pragma unroll
-    for (int x = 0; x < F_; ++x) {
-      tfv[u][x] = 0; flv[u][x] = 1;
-      if (on[u]) { tfv[u][x] = p.tf[(uint64_t)x * p.P + pi[u]]; flv[u][x] = p.fl[(uint64_t)x * p.P + pi[u]]; }
-    }
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-#pragma unroll
-    for (int x = 0; x < F_; ++x) {
-      const uint32_t tfu = tfv[u][x], flu = flv[u][x];
-      const double df = (double)tfu;
-      const uint32_t den = flu > qtl ? flu : qtl;
-      const double v = fmin(sc / df, 1.0) * df / (double)den;  // zero_to_one.rs:117-120, same association as k_score
-      c[u][x] = (on[u] && tfu >= need && tfu > 0) ? v : 0.0;
-    }
-}
-
-template <int F_, int U>
-__device__ __forceinline__ void lookup_contribs_z(const KParams& p, const ps_plan_entry& en, const uint32_t (&d)[U],
-                                                  const bool (&on)[U], const uint32_t qtl, double (&c)[U][F_]) {
-  if (en.shift & DENSE_FLAG) {  // one row plane per field, already the contribution (0.0 = none)
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int x = 0; x < F_; ++x)
-        c[u][x] = on[u] ? p.rows[((uint64_t)en.node * F_ + x) * p.row_stride + d[u]] : 0.0;
-    return;
-  }
-  bool found[U];
-  uint64_t pi[U];
-  if (en.bm_off != 0xFFFFFFFFu) {
-    uint2 cell[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      cell[u] = on[u] ? *reinterpret_cast<const uint2*>(p.bits + (uint64_t)en.bm_off + 2 * (uint64_t)(d[u] >> 5)) : make_uint2(0u, 0u);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t bit = d[u] & 31u;
-      found[u] = on[u] && ((cell[u].x >> bit) & 1u);
-      pi[u] = en.post_off + cell[u].y + (uint32_t)__popc(cell[u].x & ((1u << bit) - 1u));
-    }
-  } else {
-    const uint32_t* docs = p.doc + en.post_off;
-    uint32_t lo[U], hi[U], end[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      lo[u] = 0; hi[u] = 0; end[u] = 0;
-      if (on[u]) {
-        const uint32_t slot = (d[u] >> p.t_log2) >> (en.shift & 0xFFu);
-        lo[u] = p.table[en.tbl_off + slot];
-        end[u] = p.table[en.tbl_off + slot + 1];
-        hi[u] = end[u];
-      }
-    }
-    bool more = true;  // wave-uniform
-    while (more) {
-      uint32_t v[U], mid[U];
-      bool act[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        act[u] = lo[u] < hi[u];
-        mid[u] = (lo[u] + hi[u]) >> 1;
-        v[u] = act[u] ? docs[mid[u]] : 0u;
-      }
-      bool any_act = false;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (act[u]) { if (v[u] < d[u]) lo[u] = mid[u] + 1; else hi[u] = mid[u]; }
-        any_act |= lo[u] < hi[u];
-      }
-      more = __any(any_act);
-    }
-    uint32_t chk[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) chk[u] = (on[u] && lo[u] < end[u]) ? docs[lo[u]] : 0xFFFFFFFFu;
-#pragma unroll
-    for (int u = 0; u < U; ++u) { found[u] = on[u] && lo[u] < end[u] && chk[u] == d[u]; pi[u] = en.post_off + (found[u] ? lo[u] : 0u); }
-  }
-  // en.boost = ScoreByTerm::score, en.qterm_index low 16 bits = occurrence rank of the node (the pool rule)
-  posting_contribs_z<F_, U>(p, pi, found, en.boost, en.qterm_index & 0xFFFFu, qtl, c);
-}
-
-template <int F_>
-__global__ __launch_bounds__(WAVE * 8) void k_daat_z(const KParams p) {
-  constexpr int U = 4;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t id = blockIdx.x * 8u + (uint32_t)wave;  // one wave per item (the grid covers every item)
-  if (id >= p.n_ditems) return;
-  const DItem it = p.ditems[p.item_base + id];
-  const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
-  const ps_plan_entry& own = p.plan[e_own];
-  const DEntry de = p.dentry[e_own];
-  const uint32_t q = __builtin_amdgcn_readfirstlane(de.q);
-  const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
-  const uint32_t qtl = p.qterms_len[q];
-  const double own_sc = own.boost;
-  const uint32_t own_need = own.qterm_index & 0xFFFFu;
-  const uint64_t own_off = own.post_off;
-  const uint32_t own_rank = de.rank;
-  const double skip_thr = de.skip_thr, others = de.others;
-  TopK tk;
-  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
-  double published = 0.0;
-  const uint32_t end = it.begin + it.count;
-  bool essential = true;  // wave-uniform
-  for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
-    const unsigned long long tbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)),
-                                          __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits));
-    essential = !(skip_thr < theta);
-    uint32_t d[U];
-    uint64_t pi[U];
-    bool alive[U];
-    double c_own[U][F_];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t i = i0 + u * WAVE + lane;
-      alive[u] = essential && i < end;
-      pi[u] = own_off + (i < end ? i : end - 1);
-      d[u] = p.doc[pi[u]];
-    }
-    if (p.alive != nullptr) {  // delta removals
-#pragma unroll
-      for (int u = 0; u < U; ++u) alive[u] = alive[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
-    }
-    posting_contribs_z<F_, U>(p, pi, alive, own_sc, own_need, qtl, c_own);
-    double bound[U];
-    bool any_alive = false;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      double best = 0.0;
-#pragma unroll
-      for (int x = 0; x < F_; ++x) best = fmax(best, c_own[u][x]);
-      // a posting that adds nothing here (tf below the node's occurrence rank) is not this list's document
-      alive[u] = alive[u] && best > 0.0 && (best + others >= theta);
-      bound[u] = best + others;
-      any_alive |= alive[u];
-    }
-    any_alive = __any(any_alive);
-    double P[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) P[u] = 0.0;
-    if (any_alive) {
-      const uint32_t ne = e1 - e0;
-      unsigned long long hits[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) hits[u] = 0ull;
-      // pass 1: highest-bound lists first; a list's bound is replaced by its best field's real contribution
-      for (uint32_t r = e0; r < e1 && any_alive; ++r) {
-        const uint32_t j = p.rorder[r];
-        if (j != e_own) {
-          const ps_plan_entry& en = p.plan[j];
-          const DEntry dj = p.dentry[j];
-          double c[U][F_];
-          lookup_contribs_z<F_, U>(p, en, d, alive, qtl, c);
-          bool any = false;
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (alive[u]) {
-              double sj = 0.0;
-#pragma unroll
-              for (int x = 0; x < F_; ++x) sj = fmax(sj, c[u][x]);
-              bound[u] = (bound[u] - dj.ub) + sj;
-              if (sj > 0.0 && ne <= 64u) hits[u] |= 1ull << (j - e0);
-              if (bound[u] < theta || (sj > 0.0 && dj.rank < own_rank)) alive[u] = false;
-            }
-            any |= alive[u];
-          }
-          any_alive = __any(any);
-        }
-      }
-      // pass 2: the per-field pools of the survivors, summed in record-sort order (= entry order)
-      if (any_alive) {
-        double pool[U][F_];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int x = 0; x < F_; ++x) pool[u][x] = 0.0;
-        for (uint32_t j = e0; j < e1; ++j) {
-          const ps_plan_entry& en = p.plan[j];
-          double c[U][F_];
-          if (j == e_own) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-              for (int x = 0; x < F_; ++x) c[u][x] = c_own[u][x];
-          } else {
-            bool want[U];
-            bool any = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              want[u] = alive[u] && (ne > 64u || ((hits[u] >> (j - e0)) & 1ull));
-              any |= want[u];
-#pragma unroll
-              for (int x = 0; x < F_; ++x) c[u][x] = 0.0;
-            }
-            if (__any(any)) lookup_contribs_z<F_, U>(p, en, d, want, qtl, c);
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int x = 0; x < F_; ++x)
-              if (alive[u] && c[u][x] > 0.0) pool[u][x] += c[u][x];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          double best = 0.0;  // result.score = max(score_by_pool, result.score) from the dummy 0. (zero_to_one.rs:81,122)
-#pragma unroll
-          for (int x = 0; x < F_; ++x) best = fmax(pool[u][x], best);
-          P[u] = best;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool offer = alive[u] && P[u] > 0.0 && P[u] >= theta;
-        if (__any(offer)) topk_offer(tk, p.K, lane, alive[u] && P[u] > 0.0, P[u], d[u], theta);
-      }
-      if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta) {
-        published = tk.thr_s;
-        if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
-      }
-    }
-  }
-  if ((uint32_t)lane < p.K) {
-    const uint64_t o = (uint64_t)it.slot * p.K + lane;
-    const bool ok = (uint32_t)lane < tk.n;
-    p.cand_score[o] = ok ? tk.s : 0.0;
-    p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
-    if (lane == 0) p.cand_cnt[it.slot] = tk.n;
-  }
-}
-
 // K3d: merge of the items' candidate lists of a query -> final top-K, doc id -> key.  A document is
 // evaluated by exactly one item, so the lists are disjoint.  Leaves the control words zeroed.
 __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge_items(const KParams p) {
@@ -2001,7 +1762,7 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge_items(const KParam
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
   const uint32_t K = p.K;
   const double gt = __longlong_as_double((long long)p.gthr[q]);
-  const uint32_t s0 = p.qslot[q], s1 = p.qslot[q + 1];
+  const uint32_t s0 = p.qslot[q], s1 = s0 + p.qslot_n[q];
   const uint32_t n_waves = blockDim.x >> 6;
   constexpr int U = 4;
   for (uint32_t sb = s0 + (uint32_t)wave * U; sb < s1; sb += n_waves * U) {
@@ -2041,6 +1802,9 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge_items(const KParam
     p.gthr[q] = 0ull;
     if (q == 0) *p.work_counter = 0u;
   }
+  // the preparation's control words (bucket counts, row uses, ...) are consumed: clean for the next batch
+  if (q == 0 && p.prep_ctl != nullptr)
+    for (uint32_t i = (uint32_t)lane; i < p.prep_ctl_words; i += WAVE) p.prep_ctl[i] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2218,21 +1982,6 @@ __global__ __launch_bounds__(256) void k_pack_tfl(const uint32_t* __restrict__ t
     const uint64_t i = begin + k / F;
     const uint32_t x = (uint32_t)(k % F);
     tfl[i * F + x] = tfl_pack(tf[(uint64_t)x * P + i], fl[(uint64_t)x * P + i]);
-  }
-}
-
-// K1d work items from the per-list records: one wave per list, one lane per chunk.  (The items are
-// ~16 B per 4096 postings - 1 MB for a 1024-query batch; built here they never cross PCIe.)
-__global__ __launch_bounds__(256) void k_make_items(const DItemGen* __restrict__ gen, const ps_plan_entry* __restrict__ plan,
-                                                    const uint32_t ne, DItem* __restrict__ out) {
-  const uint32_t k = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-  if (k >= ne) return;
-  const DItemGen g = gen[k];
-  const uint32_t len = plan[g.entry].len;
-  const uint32_t n = (len + g.chunk - 1) / g.chunk;
-  for (uint32_t j = threadIdx.x % WAVE; j < n; j += WAVE) {
-    const uint32_t b = j * g.chunk;
-    out[g.item_at + j] = DItem{g.entry, b, min(g.chunk, len - b), g.first_slot + j};
   }
 }
 

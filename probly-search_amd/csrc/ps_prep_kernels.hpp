@@ -1,0 +1,352 @@
+// ps_prep_kernels.hpp — device-side preparation of a K1d (k_daat) batch: everything between "the plan
+// exists in HBM" (uploaded by the host planner, or written by the device planner k_plan) and the
+// scoring launch.  Nothing here touches the host:
+//
+//   k_list_bounds  per (k1, b, avg[, boosts]): exact per-list maxima of the saturated term frequency
+//                  per field (M) and of the boosted per-posting sum (J), by the kernels' own f64
+//                  expression (bm25.rs:78-86)
+//   k_prep_query   one thread per query: upper bound of every entry, the query's processing order
+//                  (rank), what the other entries can add (`others`), the whole-list skip thresholds,
+//                  per-query-term data of multi-expansion queries, chunking, candidate slots, item
+//                  buckets, uses of dense-row candidates
+//   k_prep_finish  one small workgroup: bucket starts, the batch's item count, which dense rows are
+//                  read / have to be scored
+//   k_prep_items   one wave per list: its work items (rank-major buckets: every query's highest-bound
+//                  list first, longest lists first) and its dense-row flag
+//
+// What used to be Engine::plan_daat + select_dense_rows on the host (≈0.2 ms per 1024 queries on the
+// critical path of a 0.5 ms step).  Orders within a bucket and the placement of candidate slots come
+// from atomics: they are scheduling decisions, not results (every document is evaluated exactly once
+// whatever the order, and the merge is order-independent).
+#pragma once
+#include "ps_kernels.hpp"
+
+namespace ps {
+
+constexpr uint32_t PREP_CLASSES = 64;                 // length classes of the rank-0 lists (log2 with one fractional bit)
+constexpr uint32_t PREP_RANKS = 8;                    // ranks 1..7 get a bucket each, everything above shares the last
+constexpr uint32_t PREP_BUCKETS = PREP_CLASSES + PREP_RANKS;
+constexpr uint32_t PREP_MAX_ROWS = 64;                // dense-row candidates per snapshot
+constexpr uint32_t NO_CAND = 0xFFu;
+
+struct PrepCtl {  // per-batch control words; zeroed again behind k_merge_items
+  uint32_t total_slots;
+  uint32_t n_items;
+  uint32_t n_rows_build;   // rows k_dense_rows_dyn has to score for this batch
+  uint32_t n_rows_used;    // rows the batch reads
+  uint32_t bucket_total[PREP_BUCKETS];
+  uint32_t bucket_start[PREP_BUCKETS];
+  uint32_t bucket_fill[PREP_BUCKETS];
+  uint32_t row_use[PREP_MAX_ROWS];
+  unsigned long long row_first[PREP_MAX_ROWS];  // ~(lowest plan-entry index that uses the candidate) through atomicMax; 0 = none
+};
+
+struct RowState {  // per dense-row candidate: what its slot currently holds (device-resident across batches)
+  unsigned long long idf_bits, eb_bits;
+  uint32_t valid;   // the slot holds the row scored with (idf, eb) under the current parameters
+  uint32_t use_now; // this batch reads it
+};
+
+struct PrepParams {
+  ps_plan_entry* plan;       // [ne] (k_prep_items sets the dense-row flag / slot)
+  const uint32_t* qbeg;      // [B + 1]
+  uint32_t B, ne, F;
+  uint32_t multi;            // some query term has several entries (expansions / version layers)
+  uint32_t chunk_min, split_div;
+  double boost[MAX_F];
+  // per-list bounds (k_list_bounds)
+  const double* bound_m;     // [n_layers][F]
+  const double* bound_j;     // [n_layers]
+  // outputs
+  DEntry* dentry;            // [ne]
+  uint32_t* rorder;          // [ne]
+  DGroup* dgroup;            // [ne] (multi)
+  uint8_t* gord;             // [ne] scratch: dense ordinal of the entry's query term within its query
+  DItemGen* gen;             // [ne], indexed by ENTRY (item_at filled by k_prep_items)
+  uint32_t* qslot;           // [B] first candidate slot of the query
+  uint32_t* qslot_n;         // [B] its candidate slots
+  DItem* items;
+  uint32_t items_cap;
+  PrepCtl* ctl;
+  // dense rows
+  const uint8_t* cand_of_layer;  // [n_layers] candidate ordinal or NO_CAND
+  uint32_t n_cand, min_uses, rows_resident;
+  const uint4* layer_a;          // {post_off lo, hi, len, tbl_off}
+  RowState* row_state;           // [PREP_MAX_ROWS]
+  RowDesc* row_desc;             // [PREP_MAX_ROWS] rows to score this batch
+  unsigned long long* wstats;    // work counters (rows built / used)
+};
+
+// ---- per-list bounds --------------------------------------------------------------------------
+struct BoundUnit { uint32_t layer, begin, count; };  // a segment of one list
+
+// One wave per unit (a list, or a 16 Ki-posting segment of a long one).  M[l][x] = max over the list's
+// postings of tfn_x, J[l] = max of sum_x boost_x * tfn_x; both through bm25_tfn, the expression the scoring
+// kernels evaluate, so they bound the COMPUTED values.  Positive doubles order like their bit patterns:
+// the segments of a list meet through 64-bit atomicMax.
+__global__ __launch_bounds__(256) void k_list_bounds(const KParams p, const BoundUnit* units, const uint32_t n_units,
+                                                     const uint4* layer_a, unsigned long long* M, unsigned long long* J,
+                                                     const int with_m) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1);
+  if (wave >= n_units) return;
+  const BoundUnit u = units[wave];
+  const uint4 la = layer_a[u.layer];
+  const uint64_t off = ((uint64_t)la.x | ((uint64_t)la.y << 32)) + u.begin;
+  double mj = 0.0, mm[MAX_F];
+  for (uint32_t x = 0; x < p.F; ++x) mm[x] = 0.0;
+  for (uint32_t i = lane; i < u.count; i += WAVE) {
+    const uint64_t pi = off + i;
+    double sum = 0.0;
+    for (uint32_t x = 0; x < p.F; ++x) {
+      const uint32_t w = p.tfl[pi * p.F + x];
+      uint32_t tfu = w >> 24, flu = w & TFL_FL_ESC;
+      if (tfu == 0) continue;
+      tfl_exact(p, x, pi, tfu, flu);
+      const double t = bm25_tfn(p, x, tfu, flu);
+      if (t > mm[x]) mm[x] = t;
+      sum += p.boost[x] * t;
+    }
+    if (sum > mj) mj = sum;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mj = fmax(mj, __shfl_down(mj, o));
+    for (uint32_t x = 0; x < p.F; ++x) mm[x] = fmax(mm[x], __shfl_down(mm[x], o));
+  }
+  if (lane == 0) {
+    if (mj > 0.0) atomicMax(&J[u.layer], (unsigned long long)__double_as_longlong(mj));
+    if (with_m)
+      for (uint32_t x = 0; x < p.F; ++x)
+        if (mm[x] > 0.0) atomicMax(&M[(size_t)u.layer * p.F + x], (unsigned long long)__double_as_longlong(mm[x]));
+  }
+}
+
+// Upper bound of any posting score of plan entry `e`, rounding included: the per-field form pushes the
+// maxima through the kernels' own expression (every operation is monotone: ((tfn * idf) * boost) * eb,
+// summed over the fields in order), the joint form bounds the real-number value and is inflated past the
+// few roundings between them.
+__device__ __forceinline__ double prep_entry_ub(const PrepParams& pp, const ps_plan_entry& e) {
+  double ub_m = 0.0;
+  for (uint32_t x = 0; x < pp.F; ++x) {
+    const double t = pp.bound_m[(size_t)e.node * pp.F + x];
+    if (t > 0.0) ub_m += t * e.idf * pp.boost[x] * e.boost;
+  }
+  const double ub_j = (e.idf * e.boost) * pp.bound_j[e.node] * (1.0 + 1e-12);
+  return fmin(ub_m, ub_j);
+}
+
+__device__ __forceinline__ uint32_t prep_chunk(const PrepParams& pp, const uint32_t len) {
+  const uint32_t c = ((len + pp.split_div - 1) / pp.split_div + 255u) & ~255u;
+  return c > pp.chunk_min ? c : pp.chunk_min;
+}
+__device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint32_t len) {
+  if (rank == 0) {  // longest lists first: 64 classes, log2 with one fractional bit
+    const uint32_t l = len ? len : 1u;
+    const uint32_t lg = 31u - (uint32_t)__clz((int)l);
+    return 63u - (2u * lg + (lg ? ((l >> (lg - 1)) & 1u) : 0u));
+  }
+  return PREP_CLASSES + (rank < PREP_RANKS ? rank : PREP_RANKS) - 1u;
+}
+
+// One thread per query (plans of <= 64 entries: the host routes wider batches to k_score).
+__global__ __launch_bounds__(64) void k_prep_query(const PrepParams pp) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= pp.B) return;
+  const uint32_t b = pp.qbeg[q], e = pp.qbeg[q + 1], n = e - b;
+  constexpr double SLACK = 1.0 + 1e-9;  // the bounds are summed in another order than the scores
+  if (n == 0) { pp.qslot[q] = 0; pp.qslot_n[q] = 0; return; }
+  // bounds; dense ordinal of every entry's query term (the entries of a term are adjacent in plan order)
+  uint32_t n_groups = 0, cur = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < n; ++i) {
+    const ps_plan_entry& en = pp.plan[b + i];
+    DEntry& d = pp.dentry[b + i];
+    d.ub = prep_entry_ub(pp, en);
+    d.q = q;
+    if (en.qterm != cur) { cur = en.qterm; ++n_groups; }
+    pp.gord[b + i] = (uint8_t)(n_groups - 1);
+  }
+  // processing order: bound descending; equal bounds: the LONGER list ranks lower (it is the one that
+  // becomes non-essential); stable.  Insertion sort (n is 3..8 in practice).
+  for (uint32_t i = 0; i < n; ++i) {
+    const double ui = pp.dentry[b + i].ub;
+    const uint32_t li = pp.plan[b + i].len;
+    uint32_t j = i;
+    while (j > 0) {
+      const uint32_t pj = pp.rorder[b + j - 1];
+      const double uj = pp.dentry[pj].ub;
+      if (ui > uj || (ui == uj && li < pp.plan[pj].len)) { pp.rorder[b + j] = pj; --j; } else break;
+    }
+    pp.rorder[b + j] = b + i;
+  }
+  for (uint32_t r = 0; r < n; ++r) pp.dentry[pp.rorder[b + r]].rank = r;
+  // others: what every OTHER entry can add to a document of this list = the other query terms' maxima +
+  // the best other entry of its own term (expansions of a term merge by max, query.rs:150-164)
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t gi = pp.gord[b + i];
+    double rest = 0.0, alt = 0.0, run_max = 0.0;
+    uint32_t run = 0xFFFFFFFFu;
+    for (uint32_t j = 0; j < n; ++j) {
+      const uint32_t gj = pp.gord[b + j];
+      const double uj = pp.dentry[b + j].ub;
+      if (gj != run) {
+        if (run != 0xFFFFFFFFu && run != gi) rest += run_max;
+        run = gj;
+        run_max = 0.0;
+      }
+      run_max = fmax(run_max, uj);
+      if (gj == gi && j != i) alt = fmax(alt, uj);
+    }
+    if (run != gi) rest += run_max;
+    double o = (rest + alt) * SLACK;
+    if (!(o >= 0.0)) o = INFINITY;
+    pp.dentry[b + i].others = o;
+  }
+  // skip thresholds: a document that only occurs in the lists of rank >= r scores at most the sum over
+  // query terms of the largest bound among those of its lists - i.e. of the first entry of each term met
+  // when walking the ranks from r upwards (the bounds descend along the ranks)
+  for (uint32_t r = 0; r < n; ++r) {
+    unsigned long long seen = 0ull;
+    double bound = 0.0;
+    for (uint32_t r2 = r; r2 < n; ++r2) {
+      const uint32_t j = pp.rorder[b + r2];
+      const unsigned long long bit = 1ull << (pp.gord[j] & 63u);
+      if (!(seen & bit)) { seen |= bit; bound += pp.dentry[j].ub; }
+    }
+    double s = bound * SLACK;
+    if (!(s >= 0.0)) s = INFINITY;
+    pp.dentry[pp.rorder[b + r]].skip_thr = s;
+  }
+  if (pp.multi) {
+    // per entry: the ordinal of its query term (<= 4 terms are tracked in registers by k_daat) and the
+    // inflated bound of the next list of the same term in rank order
+    for (uint32_t r = 0; r < n; ++r) {
+      const uint32_t i = pp.rorder[b + r];
+      DGroup dg;
+      dg.grp = n_groups <= 4 ? (uint32_t)pp.gord[i] : 0xFFFFFFFFu;
+      dg.ub_s = pp.dentry[i].ub * SLACK;
+      dg.nxt_s = 0.0;
+      dg._pad[0] = dg._pad[1] = dg._pad[2] = 0;
+      for (uint32_t r2 = r + 1; r2 < n; ++r2) {
+        const uint32_t j = pp.rorder[b + r2];
+        if (pp.gord[j] == pp.gord[i]) { dg.nxt_s = pp.dentry[j].ub * SLACK; break; }
+      }
+      pp.dgroup[i] = dg;
+    }
+  }
+  // chunking, candidate slots (query-major within the query, the query's block placed by one atomic),
+  // item buckets, uses of dense-row candidates
+  uint32_t slots = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t len = pp.plan[b + i].len;
+    const uint32_t c = prep_chunk(pp, len);
+    slots += (len + c - 1) / c;
+  }
+  const uint32_t s0 = atomicAdd(&pp.ctl->total_slots, slots);
+  pp.qslot[q] = s0;
+  pp.qslot_n[q] = slots;
+  uint32_t sl = s0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const ps_plan_entry& en = pp.plan[b + i];
+    const uint32_t c = prep_chunk(pp, en.len);
+    const uint32_t nc = (en.len + c - 1) / c;
+    pp.gen[b + i] = DItemGen{b + i, 0u, c, sl};
+    sl += nc;
+    if (nc) atomicAdd(&pp.ctl->bucket_total[prep_bucket(pp.dentry[b + i].rank, en.len)], nc);
+    if (pp.n_cand) {
+      const uint32_t cd = pp.cand_of_layer[en.node];
+      if (cd != NO_CAND) {
+        atomicAdd(&pp.ctl->row_use[cd], 1u);
+        atomicMax(&pp.ctl->row_first[cd], ~(unsigned long long)(b + i));
+      }
+    }
+  }
+}
+
+// One small workgroup: bucket starts (rank-major, longest rank-0 lists first), the item count, and the
+// dense rows of this batch: a candidate used >= min_uses times is read as a row, scored with the (idf,
+// expansion_boost) of its FIRST user in plan order (deterministic); entries with other weights keep
+// their bitmap lookups.  A resident row with the same weights is not scored again.
+__global__ __launch_bounds__(64) void k_prep_finish(const PrepParams pp) {
+  PrepCtl& c = *pp.ctl;
+  if (threadIdx.x == 0) {
+    uint32_t at = 0;
+    for (uint32_t k = 0; k < PREP_BUCKETS; ++k) { c.bucket_start[k] = at; at += c.bucket_total[k]; }
+    c.n_items = at;
+    uint32_t n_build = 0, n_used = 0;
+    for (uint32_t cd = 0; cd < pp.n_cand; ++cd) {
+      RowState& rs = pp.row_state[cd];
+      rs.use_now = 0;
+      if (c.row_use[cd] < pp.min_uses || c.row_first[cd] == 0ull) continue;
+      const ps_plan_entry& en = pp.plan[~c.row_first[cd]];
+      unsigned long long ib, eb;
+      ib = (unsigned long long)__double_as_longlong(en.idf);
+      eb = (unsigned long long)__double_as_longlong(en.boost);
+      rs.use_now = 1;
+      ++n_used;
+      if (pp.rows_resident && rs.valid && rs.idf_bits == ib && rs.eb_bits == eb) continue;
+      rs.valid = 1; rs.idf_bits = ib; rs.eb_bits = eb;
+      const uint4 la = pp.layer_a[en.node];
+      RowDesc rd;
+      rd.post_off = (uint64_t)la.x | ((uint64_t)la.y << 32);
+      rd.len = la.z;
+      rd._pad = 0;
+      rd.idf = en.idf;
+      rd.eb = en.boost;
+      rd.slot = cd;
+      rd.tbl_off = la.w;  // candidates are lists with one table slot per tile (host: shift == 0)
+      pp.row_desc[n_build++] = rd;
+    }
+    c.n_rows_build = n_build;
+    c.n_rows_used = n_used;
+    if (PS_WORK_COUNTERS && (n_build | n_used)) {
+      atomicAdd(&pp.wstats[WS_ROWS_BUILT], (unsigned long long)n_build);
+      atomicAdd(&pp.wstats[WS_ROWS_USED], (unsigned long long)n_used);
+    }
+  }
+}
+
+// One wave per list: its items go to the next free places of its bucket; an entry whose list is read as
+// a dense row this batch (same weights as the row was scored with) gets the flag and the row slot.
+__global__ __launch_bounds__(256) void k_prep_items(const PrepParams pp) {
+  const uint32_t i = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (i >= pp.ne) return;
+  ps_plan_entry& en = pp.plan[i];
+  DItemGen g = pp.gen[i];
+  const uint32_t len = en.len;
+  const uint32_t n = (len + g.chunk - 1) / g.chunk;
+  uint32_t at = 0;
+  if (lane == 0) {
+    const uint32_t bk = prep_bucket(pp.dentry[i].rank, len);
+    at = n ? pp.ctl->bucket_start[bk] + atomicAdd(&pp.ctl->bucket_fill[bk], n) : 0u;
+    pp.gen[i].item_at = at;
+    if (pp.n_cand) {
+      const uint32_t cd = pp.cand_of_layer[en.node];
+      if (cd != NO_CAND) {
+        const RowState rs = pp.row_state[cd];
+        if (rs.use_now && rs.idf_bits == (unsigned long long)__double_as_longlong(en.idf) &&
+            rs.eb_bits == (unsigned long long)__double_as_longlong(en.boost)) {
+          en.shift |= DENSE_FLAG;
+          en.node = cd;
+        }
+      }
+    }
+  }
+  at = __shfl(at, 0);
+  for (uint32_t j = lane; j < n; j += WAVE) {
+    const uint32_t pb = j * g.chunk;
+    if (at + j < pp.items_cap) pp.items[at + j] = DItem{i, pb, min(g.chunk, len - pb), g.first_slot + j};
+  }
+}
+
+// K0b over the rows k_prep_finish listed: a fixed grid, every workgroup takes (row, tile range) units
+// until none are left (the host does not know how many rows the batch builds).
+__global__ __launch_bounds__(256) void k_dense_rows_dyn(const KParams p, double* rows, const PrepCtl* ctl, const uint32_t blocks_per_row) {
+  const uint32_t n_units = ctl->n_rows_build * blocks_per_row;
+  for (uint32_t w = blockIdx.x; w < n_units; w += gridDim.x) {
+    dense_row_block(p, rows, p.row_desc[w / blocks_per_row], w % blocks_per_row, blocks_per_row);
+    __syncthreads();
+  }
+}
+
+}  // namespace ps

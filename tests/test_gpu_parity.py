@@ -26,10 +26,18 @@ def scoring_kernel(request):
     L = psa.load()
     L.ps_set_option(b"PS_DAAT", 1 if request.param == "daat" else 0)
     L.ps_set_option(b"PS_DAAT_MULTI", 1)
-    L.ps_set_option(b"PS_DAAT_Z21", 1 if request.param == "daat" else 0)  # K1dz is off by default (slower than K1): test it anyway
     yield request.param
     L.ps_set_option(b"PS_DAAT", 1)
-    L.ps_set_option(b"PS_DAAT_Z21", 0)
+
+
+def row_stats(snap):
+    """(rows read, rows scored) by the most recent batch: chosen on the host for K1 (batch stats), on the
+    device for K1d (work counters; call snap.work_counters(reset=True) before the batch)."""
+    st = snap.last_stats()
+    if st["dense_rows"]:
+        return st["dense_rows"], st["dense_rows_built"]
+    wc = snap.work_counters(reset=True)
+    return wc["rows_used"], wc["rows_built"]
 
 
 def assert_same(got, exp, ctx):
@@ -283,9 +291,11 @@ def test_full_size_c2_properties(c2_full, scoring_kernel):
     sc = psa.bm25.new()
     b1 = [1.0, 1.0]
     queries = corpus.queries(1024, 3)
+    snap.work_counters(reset=True)
     top = snap.query_batch(queries, sc, None, b1, top_k=10)
-    assert snap.last_stats()["dense_rows"] > 0
     assert snap.kernel_breakdown(reset=True)["score_kernel"].startswith("ps::k_daat" if scoring_kernel == "daat" else "ps::k_score")
+    # dense score rows were in play: chosen on the host for K1 (batch stats), on the device for K1d (work counters)
+    assert row_stats(snap)[0] > 0
     for qi in (0, 17, 333, 1023):
         full = snap.query(queries[qi], sc, None, b1)
         assert top[qi] == full[:10], qi
@@ -354,8 +364,9 @@ def test_dense_rows_path_forced(seed, monkeypatch):
     for name, kw in (("bm25", {}), ("bm25", {"k1": 0.7, "b": 0.3}), ("zero_to_one", {})):
         sc = product_scorer(name, **kw)
         full = snap.query_batch(queries, sc, None, boosts, top_k=0)
+        snap.work_counters(reset=True)
         top = snap.query_batch(queries, sc, None, boosts, top_k=5)
-        assert snap.last_stats()["dense_rows"] > 0
+        assert row_stats(snap)[0] > 0
         for q, f, t in zip(queries, full, top):
             exp = o.query(q, oracle_scorer(name, **kw), boosts)
             assert_same([tuple(r) for r in f], exp, (seed, name, q, "dense-full"))
@@ -415,8 +426,9 @@ def test_dense_rows_first_written_last_fused(fuse, fields, monkeypatch):
         snap = p.snapshot(device=0, tile_docs=tile)
         for name in ("bm25", "zero_to_one"):  # zero_to_one: the same tricks on its per-field planes (sorted record order)
             sc = product_scorer(name)
+            snap.work_counters(reset=True)
             top = snap.query_batch(queries, sc, None, boosts, top_k=10)
-            assert snap.last_stats()["dense_rows"] > 0
+            assert row_stats(snap)[0] > 0
             full = snap.query_batch(queries[::9], sc, None, boosts, top_k=0)
             for q, t in zip(queries, top):
                 assert_same([tuple(r) for r in t], o.query(q, oracle_scorer(name), boosts)[:10], (fuse, tile, name, q))
@@ -443,9 +455,9 @@ def test_resident_rows_reuse_eviction_and_invalidation(monkeypatch):
     built = []
     for step, (name, kw, boosts) in enumerate(seq):
         queries = corpus.queries(12, 2, salt=step % 3)  # salts repeat: the same hot lists come back
+        snap.work_counters(reset=True)
         top = snap.query_batch(queries, product_scorer(name, **kw), None, boosts, top_k=10)
-        st = snap.last_stats()
-        built.append((st["dense_rows"], st["dense_rows_built"]))
+        built.append(row_stats(snap))
         for q, t in zip(queries, top):
             assert_same([tuple(r) for r in t], o.query(q, oracle_scorer(name, **kw), boosts)[:10], (step, name, kw, boosts, q))
     assert all(u > 0 for u, _ in built)
