@@ -49,8 +49,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scorer", default="", help="override: bm25 | zero_to_one")
     ap.add_argument("--device-plan", action="store_true",
-                    help="plan the batches on the device too (ps_snapshot_query_batch_device_planned_flat: BM25, K1 k_score; "
-                         "N=1): the SURVEY 8f N2 path, not the headline")
+                    help="call the explicit device-planner entry (ps_snapshot_query_batch_device_planned_flat; N=1).  The default "
+                         "entry already plans BM25 batches on the device (PS_DEVICE_PLAN=1)")
+    ap.add_argument("--host-plan", action="store_true",
+                    help="keep the query planner on the host (PS_DEVICE_PLAN=0): tokenise / trie lookup / before_each on a host "
+                         "thread pool, plan uploaded per batch; the K1d descriptors are built on the device either way")
+    ap.add_argument("--no-alternating-boosts-leg", action="store_true",
+                    help="skip the leg that alternates two fields_boost vectors between steps (reported as alternating_boosts)")
     ap.add_argument("--no-streaming-leg", action="store_true",
                     help="skip the untimed-for-headline K1 k_score leg (PS_DAAT=0) reported under roofline.streaming_kernel_leg")
     ap.add_argument("--no-bulk-index", action="store_true",
@@ -119,6 +124,8 @@ def main():
     # the row slab is disabled so each timed step builds the rows it uses (K0b inside the timed region).
     if not args.resident_rows:
         os.environ["PS_ROW_CACHE_MB"] = "0"
+    if args.host_plan:
+        os.environ["PS_DEVICE_PLAN"] = "0"
     cfg = dict(synth.CONFIGS[args.config])
     if args.n_docs:
         cfg["n_docs"] = args.n_docs
@@ -207,7 +214,7 @@ def main():
     # s+1 while the GPU scores batch s
     streams = [torch.cuda.Stream() for _ in range(n_blk)]
 
-    def step(batch, i):
+    def step(batch, i, boosts=boosts):
         text, offsets = batch
         slot = i % n_blk
         if args.device_plan and world == 1:
@@ -235,6 +242,8 @@ def main():
     dense_rows = 0
     dense_built = 0
     plan_ms = 0.0
+    dev_planned = 0
+    bounds_rc = 0
     lat = []
     t_start = time.perf_counter()
     for s in range(args.warmup, n_total):
@@ -246,6 +255,8 @@ def main():
         dense_rows += st["dense_rows"]
         dense_built += st["dense_rows_built"]
         plan_ms += st["plan_ms"]
+        dev_planned += st["device_planned"]
+        bounds_rc += st["bounds_recomputed"]
         lat.append(time.perf_counter() - ts)
     fence()
     elapsed = time.perf_counter() - t_start
@@ -294,10 +305,14 @@ def main():
                        "ncclAllGather of top-k blocks inside the library" % world if world > 1 else
                        "single GPU (no collective)",
                        "tile_docs": info["tile_docs"], "postings": info["n_postings"], "pointers": info["n_pointers"],
-                       "planner": "device (k_plan)" if args.device_plan else "host"},
+                       "planner": "device (k_plan: tokenise, trie lookup, expansion, before_each in HBM)" if dev_planned == steps
+                       else "host (thread pool)" if dev_planned == 0 else "mixed"},
             "p50_single_query_ms": float(np.median(single) * 1e3) if single else None,
             "p50_batch_submit_ms": float(np.median(lat) * 1e3),
             "host_plan_ms_per_step": plan_ms / steps,
+            "host_plan_note": ("device-planned: the host's wait for the planner's totals (one sync of the planning stream per batch)"
+                               if dev_planned else "host planner: tokenise + expand + before_each on the host"),
+            "bounds_recomputed_in_timed_steps": bounds_rc,
             "postings_per_step": postings / steps,
             "index_build_s": t_index, "gpu_bulk_index": bulk, "corpus_generation_s": t_generate, "snapshot_s": t_snap,
             "hbm_resident_bytes": info["device_bytes"],
@@ -305,6 +320,28 @@ def main():
                                  alg_bytes_launch, layout_bytes / max(1, steps), dense_rows / max(1, steps),
                                  dense_built / max(1, steps), wc, F),
         }
+        if world == 1 and cfg["scorer"] == "bm25" and not args.no_alternating_boosts_leg:
+            # fields_boost is a per-call argument of Index::query (src/query.rs:26): two vectors alternating between steps
+            n = min(len(packed), max(4, min(args.steps, 10)))
+            alt = [[1.0] * F, [2.0] + [0.5] * (F - 1)]
+            for s in range(2):
+                step(packed[s], s, alt[s % 2])
+            fence()
+            rc = 0
+            t0 = time.perf_counter()
+            for s in range(n):
+                step(packed[-1 - s], s, alt[s % 2])
+                rc += snap.last_stats()["bounds_recomputed"]
+            fence()
+            wall = time.perf_counter() - t0
+            result["alternating_boosts"] = {"queries_per_s": B * n / wall, "ms_per_step": wall / n * 1e3, "steps": n,
+                                            "relative_to_fixed_boosts": (B * n / wall) / qps,
+                                            "bounds_recomputed": rc,
+                                            "what": "fields_boost alternates between %s and %s from step to step; the per-list bounds of both "
+                                                    "vectors stay resident (k_list_bounds runs on the device when a vector is new), dense rows "
+                                                    "are re-scored whenever the boosts change" % (alt[0], alt[1])}
+            snap.kernel_breakdown(reset=True)
+            snap.work_counters(reset=True)
         if world == 1 and cfg["scorer"] == "bm25" and not args.device_plan and not args.no_streaming_leg \
                 and kt["score_kernel"].startswith("ps::k_daat"):
             # the streaming kernel the north star describes (K1 k_score: every posting of every list through

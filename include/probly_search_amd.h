@@ -323,9 +323,12 @@ ps_status ps_snapshot_query_batch_allgather_flat(ps_snapshot* snap, ps_comm* com
 /* SURVEY 8f N2 - the same batch call with the PLANNER on the device too: tokenising (split on ' '),
  * term lookup in the frozen trie, prefix expansion in the reference's newest-first DFS order
  * (src/query.rs:109-147, src/index.rs:300-337) and BM25's before_each (src/score/default/bm25.rs:35-58)
- * run in a kernel over the trie kept in HBM; the plan never exists on the host (the host learns four
- * totals to size the launch).  BM25 with the built-in tokenizer; scoring is K1 k_score (the exact
- * pruning kernel needs host-built descriptors).  Same results as ps_snapshot_query_batch_device_flat. */
+ * run in a kernel over the trie kept in HBM; the plan never exists on the host (the host learns the
+ * plan's totals to size the launches).  BM25 with the built-in tokenizer.  The K1d work descriptors
+ * (per-list bounds, ranks, skip thresholds, items, dense-row choice) are built on the device as well,
+ * so such a batch runs the same kernels as a host-planned one.  The flat batch entry points above take
+ * this path by themselves for BM25 top-k batches with the built-in tokenizer (knob PS_DEVICE_PLAN,
+ * default 1); this entry forces it.  Same results as ps_snapshot_query_batch_device_flat. */
 ps_status ps_snapshot_query_batch_device_planned_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text,
                                                       const uint64_t* offsets, size_t n_queries, const double* fields_boost,
                                                       size_t n_boost, size_t top_k, void* d_keys, void* d_scores,
@@ -347,6 +350,11 @@ typedef struct ps_batch_stats {
   uint32_t dense_rows;         /* hot (list, idf, boost) combinations the batch read as dense rows */
   uint32_t dense_rows_built;   /* ... of which had to be scored for this batch (the rest were resident
                                   in the snapshot's row slab from earlier batches)                  */
+  uint32_t device_planned;     /* 1: the batch was planned by k_plan on the device (plan_ms is then the
+                                  host's wait for the planner's totals), 0: by the host planner      */
+  uint32_t bounds_recomputed;  /* 1: the batch had to (re)compute the per-list score bounds K1d prunes with
+                                  (k_list_bounds, on the device: new k1 / b / averages, or a fields_boost vector
+                                  not among the few most recent ones)                                  */
 } ps_batch_stats;
 ps_status ps_snapshot_last_stats(const ps_snapshot* snap, ps_batch_stats* out);
 /* HIP-event time (ms) summed over every launch of the posting-accumulate kernel on this

@@ -100,7 +100,7 @@ class BatchStats(C.Structure):
                 ("algorithmic_bytes", C.c_uint64), ("plan_ms", C.c_double), ("h2d_ms", C.c_double),
                 ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("score_kernel_ms", C.c_double),
                 ("total_ms", C.c_double), ("layout_bytes", C.c_uint64), ("dense_rows", C.c_uint32),
-                ("dense_rows_built", C.c_uint32)]
+                ("dense_rows_built", C.c_uint32), ("device_planned", C.c_uint32), ("bounds_recomputed", C.c_uint32)]
 
 
 class PlanEntry(C.Structure):

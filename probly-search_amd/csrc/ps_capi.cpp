@@ -166,6 +166,21 @@ ps_status run_device_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const
                           void* user, size_t top_k, void* d_keys, void* d_scores, void* d_counts, void* hip_stream) {
   return guard([&]() -> ps_status {
     if (n_queries && (!text || !offsets)) return fail(PS_EINVAL, "null argument");
+    // BM25 top-k batches with the built-in tokenizer are planned on the device too (k_plan): the host
+    // hands the text over and sizes the launches from the plan's totals
+    if (!tokenizer && snap && scorer && scorer->kind == PS_SCORER_BM25 && snap->engine && top_k >= 1 && top_k <= PS_MAX_DEVICE_TOPK &&
+        offsets && snap->engine->wants_device_plan(n_queries)) {
+      ps_status st = check_query_args(snap, scorer, fields_boost, n_boost);
+      if (st != PS_OK) return st;
+      if (!d_keys || !d_scores || !d_counts) return fail(PS_EINVAL, "null argument");
+      const double t0 = wall_ms();
+      ps_batch_stats stats;
+      snap->engine->run_device_planned(*scorer, fields_boost, text, offsets, n_queries, top_k, d_keys, d_scores, d_counts, hip_stream,
+                                       stats);
+      stats.total_ms = wall_ms() - t0;
+      set_stats(snap, stats);
+      return PS_OK;
+    }
     std::vector<std::string_view> qs(n_queries);
     for (size_t i = 0; i < n_queries; ++i) qs[i] = std::string_view(text + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
     return run_device_views(snap, scorer, qs, fields_boost, n_boost, tokenizer, user, top_k, d_keys, d_scores, d_counts,

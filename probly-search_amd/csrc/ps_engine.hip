@@ -241,16 +241,37 @@ struct EngineImpl {
   DevBuf<uint64_t> d_term_df;
   DevBuf<double> d_term_idf, d_eb_table;
   uint32_t eb_n = 0;
-  DevBuf<char> d_qtext;
-  DevBuf<uint64_t> d_qoff;
-  DevBuf<uint32_t> d_pl_cnt, d_pl_qtl, d_pl_nterms, d_pl_multi, d_pl_qbeg, d_pl_qorder;
-  DevBuf<unsigned long long> d_pl_post;
-  DevBuf<ps_plan_entry> d_pl_entries;
+  // A device-built plan lives in one of two buffer sets: batch s + 1 is planned on `plan_stream` (count ->
+  // scan -> the host reads the totals -> fill) while batch s is still being scored from the other set.
+  struct PlanSet {
+    DevBuf<char> qtext;
+    DevBuf<uint64_t> qoff;
+    DevBuf<uint32_t> cnt, qtl, nterms, multi, qbeg, qorder, items;
+    DevBuf<unsigned long long> post;
+    DevBuf<ps_plan_entry> entries;
+    DevBuf<PlanTotals> tot;
+    Stage h;                       // pinned copy of the batch's text + offsets (the caller's buffer may be pageable)
+    hipEvent_t planned = nullptr;  // behind the fill pass, on plan_stream
+    hipEvent_t done = nullptr;     // behind the batch that was scored from this set, on its stream
+    bool busy = false;
+    void release() {
+      qtext.release(); qoff.release(); cnt.release(); qtl.release(); nterms.release(); multi.release(); qbeg.release();
+      qorder.release(); items.release(); post.release(); entries.release(); tot.release();
+      if (h.p) (void)hipHostFree(h.p);
+      if (h.done) (void)hipEventDestroy(h.done);
+      if (planned) (void)hipEventDestroy(planned);
+      if (done) (void)hipEventDestroy(done);
+    }
+  };
+  PlanSet pset[2];
+  int next_pset = 0;
+  hipStream_t plan_stream = nullptr;
   PlanTotals* h_totals = nullptr;  // pinned
   uint32_t daat_max_slots = 0;  // K1d: most candidate slots of one query in the batch being enqueued (0 = unknown: device-built plan)
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0, last_rows_built = 0;
+  bool last_bounds_recomputed = false;
   // Row slab: the dense score row of a hot (list, weight) combination only depends on the
   // snapshot, the scorer parameters and the boosts, so rows stay resident across batches (288 GB
   // of HBM: a few GB of slots is nothing) and K0b only scores the combinations it has not seen.
@@ -387,8 +408,8 @@ Engine::~Engine() {
     if (p) (void)hipFree(p);
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fchar.release(); m.d_fchild.release();
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release();
-  m.d_qtext.release(); m.d_qoff.release(); m.d_pl_cnt.release(); m.d_pl_qtl.release(); m.d_pl_nterms.release();
-  m.d_pl_multi.release(); m.d_pl_qbeg.release(); m.d_pl_qorder.release(); m.d_pl_post.release(); m.d_pl_entries.release();
+  for (auto& ps_ : m.pset) ps_.release();
+  if (m.plan_stream) (void)hipStreamDestroy(m.plan_stream);
   if (m.h_totals) (void)hipHostFree(m.h_totals);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
   m.d_sort_tmp.release(); m.d_pack.release();
@@ -830,7 +851,9 @@ void ensure_row_candidates(EngineImpl& m, hipStream_t st) {
 void launch_prep(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, KParams& kp, hipStream_t st, ps_plan_entry* d_plan,
                  const uint32_t* d_qbeg, size_t B, size_t ne, bool multi, size_t items_bound) {
   const Snapshot& s = *m.snap;
+  const uint64_t rc0 = m.bounds.recomputed;
   const BoundsRef br = ensure_list_bounds(m, sc, boosts, kp, st);
+  m.last_bounds_recomputed = m.bounds.recomputed != rc0;
   ensure_row_candidates(m, st);
   // resident rows are only valid for the parameters they were scored with
   {
@@ -1254,6 +1277,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
                 KParams& kp, bool topk_path, bool sync_path) {
   const Snapshot& s = *m.snap;
   refresh_tuning(m);
+  m.last_bounds_recomputed = false;
   // K1d (exact dynamic pruning) takes BM25 top-k batches whose parameters make every score a
   // positive, monotone function of the saturated term frequency and whose plans have at most 64
   // entries per query; everything else stays on K1.  Its descriptors are built on the device.
@@ -1614,6 +1638,7 @@ void fill_stats(const EngineImpl& m, ps_batch_stats& st, const Snapshot& s, cons
   st.layout_bytes = m.last_layout_bytes + emitted * 16;
   st.dense_rows = m.last_rows;
   st.dense_rows_built = m.last_rows_built;
+  st.bounds_recomputed = m.last_bounds_recomputed ? 1u : 0u;
   st.n_queries = plan.qbeg.size() - 1;
   st.n_plan_entries = plan.entries.size();
   st.postings_visited = plan.postings;
@@ -1792,36 +1817,74 @@ void ensure_dev_trie(EngineImpl& m) {
   m.dev_trie_valid = true;
 }
 
-// Plans a flat BM25 batch on the device (stream `st`); returns the totals (one small synchronisation).
-PlanTotals device_plan(EngineImpl& m, const char* text, const uint64_t* offsets, size_t B, hipStream_t st) {
+// Plans a flat BM25 batch on the device into plan set `ps_`: text -> k_plan count pass -> k_plan_scan -> (the
+// host reads the totals: one short synchronisation of `plan_stream`, never of the scoring stream) -> k_plan
+// fill pass.  Everything runs on `plan_stream`, so it overlaps the scoring of the previous batch.
+PlanTotals device_plan(EngineImpl& m, EngineImpl::PlanSet& ps_, const char* text, const uint64_t* offsets, size_t B) {
   ensure_dev_trie(m);
+  if (!m.plan_stream) PS_HIP(hipStreamCreateWithFlags(&m.plan_stream, hipStreamNonBlocking));
+  if (!ps_.planned) {
+    PS_HIP(hipEventCreateWithFlags(&ps_.planned, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&ps_.done, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&ps_.h.done, hipEventDisableTiming));
+  }
+  hipStream_t st = m.plan_stream;
+  // the batch that was scored from this set must be through before the set is written again
+  if (ps_.busy) { PS_HIP(hipStreamWaitEvent(st, ps_.done, 0)); ps_.busy = false; }
   const size_t n_bytes = B ? (size_t)offsets[B] : 0;
   if (n_bytes >= 0xFFFFFFF0ull) throw std::length_error("device planner: more than 4 GiB of query text");
-  m.d_qtext.ensure(n_bytes + 16);
-  m.d_qoff.ensure(B + 2);
-  PS_HIP(hipMemcpyAsync(m.d_qtext.p, text, n_bytes, hipMemcpyHostToDevice, st));
-  PS_HIP(hipMemcpyAsync(m.d_qoff.p, offsets, (B + 1) * 8, hipMemcpyHostToDevice, st));
-  m.d_pl_cnt.ensure(B + 1); m.d_pl_qtl.ensure(B + 1); m.d_pl_nterms.ensure(B + 1); m.d_pl_multi.ensure(B + 1);
-  m.d_pl_post.ensure(B + 1); m.d_pl_qbeg.ensure(B + 2); m.d_pl_qorder.ensure(B + 1);
+  const size_t off_bytes = (B + 1) * 8, text_at = (off_bytes + 15) & ~(size_t)15;
+  ps_.h.ensure(text_at + n_bytes + 16);  // (its previous copy finished before the previous totals were read)
+  memcpy(ps_.h.p, offsets, off_bytes);
+  if (n_bytes) memcpy(ps_.h.p + text_at, text, n_bytes);
+  ps_.qtext.ensure(n_bytes + 16);
+  ps_.qoff.ensure(B + 2);
+  PS_HIP(hipMemcpyAsync(ps_.qoff.p, ps_.h.p, off_bytes, hipMemcpyHostToDevice, st));
+  if (n_bytes) PS_HIP(hipMemcpyAsync(ps_.qtext.p, ps_.h.p + text_at, n_bytes, hipMemcpyHostToDevice, st));
+  ps_.cnt.ensure(B + 1); ps_.qtl.ensure(B + 1); ps_.nterms.ensure(B + 1); ps_.multi.ensure(B + 1); ps_.items.ensure(B + 1);
+  ps_.post.ensure(B + 1); ps_.qbeg.ensure(B + 2); ps_.qorder.ensure(B + 1); ps_.tot.ensure(1);
   DevTrie t{m.d_fnodes.p, m.d_fchar.p, m.d_fchild.p, m.d_term_df.p, m.d_term_meta.p, m.d_term_delta.p, m.d_term_idf.p,
             m.d_layer_a.p, m.d_layer_b.p, m.d_eb_table.p, m.eb_n};
   const uint32_t blocks = (uint32_t)((B + 63) / 64);
-  hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, m.d_qtext.p, m.d_qoff.p, (uint32_t)B, nullptr,
-                     nullptr, m.d_pl_cnt.p, m.d_pl_qtl.p, m.d_pl_nterms.p, m.d_pl_multi.p, m.d_pl_post.p, nullptr);
-  // totals land in a small device buffer, then in pinned memory
-  m.d_removed_df.ensure(8);
-  PlanTotals* d_tot = reinterpret_cast<PlanTotals*>(m.d_removed_df.p);
-  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, m.d_pl_cnt.p, m.d_pl_nterms.p, m.d_pl_multi.p, m.d_pl_post.p, (uint32_t)B,
-                     m.d_pl_qbeg.p, d_tot);
+  hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, ps_.qtext.p, ps_.qoff.p, (uint32_t)B, nullptr,
+                     nullptr, ps_.cnt.p, ps_.qtl.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, nullptr, ps_.items.p, m.tune.daat_chunk,
+                     m.tune.daat_split_div);
+  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
+                     ps_.qbeg.p, ps_.tot.p);
   PS_HIP(hipGetLastError());
-  PS_HIP(hipMemcpyAsync(m.h_totals, d_tot, sizeof(PlanTotals), hipMemcpyDeviceToHost, st));
-  PS_HIP(hipStreamSynchronize(st));
+  PS_HIP(hipMemcpyAsync(m.h_totals, ps_.tot.p, sizeof(PlanTotals), hipMemcpyDeviceToHost, st));
+  sync_stream(st);
   const PlanTotals tot = *m.h_totals;
-  m.d_pl_entries.ensure((size_t)tot.n_entries + 1);
-  hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, m.d_qtext.p, m.d_qoff.p, (uint32_t)B, m.d_pl_qbeg.p,
-                     m.d_pl_entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, m.d_pl_qorder.p);
+  ps_.entries.ensure((size_t)tot.n_entries + 1);
+  hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, ps_.qtext.p, ps_.qoff.p, (uint32_t)B, ps_.qbeg.p,
+                     ps_.entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, ps_.qorder.p, nullptr, 0u, 1u);
   PS_HIP(hipGetLastError());
+  PS_HIP(hipEventRecord(ps_.planned, st));
   return tot;
+}
+
+// The parts of KParams every top-k launch over this snapshot shares.
+void fill_common_kparams(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, size_t B, uint32_t max_qterms, KParams& kp) {
+  const Snapshot& s = *m.snap;
+  memset(&kp, 0, sizeof(kp));
+  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.tfl = m.d_tfl; kp.table = m.d_table; kp.keys = m.d_keys; kp.bits = m.d_bits;
+  kp.alive = s.any_dead ? m.d_alive : nullptr;
+  kp.work_counter = m.d_work;
+  kp.wstats = m.d_wstats;
+  kp.P = s.P;
+  while ((1u << kp.t_log2) < s.T) ++kp.t_log2;
+  kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_ids; kp.F = s.F;
+  kp.max_qterms = std::max<uint32_t>(1, max_qterms);
+  kp.ablate = m.tune.ablate;
+  kp.k1 = sc.bm25_k1; kp.b = sc.bm25_b; kp.k1p1 = sc.bm25_k1 + 1.0; kp.one_minus_b = 1.0 - sc.bm25_b;
+  for (uint32_t x = 0; x < s.F; ++x) { kp.avg[x] = s.avg[x]; kp.boost[x] = boosts[x]; }
+  if (sc.kind == PS_SCORER_BM25 && m.tune.lut) {
+    kp.lut = m.d_lut;
+    kp.lut_rows = s.lut_rows;
+    kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;
+    for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
+  }
+  kp.row_stride = (uint64_t)s.tiles_cap * s.T;
 }
 
 }  // namespace
@@ -1831,25 +1894,36 @@ void Engine::plan_device(const char* text, const uint64_t* offsets, size_t B, Pl
   EngineImpl& m = *impl_;
   std::lock_guard<std::mutex> lock(m.mu);
   PS_HIP(hipSetDevice(m.device));
-  const PlanTotals tot = device_plan(m, text, offsets, B, m.stream);
+  refresh_tuning(m);
+  EngineImpl::PlanSet& ps_ = m.pset[m.next_pset];
+  m.next_pset ^= 1;
+  const PlanTotals tot = device_plan(m, ps_, text, offsets, B);
   out = Plan{};
   out.entries.resize(tot.n_entries);
   out.qbeg.resize(B + 1);
   out.qterms_len.resize(B);
   out.n_nodes.assign(B, 0);
-  PS_HIP(hipStreamSynchronize(m.stream));
-  if (tot.n_entries) PS_HIP(hipMemcpy(out.entries.data(), m.d_pl_entries.p, (size_t)tot.n_entries * sizeof(ps_plan_entry), hipMemcpyDeviceToHost));
-  PS_HIP(hipMemcpy(out.qbeg.data(), m.d_pl_qbeg.p, (B + 1) * 4, hipMemcpyDeviceToHost));
-  if (B) PS_HIP(hipMemcpy(out.qterms_len.data(), m.d_pl_qtl.p, B * 4, hipMemcpyDeviceToHost));
+  PS_HIP(hipStreamSynchronize(m.plan_stream));
+  if (tot.n_entries) PS_HIP(hipMemcpy(out.entries.data(), ps_.entries.p, (size_t)tot.n_entries * sizeof(ps_plan_entry), hipMemcpyDeviceToHost));
+  PS_HIP(hipMemcpy(out.qbeg.data(), ps_.qbeg.p, (B + 1) * 4, hipMemcpyDeviceToHost));
+  if (B) PS_HIP(hipMemcpy(out.qterms_len.data(), ps_.qtl.p, B * 4, hipMemcpyDeviceToHost));
   out.postings = tot.postings;
   out.max_entries = tot.max_entries;
   out.max_qterms = tot.max_qterms;
   out.multi_expansion = tot.multi != 0;
 }
 
-// N2: a BM25 top-k batch whose plan never exists on the host: query text -> k_plan (count, scan,
-// fill) -> K1 k_score -> K3 k_merge.  The host only learns four totals (entries, largest plan, most
-// query terms, whether any term has several expansions) to size the launch.
+bool Engine::wants_device_plan(size_t n_queries) {
+  EngineImpl& m = *impl_;
+  std::lock_guard<std::mutex> lock(m.mu);
+  refresh_tuning(m);
+  return m.tune.device_plan && m.tune.daat && n_queries >= m.tune.daat_min_batch;
+}
+
+// N2: a BM25 top-k batch whose plan never exists on the host: query text -> k_plan (count, scan, fill) ->
+// device-side preparation -> K1d k_daat -> K3d k_merge_items (K1 k_score / K3 k_merge for the batches K1d
+// does not take).  The host only learns the plan's totals (entries, largest plan, most query terms,
+// whether any term has several expansions, work items) to size the launches.
 void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, const char* text, const uint64_t* offsets,
                                 size_t B, size_t top_k, void* d_keys, void* d_scores, void* d_counts, void* stream,
                                 ps_batch_stats& stats) {
@@ -1860,54 +1934,52 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   if (top_k < 1 || top_k > PS_MAX_DEVICE_TOPK) throw std::invalid_argument("top_k must be in [1, 64] for the device top-k path");
   std::lock_guard<std::mutex> lock(m.mu);
   PS_HIP(hipSetDevice(m.device));
+  refresh_tuning(m);
   const double t0 = now_ms();
+  m.last_bounds_recomputed = false;
   hipStream_t st = stream ? (hipStream_t)stream : m.stream;
-  if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
-  m.tail_pending = false;
-  const PlanTotals tot = device_plan(m, text, offsets, B, st);
+  EngineImpl::PlanSet& ps_ = m.pset[m.next_pset];
+  m.next_pset ^= 1;
+  const PlanTotals tot = device_plan(m, ps_, text, offsets, B);
   if (tot.max_qterms >= 0x7FFF) throw std::length_error("more than 32766 non-empty terms in one query");
   const double t1 = now_ms();
+  if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
+  m.tail_pending = false;
+  PS_HIP(hipStreamWaitEvent(st, ps_.planned, 0));
   Plan shape;  // the scalars the launch geometry needs; the entries stay on the device
   shape.max_entries = tot.max_entries;
   shape.max_qterms = tot.max_qterms;
   shape.multi_expansion = tot.multi != 0;
   shape.postings = tot.postings;
   KParams kp;
-  memset(&kp, 0, sizeof(kp));
-  kp.doc = m.d_doc; kp.tf = m.d_tf; kp.fl = m.d_fl; kp.tfl = m.d_tfl; kp.table = m.d_table; kp.keys = m.d_keys; kp.bits = m.d_bits;
-  kp.alive = s.any_dead ? m.d_alive : nullptr;
-  kp.plan = m.d_pl_entries.p;
-  kp.qbeg = m.d_pl_qbeg.p;
-  kp.qterms_len = m.d_pl_qtl.p;
-  kp.qorder = m.d_pl_qorder.p;
+  try {
+  fill_common_kparams(m, sc, boosts, B, shape.max_qterms, kp);
+  kp.plan = ps_.entries.p;
+  kp.qbeg = ps_.qbeg.p;
+  kp.qterms_len = ps_.qtl.p;
+  kp.qorder = ps_.qorder.p;
   const size_t n_thr = B + 2;
   const bool fresh = m.d_gthr.ensure(n_thr, true);
-  kp.work_counter = m.d_work;
-  kp.wstats = m.d_wstats;
   kp.gthr = m.d_gthr.p;
   if (!(m.ctl_clean && !fresh)) {
     PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
-    PS_HIP(hipMemsetAsync(m.d_work, 0, 64, st));
+    PS_HIP(hipMemsetAsync(m.d_work, 0, 256, st));
+    PS_HIP(hipMemsetAsync(m.d_prep_ctl, 0, sizeof(PrepCtl), st));
   }
   m.ctl_clean = false;
-  kp.P = s.P;
-  while ((1u << kp.t_log2) < s.T) ++kp.t_log2;
-  kp.B = (uint32_t)B; kp.n_tiles = s.n_tiles; kp.T = s.T; kp.n_docs = (uint32_t)s.n_ids; kp.F = s.F;
-  kp.max_qterms = std::max<uint32_t>(1, shape.max_qterms);
-  kp.k1 = sc.bm25_k1; kp.b = sc.bm25_b; kp.k1p1 = sc.bm25_k1 + 1.0; kp.one_minus_b = 1.0 - sc.bm25_b;
-  for (uint32_t x = 0; x < s.F; ++x) { kp.avg[x] = s.avg[x]; kp.boost[x] = boosts[x]; }
-  if (m.tune.lut) {
-    kp.lut = m.d_lut;
-    kp.lut_rows = s.lut_rows;
-    kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;
-    for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
-  }
-  kp.row_stride = (uint64_t)s.tiles_cap * s.T;
+  const bool daat = m.tune.daat && B >= m.tune.daat_min_batch && tot.n_entries && tot.n_items && m.tune.lut && bm25_params_sane(s, sc, boosts) &&
+                    tot.max_entries <= 64 && (!shape.multi_expansion || m.tune.daat_multi) && tot.n_items < 0xFFFFFFF0ull;
   BatchImage img;
   img.B = B;
-  choose_run_length(m, sc, shape, img, true, kp);
+  if (daat) {
+    kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0;
+    launch_prep(m, sc, boosts, kp, st, ps_.entries.p, ps_.qbeg.p, B, tot.n_entries, shape.multi_expansion, (size_t)tot.n_items);
+    m.daat_max_slots = 0;  // (unknown on the host: K3d takes its widest geometry)
+  } else {
+    choose_run_length(m, sc, shape, img, true, kp);
+  }
   kp.K = (uint32_t)top_k;
-  const size_t n_cand = (size_t)B * kp.n_super * top_k;
+  const size_t n_cand = kp.n_ditems ? (size_t)kp.n_ditems * top_k : (size_t)B * kp.n_super * top_k;
   m.d_cand_score.ensure(n_cand + 1);
   m.d_cand_doc.ensure(n_cand + 1);
   kp.cand_score = m.d_cand_score.p;
@@ -1923,11 +1995,21 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   kt->pending = true;
   m.last_kt = kt;
   if (B) {
-    const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));
-    hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
+    if (kp.n_ditems) {
+      hipLaunchKernelGGL(k_merge_items, dim3((uint32_t)B), dim3(WAVE * m.tune.daat_merge_waves), 0, st, kp);
+    } else {
+      const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));
+      hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
+    }
     PS_HIP(hipGetLastError());
     m.ctl_clean = true;
   }
+  } catch (...) {
+    forget_rows(m);
+    throw;
+  }
+  PS_HIP(hipEventRecord(ps_.done, st));  // the plan set is free again behind this batch
+  ps_.busy = true;
   PS_HIP(hipEventRecord(m.ev[0], st));
   m.tail_stream = st;
   m.tail_pending = true;
@@ -1936,7 +2018,9 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   stats.n_plan_entries = tot.n_entries;
   stats.postings_visited = tot.postings;
   stats.algorithmic_bytes = tot.postings * (4 + 8 * (uint64_t)s.F) + (uint64_t)B * top_k * 16;
-  stats.plan_ms = t1 - t0;  // device planner incl. its one synchronisation
+  stats.plan_ms = t1 - t0;  // device planner incl. its one synchronisation (of the planning stream)
+  stats.device_planned = 1;
+  stats.bounds_recomputed = m.last_bounds_recomputed ? 1u : 0u;
   if (!stream) {
     PS_HIP(hipStreamSynchronize(st));
     read_kernel_times(m, stats);

@@ -32,6 +32,9 @@ class Engine {
   // trie, prefix expansion and before_each run on the GPU.  plan_device copies the plan back (tests);
   // run_device_planned scores the batch without the plan ever existing on the host.
   void plan_device(const char* text, const uint64_t* offsets, size_t n_queries, Plan& out);
+  // Whether a flat BM25 top-k batch of this size (built-in tokenizer) should be planned on the device
+  // (PS_DEVICE_PLAN, default on; small batches keep the host planner's latency path).
+  bool wants_device_plan(size_t n_queries);
   void run_device_planned(const ps_scorer_desc& sc, const double* boosts, const char* text, const uint64_t* offsets,
                           size_t n_queries, size_t top_k, void* d_keys, void* d_scores, void* d_counts, void* stream,
                           ps_batch_stats& stats);

@@ -1836,6 +1836,7 @@ struct DevTrie {
 struct PlanTotals {  // written by k_plan_scan
   uint32_t n_entries, max_entries, max_qterms, multi;
   unsigned long long postings;
+  unsigned long long n_items;  // K1d work items of the batch under the chunking rule (chunk_min, split_div)
 };
 
 __device__ __forceinline__ uint32_t utf8_next(const char* s, uint32_t& i, const uint32_t end) {
@@ -1868,12 +1869,12 @@ template <bool FILL>
 __global__ __launch_bounds__(64) void k_plan(const DevTrie t, const char* text, const uint64_t* offsets, const uint32_t B,
                                              const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt, uint32_t* q_terms_len,
                                              uint32_t* q_nterms, uint32_t* q_multi, unsigned long long* q_postings,
-                                             uint32_t* qorder) {
+                                             uint32_t* qorder, uint32_t* q_items, const uint32_t chunk_min, const uint32_t split_div) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= B) return;
   const uint32_t qb = (uint32_t)offsets[q], qe = (uint32_t)offsets[q + 1];
   const char* s = text;
-  uint32_t n_tokens = 0, qord = 0, n_ent = 0, multi = 0;
+  uint32_t n_tokens = 0, qord = 0, n_ent = 0, multi = 0, items = 0;
   unsigned long long postings = 0;
   uint32_t w = FILL ? qbeg[q] : 0u;
   // s.split(' ') (lib.rs:42-44): k separators -> k + 1 tokens; empty ones are skipped but counted (query.rs:32-35)
@@ -1913,6 +1914,11 @@ __global__ __launch_bounds__(64) void k_plan(const DevTrie t, const char* text, 
               entries[w++] = e;
             }
             postings += la.z;
+            if (!FILL) {  // K1d work items of this list (the rule of k_prep_query)
+              uint32_t c = ((la.z + split_div - 1) / split_div + 255u) & ~255u;
+              c = c > chunk_min ? c : chunk_min;
+              items += (la.z + c - 1) / c;
+            }
             ++here;
             ++l;
             // base layers are contiguous, then the delta chain
@@ -1934,6 +1940,7 @@ __global__ __launch_bounds__(64) void k_plan(const DevTrie t, const char* text, 
     q_nterms[q] = qord;
     q_multi[q] = multi;
     q_postings[q] = postings;
+    q_items[q] = items;
   } else {
     qorder[q] = q;
   }
@@ -1941,23 +1948,23 @@ __global__ __launch_bounds__(64) void k_plan(const DevTrie t, const char* text, 
 
 // one workgroup: exclusive scan of the per-query entry counts + the batch totals
 __global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t* q_cnt, const uint32_t* q_nterms, const uint32_t* q_multi,
-                                                     const unsigned long long* q_postings, const uint32_t B, uint32_t* qbeg,
-                                                     PlanTotals* tot) {
+                                                     const unsigned long long* q_postings, const uint32_t* q_items, const uint32_t B,
+                                                     uint32_t* qbeg, PlanTotals* tot) {
   __shared__ uint32_t part[1024];
-  __shared__ uint32_t mx_e[1024], mx_t[1024], any_m[1024];
+  __shared__ uint32_t mx_e[1024], mx_t[1024], any_m[1024], itm[1024];
   __shared__ unsigned long long post[1024];
   const uint32_t tid = threadIdx.x, per = (B + 1023) / 1024;
   const uint32_t b = min(B, tid * per), e = min(B, b + per);
-  uint32_t sum = 0, me = 0, mt = 0, mm = 0;
+  uint32_t sum = 0, me = 0, mt = 0, mm = 0, it = 0;
   unsigned long long ps = 0;
-  for (uint32_t i = b; i < e; ++i) { sum += q_cnt[i]; me = max(me, q_cnt[i]); mt = max(mt, q_nterms[i]); mm |= q_multi[i]; ps += q_postings[i]; }
-  part[tid] = sum; mx_e[tid] = me; mx_t[tid] = mt; any_m[tid] = mm; post[tid] = ps;
+  for (uint32_t i = b; i < e; ++i) { sum += q_cnt[i]; me = max(me, q_cnt[i]); mt = max(mt, q_nterms[i]); mm |= q_multi[i]; ps += q_postings[i]; it += q_items[i]; }
+  part[tid] = sum; mx_e[tid] = me; mx_t[tid] = mt; any_m[tid] = mm; post[tid] = ps; itm[tid] = it;
   __syncthreads();
   if (tid == 0) {
     uint32_t run = 0, a = 0, c = 0, d = 0;
-    unsigned long long pp = 0;
-    for (uint32_t i = 0; i < 1024; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; a = max(a, mx_e[i]); c = max(c, mx_t[i]); d |= any_m[i]; pp += post[i]; }
-    tot->n_entries = run; tot->max_entries = a; tot->max_qterms = c; tot->multi = d; tot->postings = pp;
+    unsigned long long pp = 0, ii = 0;
+    for (uint32_t i = 0; i < 1024; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; a = max(a, mx_e[i]); c = max(c, mx_t[i]); d |= any_m[i]; pp += post[i]; ii += itm[i]; }
+    tot->n_entries = run; tot->max_entries = a; tot->max_qterms = c; tot->multi = d; tot->postings = pp; tot->n_items = ii;
     qbeg[B] = run;
   }
   __syncthreads();

@@ -72,3 +72,17 @@ def replay(steps, fields_num, *indexes):
                 ix.remove_document(st["remove"])
             elif "vacuum" in st:
                 ix.vacuum()
+
+
+def run_device_planned(snap, queries, boosts, top_k, scorer=None):
+    """A batch through ps_snapshot_query_batch_device_planned_flat (planner + K1d preparation on the
+    device): per query [(key, score), ...]."""
+    import probly_search_amd as psa
+    from probly_search_amd import dist as psd, synth
+    text, offsets = synth.pack_queries(list(queries))
+    B = len(queries)
+    buf = psd._DeviceBuffer(psd.block_bytes(B, top_k))
+    base = buf.ptr.value
+    snap.query_batch_device_planned_flat(text, offsets, scorer or psa.bm25.new(), boosts, top_k, base, base + 8 * B * top_k,
+                                         base + 16 * B * top_k, stream=None)
+    return psd.unpack_blocks(buf.to_host(), 1, B, top_k, [B])

@@ -26,14 +26,25 @@ def test_header_symbols_are_exported_and_bound():
     assert names == set(_lib.SYMBOLS), (names ^ set(_lib.SYMBOLS))
 
 
-def test_struct_sizes_match_header():
-    assert ctypes.sizeof(_lib.PlanEntry) == 56
-    assert ctypes.sizeof(_lib.Result) == 16
-    assert ctypes.sizeof(_lib.ScorerDesc) == 32
-    assert ctypes.sizeof(_lib.KernelTimes) == 120
-    assert ctypes.sizeof(_lib.ScoreCallbacks) == 40
-    assert ctypes.sizeof(_lib.TermData) == 48
-    assert ctypes.sizeof(_lib.BatchStats) == 96
+def test_struct_sizes_match_header(tmp_path):
+    """sizeof of every struct that crosses the ABI, as a C compiler sees the header, against the ctypes
+    mirrors the tests and the bench use."""
+    import os
+    import subprocess
+    pairs = [("ps_plan_entry", _lib.PlanEntry), ("ps_result", _lib.Result), ("ps_scorer_desc", _lib.ScorerDesc),
+             ("ps_kernel_times", _lib.KernelTimes), ("ps_score_callbacks", _lib.ScoreCallbacks), ("ps_term_data", _lib.TermData),
+             ("ps_batch_stats", _lib.BatchStats), ("ps_work_counters", _lib.WorkCounters), ("ps_snapshot_info", _lib.SnapshotInfo),
+             ("ps_update_stats", _lib.UpdateStats), ("ps_field_data", _lib.FieldData), ("ps_host_csr", _lib.HostCsr)]
+    src = tmp_path / "sizes.c"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src.write_text('#include <stdio.h>\n#include "probly_search_amd.h"\nint main(void) {\n' +
+                   "".join('  printf("%%zu\\n", sizeof(%s));\n' % c for c, _ in pairs) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    for (cname, ct), n in zip(pairs, sizes):
+        assert ctypes.sizeof(ct) == n, (cname, ctypes.sizeof(ct), n)
+    assert ctypes.sizeof(_lib.PlanEntry) == 56 and ctypes.sizeof(_lib.Result) == 16
 
 
 def test_queries_fail_loudly_without_device_snapshot():

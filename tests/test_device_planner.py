@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import probly_search_amd as psa
-from adapters import ProductIndex, replay
+from adapters import ProductIndex, replay, run_device_planned
 from corpus_util import build_script, random_queries
 from emu import bits
 from oracle import oracle as orc
@@ -56,17 +56,22 @@ def test_device_plan_equals_host_plan_random_corpora(seed):
 
 
 def _run_planned(snap, queries, boosts, top_k):
-    text, offsets = synth.pack_queries(queries)
-    B = len(queries)
-    buf = psd._DeviceBuffer(psd.block_bytes(B, top_k))
-    base = buf.ptr.value
-    snap.query_batch_device_planned_flat(text, offsets, psa.bm25.new(), boosts, top_k, base, base + 8 * B * top_k,
-                                         base + 16 * B * top_k, stream=None)
-    return psd.unpack_blocks(buf.to_host(), 1, B, top_k, [B])
+    return run_device_planned(snap, queries, boosts, top_k)
 
 
+@pytest.mark.parametrize("kernel", ["daat", "k_score"])
 @pytest.mark.parametrize("cfg_name,n_docs", [("C2", 40_000), ("C5", 20_000)])
-def test_batches_scored_from_a_device_built_plan(cfg_name, n_docs):
+def test_batches_scored_from_a_device_built_plan(cfg_name, n_docs, kernel):
+    """Device-built plan -> device-built K1d descriptors -> k_daat (default), or -> k_score (PS_DAAT=0):
+    the oracle's answers either way, also after a delta (new terms, removals) and with other boosts."""
+    psa.load().ps_set_option(b"PS_DAAT", 1 if kernel == "daat" else 0)
+    try:
+        _device_planned_batches(cfg_name, n_docs, kernel)
+    finally:
+        psa.load().ps_set_option(b"PS_DAAT", 1)
+
+
+def _device_planned_batches(cfg_name, n_docs, kernel):
     cfg = dict(synth.CONFIGS[cfg_name], n_docs=n_docs, vocab=2_000)
     corpus = synth.Corpus(**cfg)
     p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
@@ -77,7 +82,8 @@ def test_batches_scored_from_a_device_built_plan(cfg_name, n_docs):
     for q, g in zip(queries, got):
         exp = o.query(q, orc.bm25(), [1.0, 1.0])[:10]
         assert [(k, bits(s)) for k, s in g] == [(k, bits(s)) for k, s in exp], q
-    assert snap.last_stats()["plan_ms"] >= 0.0 and snap.kernel_breakdown()["score_kernel"].startswith("ps::k_score")
+    assert snap.last_stats()["device_planned"] == 1
+    assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_daat" if kernel == "daat" else "ps::k_score")
     # the device trie follows a delta (new terms re-freeze the trie on the host; the device copy is refreshed)
     for i in range(50):
         f = ["fresh term%d" % (i % 3), queries[0]]

@@ -7,6 +7,7 @@ disk against the oracle."""
 import pytest
 
 import probly_search_amd as psa
+from adapters import run_device_planned
 from emu import bits
 from oracle import oracle as orc
 from probly_search_amd import synth
@@ -63,6 +64,10 @@ def _full_size(config, n_full_lists, batch, n_oracle_topk=64):
     kernel = snap.kernel_breakdown(reset=True)["score_kernel"]
     if bm25:
         assert kernel.startswith("ps::k_daat"), kernel
+        # the same batch with the planner on the device too (k_plan -> device-built descriptors -> K1d)
+        dev = run_device_planned(snap, queries, boosts, K)
+        assert snap.last_stats()["device_planned"] == 1
+        assert [[(k, bits(sc_)) for k, sc_ in rs] for rs in dev] == _tuples(top), (config, "device-planned batch != host-planned batch")
         for rep in range(4):
             assert _tuples(snap.query_batch(queries, ps_sc, None, boosts, top_k=K)) == _tuples(top), ("repeat", rep)
         _set("PS_DAAT", 0)
