@@ -178,17 +178,6 @@ struct EngineImpl {
   DevBuf<uint64_t> d_out_keys, d_full_off;
   DevBuf<unsigned long long> d_gthr;
   DevBuf<double> d_rows;  // dense per-document score rows of the batch's hot lists
-  DevBuf<uint32_t> d_cand_cnt;  // K1d: candidates per item
-  DevBuf<DItem> d_ditems;       // K1d: work items (k_prep_items)
-  // K1d batch preparation on the device (ps_prep_kernels.hpp): descriptors, order, candidate slots
-  DevBuf<DEntry> d_dentry;
-  DevBuf<DGroup> d_dgroup;
-  DevBuf<DItemGen> d_gen;
-  DevBuf<uint32_t> d_rorder, d_qslot, d_qslot_n;
-  DevBuf<uint8_t> d_gord;
-  PrepCtl* d_prep_ctl = nullptr;
-  RowState* d_row_state = nullptr;
-  RowDesc* d_row_desc = nullptr;
   // K1d: per list (layer) upper bounds of the saturated term frequency, exact for the current
   // (k1, b, avg): M[l*F+x] = max tfn_x over the list's postings, J[l] = max over postings of
   // sum_x boost_x * tfn_x (k_list_bounds).  M does not depend on the boosts; J does, and a few J
@@ -200,7 +189,8 @@ struct EngineImpl {
     std::vector<double> avg;
     size_t n_layers = 0;
     DevBuf<unsigned long long> M;
-    struct JSet { std::vector<double> boosts; DevBuf<unsigned long long> J; uint64_t last_use = 0; bool valid = false; };
+    struct JSet { std::vector<double> boosts; DevBuf<unsigned long long> J; uint64_t last_use = 0; bool valid = false; hipEvent_t ready = nullptr; };
+    hipEvent_t m_ready = nullptr;  // behind the kernel that last wrote M (batches on other streams wait for it)
     JSet j[4];
     uint64_t epoch = 0;
     DevBuf<BoundUnit> units;
@@ -215,8 +205,7 @@ struct EngineImpl {
     uint32_t n = 0;
     std::vector<double> sig;  // knobs the choice was made with
     DevBuf<uint8_t> of_layer;
-    DevBuf<double> rows;
-    std::vector<double> row_sig;  // scorer parameters + boosts the resident rows were scored with
+    uint64_t gen = 0;  // bumped whenever the choice changes (the contexts' resident rows follow)
   } cands;
   std::vector<uint32_t> z_minfl;  // zero_to_one field pruning: [layer][field] shortest field length holding the term (compute_z_bounds)
   std::unordered_map<uint64_t, uint32_t> z_layer_of;  // post_off -> layer (zero_to_one plan entries do not carry it)
@@ -241,33 +230,54 @@ struct EngineImpl {
   DevBuf<uint64_t> d_term_df;
   DevBuf<double> d_term_idf, d_eb_table;
   uint32_t eb_n = 0;
-  // A device-built plan lives in one of two buffer sets: batch s + 1 is planned on `plan_stream` (count ->
-  // scan -> the host reads the totals -> fill) while batch s is still being scored from the other set.
+  // A device-built plan (k_plan): the batch's text, the per-query counts of the count pass, the entries.
   struct PlanSet {
-    DevBuf<char> qtext;
-    DevBuf<uint64_t> qoff;
+    DevBuf<char> qtext;  // offsets | text
     DevBuf<uint32_t> cnt, qtl, nterms, multi, qbeg, qorder, items;
     DevBuf<unsigned long long> post;
     DevBuf<ps_plan_entry> entries;
-    DevBuf<PlanTotals> tot;
-    Stage h;                       // pinned copy of the batch's text + offsets (the caller's buffer may be pageable)
-    hipEvent_t planned = nullptr;  // behind the fill pass, on plan_stream
-    hipEvent_t done = nullptr;     // behind the batch that was scored from this set, on its stream
-    bool busy = false;
+    Stage h;  // pinned copy of the batch's offsets | text (the caller's buffer may be pageable)
     void release() {
-      qtext.release(); qoff.release(); cnt.release(); qtl.release(); nterms.release(); multi.release(); qbeg.release();
-      qorder.release(); items.release(); post.release(); entries.release(); tot.release();
+      qtext.release(); cnt.release(); qtl.release(); nterms.release(); multi.release(); qbeg.release();
+      qorder.release(); items.release(); post.release(); entries.release();
       if (h.p) (void)hipHostFree(h.p);
       if (h.done) (void)hipEventDestroy(h.done);
-      if (planned) (void)hipEventDestroy(planned);
-      if (done) (void)hipEventDestroy(done);
     }
   };
-  PlanSet pset[2];
-  int next_pset = 0;
-  hipStream_t plan_stream = nullptr;
-  PlanTotals* h_totals = nullptr;  // pinned
-  uint32_t daat_max_slots = 0;  // K1d: most candidate slots of one query in the batch being enqueued (0 = unknown: device-built plan)
+  // Everything one K1d batch owns on the device, twice: batch s + 1 is planned, prepared and scored on
+  // the other context's stream while batch s is still in flight, so the GPU never idles between a
+  // batch's merge and the next batch's first kernel (and the tail of one k_daat launch is filled by the
+  // head of the next).  Only the merge - the kernel that writes the caller's output buffers - waits for
+  // the caller's stream; the caller's stream in turn waits for the batch's `done` event.
+  struct DaatCtx {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;     // behind the batch's last kernel
+    hipEvent_t entry = nullptr;    // the caller stream's position when the batch was submitted
+    hipEvent_t planned = nullptr;  // behind the planner's fill pass (batches that fall back to k_score)
+    bool busy = false;
+    PlanSet plan;                  // device-planned batches
+    DevBuf<unsigned char> stage;   // host-planned batches: entries | qbeg | qterms_len as uploaded
+    DevBuf<DEntry> dentry;
+    DevBuf<DGroup> dgroup;
+    DevBuf<DItemGen> gen;
+    DevBuf<uint32_t> rorder, qslot, qslot_n, cand_cnt, cand_doc;
+    DevBuf<uint8_t> gord;
+    DevBuf<DItem> ditems;
+    DevBuf<double> cand_score, rows;
+    DevBuf<unsigned long long> gthr;
+    PrepCtl* ctl = nullptr;
+    uint32_t* work = nullptr;
+    RowState* row_state = nullptr;
+    RowDesc* row_desc = nullptr;
+    std::vector<double> row_sig;   // scorer parameters + boosts the context's resident rows were scored with
+    uint64_t cands_gen = 0;        // RowCands::gen its rows belong to
+    bool ctl_clean = false;        // k_merge_items left the control words zeroed
+  };
+  DaatCtx dctx[2];
+  int next_dctx = 0;
+  hipEvent_t lut_ready = nullptr;  // behind the most recent k_bm25_lut
+  PlanTotals* h_totals = nullptr;  // pinned, device-mapped: k_plan_scan writes the totals where the host reads them
+  PlanTotals* d_totals_mapped = nullptr;
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0, last_rows_built = 0;
@@ -346,11 +356,9 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     m.tune_gen = g_opt_gen.load();
     PS_HIP(hipMalloc((void**)&m.d_work, 256));
     PS_HIP(hipMemset(m.d_work, 0, 256));
-    PS_HIP(hipMalloc((void**)&m.d_prep_ctl, sizeof(PrepCtl)));
-    PS_HIP(hipMemset(m.d_prep_ctl, 0, sizeof(PrepCtl)));
-    PS_HIP(hipMalloc((void**)&m.d_row_state, sizeof(RowState) * PREP_MAX_ROWS));
-    PS_HIP(hipMemset(m.d_row_state, 0, sizeof(RowState) * PREP_MAX_ROWS));
-    PS_HIP(hipMalloc((void**)&m.d_row_desc, sizeof(RowDesc) * PREP_MAX_ROWS));
+    PS_HIP(hipEventCreateWithFlags(&m.lut_ready, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&m.bounds.m_ready, hipEventDisableTiming));
+    for (auto& js : m.bounds.j) PS_HIP(hipEventCreateWithFlags(&js.ready, hipEventDisableTiming));
     PS_HIP(hipMalloc((void**)&m.d_wstats, (size_t)WS_SLOTS * WS_WORDS * 8));
     PS_HIP(hipMemset(m.d_wstats, 0, (size_t)WS_SLOTS * WS_WORDS * 8));
     PS_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
@@ -399,17 +407,24 @@ Engine::~Engine() {
   m.d_stage.release(); m.d_cand_doc.release();
   m.d_out_counts.release(); m.d_full_doc.release(); m.d_full_cnt.release(); m.d_cand_score.release();
   m.d_out_scores.release(); m.d_full_score.release(); m.d_out_keys.release(); m.d_full_off.release();
-  m.d_gthr.release(); m.d_rows.release(); m.d_cand_cnt.release(); m.d_ditems.release(); m.d_removed_df.release();
-  m.d_dentry.release(); m.d_dgroup.release(); m.d_gen.release(); m.d_rorder.release(); m.d_qslot.release(); m.d_qslot_n.release();
-  m.d_gord.release(); m.bounds.M.release(); m.bounds.units.release();
-  for (auto& js : m.bounds.j) js.J.release();
-  m.cands.of_layer.release(); m.cands.rows.release();
-  for (void* p : {(void*)m.d_prep_ctl, (void*)m.d_row_state, (void*)m.d_row_desc})
-    if (p) (void)hipFree(p);
+  m.d_gthr.release(); m.d_rows.release(); m.d_removed_df.release();
+  m.bounds.M.release(); m.bounds.units.release();
+  if (m.bounds.m_ready) (void)hipEventDestroy(m.bounds.m_ready);
+  for (auto& js : m.bounds.j) { js.J.release(); if (js.ready) (void)hipEventDestroy(js.ready); }
+  if (m.lut_ready) (void)hipEventDestroy(m.lut_ready);
+  m.cands.of_layer.release();
+  for (auto& c : m.dctx) {
+    c.plan.release(); c.stage.release(); c.dentry.release(); c.dgroup.release(); c.gen.release(); c.rorder.release();
+    c.qslot.release(); c.qslot_n.release(); c.cand_cnt.release(); c.cand_doc.release(); c.gord.release(); c.ditems.release();
+    c.cand_score.release(); c.rows.release(); c.gthr.release();
+    for (void* p : {(void*)c.ctl, (void*)c.work, (void*)c.row_state, (void*)c.row_desc})
+      if (p) (void)hipFree(p);
+    for (hipEvent_t e : {c.done, c.entry, c.planned})
+      if (e) (void)hipEventDestroy(e);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+  }
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fchar.release(); m.d_fchild.release();
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release();
-  for (auto& ps_ : m.pset) ps_.release();
-  if (m.plan_stream) (void)hipStreamDestroy(m.plan_stream);
   if (m.h_totals) (void)hipHostFree(m.h_totals);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
   m.d_sort_tmp.release(); m.d_pack.release();
@@ -706,8 +721,6 @@ struct BatchImage {
   uint32_t n_used = 0;           // rows the batch reads (resident ones included)
   uint32_t n_simple = 0, n_general = 0, z_masked = 0;
   uint32_t z_qterms = 0;  // most query terms with entries in one general zero_to_one query
-  bool daat = false;  // K1d: descriptors, items and dense-row flags are built on the device from the uploaded plan
-  size_t n_ditems = 0;  // its work items (exact: the host knows the list lengths)
   size_t off_zf = 0;  // zero_to_one: per-query per-field pool bounds (k_score's field pruning)
 };
 
@@ -774,8 +787,14 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
     if (js.valid && js.boosts == bv) tgt = &js;
   if (m_ok && tgt) {
     tgt->last_use = lb.epoch;
+    // (they may have been computed on another context's stream a moment ago)
+    PS_HIP(hipStreamWaitEvent(st, lb.m_ready, 0));
+    PS_HIP(hipStreamWaitEvent(st, tgt->ready, 0));
     return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p)};
   }
+  // M is rewritten in place (and a J array may be recycled): nothing that reads them may still be in flight
+  for (auto& c : m.dctx)
+    if (c.busy && c.stream != st) PS_HIP(hipStreamWaitEvent(st, c.done, 0));
   const double t0 = now_ms();
   if (lb.n_layers != nl || lb.n_units == 0) {  // the work list: one wave per list, long lists in 16 Ki-posting segments
     std::vector<BoundUnit> units;
@@ -802,6 +821,8 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
                        tgt->J.p, m_ok ? 0 : 1);
     PS_HIP(hipGetLastError());
   }
+  if (!m_ok) PS_HIP(hipEventRecord(lb.m_ready, st)); else PS_HIP(hipStreamWaitEvent(st, lb.m_ready, 0));
+  PS_HIP(hipEventRecord(tgt->ready, st));
   lb.m_valid = true; lb.k1 = sc.bm25_k1; lb.b = sc.bm25_b; lb.avg = avg; lb.n_layers = nl;
   tgt->valid = true; tgt->boosts = bv; tgt->last_use = lb.epoch;
   lb.last_ms = now_ms() - t0;
@@ -836,11 +857,9 @@ void ensure_row_candidates(EngineImpl& m, hipStream_t st) {
   rc.of_layer.ensure(of.size() + 1);
   PS_HIP(hipMemcpyAsync(rc.of_layer.p, of.data(), of.size(), hipMemcpyHostToDevice, st));
   PS_HIP(hipStreamSynchronize(st));  // (`of` is pageable and leaves scope; this happens once per snapshot state)
-  rc.rows.ensure(std::max<size_t>(1, c.size()) * (size_t)s.tiles_cap * s.T + 16);
-  PS_HIP(hipMemsetAsync(m.d_row_state, 0, sizeof(RowState) * PREP_MAX_ROWS, st));
   rc.n = (uint32_t)c.size();
   rc.sig = sig;
-  rc.row_sig.clear();
+  ++rc.gen;  // every context drops its resident rows
   rc.valid = true;
 }
 
@@ -848,27 +867,30 @@ void ensure_row_candidates(EngineImpl& m, hipStream_t st) {
 // HBM - uploaded by the host planner or written by the device planner: bounds -> descriptors / order /
 // candidate slots -> items and dense-row flags.  `items_bound` >= the batch's item count (exact when the
 // host knows the list lengths).  Fills the K1d members of `kp`.
-void launch_prep(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, KParams& kp, hipStream_t st, ps_plan_entry* d_plan,
+void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, KParams& kp, ps_plan_entry* d_plan,
                  const uint32_t* d_qbeg, size_t B, size_t ne, bool multi, size_t items_bound) {
   const Snapshot& s = *m.snap;
+  hipStream_t st = c.stream;
   const uint64_t rc0 = m.bounds.recomputed;
   const BoundsRef br = ensure_list_bounds(m, sc, boosts, kp, st);
   m.last_bounds_recomputed = m.bounds.recomputed != rc0;
   ensure_row_candidates(m, st);
-  // resident rows are only valid for the parameters they were scored with
+  // the context's resident rows are only valid for the candidates and parameters they were scored with
   {
     std::vector<double> sig{sc.bm25_k1, sc.bm25_b};
     for (uint32_t x = 0; x < s.F; ++x) { sig.push_back(boosts[x]); sig.push_back(s.avg[x]); }
-    if (sig != m.cands.row_sig) {
-      PS_HIP(hipMemsetAsync(m.d_row_state, 0, sizeof(RowState) * PREP_MAX_ROWS, st));
-      m.cands.row_sig = sig;
+    if (sig != c.row_sig || c.cands_gen != m.cands.gen) {
+      PS_HIP(hipMemsetAsync(c.row_state, 0, sizeof(RowState) * PREP_MAX_ROWS, st));
+      c.row_sig = sig;
+      c.cands_gen = m.cands.gen;
     }
+    c.rows.ensure(std::max<size_t>(1, m.cands.n) * (size_t)s.tiles_cap * s.T + 16);
   }
-  m.d_dentry.ensure(ne + 1); m.d_rorder.ensure(ne + 1); m.d_gord.ensure(ne + 16); m.d_gen.ensure(ne + 1);
-  if (multi) m.d_dgroup.ensure(ne + 1);
-  m.d_qslot.ensure(B + 1); m.d_qslot_n.ensure(B + 1);
-  m.d_ditems.ensure(items_bound + 1);
-  m.d_cand_cnt.ensure(items_bound + 1);
+  c.dentry.ensure(ne + 1); c.rorder.ensure(ne + 1); c.gord.ensure(ne + 16); c.gen.ensure(ne + 1);
+  if (multi) c.dgroup.ensure(ne + 1);
+  c.qslot.ensure(B + 1); c.qslot_n.ensure(B + 1);
+  c.ditems.ensure(items_bound + 1);
+  c.cand_cnt.ensure(items_bound + 1);
   PrepParams pp;
   memset(&pp, 0, sizeof(pp));
   pp.plan = d_plan; pp.qbeg = d_qbeg;
@@ -876,28 +898,55 @@ void launch_prep(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, 
   pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div;
   for (uint32_t x = 0; x < s.F; ++x) pp.boost[x] = boosts[x];
   pp.bound_m = br.M; pp.bound_j = br.J;
-  pp.dentry = m.d_dentry.p; pp.rorder = m.d_rorder.p; pp.dgroup = multi ? m.d_dgroup.p : nullptr; pp.gord = m.d_gord.p;
-  pp.gen = m.d_gen.p; pp.qslot = m.d_qslot.p; pp.qslot_n = m.d_qslot_n.p;
-  pp.items = m.d_ditems.p; pp.items_cap = (uint32_t)items_bound;
-  pp.ctl = m.d_prep_ctl;
+  pp.dentry = c.dentry.p; pp.rorder = c.rorder.p; pp.dgroup = multi ? c.dgroup.p : nullptr; pp.gord = c.gord.p;
+  pp.gen = c.gen.p; pp.qslot = c.qslot.p; pp.qslot_n = c.qslot_n.p;
+  pp.items = c.ditems.p; pp.items_cap = (uint32_t)items_bound;
+  pp.ctl = c.ctl;
   pp.cand_of_layer = m.cands.of_layer.p; pp.n_cand = m.cands.n; pp.min_uses = std::max(1u, m.tune.dense_min_uses);
   pp.rows_resident = m.tune.row_cache_mb != 0;
-  pp.layer_a = m.d_layer_a.p; pp.row_state = m.d_row_state; pp.row_desc = m.d_row_desc; pp.wstats = m.d_wstats;
+  pp.layer_a = m.d_layer_a.p; pp.row_state = c.row_state; pp.row_desc = c.row_desc; pp.wstats = m.d_wstats;
   if (B) {
     hipLaunchKernelGGL(k_prep_query, dim3((uint32_t)((B + 63) / 64)), dim3(64), 0, st, pp);
     hipLaunchKernelGGL(k_prep_finish, dim3(1), dim3(64), 0, st, pp);
     if (ne) hipLaunchKernelGGL(k_prep_items, dim3((uint32_t)((ne + 3) / 4)), dim3(256), 0, st, pp);
     PS_HIP(hipGetLastError());
   }
-  kp.dentry = m.d_dentry.p; kp.ditems = m.d_ditems.p; kp.qslot = m.d_qslot.p; kp.qslot_n = m.d_qslot_n.p;
-  kp.rorder = m.d_rorder.p; kp.dgroup = multi ? m.d_dgroup.p : nullptr;
+  kp.dentry = c.dentry.p; kp.ditems = c.ditems.p; kp.qslot = c.qslot.p; kp.qslot_n = c.qslot_n.p;
+  kp.rorder = c.rorder.p; kp.dgroup = multi ? c.dgroup.p : nullptr;
   kp.n_ditems = (uint32_t)items_bound;
-  kp.n_ditems_dev = &m.d_prep_ctl->n_items;
-  kp.prep_ctl = reinterpret_cast<uint32_t*>(m.d_prep_ctl);
+  kp.n_ditems_dev = &c.ctl->n_items;
+  kp.prep_ctl = reinterpret_cast<uint32_t*>(c.ctl);
   kp.prep_ctl_words = (uint32_t)(sizeof(PrepCtl) / 4);
-  kp.cand_cnt = m.d_cand_cnt.p;
-  kp.rows = m.cands.rows.p; kp.row_desc = m.d_row_desc; kp.n_rows = 0;
+  kp.cand_cnt = c.cand_cnt.p;
+  kp.rows = c.rows.p; kp.row_desc = c.row_desc; kp.n_rows = 0;
   kp.row_planes = 1; kp.row_mode = 0; kp.row_stride = (uint64_t)s.tiles_cap * s.T;
+}
+
+// The next K1d batch context (they alternate); its stream, events and control blocks exist from first use.
+EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
+  EngineImpl::DaatCtx& c = m.dctx[m.next_dctx];
+  m.next_dctx ^= 1;
+  if (!c.stream) {
+    PS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    PS_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&c.entry, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&c.planned, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&c.plan.h.done, hipEventDisableTiming));
+    PS_HIP(hipMalloc((void**)&c.ctl, sizeof(PrepCtl)));
+    PS_HIP(hipMalloc((void**)&c.work, 256));
+    PS_HIP(hipMalloc((void**)&c.row_state, sizeof(RowState) * PREP_MAX_ROWS));
+    PS_HIP(hipMalloc((void**)&c.row_desc, sizeof(RowDesc) * PREP_MAX_ROWS));
+    PS_HIP(hipMemset(c.row_state, 0, sizeof(RowState) * PREP_MAX_ROWS));
+    c.ctl_clean = false;
+  }
+  return c;
+}
+
+// Batches that do not run in a K1d context (k_score, zero_to_one, full-result mode) share the engine's
+// single set of per-batch buffers and the saturated-tf table with nothing else in flight.
+void wait_daat_contexts(EngineImpl& m, hipStream_t st) {
+  for (auto& c : m.dctx)
+    if (c.busy) PS_HIP(hipStreamWaitEvent(st, c.done, 0));
 }
 
 // Items a batch has under the chunking rule of k_prep_query (host-planned batches: exact).
@@ -1070,7 +1119,6 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
   uint32_t& n_rows = img.n_rows;
   uint32_t& n_used = img.n_used;
   const uint32_t z_masked = img.z_masked;
-  if (img.daat) return;  // K1d: which dense rows the batch reads is decided on the device (k_prep_finish)
   {
     bool sane = max_rows > 0 && s.n_docs > 0;
     if (!z) {
@@ -1080,7 +1128,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
     }
     const uint32_t min_uses = m.tune.dense_min_uses;
     // (K1d only looks rows up: below ~40 % density the bitmap cell + posting is as good as the row costs to build)
-    const double min_density = (img.daat ? std::max(m.tune.dense_min_density_pct, m.tune.daat_dense_min_density_pct) : m.tune.dense_min_density_pct) / 100.0;
+    const double min_density = m.tune.dense_min_density_pct / 100.0;
     const uint32_t planes = z ? s.F : 1u;
     if (sane && ne) {
       struct Key { uint64_t post_off, w, k3; };
@@ -1197,7 +1245,7 @@ void select_dense_rows(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
           // (zero_to_one simple queries without consumed-term masks sum their records the same way,
           // in sorted order: same two tricks, for 1 or 2 fields)
           const bool plain_sum = z ? (z_masked == 0 && s.F <= 2) : !plan.multi_expansion;
-          if (plain_sum && m.tune.dense_fuse && e > b && !img.daat) {  // (K1d keeps plan order: no tile to write into)
+          if (plain_sum && m.tune.dense_fuse && e > b) {
             if ((m.tune.dense_fuse & 1u) && (he[e - 1].shift & DENSE_FLAG)) he[e - 1].shift |= DENSE_FUSE_FLAG;
             if ((m.tune.dense_fuse & 2u) && e - b >= 2) {
               const bool d0 = (he[b].shift & DENSE_FLAG) != 0;
@@ -1278,9 +1326,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   const Snapshot& s = *m.snap;
   refresh_tuning(m);
   m.last_bounds_recomputed = false;
-  // K1d (exact dynamic pruning) takes BM25 top-k batches whose parameters make every score a
-  // positive, monotone function of the saturated term frequency and whose plans have at most 64
-  // entries per query; everything else stays on K1.  Its descriptors are built on the device.
+  // (BM25 top-k batches that qualify for K1d never get here: enqueue_daat_host / run_device_planned)
   static const bool trace_sp = env_u32("PS_TRACE", 0) != 0;
   double tsp = now_ms();
   auto SP = [&](const char* what) {
@@ -1289,20 +1335,12 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     fprintf(stderr, "[ps]   stage %-10s %.3f ms\n", what, n - tsp);
     tsp = now_ms();
   };
-  const bool daat_batch = topk_path && m.tune.daat && plan.qbeg.size() - 1 >= m.tune.daat_min_batch && !plan.entries.empty();
-  size_t n_ditems = 0;
-  uint32_t max_slots = 0;
-  if (daat_batch && sc.kind == PS_SCORER_BM25 && m.tune.lut && bm25_params_sane(s, sc, boosts) && plan.max_entries <= 64 &&
-      (!plan.multi_expansion || m.tune.daat_multi))
-    n_ditems = count_daat_items(m, plan, &max_slots);
-  SP("daat");
+  wait_daat_contexts(m, st);
   BatchImage img = lay_out_batch(m, sc, plan);
-  img.daat = n_ditems != 0;
-  img.n_ditems = n_ditems;
   SP("layout");
   const size_t B = img.B;
   const bool z = img.z;
-  if (!img.daat) order_queries(m, plan, img);  // (K1d has its own item order)
+  order_queries(m, plan, img);
   if (z) classify_zero_to_one(m, plan, img);
   if (z && m.tune.z21_exact_numerator) {
     // k_score's one-division arm (score_trip): per entry the largest L with fmin(score / t, 1.) * t == score
@@ -1360,8 +1398,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   // place from the pinned slot: a few hundred bytes over PCIe per wave, in parallel, instead of a
   // copy-engine hand-over in front of the kernel (latency path of a single query).
   const uint32_t g_regs = (s.F == 1 || s.F == 2) ? (uint32_t)PS_G : 1u;
-  const bool zero_copy = B <= 4 && plan.max_entries <= g_regs && n_used == 0 && n_general == 0 &&
-                         m.tune.zero_copy && !img.daat;
+  const bool zero_copy = B <= 4 && plan.max_entries <= g_regs && n_used == 0 && n_general == 0 && m.tune.zero_copy;
   const unsigned char* dbase;
   m.cur_stage = &sg;
   m.cur_zero_copy = zero_copy;
@@ -1425,7 +1462,6 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
   if (!(m.ctl_clean && topk_path && !fresh)) {
     PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
     PS_HIP(hipMemsetAsync(m.d_work, 0, 256, st));
-    PS_HIP(hipMemsetAsync(m.d_prep_ctl, 0, sizeof(PrepCtl), st));
   }
   m.ctl_clean = false;  // enqueue_topk sets it once k_merge is in the stream
   kp.n_simple = img.n_simple; kp.n_general = n_general; kp.z_masked = img.z_masked;
@@ -1450,15 +1486,7 @@ void stage_plan(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, c
     kp.lut_stride = s.lut_rows ? ((s.lut_rows + 1) | 1u) : 0;  // odd stride; LUT bytes = stride*128, so tiles stay 16-B aligned
     for (uint32_t x = 0; x < s.F; ++x) { kp.lut_cap[x] = s.lut_cap[x]; kp.lut_base[x] = s.lut_base[x]; }
   }
-  if (!img.daat) {
-    choose_run_length(m, sc, plan, img, topk_path, kp);
-  } else {
-    kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0;
-    if (zero_copy) throw std::logic_error("K1d batches upload their plan");  // (B >= daat_min_batch > 4: never zero-copy)
-    launch_prep(m, sc, boosts, kp, st, reinterpret_cast<ps_plan_entry*>(m.d_stage.p + off_e),
-                reinterpret_cast<const uint32_t*>(m.d_stage.p + off_q), B, img.ne, plan.multi_expansion, img.n_ditems);
-    m.daat_max_slots = max_slots;
-  }
+  choose_run_length(m, sc, plan, img, topk_path, kp);
   SP("rest");
   static const bool trace = env_u32("PS_TRACE", 0) != 0;
   if (trace && B > 1)
@@ -1571,18 +1599,25 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
     if (kp.n_ditems) m.wc_items += kp.n_ditems; else m.wc_cand_slots += (uint64_t)n_items * kp.K;
   }
   if (sc.kind == PS_SCORER_BM25) {
-    // K0 runs when (k1, b) change (or the stream does: no cross-stream ordering is assumed)
-    if (kp.lut_rows && !(m.lut_valid && m.lut_k1 == sc.bm25_k1 && m.lut_b == sc.bm25_b && m.lut_stream == st &&
-                         m.tune.lut_cache)) {
+    // K0 runs when (k1, b) change.  The table is shared by every stream: a rebuild first waits for the K1d
+    // contexts still reading it, and launches on other streams wait for the rebuild's event.
+    if (kp.lut_rows && !(m.lut_valid && m.lut_k1 == sc.bm25_k1 && m.lut_b == sc.bm25_b && m.tune.lut_cache)) {
+      for (auto& c : m.dctx)
+        if (c.busy && c.stream != st) PS_HIP(hipStreamWaitEvent(st, c.done, 0));
+      if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
       hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
+      PS_HIP(hipEventRecord(m.lut_ready, st));
       m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = st;
+    } else if (kp.lut_rows && m.lut_stream != st) {
+      PS_HIP(hipStreamWaitEvent(st, m.lut_ready, 0));
     }
     if (!FULL && kp.n_ditems) {
       // K1d: the rows to score were listed on the device (k_prep_finish); a fixed grid takes (row, tile range) units
       if (m.cands.n) {
         const uint32_t per_row = std::min(2048u, std::max(256u, kp.n_tiles));
         const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_row * m.cands.n, 4096);
-        hipLaunchKernelGGL(k_dense_rows_dyn, dim3(grid), dim3(256), 0, st, kp, m.cands.rows.p, m.d_prep_ctl, per_row);
+        hipLaunchKernelGGL(k_dense_rows_dyn, dim3(grid), dim3(256), 0, st, kp, const_cast<double*>(kp.rows),
+                           reinterpret_cast<const PrepCtl*>(kp.prep_ctl), per_row);
       }
       if (mid) PS_HIP(hipEventRecord(mid, st));
       launch_daat(m, kp, plan.multi_expansion, n_cu, st);
@@ -1632,6 +1667,7 @@ void forget_rows(EngineImpl& m) {
   m.bounds.n_units = 0;
   for (auto& js : m.bounds.j) js.valid = false;
   m.cands.valid = false;
+  for (auto& c : m.dctx) { c.row_sig.clear(); c.ctl_clean = false; }
 }
 
 void fill_stats(const EngineImpl& m, ps_batch_stats& st, const Snapshot& s, const Plan& plan, uint64_t emitted) {
@@ -1643,6 +1679,108 @@ void fill_stats(const EngineImpl& m, ps_batch_stats& st, const Snapshot& s, cons
   st.n_plan_entries = plan.entries.size();
   st.postings_visited = plan.postings;
   st.algorithmic_bytes = plan.postings * (4 + 8 * (uint64_t)s.F) + emitted * 16;
+}
+
+void fill_common_kparams(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, size_t B, uint32_t max_qterms, KParams& kp);
+
+// K1d takes BM25 top-k batches whose parameters make every score a positive, monotone function of the
+// saturated term frequency and whose plans have at most 64 entries per query; everything else stays on K1.
+bool daat_eligible(const EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, size_t B, size_t n_entries, uint32_t max_entries,
+                   bool multi) {
+  return m.tune.daat && sc.kind == PS_SCORER_BM25 && B >= m.tune.daat_min_batch && n_entries != 0 && m.tune.lut &&
+         bm25_params_sane(*m.snap, sc, boosts) && max_entries <= 64 && (!multi || m.tune.daat_multi) && m.snap->lut_rows != 0;
+}
+
+// The part every K1d batch shares, on its context's stream: control words, device-side preparation,
+// K0b over the rows the preparation listed, k_daat, then - once the caller's stream has reached the
+// point of the call, because the merge is the kernel that writes the caller's buffers - k_merge_items.
+// The caller's stream is made to wait for the batch, so work enqueued on it afterwards sees the results.
+void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, ps_plan_entry* d_plan,
+                  const uint32_t* d_qbeg, const uint32_t* d_qtl, size_t B, size_t ne, uint32_t max_qterms, bool multi, size_t n_items,
+                  uint32_t max_slots, size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller) {
+  const Snapshot& s = *m.snap;
+  hipStream_t st = c.stream;
+  KParams kp;
+  EngineImpl::KTimer* kt = nullptr;
+  try {
+    fill_common_kparams(m, sc, boosts, B, max_qterms, kp);
+    kp.plan = d_plan; kp.qbeg = d_qbeg; kp.qterms_len = d_qtl;
+    kp.work_counter = c.work;
+    const size_t n_thr = B + 2;
+    const bool fresh = c.gthr.ensure(n_thr, true);
+    kp.gthr = c.gthr.p;
+    if (!(c.ctl_clean && !fresh)) {
+      PS_HIP(hipMemsetAsync(c.gthr.p, 0, n_thr * 8, st));
+      PS_HIP(hipMemsetAsync(c.work, 0, 256, st));
+      PS_HIP(hipMemsetAsync(c.ctl, 0, sizeof(PrepCtl), st));
+    }
+    c.ctl_clean = false;
+    kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0;
+    launch_prep(m, c, sc, boosts, kp, d_plan, d_qbeg, B, ne, multi, n_items);
+    kp.K = (uint32_t)top_k;
+    const size_t n_cand = n_items * top_k;
+    c.cand_score.ensure(n_cand + 1);
+    c.cand_doc.ensure(n_cand + 1);
+    kp.cand_score = c.cand_score.p;
+    kp.cand_doc = c.cand_doc.p;
+    kp.out_keys = (uint64_t*)d_keys; kp.out_scores = (double*)d_scores; kp.out_counts = (uint32_t*)d_counts;
+    kt = &m.kt[m.next_kt];
+    m.next_kt = (m.next_kt + 1) % N_KTIMER;
+    m.harvest(*kt, true);
+    PS_HIP(hipEventRecord(kt->a, st));
+    Plan shape;
+    shape.multi_expansion = multi;
+    launch_score<false>(m, sc, shape, kp, m.n_cu, st, kt->m);
+    PS_HIP(hipEventRecord(kt->b, st));
+    kt->pending = true;
+    m.last_kt = kt;
+    if (caller && caller != st) {  // the merge overwrites the caller's output buffers: not before the caller's earlier work is through
+      PS_HIP(hipEventRecord(c.entry, caller));
+      PS_HIP(hipStreamWaitEvent(st, c.entry, 0));
+    }
+    const uint32_t mw = max_slots ? std::min<uint32_t>(m.tune.daat_merge_waves, std::max<uint32_t>(1, (max_slots + 7) / 8)) : m.tune.daat_merge_waves;
+    hipLaunchKernelGGL(k_merge_items, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
+    PS_HIP(hipGetLastError());
+    c.ctl_clean = true;  // k_merge_items zeroes the context's control words behind itself
+  } catch (...) {
+    c.ctl_clean = false;
+    c.row_sig.clear();
+    forget_rows(m);
+    throw;
+  }
+  PS_HIP(hipEventRecord(c.done, st));
+  c.busy = true;
+  if (caller && caller != st) PS_HIP(hipStreamWaitEvent(caller, c.done, 0));
+  m.last_layout_bytes = 0;
+  m.last_rows = 0;
+  m.last_rows_built = 0;
+}
+
+// A host-planned K1d batch: the plan image (entries | qbeg | qterms_len) goes through a pinned slot into
+// the context's device buffer (k_upload on the context's stream), everything else as above.
+void enqueue_daat_host(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t n_items, uint32_t max_slots,
+                       size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller) {
+  EngineImpl::DaatCtx& c = acquire_ctx(m);
+  hipStream_t st = c.stream;
+  if (m.tail_pending) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));  // (a k_score / full-result batch still in flight)
+  const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size();
+  const size_t off_q = ne * sizeof(ps_plan_entry), off_l = off_q + (B + 1) * 4, total = (off_l + B * 4 + 15) & ~(size_t)15;
+  Stage& sg = m.stage[m.next_stage];
+  m.next_stage = (m.next_stage + 1) % N_STAGE;
+  sg.ensure(total + 16);
+  memcpy(sg.p, plan.entries.data(), ne * sizeof(ps_plan_entry));
+  memcpy(sg.p + off_q, plan.qbeg.data(), (B + 1) * 4);
+  if (B) memcpy(sg.p + off_l, plan.qterms_len.data(), B * 4);
+  c.stage.ensure(total + 64);
+  const size_t n16 = (total + 15) / 16;
+  hipLaunchKernelGGL(k_upload, dim3((uint32_t)std::max<size_t>(1, std::min<size_t>(256, (n16 + 255) / 256))), dim3(256), 0, st,
+                     reinterpret_cast<const uint4*>(sg.dp), reinterpret_cast<uint4*>(c.stage.p), n16);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipEventRecord(sg.done, st));
+  sg.pending = true;
+  enqueue_daat(m, c, sc, boosts, reinterpret_cast<ps_plan_entry*>(c.stage.p), reinterpret_cast<const uint32_t*>(c.stage.p + off_q),
+               reinterpret_cast<const uint32_t*>(c.stage.p + off_l), B, ne, plan.max_qterms, plan.multi_expansion, n_items, max_slots, top_k,
+               d_keys, d_scores, d_counts, caller);
 }
 
 // Enqueue plan upload + K1/K2 + K3 on `st`, writing the final top-k to the given buffers (device
@@ -1662,6 +1800,17 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     fprintf(stderr, "[ps] %-12s %.3f ms\n", what, n - tt);
     tt = now_ms();
   };
+  refresh_tuning(m);
+  m.last_bounds_recomputed = false;
+  if (daat_eligible(m, sc, boosts, B, plan.entries.size(), plan.max_entries, plan.multi_expansion)) {
+    uint32_t max_slots = 0;
+    const size_t n_items = count_daat_items(m, plan, &max_slots);
+    if (n_items && n_items < 0xFFFFFFF0ull) {
+      enqueue_daat_host(m, sc, boosts, plan, n_items, max_slots, top_k, d_keys, d_scores, d_counts, st);
+      TT("k1d batch");
+      return;
+    }
+  }
   if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
   m.tail_pending = false;
   const bool timed = !sync_path || B >= 8 || time_all;
@@ -1670,15 +1819,11 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   stage_plan(m, sc, boosts, plan, st, kp, true, sync_path);
   TT("stage_plan");
   kp.K = (uint32_t)top_k;
-  const size_t n_cand = kp.n_ditems ? (size_t)kp.n_ditems * top_k : (size_t)B * kp.n_super * top_k;
+  const size_t n_cand = (size_t)B * kp.n_super * top_k;
   m.d_cand_score.ensure(n_cand + 1);
   m.d_cand_doc.ensure(n_cand + 1);
   kp.cand_score = m.d_cand_score.p;
   kp.cand_doc = m.d_cand_doc.p;
-  if (kp.n_ditems) {
-    m.d_cand_cnt.ensure((size_t)kp.n_ditems + 1);
-    kp.cand_cnt = m.d_cand_cnt.p;
-  }
   TT("ctl");
   kp.out_keys = (uint64_t*)d_keys;
   kp.out_scores = (double*)d_scores;
@@ -1704,14 +1849,8 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   }
   if (B) {
     // one wave per ~4 wave-wide candidate loads, at most MERGE_WAVES
-    if (kp.n_ditems) {
-      const uint32_t mw = m.daat_max_slots ? std::min<uint32_t>(m.tune.daat_merge_waves, std::max<uint32_t>(1, (m.daat_max_slots + 7) / 8))
-                                           : m.tune.daat_merge_waves;
-      hipLaunchKernelGGL(k_merge_items, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
-    } else {
     const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));
     hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
-    }
     PS_HIP(hipGetLastError());
     m.ctl_clean = true;  // k_merge zeroes the control words behind itself
   }
@@ -1813,53 +1952,52 @@ void ensure_dev_trie(EngineImpl& m) {
   std::vector<uint32_t> fc(s.fchar.begin(), s.fchar.end()), fd(s.fchild.begin(), s.fchild.end());
   if (fc.empty()) { fc.push_back(0); fd.push_back(0); }
   up(m.d_fchar, fc); up(m.d_fchild, fd);
-  if (!m.h_totals) PS_HIP(hipHostMalloc((void**)&m.h_totals, sizeof(PlanTotals), hipHostMallocDefault));
+  if (!m.h_totals) {
+    PS_HIP(hipHostMalloc((void**)&m.h_totals, sizeof(PlanTotals), hipHostMallocMapped | hipHostMallocCoherent));
+    PS_HIP(hipHostGetDevicePointer((void**)&m.d_totals_mapped, m.h_totals, 0));
+  }
   m.dev_trie_valid = true;
 }
 
-// Plans a flat BM25 batch on the device into plan set `ps_`: text -> k_plan count pass -> k_plan_scan -> (the
-// host reads the totals: one short synchronisation of `plan_stream`, never of the scoring stream) -> k_plan
-// fill pass.  Everything runs on `plan_stream`, so it overlaps the scoring of the previous batch.
-PlanTotals device_plan(EngineImpl& m, EngineImpl::PlanSet& ps_, const char* text, const uint64_t* offsets, size_t B) {
+// Plans a flat BM25 batch on the device into context `c`: text -> k_plan count pass -> k_plan_scan -> (the
+// host reads the totals: one short synchronisation of the CONTEXT's stream - the other context's batch keeps
+// running) -> k_plan fill pass.
+PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, const uint64_t* offsets, size_t B) {
   ensure_dev_trie(m);
-  if (!m.plan_stream) PS_HIP(hipStreamCreateWithFlags(&m.plan_stream, hipStreamNonBlocking));
-  if (!ps_.planned) {
-    PS_HIP(hipEventCreateWithFlags(&ps_.planned, hipEventDisableTiming));
-    PS_HIP(hipEventCreateWithFlags(&ps_.done, hipEventDisableTiming));
-    PS_HIP(hipEventCreateWithFlags(&ps_.h.done, hipEventDisableTiming));
-  }
-  hipStream_t st = m.plan_stream;
-  // the batch that was scored from this set must be through before the set is written again
-  if (ps_.busy) { PS_HIP(hipStreamWaitEvent(st, ps_.done, 0)); ps_.busy = false; }
+  EngineImpl::PlanSet& ps_ = c.plan;
+  hipStream_t st = c.stream;
   const size_t n_bytes = B ? (size_t)offsets[B] : 0;
   if (n_bytes >= 0xFFFFFFF0ull) throw std::length_error("device planner: more than 4 GiB of query text");
   const size_t off_bytes = (B + 1) * 8, text_at = (off_bytes + 15) & ~(size_t)15;
   ps_.h.ensure(text_at + n_bytes + 16);  // (its previous copy finished before the previous totals were read)
   memcpy(ps_.h.p, offsets, off_bytes);
   if (n_bytes) memcpy(ps_.h.p + text_at, text, n_bytes);
-  ps_.qtext.ensure(n_bytes + 16);
-  ps_.qoff.ensure(B + 2);
-  PS_HIP(hipMemcpyAsync(ps_.qoff.p, ps_.h.p, off_bytes, hipMemcpyHostToDevice, st));
-  if (n_bytes) PS_HIP(hipMemcpyAsync(ps_.qtext.p, ps_.h.p + text_at, n_bytes, hipMemcpyHostToDevice, st));
+  // offsets | text in one image, copied by a kernel that reads the device-mapped pinned slot (the copy
+  // engine's hand-over costs tens of microseconds per transfer, and the host waits for this stream below)
+  const size_t n16 = (text_at + n_bytes + 15) / 16;
+  ps_.qtext.ensure(n16 * 16 + 64);
+  hipLaunchKernelGGL(k_upload, dim3((uint32_t)std::max<size_t>(1, std::min<size_t>(256, (n16 + 255) / 256))), dim3(256), 0, st,
+                     reinterpret_cast<const uint4*>(ps_.h.dp), reinterpret_cast<uint4*>(ps_.qtext.p), n16);
+  const uint64_t* d_qoff = reinterpret_cast<const uint64_t*>(ps_.qtext.p);
+  const char* d_qtext = ps_.qtext.p + text_at;
   ps_.cnt.ensure(B + 1); ps_.qtl.ensure(B + 1); ps_.nterms.ensure(B + 1); ps_.multi.ensure(B + 1); ps_.items.ensure(B + 1);
-  ps_.post.ensure(B + 1); ps_.qbeg.ensure(B + 2); ps_.qorder.ensure(B + 1); ps_.tot.ensure(1);
+  ps_.post.ensure(B + 1); ps_.qbeg.ensure(B + 2); ps_.qorder.ensure(B + 1);
   DevTrie t{m.d_fnodes.p, m.d_fchar.p, m.d_fchild.p, m.d_term_df.p, m.d_term_meta.p, m.d_term_delta.p, m.d_term_idf.p,
             m.d_layer_a.p, m.d_layer_b.p, m.d_eb_table.p, m.eb_n};
   const uint32_t blocks = (uint32_t)((B + 63) / 64);
-  hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, ps_.qtext.p, ps_.qoff.p, (uint32_t)B, nullptr,
+  hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, d_qtext, d_qoff, (uint32_t)B, nullptr,
                      nullptr, ps_.cnt.p, ps_.qtl.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, nullptr, ps_.items.p, m.tune.daat_chunk,
                      m.tune.daat_split_div);
+  // (the totals are written straight into pinned, device-mapped host memory: no copy-engine transfer to wait for)
   hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
-                     ps_.qbeg.p, ps_.tot.p);
+                     ps_.qbeg.p, m.d_totals_mapped);
   PS_HIP(hipGetLastError());
-  PS_HIP(hipMemcpyAsync(m.h_totals, ps_.tot.p, sizeof(PlanTotals), hipMemcpyDeviceToHost, st));
   sync_stream(st);
   const PlanTotals tot = *m.h_totals;
   ps_.entries.ensure((size_t)tot.n_entries + 1);
-  hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, ps_.qtext.p, ps_.qoff.p, (uint32_t)B, ps_.qbeg.p,
+  hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, d_qtext, d_qoff, (uint32_t)B, ps_.qbeg.p,
                      ps_.entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, ps_.qorder.p, nullptr, 0u, 1u);
   PS_HIP(hipGetLastError());
-  PS_HIP(hipEventRecord(ps_.planned, st));
   return tot;
 }
 
@@ -1895,18 +2033,17 @@ void Engine::plan_device(const char* text, const uint64_t* offsets, size_t B, Pl
   std::lock_guard<std::mutex> lock(m.mu);
   PS_HIP(hipSetDevice(m.device));
   refresh_tuning(m);
-  EngineImpl::PlanSet& ps_ = m.pset[m.next_pset];
-  m.next_pset ^= 1;
-  const PlanTotals tot = device_plan(m, ps_, text, offsets, B);
+  EngineImpl::DaatCtx& c = acquire_ctx(m);
+  const PlanTotals tot = device_plan(m, c, text, offsets, B);
   out = Plan{};
   out.entries.resize(tot.n_entries);
   out.qbeg.resize(B + 1);
   out.qterms_len.resize(B);
   out.n_nodes.assign(B, 0);
-  PS_HIP(hipStreamSynchronize(m.plan_stream));
-  if (tot.n_entries) PS_HIP(hipMemcpy(out.entries.data(), ps_.entries.p, (size_t)tot.n_entries * sizeof(ps_plan_entry), hipMemcpyDeviceToHost));
-  PS_HIP(hipMemcpy(out.qbeg.data(), ps_.qbeg.p, (B + 1) * 4, hipMemcpyDeviceToHost));
-  if (B) PS_HIP(hipMemcpy(out.qterms_len.data(), ps_.qtl.p, B * 4, hipMemcpyDeviceToHost));
+  PS_HIP(hipStreamSynchronize(c.stream));
+  if (tot.n_entries) PS_HIP(hipMemcpy(out.entries.data(), c.plan.entries.p, (size_t)tot.n_entries * sizeof(ps_plan_entry), hipMemcpyDeviceToHost));
+  PS_HIP(hipMemcpy(out.qbeg.data(), c.plan.qbeg.p, (B + 1) * 4, hipMemcpyDeviceToHost));
+  if (B) PS_HIP(hipMemcpy(out.qterms_len.data(), c.plan.qtl.p, B * 4, hipMemcpyDeviceToHost));
   out.postings = tot.postings;
   out.max_entries = tot.max_entries;
   out.max_qterms = tot.max_qterms;
@@ -1938,87 +2075,84 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   const double t0 = now_ms();
   m.last_bounds_recomputed = false;
   hipStream_t st = stream ? (hipStream_t)stream : m.stream;
-  EngineImpl::PlanSet& ps_ = m.pset[m.next_pset];
-  m.next_pset ^= 1;
-  const PlanTotals tot = device_plan(m, ps_, text, offsets, B);
+  EngineImpl::DaatCtx& c = acquire_ctx(m);
+  if (m.tail_pending) PS_HIP(hipStreamWaitEvent(c.stream, m.ev[0], 0));  // (a k_score / full-result batch still in flight)
+  const PlanTotals tot = device_plan(m, c, text, offsets, B);
   if (tot.max_qterms >= 0x7FFF) throw std::length_error("more than 32766 non-empty terms in one query");
   const double t1 = now_ms();
-  if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
-  m.tail_pending = false;
-  PS_HIP(hipStreamWaitEvent(st, ps_.planned, 0));
-  Plan shape;  // the scalars the launch geometry needs; the entries stay on the device
-  shape.max_entries = tot.max_entries;
-  shape.max_qterms = tot.max_qterms;
-  shape.multi_expansion = tot.multi != 0;
-  shape.postings = tot.postings;
-  KParams kp;
-  try {
-  fill_common_kparams(m, sc, boosts, B, shape.max_qterms, kp);
-  kp.plan = ps_.entries.p;
-  kp.qbeg = ps_.qbeg.p;
-  kp.qterms_len = ps_.qtl.p;
-  kp.qorder = ps_.qorder.p;
-  const size_t n_thr = B + 2;
-  const bool fresh = m.d_gthr.ensure(n_thr, true);
-  kp.gthr = m.d_gthr.p;
-  if (!(m.ctl_clean && !fresh)) {
-    PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
-    PS_HIP(hipMemsetAsync(m.d_work, 0, 256, st));
-    PS_HIP(hipMemsetAsync(m.d_prep_ctl, 0, sizeof(PrepCtl), st));
-  }
-  m.ctl_clean = false;
-  const bool daat = m.tune.daat && B >= m.tune.daat_min_batch && tot.n_entries && tot.n_items && m.tune.lut && bm25_params_sane(s, sc, boosts) &&
-                    tot.max_entries <= 64 && (!shape.multi_expansion || m.tune.daat_multi) && tot.n_items < 0xFFFFFFF0ull;
-  BatchImage img;
-  img.B = B;
-  if (daat) {
-    kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0;
-    launch_prep(m, sc, boosts, kp, st, ps_.entries.p, ps_.qbeg.p, B, tot.n_entries, shape.multi_expansion, (size_t)tot.n_items);
-    m.daat_max_slots = 0;  // (unknown on the host: K3d takes its widest geometry)
+  EngineImpl::PlanSet& ps_ = c.plan;
+  if (daat_eligible(m, sc, boosts, B, tot.n_entries, tot.max_entries, tot.multi != 0) && tot.n_items && tot.n_items < 0xFFFFFFF0ull) {
+    enqueue_daat(m, c, sc, boosts, ps_.entries.p, ps_.qbeg.p, ps_.qtl.p, B, tot.n_entries, tot.max_qterms, tot.multi != 0,
+                 (size_t)tot.n_items, 0u, top_k, d_keys, d_scores, d_counts, st);
   } else {
-    choose_run_length(m, sc, shape, img, true, kp);
-  }
-  kp.K = (uint32_t)top_k;
-  const size_t n_cand = kp.n_ditems ? (size_t)kp.n_ditems * top_k : (size_t)B * kp.n_super * top_k;
-  m.d_cand_score.ensure(n_cand + 1);
-  m.d_cand_doc.ensure(n_cand + 1);
-  kp.cand_score = m.d_cand_score.p;
-  kp.cand_doc = m.d_cand_doc.p;
-  kp.out_keys = (uint64_t*)d_keys; kp.out_scores = (double*)d_scores; kp.out_counts = (uint32_t*)d_counts;
-  EngineImpl::KTimer* kt = &m.kt[m.next_kt];
-  m.next_kt = (m.next_kt + 1) % N_KTIMER;
-  m.harvest(*kt, true);
-  PS_HIP(hipEventRecord(kt->a, st));
-  m.build_slots.clear();
-  launch_score<false>(m, sc, shape, kp, m.n_cu, st, kt->m);
-  PS_HIP(hipEventRecord(kt->b, st));
-  kt->pending = true;
-  m.last_kt = kt;
-  if (B) {
-    if (kp.n_ditems) {
-      hipLaunchKernelGGL(k_merge_items, dim3((uint32_t)B), dim3(WAVE * m.tune.daat_merge_waves), 0, st, kp);
-    } else {
-      const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));
-      hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
+    // the batches K1d does not take: K1 k_score / K3 k_merge from the device-built plan, in the engine's
+    // single set of per-batch buffers, once nothing else is in flight
+    PS_HIP(hipEventRecord(c.planned, c.stream));
+    wait_daat_contexts(m, st);
+    if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
+    m.tail_pending = false;
+    PS_HIP(hipStreamWaitEvent(st, c.planned, 0));
+    Plan shape;  // the scalars the launch geometry needs; the entries stay on the device
+    shape.max_entries = tot.max_entries;
+    shape.max_qterms = tot.max_qterms;
+    shape.multi_expansion = tot.multi != 0;
+    shape.postings = tot.postings;
+    KParams kp;
+    try {
+      fill_common_kparams(m, sc, boosts, B, shape.max_qterms, kp);
+      kp.plan = ps_.entries.p;
+      kp.qbeg = ps_.qbeg.p;
+      kp.qterms_len = ps_.qtl.p;
+      kp.qorder = ps_.qorder.p;
+      const size_t n_thr = B + 2;
+      const bool fresh = m.d_gthr.ensure(n_thr, true);
+      kp.gthr = m.d_gthr.p;
+      if (!(m.ctl_clean && !fresh)) {
+        PS_HIP(hipMemsetAsync(m.d_gthr.p, 0, n_thr * 8, st));
+        PS_HIP(hipMemsetAsync(m.d_work, 0, 256, st));
+      }
+      m.ctl_clean = false;
+      BatchImage img;
+      img.B = B;
+      choose_run_length(m, sc, shape, img, true, kp);
+      kp.K = (uint32_t)top_k;
+      const size_t n_cand = (size_t)B * kp.n_super * top_k;
+      m.d_cand_score.ensure(n_cand + 1);
+      m.d_cand_doc.ensure(n_cand + 1);
+      kp.cand_score = m.d_cand_score.p;
+      kp.cand_doc = m.d_cand_doc.p;
+      kp.out_keys = (uint64_t*)d_keys; kp.out_scores = (double*)d_scores; kp.out_counts = (uint32_t*)d_counts;
+      EngineImpl::KTimer* kt = &m.kt[m.next_kt];
+      m.next_kt = (m.next_kt + 1) % N_KTIMER;
+      m.harvest(*kt, true);
+      PS_HIP(hipEventRecord(kt->a, st));
+      m.build_slots.clear();
+      launch_score<false>(m, sc, shape, kp, m.n_cu, st, kt->m);
+      PS_HIP(hipEventRecord(kt->b, st));
+      kt->pending = true;
+      m.last_kt = kt;
+      if (B) {
+        const uint32_t mw = (uint32_t)std::min<size_t>(MERGE_WAVES, std::max<size_t>(1, ((size_t)kp.n_super * top_k + 255) / 256));
+        hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
+        PS_HIP(hipGetLastError());
+        m.ctl_clean = true;
+      }
+    } catch (...) {
+      forget_rows(m);
+      throw;
     }
-    PS_HIP(hipGetLastError());
-    m.ctl_clean = true;
+    PS_HIP(hipEventRecord(c.done, st));  // the context's plan buffers are free again behind this batch
+    c.busy = true;
+    PS_HIP(hipEventRecord(m.ev[0], st));
+    m.tail_stream = st;
+    m.tail_pending = true;
   }
-  } catch (...) {
-    forget_rows(m);
-    throw;
-  }
-  PS_HIP(hipEventRecord(ps_.done, st));  // the plan set is free again behind this batch
-  ps_.busy = true;
-  PS_HIP(hipEventRecord(m.ev[0], st));
-  m.tail_stream = st;
-  m.tail_pending = true;
   memset(&stats, 0, sizeof(stats));
   stats.n_queries = B;
   stats.n_plan_entries = tot.n_entries;
   stats.postings_visited = tot.postings;
   stats.algorithmic_bytes = tot.postings * (4 + 8 * (uint64_t)s.F) + (uint64_t)B * top_k * 16;
-  stats.plan_ms = t1 - t0;  // device planner incl. its one synchronisation (of the planning stream)
+  stats.plan_ms = t1 - t0;  // device planner incl. its one synchronisation (of the context's stream)
   stats.device_planned = 1;
   stats.bounds_recomputed = m.last_bounds_recomputed ? 1u : 0u;
   if (!stream) {
