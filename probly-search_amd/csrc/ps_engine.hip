@@ -9,7 +9,7 @@
 //
 //       k_pack_tfl   per snapshot (and per delta): the packed {tf, field length} posting words the hot kernels stream
 //       k_upload     per batch: the staged plan, read from the device-mapped pinned slot
-//       k_list_bounds / k_prep_query / k_prep_finish / k_prep_items  per K1d batch (ps_prep_kernels.hpp): per-list score
+//       k_list_bounds / k_prep_batch / k_prep_items  per K1d batch (ps_prep_kernels.hpp): per-list score
 //                    bounds, work descriptors, item order, candidate slots and dense-row choice, all on the device
 //   K0  k_bm25_lut   per (k1, b): saturated-tf table tfn(field, tf < 16, field length), same f64 expression
 //   K0b k_dense_rows per-document score rows of the hot (list, idf, boost) combinations not yet resident
@@ -219,7 +219,7 @@ struct EngineImpl {
   // HIP-event pairs around every launch of the scoring kernel (K1/K2), harvested lazily so a
   // caller that pipelines batches on its own stream still gets per-launch durations.
   // a: before K0/K0b, m: before the scoring kernel (K1 / K2 / K1d), b: after it
-  struct KTimer { hipEvent_t a = nullptr, m = nullptr, b = nullptr; bool pending = false; };
+  struct KTimer { hipEvent_t a = nullptr, m = nullptr, b = nullptr, r = nullptr; bool pending = false, split = false; };
   KTimer kt[N_KTIMER];
   KTimer* last_kt = nullptr;
   // N2 device-side planner: the frozen trie + per-term / per-layer tables in HBM (uploaded on first
@@ -236,24 +236,25 @@ struct EngineImpl {
     DevBuf<uint32_t> cnt, qtl, nterms, multi, qbeg, qorder, items;
     DevBuf<unsigned long long> post;
     DevBuf<ps_plan_entry> entries;
+    DevBuf<int32_t> tok_node;  // [B][64] trie node of every token (count pass -> fill pass)
     Stage h;  // pinned copy of the batch's offsets | text (the caller's buffer may be pageable)
     void release() {
       qtext.release(); cnt.release(); qtl.release(); nterms.release(); multi.release(); qbeg.release();
-      qorder.release(); items.release(); post.release(); entries.release();
+      qorder.release(); items.release(); post.release(); entries.release(); tok_node.release();
       if (h.p) (void)hipHostFree(h.p);
       if (h.done) (void)hipEventDestroy(h.done);
     }
   };
-  // Everything one K1d batch owns on the device, twice: batch s + 1 is planned, prepared and scored on
-  // the other context's stream while batch s is still in flight, so the GPU never idles between a
-  // batch's merge and the next batch's first kernel (and the tail of one k_daat launch is filled by the
-  // head of the next).  Only the merge - the kernel that writes the caller's output buffers - waits for
-  // the caller's stream; the caller's stream in turn waits for the batch's `done` event.
+  // Everything one K1d batch owns on the device, twice.  Batch s + 1 is uploaded / planned, prepared and
+  // has its dense rows scored on the engine's PREPARATION stream (high priority: its own hardware queue,
+  // and its small kernels are dispatched between the workgroups of a running k_daat) while batch s is
+  // still being scored on the SCORING stream; the scoring stream then only carries k_daat and the merge
+  // of consecutive batches, back to back.  Only the merge - the kernel that writes the caller's output
+  // buffers - waits for the caller's stream; the caller's stream in turn waits for the batch's `done`.
   struct DaatCtx {
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;     // behind the batch's last kernel
+    hipEvent_t done = nullptr;     // behind the batch's merge (scoring stream)
     hipEvent_t entry = nullptr;    // the caller stream's position when the batch was submitted
-    hipEvent_t planned = nullptr;  // behind the planner's fill pass (batches that fall back to k_score)
+    hipEvent_t prepared = nullptr; // behind the batch's preparation (preparation stream)
     bool busy = false;
     PlanSet plan;                  // device-planned batches
     DevBuf<unsigned char> stage;   // host-planned batches: entries | qbeg | qterms_len as uploaded
@@ -275,6 +276,7 @@ struct EngineImpl {
   };
   DaatCtx dctx[2];
   int next_dctx = 0;
+  hipStream_t prep_stream = nullptr, score_stream = nullptr;
   hipEvent_t lut_ready = nullptr;  // behind the most recent k_bm25_lut
   PlanTotals* h_totals = nullptr;  // pinned, device-mapped: k_plan_scan writes the totals where the host reads them
   PlanTotals* d_totals_mapped = nullptr;
@@ -323,7 +325,8 @@ struct EngineImpl {
     if (wait) (void)hipEventSynchronize(t.b);
     float ms = 0, ms0 = 0;
     if (hipEventElapsedTime(&ms, t.m, t.b) == hipSuccess) { kt_total_ms += ms; kt_launches++; }
-    if (hipEventElapsedTime(&ms0, t.a, t.m) == hipSuccess) kt_rows_ms += ms0;
+    // (K1d batches score their rows on the preparation stream: a -> r there, m -> b on the scoring stream)
+    if (hipEventElapsedTime(&ms0, t.a, t.split ? t.r : t.m) == hipSuccess) kt_rows_ms += ms0;
     t.pending = false;
   }
 };
@@ -365,7 +368,7 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     for (auto& ev : m.ev) PS_HIP(hipEventCreate(&ev));
     for (auto& sg : m.stage) PS_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&m.result.done, hipEventDisableTiming));
-    for (auto& t : m.kt) { PS_HIP(hipEventCreate(&t.a)); PS_HIP(hipEventCreate(&t.m)); PS_HIP(hipEventCreate(&t.b)); }
+    for (auto& t : m.kt) { PS_HIP(hipEventCreate(&t.a)); PS_HIP(hipEventCreate(&t.m)); PS_HIP(hipEventCreate(&t.b)); PS_HIP(hipEventCreate(&t.r)); }
     const size_t P = snap.P, F = snap.F;
     PS_HIP(hipMalloc((void**)&m.d_doc, P * 4));
     PS_HIP(hipMalloc((void**)&m.d_tf, P * F * 4));
@@ -419,10 +422,11 @@ Engine::~Engine() {
     c.cand_score.release(); c.rows.release(); c.gthr.release();
     for (void* p : {(void*)c.ctl, (void*)c.work, (void*)c.row_state, (void*)c.row_desc})
       if (p) (void)hipFree(p);
-    for (hipEvent_t e : {c.done, c.entry, c.planned})
+    for (hipEvent_t e : {c.done, c.entry, c.prepared})
       if (e) (void)hipEventDestroy(e);
-    if (c.stream) (void)hipStreamDestroy(c.stream);
   }
+  if (m.prep_stream) (void)hipStreamDestroy(m.prep_stream);
+  if (m.score_stream) (void)hipStreamDestroy(m.score_stream);
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fchar.release(); m.d_fchild.release();
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release();
   if (m.h_totals) (void)hipHostFree(m.h_totals);
@@ -440,6 +444,7 @@ Engine::~Engine() {
     if (t.a) (void)hipEventDestroy(t.a);
     if (t.m) (void)hipEventDestroy(t.m);
     if (t.b) (void)hipEventDestroy(t.b);
+    if (t.r) (void)hipEventDestroy(t.r);
   }
   if (m.stream) (void)hipStreamDestroy(m.stream);
   delete impl_;
@@ -792,9 +797,8 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
     PS_HIP(hipStreamWaitEvent(st, tgt->ready, 0));
     return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p)};
   }
-  // M is rewritten in place (and a J array may be recycled): nothing that reads them may still be in flight
-  for (auto& c : m.dctx)
-    if (c.busy && c.stream != st) PS_HIP(hipStreamWaitEvent(st, c.done, 0));
+  // (M is rewritten in place and a J array may be recycled: their only readers are the preparation kernels,
+  // which run on this same stream, in order)
   const double t0 = now_ms();
   if (lb.n_layers != nl || lb.n_units == 0) {  // the work list: one wave per list, long lists in 16 Ki-posting segments
     std::vector<BoundUnit> units;
@@ -870,7 +874,7 @@ void ensure_row_candidates(EngineImpl& m, hipStream_t st) {
 void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, KParams& kp, ps_plan_entry* d_plan,
                  const uint32_t* d_qbeg, size_t B, size_t ne, bool multi, size_t items_bound) {
   const Snapshot& s = *m.snap;
-  hipStream_t st = c.stream;
+  hipStream_t st = m.prep_stream;
   const uint64_t rc0 = m.bounds.recomputed;
   const BoundsRef br = ensure_list_bounds(m, sc, boosts, kp, st);
   m.last_bounds_recomputed = m.bounds.recomputed != rc0;
@@ -906,8 +910,7 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   pp.rows_resident = m.tune.row_cache_mb != 0;
   pp.layer_a = m.d_layer_a.p; pp.row_state = c.row_state; pp.row_desc = c.row_desc; pp.wstats = m.d_wstats;
   if (B) {
-    hipLaunchKernelGGL(k_prep_query, dim3((uint32_t)((B + 63) / 64)), dim3(64), 0, st, pp);
-    hipLaunchKernelGGL(k_prep_finish, dim3(1), dim3(64), 0, st, pp);
+    hipLaunchKernelGGL(k_prep_batch, dim3(1), dim3(1024), 0, st, pp);
     if (ne) hipLaunchKernelGGL(k_prep_items, dim3((uint32_t)((ne + 3) / 4)), dim3(256), 0, st, pp);
     PS_HIP(hipGetLastError());
   }
@@ -922,15 +925,22 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   kp.row_planes = 1; kp.row_mode = 0; kp.row_stride = (uint64_t)s.tiles_cap * s.T;
 }
 
-// The next K1d batch context (they alternate); its stream, events and control blocks exist from first use.
+// The next K1d batch context (they alternate); the two streams, its events and control blocks exist from first use.
 EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
+  if (!m.prep_stream) {
+    // the preparation stream at the highest priority: a queue of its own (queues are pooled per priority),
+    // and its small kernels do not wait behind the tens of thousands of workgroups of a running k_daat
+    int lo = 0, hi = 0;
+    PS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    PS_HIP(hipStreamCreateWithPriority(&m.prep_stream, hipStreamNonBlocking, hi));
+    PS_HIP(hipStreamCreateWithFlags(&m.score_stream, hipStreamNonBlocking));
+  }
   EngineImpl::DaatCtx& c = m.dctx[m.next_dctx];
   m.next_dctx ^= 1;
-  if (!c.stream) {
-    PS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  if (!c.done) {
     PS_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.entry, hipEventDisableTiming));
-    PS_HIP(hipEventCreateWithFlags(&c.planned, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&c.prepared, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.plan.h.done, hipEventDisableTiming));
     PS_HIP(hipMalloc((void**)&c.ctl, sizeof(PrepCtl)));
     PS_HIP(hipMalloc((void**)&c.work, 256));
@@ -939,6 +949,9 @@ EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
     PS_HIP(hipMemset(c.row_state, 0, sizeof(RowState) * PREP_MAX_ROWS));
     c.ctl_clean = false;
   }
+  // the batch that used this context last must be through before its buffers are written again
+  if (c.busy) PS_HIP(hipStreamWaitEvent(m.prep_stream, c.done, 0));
+  if (m.tail_pending) PS_HIP(hipStreamWaitEvent(m.prep_stream, m.ev[0], 0));  // (a k_score / full-result batch still in flight)
   return c;
 }
 
@@ -1596,14 +1609,14 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
   if (!FULL) {
     m.wc_k = kp.K;
     m.wc_results += (uint64_t)kp.B * kp.K;
-    if (kp.n_ditems) m.wc_items += kp.n_ditems; else m.wc_cand_slots += (uint64_t)n_items * kp.K;
+    m.wc_cand_slots += (uint64_t)n_items * kp.K;
   }
   if (sc.kind == PS_SCORER_BM25) {
     // K0 runs when (k1, b) change.  The table is shared by every stream: a rebuild first waits for the K1d
     // contexts still reading it, and launches on other streams wait for the rebuild's event.
     if (kp.lut_rows && !(m.lut_valid && m.lut_k1 == sc.bm25_k1 && m.lut_b == sc.bm25_b && m.tune.lut_cache)) {
       for (auto& c : m.dctx)
-        if (c.busy && c.stream != st) PS_HIP(hipStreamWaitEvent(st, c.done, 0));
+        if (c.busy) PS_HIP(hipStreamWaitEvent(st, c.done, 0));
       if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
       hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, st, kp, const_cast<double*>(kp.lut));
       PS_HIP(hipEventRecord(m.lut_ready, st));
@@ -1611,21 +1624,9 @@ void launch_score(EngineImpl& m, const ps_scorer_desc& sc, const Plan& plan, KPa
     } else if (kp.lut_rows && m.lut_stream != st) {
       PS_HIP(hipStreamWaitEvent(st, m.lut_ready, 0));
     }
-    if (!FULL && kp.n_ditems) {
-      // K1d: the rows to score were listed on the device (k_prep_finish); a fixed grid takes (row, tile range) units
-      if (m.cands.n) {
-        const uint32_t per_row = std::min(2048u, std::max(256u, kp.n_tiles));
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_row * m.cands.n, 4096);
-        hipLaunchKernelGGL(k_dense_rows_dyn, dim3(grid), dim3(256), 0, st, kp, const_cast<double*>(kp.rows),
-                           reinterpret_cast<const PrepCtl*>(kp.prep_ctl), per_row);
-      }
-      if (mid) PS_HIP(hipEventRecord(mid, st));
-      launch_daat(m, kp, plan.multi_expansion, n_cu, st);
-    } else {
-      launch_rows(kp, m.build_slots, st);
-      if (mid) PS_HIP(hipEventRecord(mid, st));
-      launch_k_score<MODE_BM25, FULL>(m, kp, plan.multi_expansion, n_cu, st);
-    }
+    launch_rows(kp, m.build_slots, st);
+    if (mid) PS_HIP(hipEventRecord(mid, st));
+    launch_k_score<MODE_BM25, FULL>(m, kp, plan.multi_expansion, n_cu, st);
   } else {
     launch_rows(kp, m.build_slots, st);
     if (mid) PS_HIP(hipEventRecord(mid, st));
@@ -1691,15 +1692,15 @@ bool daat_eligible(const EngineImpl& m, const ps_scorer_desc& sc, const double* 
          bm25_params_sane(*m.snap, sc, boosts) && max_entries <= 64 && (!multi || m.tune.daat_multi) && m.snap->lut_rows != 0;
 }
 
-// The part every K1d batch shares, on its context's stream: control words, device-side preparation,
-// K0b over the rows the preparation listed, k_daat, then - once the caller's stream has reached the
+// The part every K1d batch shares.  Preparation stream: control words, device-side preparation, K0b over
+// the rows the preparation listed.  Scoring stream: k_daat, then - once the caller's stream has reached the
 // point of the call, because the merge is the kernel that writes the caller's buffers - k_merge_items.
 // The caller's stream is made to wait for the batch, so work enqueued on it afterwards sees the results.
 void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, ps_plan_entry* d_plan,
                   const uint32_t* d_qbeg, const uint32_t* d_qtl, size_t B, size_t ne, uint32_t max_qterms, bool multi, size_t n_items,
                   uint32_t max_slots, size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller) {
   const Snapshot& s = *m.snap;
-  hipStream_t st = c.stream;
+  hipStream_t P = m.prep_stream, S = m.score_stream;
   KParams kp;
   EngineImpl::KTimer* kt = nullptr;
   try {
@@ -1710,9 +1711,9 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     const bool fresh = c.gthr.ensure(n_thr, true);
     kp.gthr = c.gthr.p;
     if (!(c.ctl_clean && !fresh)) {
-      PS_HIP(hipMemsetAsync(c.gthr.p, 0, n_thr * 8, st));
-      PS_HIP(hipMemsetAsync(c.work, 0, 256, st));
-      PS_HIP(hipMemsetAsync(c.ctl, 0, sizeof(PrepCtl), st));
+      PS_HIP(hipMemsetAsync(c.gthr.p, 0, n_thr * 8, P));
+      PS_HIP(hipMemsetAsync(c.work, 0, 256, P));
+      PS_HIP(hipMemsetAsync(c.ctl, 0, sizeof(PrepCtl), P));
     }
     c.ctl_clean = false;
     kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0;
@@ -1727,19 +1728,44 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     kt = &m.kt[m.next_kt];
     m.next_kt = (m.next_kt + 1) % N_KTIMER;
     m.harvest(*kt, true);
-    PS_HIP(hipEventRecord(kt->a, st));
-    Plan shape;
-    shape.multi_expansion = multi;
-    launch_score<false>(m, sc, shape, kp, m.n_cu, st, kt->m);
-    PS_HIP(hipEventRecord(kt->b, st));
+    kt->split = true;
+    // K0b on the preparation stream too: the rows to score were listed on the device (k_prep_finish); a fixed
+    // grid takes (row, tile range) units.  (It evaluates the BM25 expression itself: no table involved.)
+    PS_HIP(hipEventRecord(kt->a, P));
+    if (m.cands.n) {
+      const uint32_t per_row = std::min(2048u, std::max(256u, kp.n_tiles));
+      const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_row * m.cands.n, 4096);
+      hipLaunchKernelGGL(k_dense_rows_dyn, dim3(grid), dim3(256), 0, P, kp, c.rows.p, c.ctl, per_row);
+    }
+    PS_HIP(hipEventRecord(kt->r, P));
+    PS_HIP(hipEventRecord(c.prepared, P));
+    // ---- scoring stream ----
+    PS_HIP(hipStreamWaitEvent(S, c.prepared, 0));
+    // K0 (the saturated-tf table k_daat stages in LDS) runs when (k1, b) change; it is shared by every stream
+    if (kp.lut_rows && !(m.lut_valid && m.lut_k1 == sc.bm25_k1 && m.lut_b == sc.bm25_b && m.tune.lut_cache)) {
+      if (m.tail_pending && m.tail_stream != S) PS_HIP(hipStreamWaitEvent(S, m.ev[0], 0));
+      hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, S, kp, const_cast<double*>(kp.lut));
+      PS_HIP(hipEventRecord(m.lut_ready, S));
+      m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = S;
+    } else if (kp.lut_rows && m.lut_stream != S) {
+      PS_HIP(hipStreamWaitEvent(S, m.lut_ready, 0));
+    }
+    m.wc_launches++;
+    m.wc_k = kp.K;
+    m.wc_results += (uint64_t)kp.B * kp.K;
+    m.wc_items += kp.n_ditems;
+    PS_HIP(hipEventRecord(kt->m, S));
+    launch_daat(m, kp, multi, m.n_cu, S);
+    PS_HIP(hipGetLastError());
+    PS_HIP(hipEventRecord(kt->b, S));
     kt->pending = true;
     m.last_kt = kt;
-    if (caller && caller != st) {  // the merge overwrites the caller's output buffers: not before the caller's earlier work is through
+    if (caller && caller != S) {  // the merge overwrites the caller's output buffers: not before the caller's earlier work is through
       PS_HIP(hipEventRecord(c.entry, caller));
-      PS_HIP(hipStreamWaitEvent(st, c.entry, 0));
+      PS_HIP(hipStreamWaitEvent(S, c.entry, 0));
     }
     const uint32_t mw = max_slots ? std::min<uint32_t>(m.tune.daat_merge_waves, std::max<uint32_t>(1, (max_slots + 7) / 8)) : m.tune.daat_merge_waves;
-    hipLaunchKernelGGL(k_merge_items, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
+    hipLaunchKernelGGL(k_merge_items, dim3((uint32_t)B), dim3(WAVE * mw), 0, S, kp);
     PS_HIP(hipGetLastError());
     c.ctl_clean = true;  // k_merge_items zeroes the context's control words behind itself
   } catch (...) {
@@ -1748,9 +1774,9 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     forget_rows(m);
     throw;
   }
-  PS_HIP(hipEventRecord(c.done, st));
+  PS_HIP(hipEventRecord(c.done, S));
   c.busy = true;
-  if (caller && caller != st) PS_HIP(hipStreamWaitEvent(caller, c.done, 0));
+  if (caller && caller != S) PS_HIP(hipStreamWaitEvent(caller, c.done, 0));
   m.last_layout_bytes = 0;
   m.last_rows = 0;
   m.last_rows_built = 0;
@@ -1761,8 +1787,7 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
 void enqueue_daat_host(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t n_items, uint32_t max_slots,
                        size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller) {
   EngineImpl::DaatCtx& c = acquire_ctx(m);
-  hipStream_t st = c.stream;
-  if (m.tail_pending) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));  // (a k_score / full-result batch still in flight)
+  hipStream_t st = m.prep_stream;
   const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size();
   const size_t off_q = ne * sizeof(ps_plan_entry), off_l = off_q + (B + 1) * 4, total = (off_l + B * 4 + 15) & ~(size_t)15;
   Stage& sg = m.stage[m.next_stage];
@@ -1833,6 +1858,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     kt = &m.kt[m.next_kt];
     m.next_kt = (m.next_kt + 1) % N_KTIMER;
     m.harvest(*kt, true);
+    kt->split = false;
     TT("harvest");
     PS_HIP(hipEventRecord(kt->a, st));
   }
@@ -1882,7 +1908,7 @@ void sync_stream(hipStream_t st) {
 void read_kernel_times(EngineImpl& m, ps_batch_stats& stats) {
   float b = 0, r = 0;
   if (m.last_kt && hipEventElapsedTime(&b, m.last_kt->m, m.last_kt->b) != hipSuccess) b = 0;
-  if (m.last_kt && hipEventElapsedTime(&r, m.last_kt->a, m.last_kt->m) != hipSuccess) r = 0;
+  if (m.last_kt && hipEventElapsedTime(&r, m.last_kt->a, m.last_kt->split ? m.last_kt->r : m.last_kt->m) != hipSuccess) r = 0;
   stats.h2d_ms = 0;
   stats.score_kernel_ms = b;  // the posting-accumulate kernel alone
   stats.kernel_ms = b + r;    // ... plus K0 / K0b in front of it
@@ -1960,12 +1986,12 @@ void ensure_dev_trie(EngineImpl& m) {
 }
 
 // Plans a flat BM25 batch on the device into context `c`: text -> k_plan count pass -> k_plan_scan -> (the
-// host reads the totals: one short synchronisation of the CONTEXT's stream - the other context's batch keeps
-// running) -> k_plan fill pass.
+// host reads the totals: one short synchronisation of the PREPARATION stream - the scoring stream keeps
+// running the previous batch) -> k_plan fill pass.
 PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, const uint64_t* offsets, size_t B) {
   ensure_dev_trie(m);
   EngineImpl::PlanSet& ps_ = c.plan;
-  hipStream_t st = c.stream;
+  hipStream_t st = m.prep_stream;
   const size_t n_bytes = B ? (size_t)offsets[B] : 0;
   if (n_bytes >= 0xFFFFFFF0ull) throw std::length_error("device planner: more than 4 GiB of query text");
   const size_t off_bytes = (B + 1) * 8, text_at = (off_bytes + 15) & ~(size_t)15;
@@ -1984,10 +2010,11 @@ PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
   ps_.post.ensure(B + 1); ps_.qbeg.ensure(B + 2); ps_.qorder.ensure(B + 1);
   DevTrie t{m.d_fnodes.p, m.d_fchar.p, m.d_fchild.p, m.d_term_df.p, m.d_term_meta.p, m.d_term_delta.p, m.d_term_idf.p,
             m.d_layer_a.p, m.d_layer_b.p, m.d_eb_table.p, m.eb_n};
-  const uint32_t blocks = (uint32_t)((B + 63) / 64);
-  hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, d_qtext, d_qoff, (uint32_t)B, nullptr,
+  const uint32_t blocks = (uint32_t)((B + PLAN_WAVES - 1) / PLAN_WAVES);
+  ps_.tok_node.ensure(B * (size_t)WAVE + 1);
+  hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, nullptr,
                      nullptr, ps_.cnt.p, ps_.qtl.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, nullptr, ps_.items.p, m.tune.daat_chunk,
-                     m.tune.daat_split_div);
+                     m.tune.daat_split_div, ps_.tok_node.p);
   // (the totals are written straight into pinned, device-mapped host memory: no copy-engine transfer to wait for)
   hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
                      ps_.qbeg.p, m.d_totals_mapped);
@@ -1995,8 +2022,9 @@ PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
   sync_stream(st);
   const PlanTotals tot = *m.h_totals;
   ps_.entries.ensure((size_t)tot.n_entries + 1);
-  hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(64), 0, st, t, d_qtext, d_qoff, (uint32_t)B, ps_.qbeg.p,
-                     ps_.entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, ps_.qorder.p, nullptr, 0u, 1u);
+  hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, ps_.qbeg.p,
+                     ps_.entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, ps_.qorder.p, nullptr, m.tune.daat_chunk,
+                     m.tune.daat_split_div, ps_.tok_node.p);
   PS_HIP(hipGetLastError());
   return tot;
 }
@@ -2040,7 +2068,7 @@ void Engine::plan_device(const char* text, const uint64_t* offsets, size_t B, Pl
   out.qbeg.resize(B + 1);
   out.qterms_len.resize(B);
   out.n_nodes.assign(B, 0);
-  PS_HIP(hipStreamSynchronize(c.stream));
+  PS_HIP(hipStreamSynchronize(m.prep_stream));
   if (tot.n_entries) PS_HIP(hipMemcpy(out.entries.data(), c.plan.entries.p, (size_t)tot.n_entries * sizeof(ps_plan_entry), hipMemcpyDeviceToHost));
   PS_HIP(hipMemcpy(out.qbeg.data(), c.plan.qbeg.p, (B + 1) * 4, hipMemcpyDeviceToHost));
   if (B) PS_HIP(hipMemcpy(out.qterms_len.data(), c.plan.qtl.p, B * 4, hipMemcpyDeviceToHost));
@@ -2076,7 +2104,6 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   m.last_bounds_recomputed = false;
   hipStream_t st = stream ? (hipStream_t)stream : m.stream;
   EngineImpl::DaatCtx& c = acquire_ctx(m);
-  if (m.tail_pending) PS_HIP(hipStreamWaitEvent(c.stream, m.ev[0], 0));  // (a k_score / full-result batch still in flight)
   const PlanTotals tot = device_plan(m, c, text, offsets, B);
   if (tot.max_qterms >= 0x7FFF) throw std::length_error("more than 32766 non-empty terms in one query");
   const double t1 = now_ms();
@@ -2087,11 +2114,11 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   } else {
     // the batches K1d does not take: K1 k_score / K3 k_merge from the device-built plan, in the engine's
     // single set of per-batch buffers, once nothing else is in flight
-    PS_HIP(hipEventRecord(c.planned, c.stream));
+    PS_HIP(hipEventRecord(c.prepared, m.prep_stream));
     wait_daat_contexts(m, st);
     if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
     m.tail_pending = false;
-    PS_HIP(hipStreamWaitEvent(st, c.planned, 0));
+    PS_HIP(hipStreamWaitEvent(st, c.prepared, 0));
     Plan shape;  // the scalars the launch geometry needs; the entries stay on the device
     shape.max_entries = tot.max_entries;
     shape.max_qterms = tot.max_qterms;
@@ -2125,6 +2152,7 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
       EngineImpl::KTimer* kt = &m.kt[m.next_kt];
       m.next_kt = (m.next_kt + 1) % N_KTIMER;
       m.harvest(*kt, true);
+      kt->split = false;
       PS_HIP(hipEventRecord(kt->a, st));
       m.build_slots.clear();
       launch_score<false>(m, sc, shape, kp, m.n_cu, st, kt->m);
@@ -2293,6 +2321,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   m.last_kt_pending = &kt;
   m.next_kt = (m.next_kt + 1) % N_KTIMER;
   m.harvest(kt, true);
+  kt.split = false;
   PS_HIP(hipEventRecord(kt.a, st));
   launch_score<true>(m, sc, plan, kp, m.n_cu, st, kt.m);
   } catch (...) {

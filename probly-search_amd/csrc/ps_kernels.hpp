@@ -1865,15 +1865,62 @@ __device__ __forceinline__ int64_t dev_find_node(const DevTrie& t, const char* s
   return (int64_t)n;
 }
 
+// One non-empty query token whose trie node is `fn` (-1: no such path): its expansions in expand_term order
+// (query.rs:130-147), one entry per (expanded term, version / delta layer).  FILL writes the entries at
+// entries[w...]; both passes return the counts.
 template <bool FILL>
-__global__ __launch_bounds__(64) void k_plan(const DevTrie t, const char* text, const uint64_t* offsets, const uint32_t B,
-                                             const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt, uint32_t* q_terms_len,
-                                             uint32_t* q_nterms, uint32_t* q_multi, unsigned long long* q_postings,
-                                             uint32_t* qorder, uint32_t* q_items, const uint32_t chunk_min, const uint32_t split_div) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= B) return;
-  const uint32_t qb = (uint32_t)offsets[q], qe = (uint32_t)offsets[q + 1];
-  const char* s = text;
+__device__ __forceinline__ void plan_token(const DevTrie& t, const int64_t fn, const uint32_t tok_bytes, const uint32_t qord, const uint32_t qi,
+                                           const uint32_t chunk_min, const uint32_t split_div, ps_plan_entry* entries, uint32_t w,
+                                           uint32_t& here, unsigned long long& postings, uint32_t& items) {
+  here = 0; postings = 0; items = 0;
+  if (fn < 0) return;
+  const uint4 node = t.fnodes[fn];
+  for (uint32_t o = node.z; o < node.w; ++o) {  // == expand_term order (query.rs:130-147)
+    const uint64_t df = t.term_df[o];
+    const uint32_t byte_len = t.term_meta[4 * o], first_layer = t.term_meta[4 * o + 1], n_layers = t.term_meta[4 * o + 2];
+    const uint32_t delta_head = t.term_delta[o];
+    if (df == 0 || (n_layers == 0 && delta_head == 0xFFFFFFFFu)) continue;  // query.rs:47-48
+    uint32_t l = 0, li = n_layers ? first_layer : delta_head;
+    while (li != 0xFFFFFFFFu) {
+      const uint4 la = t.layer_a[li], lb = t.layer_b[li];
+      if (FILL) {
+        ps_plan_entry e;
+        e.post_off = (uint64_t)la.x | ((uint64_t)la.y << 32);
+        e.len = la.z;
+        e.tbl_off = la.w;
+        e.shift = lb.x | (l << 8);
+        e.qterm = qord;
+        e.idf = t.term_idf[o];
+        // bm25.rs:45-53: 1 for the query term itself, else ln(1 + 1/((1 + len_exp) - len_q)), tabulated
+        const uint32_t delta = byte_len - tok_bytes;
+        e.boost = (t.term_meta[4 * o + 3] == (uint32_t)fn) ? 1.0 : t.eb_table[delta < t.eb_n ? delta : 0];
+        e.node = li;
+        e.qterm_index = qi;
+        e.bm_off = lb.y;
+        e._pad = 0;
+        entries[w++] = e;
+      } else {  // K1d work items of this list (the rule of k_prep_batch)
+        uint32_t c = ((la.z + split_div - 1) / split_div + 255u) & ~255u;
+        c = c > chunk_min ? c : chunk_min;
+        items += (la.z + c - 1) / c;
+      }
+      postings += la.z;
+      ++here;
+      ++l;
+      // base layers are contiguous, then the delta chain
+      if (l < n_layers) li = first_layer + l;
+      else if (l == n_layers) li = delta_head;
+      else li = lb.z;
+    }
+  }
+}
+
+// A whole query by one thread (queries of more than 64 tokens; k_plan's wave hands them to its lane 0).
+template <bool FILL>
+__device__ __noinline__ void plan_query_seq(const DevTrie& t, const char* s, const uint32_t qb, const uint32_t qe, const uint32_t q,
+                                            const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt, uint32_t* q_terms_len,
+                                            uint32_t* q_nterms, uint32_t* q_multi, unsigned long long* q_postings, uint32_t* q_items,
+                                            const uint32_t chunk_min, const uint32_t split_div) {
   uint32_t n_tokens = 0, qord = 0, n_ent = 0, multi = 0, items = 0;
   unsigned long long postings = 0;
   uint32_t w = FILL ? qbeg[q] : 0u;
@@ -1884,50 +1931,10 @@ __global__ __launch_bounds__(64) void k_plan(const DevTrie t, const char* text, 
     const uint32_t te = i;
     const uint32_t qi = n_tokens++;
     if (te > tb) {
-      const int64_t fn = dev_find_node(t, s, tb, te);
-      uint32_t here = 0;
-      if (fn >= 0) {
-        const uint4 node = t.fnodes[fn];
-        for (uint32_t o = node.z; o < node.w; ++o) {  // == expand_term order (query.rs:130-147)
-          const uint64_t df = t.term_df[o];
-          const uint32_t byte_len = t.term_meta[4 * o], first_layer = t.term_meta[4 * o + 1], n_layers = t.term_meta[4 * o + 2];
-          const uint32_t delta_head = t.term_delta[o];
-          if (df == 0 || (n_layers == 0 && delta_head == 0xFFFFFFFFu)) continue;  // query.rs:47-48
-          uint32_t l = 0, li = n_layers ? first_layer : delta_head;
-          while (li != 0xFFFFFFFFu) {
-            const uint4 la = t.layer_a[li], lb = t.layer_b[li];
-            if (FILL) {
-              ps_plan_entry e;
-              e.post_off = (uint64_t)la.x | ((uint64_t)la.y << 32);
-              e.len = la.z;
-              e.tbl_off = la.w;
-              e.shift = lb.x | (l << 8);
-              e.qterm = qord;
-              e.idf = t.term_idf[o];
-              // bm25.rs:45-53: 1 for the query term itself, else ln(1 + 1/((1 + len_exp) - len_q)), tabulated
-              const uint32_t delta = byte_len - (te - tb);
-              e.boost = (t.term_meta[4 * o + 3] == (uint32_t)fn) ? 1.0 : t.eb_table[delta < t.eb_n ? delta : 0];
-              e.node = li;
-              e.qterm_index = qi;
-              e.bm_off = lb.y;
-              e._pad = 0;
-              entries[w++] = e;
-            }
-            postings += la.z;
-            if (!FILL) {  // K1d work items of this list (the rule of k_prep_query)
-              uint32_t c = ((la.z + split_div - 1) / split_div + 255u) & ~255u;
-              c = c > chunk_min ? c : chunk_min;
-              items += (la.z + c - 1) / c;
-            }
-            ++here;
-            ++l;
-            // base layers are contiguous, then the delta chain
-            if (l < n_layers) li = first_layer + l;
-            else if (l == n_layers) li = delta_head;
-            else li = lb.z;
-          }
-        }
-      }
+      uint32_t here, it;
+      unsigned long long po;
+      plan_token<FILL>(t, dev_find_node(t, s, tb, te), te - tb, qord, qi, chunk_min, split_div, entries, w, here, po, it);
+      w += here; postings += po; items += it;
       if (here > 1) multi = 1;
       n_ent += here;
       ++qord;
@@ -1941,35 +1948,136 @@ __global__ __launch_bounds__(64) void k_plan(const DevTrie t, const char* text, 
     q_multi[q] = multi;
     q_postings[q] = postings;
     q_items[q] = items;
-  } else {
-    qorder[q] = q;
   }
 }
 
-// one workgroup: exclusive scan of the per-query entry counts + the batch totals
+// One WAVE per query: the lanes find the token boundaries together (a ballot of the separators per 64
+// bytes of text), then lane i plans token i - the trie walks of a query's terms, which are chains of
+// dependent loads, run side by side instead of one after the other.  The count pass leaves every token's
+// trie node in `tok_node` ([B][64]; -2 = empty token), so the fill pass walks nothing.
+constexpr int PLAN_WAVES = 16;  // queries per workgroup (few fat workgroups: while a k_daat launch floods the dispatcher, every extra workgroup of another queue waits its turn)
+template <bool FILL>
+__global__ __launch_bounds__(WAVE * PLAN_WAVES) void k_plan(const DevTrie t, const char* text, const uint64_t* offsets, const uint32_t B,
+                                                          const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt,
+                                                          uint32_t* q_terms_len, uint32_t* q_nterms, uint32_t* q_multi,
+                                                          unsigned long long* q_postings, uint32_t* qorder, uint32_t* q_items,
+                                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node) {
+  __shared__ uint32_t sh_tb[PLAN_WAVES][WAVE], sh_te[PLAN_WAVES][WAVE];
+  const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  const uint32_t q = blockIdx.x * PLAN_WAVES + wv;
+  if (q >= B) return;
+  const uint32_t qb = (uint32_t)offsets[q], qe = (uint32_t)offsets[q + 1];
+  const char* s = text;
+  // token boundaries: every ' ' ends a token and starts the next (s.split(' '), lib.rs:42-44)
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  uint32_t n_tokens = 0, start = qb;  // wave-uniform
+  bool overflow = false;
+  for (uint32_t pos = qb; pos < qe; pos += WAVE) {
+    const bool in = pos + lane < qe;
+    const bool sp = in && s[pos + lane] == ' ';
+    const unsigned long long m = __ballot(sp);
+    if (sp) {
+      const unsigned long long before = m & lt;
+      const uint32_t idx = n_tokens + (uint32_t)__popcll(before);
+      const uint32_t tb = before ? pos + (63u - (uint32_t)__clzll(before)) + 1u : start;
+      if (idx < (uint32_t)WAVE) { sh_tb[wv][idx] = tb; sh_te[wv][idx] = pos + lane; }
+    }
+    if (m) {
+      n_tokens += (uint32_t)__popcll(m);
+      start = pos + (63u - (uint32_t)__clzll(m)) + 1u;
+    }
+  }
+  if (n_tokens < (uint32_t)WAVE) {
+    if (lane == 0) { sh_tb[wv][n_tokens] = start; sh_te[wv][n_tokens] = qe; }
+  } else {
+    overflow = true;
+  }
+  ++n_tokens;  // the last token (k separators -> k + 1 tokens)
+  if (overflow) {  // more than 64 tokens: one lane walks the query
+    if (lane == 0) {
+      plan_query_seq<FILL>(t, s, qb, qe, q, qbeg, entries, q_cnt, q_terms_len, q_nterms, q_multi, q_postings, q_items, chunk_min, split_div);
+      if (FILL) qorder[q] = q;
+    }
+    return;
+  }
+  // (the wave's LDS writes above are visible to its own lanes in program order)
+  const bool mine = lane < n_tokens;
+  const uint32_t tb = mine ? sh_tb[wv][lane] : 0u, te = mine ? sh_te[wv][lane] : 0u;
+  const bool nonempty = mine && te > tb;
+  const unsigned long long ne_mask = __ballot(nonempty);
+  const uint32_t qord = (uint32_t)__popcll(ne_mask & lt);  // ordinal among the non-empty tokens (query.rs:33-37)
+  int64_t fn = -1;
+  if (nonempty) {
+    if (FILL) fn = tok_node[(size_t)q * WAVE + lane];
+    else { fn = dev_find_node(t, s, tb, te); tok_node[(size_t)q * WAVE + lane] = (int32_t)fn; }
+  }
+  uint32_t here = 0, items = 0;
+  unsigned long long postings = 0;
+  if (!FILL) {
+    if (nonempty) plan_token<false>(t, fn, te - tb, qord, lane, chunk_min, split_div, nullptr, 0u, here, postings, items);
+    // per-query totals
+    uint32_t n_ent = here, multi = here > 1 ? 1u : 0u, it = items;
+    unsigned long long po = postings;
+    for (int o = 32; o > 0; o >>= 1) {
+      n_ent += __shfl_xor(n_ent, o); multi |= __shfl_xor(multi, o); it += __shfl_xor(it, o); po += __shfl_xor(po, o);
+    }
+    if (lane == 0) {
+      q_cnt[q] = n_ent;
+      q_terms_len[q] = n_tokens;
+      q_nterms[q] = (uint32_t)__popcll(ne_mask);
+      q_multi[q] = multi;
+      q_postings[q] = po;
+      q_items[q] = it;
+    }
+  } else {
+    // entries of token i go behind those of the tokens before it: the counts again (cheap: no trie walk),
+    // an exclusive scan over the lanes, then the writes
+    uint32_t cnt = 0, dummy_i;
+    unsigned long long dummy_p;
+    if (nonempty) plan_token<false>(t, fn, te - tb, qord, lane, chunk_min, split_div, nullptr, 0u, cnt, dummy_p, dummy_i);
+    uint32_t inc = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+    const uint32_t w = qbeg[q] + inc - cnt;
+    if (nonempty && cnt) plan_token<true>(t, fn, te - tb, qord, lane, chunk_min, split_div, entries, w, here, postings, items);
+    if (lane == 0) qorder[q] = q;
+  }
+}
+
+// one workgroup: exclusive scan of the per-query entry counts + the batch totals (wave shuffles + one
+// LDS hop: a few microseconds even while a k_daat launch owns the rest of the chip)
 __global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t* q_cnt, const uint32_t* q_nterms, const uint32_t* q_multi,
                                                      const unsigned long long* q_postings, const uint32_t* q_items, const uint32_t B,
                                                      uint32_t* qbeg, PlanTotals* tot) {
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t mx_e[1024], mx_t[1024], any_m[1024], itm[1024];
-  __shared__ unsigned long long post[1024];
-  const uint32_t tid = threadIdx.x, per = (B + 1023) / 1024;
+  __shared__ uint32_t w_sum[16], w_me[16], w_mt[16], w_mm[16];
+  __shared__ unsigned long long w_post[16], w_itm[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, per = (B + 1023) / 1024;
   const uint32_t b = min(B, tid * per), e = min(B, b + per);
-  uint32_t sum = 0, me = 0, mt = 0, mm = 0, it = 0;
-  unsigned long long ps = 0;
+  uint32_t sum = 0, me = 0, mt = 0, mm = 0;
+  unsigned long long ps = 0, it = 0;
   for (uint32_t i = b; i < e; ++i) { sum += q_cnt[i]; me = max(me, q_cnt[i]); mt = max(mt, q_nterms[i]); mm |= q_multi[i]; ps += q_postings[i]; it += q_items[i]; }
-  part[tid] = sum; mx_e[tid] = me; mx_t[tid] = mt; any_m[tid] = mm; post[tid] = ps; itm[tid] = it;
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0, a = 0, c = 0, d = 0;
-    unsigned long long pp = 0, ii = 0;
-    for (uint32_t i = 0; i < 1024; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; a = max(a, mx_e[i]); c = max(c, mx_t[i]); d |= any_m[i]; pp += post[i]; ii += itm[i]; }
-    tot->n_entries = run; tot->max_entries = a; tot->max_qterms = c; tot->multi = d; tot->postings = pp; tot->n_items = ii;
-    qbeg[B] = run;
+  // inclusive scan of `sum` within the wave; reductions of the rest
+  uint32_t inc = sum;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+  for (int o = 32; o > 0; o >>= 1) {
+    me = max(me, __shfl_xor(me, o)); mt = max(mt, __shfl_xor(mt, o)); mm |= __shfl_xor(mm, o);
+    ps += __shfl_xor(ps, o); it += __shfl_xor(it, o);
   }
+  if (lane == 63) w_sum[wave] = inc;
+  if (lane == 0) { w_me[wave] = me; w_mt[wave] = mt; w_mm[wave] = mm; w_post[wave] = ps; w_itm[wave] = it; }
   __syncthreads();
-  uint32_t run = part[tid];
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; ++w) base += w_sum[w];
+  uint32_t run = base + inc - sum;  // exclusive prefix of this thread's first query
   for (uint32_t i = b; i < e; ++i) { qbeg[i] = run; run += q_cnt[i]; }
+  if (tid == 0) {
+    uint32_t total = 0, a = 0, c = 0, d = 0;
+    unsigned long long pp = 0, ii = 0;
+    for (uint32_t w = 0; w < 16; ++w) { total += w_sum[w]; a = max(a, w_me[w]); c = max(c, w_mt[w]); d |= w_mm[w]; pp += w_post[w]; ii += w_itm[w]; }
+    qbeg[B] = total;
+    tot->max_entries = a; tot->max_qterms = c; tot->multi = d; tot->postings = pp; tot->n_items = ii;
+    __threadfence_system();
+    tot->n_entries = total;
+  }
 }
 
 // Plan upload without the copy engine: the staged batch is read from the pinned, device-mapped

@@ -5,14 +5,12 @@
 //   k_list_bounds  per (k1, b, avg[, boosts]): exact per-list maxima of the saturated term frequency
 //                  per field (M) and of the boosted per-posting sum (J), by the kernels' own f64
 //                  expression (bm25.rs:78-86)
-//   k_prep_query   one thread per query: upper bound of every entry, the query's processing order
-//                  (rank), what the other entries can add (`others`), the whole-list skip thresholds,
-//                  per-query-term data of multi-expansion queries, chunking, candidate slots, item
-//                  buckets, uses of dense-row candidates
-//   k_prep_finish  one small workgroup: bucket starts, the batch's item count, which dense rows are
-//                  read / have to be scored
-//   k_prep_items   one wave per list: its work items (rank-major buckets: every query's highest-bound
-//                  list first, longest lists first) and its dense-row flag
+//   k_prep_batch   one workgroup, a thread per query: upper bound of every entry, the query's processing
+//                  order (rank), what the other entries can add (`others`), the whole-list skip thresholds,
+//                  per-query-term data of multi-expansion queries, chunking, candidate slots; with its
+//                  counters in LDS: item buckets (rank-major: every query's highest-bound list first, longest
+//                  lists first), the batch's item count, which dense rows are read / have to be scored
+//   k_prep_items   one wave per list: its work items and its dense-row flag
 //
 // What used to be Engine::plan_daat + select_dense_rows on the host (≈0.2 ms per 1024 queries on the
 // critical path of a 0.5 ms step).  Orders within a bucket and the placement of candidate slots come
@@ -148,13 +146,112 @@ __device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint3
   return PREP_CLASSES + (rank < PREP_RANKS ? rank : PREP_RANKS) - 1u;
 }
 
-// One thread per query (plans of <= 64 entries: the host routes wider batches to k_score).
-__global__ __launch_bounds__(64) void k_prep_query(const PrepParams pp) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= pp.B) return;
-  const uint32_t b = pp.qbeg[q], e = pp.qbeg[q + 1], n = e - b;
-  constexpr double SLACK = 1.0 + 1e-9;  // the bounds are summed in another order than the scores
-  if (n == 0) { pp.qslot[q] = 0; pp.qslot_n[q] = 0; return; }
+// ---- descriptors of one query ---------------------------------------------------------------------
+// Result of the per-query part: candidate slots the query needs (its items), and per entry the chunking.
+// Two implementations with the same outputs: plans of <= 8 entries are handled in registers (every global
+// load of the query is issued up front, all the O(n^2) logic is ALU work), wider ones (<= 64) walk their
+// arrays in HBM.
+constexpr double PREP_SLACK = 1.0 + 1e-9;  // the bounds are summed in another order than the scores
+
+__device__ __forceinline__ bool prep_before(const double ua, const uint32_t la, const uint32_t ia, const double ub,
+                                            const uint32_t lb, const uint32_t ib) {
+  // processing order: bound descending; equal bounds: the LONGER list ranks lower (it is the one that
+  // becomes non-essential); then plan order (stable)
+  return ua > ub || (ua == ub && (la < lb || (la == lb && ia < ib)));
+}
+
+template <int NMAX>
+__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n) {
+  double ub[NMAX];
+  uint32_t len[NMAX], grp[NMAX], rank[NMAX], qt[NMAX];
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    ub[i] = 0.0; len[i] = 0; qt[i] = 0xFFFFFFFFu;
+    if ((uint32_t)i < n) {
+      const ps_plan_entry& en = pp.plan[b + i];
+      ub[i] = prep_entry_ub(pp, en);
+      len[i] = en.len;
+      qt[i] = en.qterm;
+    }
+  }
+  uint32_t n_groups = 0;
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    if ((uint32_t)i < n && (i == 0 || qt[i] != qt[i > 0 ? i - 1 : 0])) ++n_groups;
+    grp[i] = n_groups - 1;
+  }
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+      if ((uint32_t)j < n && j != i && prep_before(ub[j], len[j], (uint32_t)j, ub[i], len[i], (uint32_t)i)) ++r;
+    rank[i] = r;
+  }
+  // per entry: the maximum of its query term's bounds, and whether it is the first entry of its term
+  double gm[NMAX];
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    double m = 0.0;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+      if ((uint32_t)j < n && grp[j] == grp[i]) m = fmax(m, ub[j]);
+    gm[i] = m;
+  }
+  uint32_t slots = 0;
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    if ((uint32_t)i < n) {
+      double rest = 0.0, alt = 0.0, skip = 0.0;
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j) {
+        if ((uint32_t)j < n) {
+          const bool first_of_group = j == 0 || grp[j] != grp[j > 0 ? j - 1 : 0];
+          if (first_of_group && grp[j] != grp[i]) rest += gm[j];
+          if (grp[j] == grp[i] && j != i) alt = fmax(alt, ub[j]);
+          // skip threshold: per query term the largest bound among its entries of rank >= rank[i]
+          if (first_of_group) {
+            double m = 0.0;
+#pragma unroll
+            for (int k = 0; k < NMAX; ++k)
+              if ((uint32_t)k < n && grp[k] == grp[j] && rank[k] >= rank[i]) m = fmax(m, ub[k]);
+            skip += m;
+          }
+        }
+      }
+      DEntry d;
+      d.ub = ub[i];
+      d.q = q;
+      d.rank = rank[i];
+      d.others = (rest + alt) * PREP_SLACK;
+      if (!(d.others >= 0.0)) d.others = INFINITY;
+      d.skip_thr = skip * PREP_SLACK;
+      if (!(d.skip_thr >= 0.0)) d.skip_thr = INFINITY;
+      pp.dentry[b + i] = d;
+      pp.rorder[b + rank[i]] = b + i;
+      pp.gord[b + i] = (uint8_t)grp[i];
+      if (pp.multi) {
+        DGroup dg;
+        dg.grp = n_groups <= 4 ? grp[i] : 0xFFFFFFFFu;
+        dg.ub_s = ub[i] * PREP_SLACK;
+        // the next list of the same term in rank order: the largest bound among its entries of higher rank number
+        double nx = 0.0;
+        uint32_t nr = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+          if ((uint32_t)j < n && grp[j] == grp[i] && rank[j] > rank[i] && rank[j] < nr) { nr = rank[j]; nx = ub[j]; }
+        dg.nxt_s = nx * PREP_SLACK;
+        dg._pad[0] = dg._pad[1] = dg._pad[2] = 0;
+        pp.dgroup[b + i] = dg;
+      }
+      const uint32_t c = prep_chunk(pp, len[i]);
+      slots += (len[i] + c - 1) / c;
+    }
+  }
+  return slots;
+}
+
+__device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n) {
   // bounds; dense ordinal of every entry's query term (the entries of a term are adjacent in plan order)
   uint32_t n_groups = 0, cur = 0xFFFFFFFFu;
   for (uint32_t i = 0; i < n; ++i) {
@@ -165,16 +262,13 @@ __global__ __launch_bounds__(64) void k_prep_query(const PrepParams pp) {
     if (en.qterm != cur) { cur = en.qterm; ++n_groups; }
     pp.gord[b + i] = (uint8_t)(n_groups - 1);
   }
-  // processing order: bound descending; equal bounds: the LONGER list ranks lower (it is the one that
-  // becomes non-essential); stable.  Insertion sort (n is 3..8 in practice).
-  for (uint32_t i = 0; i < n; ++i) {
+  for (uint32_t i = 0; i < n; ++i) {  // insertion sort into the processing order
     const double ui = pp.dentry[b + i].ub;
     const uint32_t li = pp.plan[b + i].len;
     uint32_t j = i;
     while (j > 0) {
       const uint32_t pj = pp.rorder[b + j - 1];
-      const double uj = pp.dentry[pj].ub;
-      if (ui > uj || (ui == uj && li < pp.plan[pj].len)) { pp.rorder[b + j] = pj; --j; } else break;
+      if (prep_before(ui, li, b + i, pp.dentry[pj].ub, pp.plan[pj].len, pj)) { pp.rorder[b + j] = pj; --j; } else break;
     }
     pp.rorder[b + j] = b + i;
   }
@@ -197,7 +291,7 @@ __global__ __launch_bounds__(64) void k_prep_query(const PrepParams pp) {
       if (gj == gi && j != i) alt = fmax(alt, uj);
     }
     if (run != gi) rest += run_max;
-    double o = (rest + alt) * SLACK;
+    double o = (rest + alt) * PREP_SLACK;
     if (!(o >= 0.0)) o = INFINITY;
     pp.dentry[b + i].others = o;
   }
@@ -212,75 +306,92 @@ __global__ __launch_bounds__(64) void k_prep_query(const PrepParams pp) {
       const unsigned long long bit = 1ull << (pp.gord[j] & 63u);
       if (!(seen & bit)) { seen |= bit; bound += pp.dentry[j].ub; }
     }
-    double s = bound * SLACK;
-    if (!(s >= 0.0)) s = INFINITY;
-    pp.dentry[pp.rorder[b + r]].skip_thr = s;
+    double sk = bound * PREP_SLACK;
+    if (!(sk >= 0.0)) sk = INFINITY;
+    pp.dentry[pp.rorder[b + r]].skip_thr = sk;
   }
   if (pp.multi) {
-    // per entry: the ordinal of its query term (<= 4 terms are tracked in registers by k_daat) and the
-    // inflated bound of the next list of the same term in rank order
     for (uint32_t r = 0; r < n; ++r) {
       const uint32_t i = pp.rorder[b + r];
       DGroup dg;
       dg.grp = n_groups <= 4 ? (uint32_t)pp.gord[i] : 0xFFFFFFFFu;
-      dg.ub_s = pp.dentry[i].ub * SLACK;
+      dg.ub_s = pp.dentry[i].ub * PREP_SLACK;
       dg.nxt_s = 0.0;
       dg._pad[0] = dg._pad[1] = dg._pad[2] = 0;
       for (uint32_t r2 = r + 1; r2 < n; ++r2) {
         const uint32_t j = pp.rorder[b + r2];
-        if (pp.gord[j] == pp.gord[i]) { dg.nxt_s = pp.dentry[j].ub * SLACK; break; }
+        if (pp.gord[j] == pp.gord[i]) { dg.nxt_s = pp.dentry[j].ub * PREP_SLACK; break; }
       }
       pp.dgroup[i] = dg;
     }
   }
-  // chunking, candidate slots (query-major within the query, the query's block placed by one atomic),
-  // item buckets, uses of dense-row candidates
   uint32_t slots = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t len = pp.plan[b + i].len;
     const uint32_t c = prep_chunk(pp, len);
     slots += (len + c - 1) / c;
   }
-  const uint32_t s0 = atomicAdd(&pp.ctl->total_slots, slots);
-  pp.qslot[q] = s0;
-  pp.qslot_n[q] = slots;
-  uint32_t sl = s0;
-  for (uint32_t i = 0; i < n; ++i) {
-    const ps_plan_entry& en = pp.plan[b + i];
-    const uint32_t c = prep_chunk(pp, en.len);
-    const uint32_t nc = (en.len + c - 1) / c;
-    pp.gen[b + i] = DItemGen{b + i, 0u, c, sl};
-    sl += nc;
-    if (nc) atomicAdd(&pp.ctl->bucket_total[prep_bucket(pp.dentry[b + i].rank, en.len)], nc);
-    if (pp.n_cand) {
-      const uint32_t cd = pp.cand_of_layer[en.node];
-      if (cd != NO_CAND) {
-        atomicAdd(&pp.ctl->row_use[cd], 1u);
-        atomicMax(&pp.ctl->row_first[cd], ~(unsigned long long)(b + i));
+  return slots;
+}
+
+// One workgroup prepares the whole batch (thread t: queries t, t + 1024, ...; plans of <= 64 entries - the
+// host routes wider batches to k_score): descriptors per query, then - the counters live in LDS, so the
+// thousands of increments of a batch do not queue up on a few L2 lines - candidate slots, item buckets and
+// dense-row uses; after one barrier the bucket starts and the dense rows of this batch; after another every
+// list's place in the item order.  k_prep_items expands the lists into items in parallel.
+__global__ __launch_bounds__(1024) void k_prep_batch(const PrepParams pp) {
+  __shared__ uint32_t sh_total_slots, sh_bucket_total[PREP_BUCKETS], sh_bucket_start[PREP_BUCKETS], sh_bucket_fill[PREP_BUCKETS];
+  __shared__ uint32_t sh_row_use[PREP_MAX_ROWS];
+  __shared__ unsigned long long sh_row_first[PREP_MAX_ROWS];  // ~(lowest plan-entry index that uses the candidate), 0 = none
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) sh_total_slots = 0;
+  for (uint32_t k = tid; k < PREP_BUCKETS; k += blockDim.x) { sh_bucket_total[k] = 0; sh_bucket_fill[k] = 0; }
+  for (uint32_t k = tid; k < PREP_MAX_ROWS; k += blockDim.x) { sh_row_use[k] = 0; sh_row_first[k] = 0ull; }
+  __syncthreads();
+  for (uint32_t q = tid; q < pp.B; q += blockDim.x) {
+    const uint32_t b = pp.qbeg[q], e = pp.qbeg[q + 1], n = e - b;
+    if (n == 0) { pp.qslot[q] = 0; pp.qslot_n[q] = 0; continue; }
+    const uint32_t slots = n <= 4 ? prep_query_small<4>(pp, q, b, n) : n <= 8 ? prep_query_small<8>(pp, q, b, n) : prep_query_general(pp, q, b, n);
+    // candidate slots: query-major within the query, the query's block placed by one (LDS) atomic
+    const uint32_t s0 = atomicAdd(&sh_total_slots, slots);
+    pp.qslot[q] = s0;
+    pp.qslot_n[q] = slots;
+    uint32_t sl = s0;
+    for (uint32_t i = 0; i < n; ++i) {
+      const ps_plan_entry& en = pp.plan[b + i];
+      const uint32_t c = prep_chunk(pp, en.len);
+      const uint32_t nc = (en.len + c - 1) / c;
+      pp.gen[b + i] = DItemGen{b + i, 0u, c, sl};
+      sl += nc;
+      if (nc) atomicAdd(&sh_bucket_total[prep_bucket(pp.dentry[b + i].rank, en.len)], nc);
+      if (pp.n_cand) {
+        const uint32_t cd = pp.cand_of_layer[en.node];
+        if (cd != NO_CAND) {
+          atomicAdd(&sh_row_use[cd], 1u);
+          atomicMax(&sh_row_first[cd], ~(unsigned long long)(b + i));
+        }
       }
     }
   }
-}
-
-// One small workgroup: bucket starts (rank-major, longest rank-0 lists first), the item count, and the
-// dense rows of this batch: a candidate used >= min_uses times is read as a row, scored with the (idf,
-// expansion_boost) of its FIRST user in plan order (deterministic); entries with other weights keep
-// their bitmap lookups.  A resident row with the same weights is not scored again.
-__global__ __launch_bounds__(64) void k_prep_finish(const PrepParams pp) {
-  PrepCtl& c = *pp.ctl;
-  if (threadIdx.x == 0) {
+  __syncthreads();
+  // bucket starts (rank-major, longest rank-0 lists first) and the item count
+  if (tid == 0) {
     uint32_t at = 0;
-    for (uint32_t k = 0; k < PREP_BUCKETS; ++k) { c.bucket_start[k] = at; at += c.bucket_total[k]; }
-    c.n_items = at;
+    for (uint32_t k = 0; k < PREP_BUCKETS; ++k) { sh_bucket_start[k] = at; at += sh_bucket_total[k]; }
+    pp.ctl->n_items = at;
+    pp.ctl->total_slots = sh_total_slots;
+  }
+  // the dense rows of this batch: a candidate used >= min_uses times is read as a row, scored with the (idf,
+  // expansion_boost) of its FIRST user in plan order (deterministic); entries with other weights keep their
+  // bitmap lookups.  A resident row with the same weights is not scored again.
+  if (tid == 64) {
     uint32_t n_build = 0, n_used = 0;
     for (uint32_t cd = 0; cd < pp.n_cand; ++cd) {
       RowState& rs = pp.row_state[cd];
       rs.use_now = 0;
-      if (c.row_use[cd] < pp.min_uses || c.row_first[cd] == 0ull) continue;
-      const ps_plan_entry& en = pp.plan[~c.row_first[cd]];
-      unsigned long long ib, eb;
-      ib = (unsigned long long)__double_as_longlong(en.idf);
-      eb = (unsigned long long)__double_as_longlong(en.boost);
+      if (sh_row_use[cd] < pp.min_uses || sh_row_first[cd] == 0ull) continue;
+      const ps_plan_entry& en = pp.plan[~sh_row_first[cd]];
+      const unsigned long long ib = (unsigned long long)__double_as_longlong(en.idf), eb = (unsigned long long)__double_as_longlong(en.boost);
       rs.use_now = 1;
       ++n_used;
       if (pp.rows_resident && rs.valid && rs.idf_bits == ib && rs.eb_bits == eb) continue;
@@ -296,46 +407,51 @@ __global__ __launch_bounds__(64) void k_prep_finish(const PrepParams pp) {
       rd.tbl_off = la.w;  // candidates are lists with one table slot per tile (host: shift == 0)
       pp.row_desc[n_build++] = rd;
     }
-    c.n_rows_build = n_build;
-    c.n_rows_used = n_used;
+    pp.ctl->n_rows_build = n_build;
+    pp.ctl->n_rows_used = n_used;
     if (PS_WORK_COUNTERS && (n_build | n_used)) {
       atomicAdd(&pp.wstats[WS_ROWS_BUILT], (unsigned long long)n_build);
       atomicAdd(&pp.wstats[WS_ROWS_USED], (unsigned long long)n_used);
     }
   }
+  __syncthreads();
+  // every list's place in the item order: the next free items of its bucket
+  for (uint32_t q = tid; q < pp.B; q += blockDim.x) {
+    const uint32_t b = pp.qbeg[q], e = pp.qbeg[q + 1];
+    for (uint32_t i = b; i < e; ++i) {
+      const uint32_t len = pp.plan[i].len, c = pp.gen[i].chunk;
+      const uint32_t nc = (len + c - 1) / c;
+      if (!nc) continue;
+      const uint32_t bk = prep_bucket(pp.dentry[i].rank, len);
+      pp.gen[i].item_at = sh_bucket_start[bk] + atomicAdd(&sh_bucket_fill[bk], nc);
+    }
+  }
 }
 
-// One wave per list: its items go to the next free places of its bucket; an entry whose list is read as
-// a dense row this batch (same weights as the row was scored with) gets the flag and the row slot.
+// One wave per list: its items at the place k_prep_batch gave it; an entry whose list is read as a dense
+// row this batch (same weights as the row was scored with) gets the flag and the row slot.
 __global__ __launch_bounds__(256) void k_prep_items(const PrepParams pp) {
   const uint32_t i = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (i >= pp.ne) return;
   ps_plan_entry& en = pp.plan[i];
-  DItemGen g = pp.gen[i];
+  const DItemGen g = pp.gen[i];
   const uint32_t len = en.len;
   const uint32_t n = (len + g.chunk - 1) / g.chunk;
-  uint32_t at = 0;
-  if (lane == 0) {
-    const uint32_t bk = prep_bucket(pp.dentry[i].rank, len);
-    at = n ? pp.ctl->bucket_start[bk] + atomicAdd(&pp.ctl->bucket_fill[bk], n) : 0u;
-    pp.gen[i].item_at = at;
-    if (pp.n_cand) {
-      const uint32_t cd = pp.cand_of_layer[en.node];
-      if (cd != NO_CAND) {
-        const RowState rs = pp.row_state[cd];
-        if (rs.use_now && rs.idf_bits == (unsigned long long)__double_as_longlong(en.idf) &&
-            rs.eb_bits == (unsigned long long)__double_as_longlong(en.boost)) {
-          en.shift |= DENSE_FLAG;
-          en.node = cd;
-        }
+  if (lane == 0 && pp.n_cand) {
+    const uint32_t cd = pp.cand_of_layer[en.node];
+    if (cd != NO_CAND) {
+      const RowState rs = pp.row_state[cd];
+      if (rs.use_now && rs.idf_bits == (unsigned long long)__double_as_longlong(en.idf) &&
+          rs.eb_bits == (unsigned long long)__double_as_longlong(en.boost)) {
+        en.shift |= DENSE_FLAG;
+        en.node = cd;
       }
     }
   }
-  at = __shfl(at, 0);
   for (uint32_t j = lane; j < n; j += WAVE) {
     const uint32_t pb = j * g.chunk;
-    if (at + j < pp.items_cap) pp.items[at + j] = DItem{i, pb, min(g.chunk, len - pb), g.first_slot + j};
+    if (g.item_at + j < pp.items_cap) pp.items[g.item_at + j] = DItem{i, pb, min(g.chunk, len - pb), g.first_slot + j};
   }
 }
 
