@@ -141,6 +141,7 @@ struct Tuning {
   uint32_t z21_exact_numerator = 1;  // PS_Z21_EXACT_NUMERATOR: k_score<MODE_Z21S> one-division arm for small term frequencies (score_trip)
   uint32_t z21_field_prune = 1;  // PS_Z21_FIELD_PRUNE: k_score<MODE_Z21S> drops fields whose pool bound fell below the query's threshold
   uint32_t daat_multi = 1;       // PS_DAAT_MULTI: also take batches with several expansions per query term (0: they stay on K1)
+  uint32_t daat_small = 1;       // PS_DAAT_SMALL: plans of <= 4 lists, one per query term, take k_daat_small (all lookups of a trip in flight together)
   uint32_t device_plan = 1;      // PS_DEVICE_PLAN: flat BM25 top-k batches (built-in tokenizer) are planned by k_plan on the device
   void load();
 };
@@ -648,6 +649,7 @@ void Tuning::load() {
     daat_split_div = std::max(1u, env_u32("PS_DAAT_SPLIT_DIV", daat_split_div));
     daat_persistent = env_u32("PS_DAAT_PERSISTENT", daat_persistent);
     device_plan = env_u32("PS_DEVICE_PLAN", device_plan);
+    daat_small = env_u32("PS_DAAT_SMALL", daat_small);
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
     z21_field_prune = env_u32("PS_Z21_FIELD_PRUNE", z21_field_prune);
     z21_exact_numerator = env_u32("PS_Z21_EXACT_NUMERATOR", z21_exact_numerator);
@@ -1558,7 +1560,7 @@ void launch_k_score(EngineImpl& m, KParams& kp, bool tags, int n_cu, hipStream_t
 }
 
 // K1d: persistent 8-wave workgroups (the LUT is the only LDS), items from the device-scope counter
-void launch_daat(EngineImpl& m, KParams& kp, bool multi, int n_cu, hipStream_t st) {
+void launch_daat(EngineImpl& m, KParams& kp, bool multi, bool small, int n_cu, hipStream_t st) {
   // (PS_DAAT_PAD_LDS: extra dynamic LDS per workgroup - an occupancy cap for experiments; 24000 = 3 waves per SIMD)
   static const size_t pad_lds = env_u32("PS_DAAT_PAD_LDS", 0);
   const size_t lds = std::max((size_t)kp.lut_stride * LUT_TF * 8, pad_lds);
@@ -1574,7 +1576,16 @@ void launch_daat(EngineImpl& m, KParams& kp, bool multi, int n_cu, hipStream_t s
     m.score_kernel_name = nm;                                                                            \
     hipLaunchKernelGGL((k_daat<FV, MU>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);                       \
   } while (0)
-  if (multi) {
+  if (small && !multi && !m.tune.daat_persistent && m.tune.daat_small) {
+    // plans of <= 4 lists, one per query term: the short-chain kernel
+    const uint32_t n_wg = (kp.n_ditems + DAAT_WGW - 1) / DAAT_WGW;
+    char nm[96];
+    snprintf(nm, sizeof(nm), "ps::k_daat_small<%d>", kp.F <= 2 ? (int)kp.F : 0);
+    m.score_kernel_name = nm;
+    if (kp.F == 1) hipLaunchKernelGGL((k_daat_small<1>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);
+    else if (kp.F == 2) hipLaunchKernelGGL((k_daat_small<2>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);
+    else hipLaunchKernelGGL((k_daat_small<0>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);
+  } else if (multi) {
     if (kp.F == 1) PS_DAAT(1, true); else if (kp.F == 2) PS_DAAT(2, true); else PS_DAAT(0, true);
   } else {
     if (kp.F == 1) PS_DAAT(1, false); else if (kp.F == 2) PS_DAAT(2, false); else PS_DAAT(0, false);
@@ -1697,8 +1708,8 @@ bool daat_eligible(const EngineImpl& m, const ps_scorer_desc& sc, const double* 
 // point of the call, because the merge is the kernel that writes the caller's buffers - k_merge_items.
 // The caller's stream is made to wait for the batch, so work enqueued on it afterwards sees the results.
 void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, ps_plan_entry* d_plan,
-                  const uint32_t* d_qbeg, const uint32_t* d_qtl, size_t B, size_t ne, uint32_t max_qterms, bool multi, size_t n_items,
-                  uint32_t max_slots, size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller) {
+                  const uint32_t* d_qbeg, const uint32_t* d_qtl, size_t B, size_t ne, uint32_t max_qterms, uint32_t max_entries, bool multi,
+                  size_t n_items, uint32_t max_slots, size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller) {
   const Snapshot& s = *m.snap;
   hipStream_t P = m.prep_stream, S = m.score_stream;
   KParams kp;
@@ -1754,8 +1765,23 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     m.wc_k = kp.K;
     m.wc_results += (uint64_t)kp.B * kp.K;
     m.wc_items += kp.n_ditems;
+#ifdef PS_ITEM_TRACE
+    static DevBuf<unsigned long long> trace_buf;
+    trace_buf.ensure((size_t)kp.n_ditems * 4 + 8);
+    PS_HIP(hipMemsetAsync(trace_buf.p, 0, (size_t)kp.n_ditems * 32, S));
+    kp.item_trace = trace_buf.p;
+#endif
     PS_HIP(hipEventRecord(kt->m, S));
-    launch_daat(m, kp, multi, m.n_cu, S);
+    launch_daat(m, kp, multi, max_entries <= (uint32_t)DAAT_SMALL_MAX, m.n_cu, S);
+#ifdef PS_ITEM_TRACE
+    {  // profiling builds: the items' start / end times of this launch -> $PS_ITEM_TRACE_FILE (last batch wins)
+      PS_HIP(hipStreamSynchronize(S));
+      std::vector<unsigned long long> h((size_t)kp.n_ditems * 4);
+      PS_HIP(hipMemcpy(h.data(), trace_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
+      const char* f = getenv("PS_ITEM_TRACE_FILE");
+      if (f) { FILE* fp = fopen(f, "wb"); if (fp) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); } }
+    }
+#endif
     PS_HIP(hipGetLastError());
     PS_HIP(hipEventRecord(kt->b, S));
     kt->pending = true;
@@ -1804,7 +1830,7 @@ void enqueue_daat_host(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
   PS_HIP(hipEventRecord(sg.done, st));
   sg.pending = true;
   enqueue_daat(m, c, sc, boosts, reinterpret_cast<ps_plan_entry*>(c.stage.p), reinterpret_cast<const uint32_t*>(c.stage.p + off_q),
-               reinterpret_cast<const uint32_t*>(c.stage.p + off_l), B, ne, plan.max_qterms, plan.multi_expansion, n_items, max_slots, top_k,
+               reinterpret_cast<const uint32_t*>(c.stage.p + off_l), B, ne, plan.max_qterms, plan.max_entries, plan.multi_expansion, n_items, max_slots, top_k,
                d_keys, d_scores, d_counts, caller);
 }
 
@@ -2109,7 +2135,7 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   const double t1 = now_ms();
   EngineImpl::PlanSet& ps_ = c.plan;
   if (daat_eligible(m, sc, boosts, B, tot.n_entries, tot.max_entries, tot.multi != 0) && tot.n_items && tot.n_items < 0xFFFFFFF0ull) {
-    enqueue_daat(m, c, sc, boosts, ps_.entries.p, ps_.qbeg.p, ps_.qtl.p, B, tot.n_entries, tot.max_qterms, tot.multi != 0,
+    enqueue_daat(m, c, sc, boosts, ps_.entries.p, ps_.qbeg.p, ps_.qtl.p, B, tot.n_entries, tot.max_qterms, tot.max_entries, tot.multi != 0,
                  (size_t)tot.n_items, 0u, top_k, d_keys, d_scores, d_counts, st);
   } else {
     // the batches K1d does not take: K1 k_score / K3 k_merge from the device-built plan, in the engine's

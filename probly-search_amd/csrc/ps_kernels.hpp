@@ -139,6 +139,7 @@ struct KParams {
   const uint32_t* qslot;        // [B] first candidate slot (= item) of query q
   const uint32_t* qslot_n;      // [B] its candidate slots
   const uint32_t* n_ditems_dev; // the batch's item count as k_prep_finish wrote it (n_ditems below is the host's upper bound = the grid)
+  unsigned long long* item_trace; // profiling builds (PS_ITEM_TRACE): [n_ditems][4] = {start, end (s_memrealtime, 100 MHz), trips | rank << 32, scanned}
   uint32_t* prep_ctl;           // the preparation's control words (ps_prep_kernels.hpp: PrepCtl), zeroed behind k_merge_items
   uint32_t prep_ctl_words;
   const uint32_t* rorder;       // [n_plan_entries] per query: its entries in rank order (highest bound first)
@@ -1306,19 +1307,14 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
 // word k_score uses; items are handed out highest-bound lists first, so by the time the long
 // low-idf lists come up most of them are skipped whole.  No LDS tiles, no harvest over N documents.
 // ------------------------------------------------------------------------------------------
-// Scores of U postings per lane (indices pi[u]); all loads of the trip are issued before the arithmetic.
+// BM25 scores of U postings per lane from their packed {tf, field length} words (already loaded).
 template <int F_, int U>
-__device__ __forceinline__ void posting_scores(const KParams& p, const double* lut, const uint64_t (&pi)[U], const bool (&on)[U],
-                                               const double idf, const double eb, double (&s)[U]) {
+__device__ __forceinline__ void scores_from_words(const KParams& p, const double* lut, const uint64_t (&pi)[U], const bool (&on)[U],
+                                                  const uint32_t (&wv)[U][F_ ? F_ : MAX_F], const double idf, const double eb,
+                                                  double (&s)[U]) {
   constexpr int FA = F_ ? F_ : MAX_F;
   const uint32_t F = F_ ? (uint32_t)F_ : p.F;
-  uint32_t wv[U][FA], tfv[U][FA], flv[U][FA];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-#pragma unroll
-    for (int x = 0; x < FA; ++x) wv[u][x] = 0;
-    if (on[u]) tfl_load<F_>(p, pi[u], wv[u]);
-  }
+  uint32_t tfv[U][FA], flv[U][FA];
   tfl_unpack<F_, U>(p, wv, tfv, flv);
   {  // saturated sub-fields: fetch the exact values now, while the posting indices are still live (rare; the whole wave goes)
     bool esc = false;
@@ -1326,7 +1322,7 @@ __device__ __forceinline__ void posting_scores(const KParams& p, const double* l
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int x = 0; x < FA; ++x)
-        if ((uint32_t)x < F) esc = esc || tfv[u][x] == TFL_TF_ESC || flv[u][x] == TFL_FL_ESC;
+        if ((uint32_t)x < F) esc = esc || (on[u] && (tfv[u][x] == TFL_TF_ESC || flv[u][x] == TFL_FL_ESC));
     if (__any(esc)) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
@@ -1351,6 +1347,21 @@ __device__ __forceinline__ void posting_scores(const KParams& p, const double* l
     }
     s[u] = on[u] ? acc : 0.0;
   }
+}
+
+// Scores of U postings per lane (indices pi[u]); all loads of the trip are issued before the arithmetic.
+template <int F_, int U>
+__device__ __forceinline__ void posting_scores(const KParams& p, const double* lut, const uint64_t (&pi)[U], const bool (&on)[U],
+                                               const double idf, const double eb, double (&s)[U]) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  uint32_t wv[U][FA];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int x = 0; x < FA; ++x) wv[u][x] = 0;
+    if (on[u]) tfl_load<F_>(p, pi[u], wv[u]);
+  }
+  scores_from_words<F_, U>(p, lut, pi, on, wv, idf, eb, s);
 }
 
 // Scores of documents d[u] (where on[u]) in list `en`; 0.0 = the list does not hold the document.
@@ -1746,6 +1757,323 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
       if (ws.hit) atomicAdd(&w[WS_HIT], (unsigned long long)ws.hit);
       if (ws.offer) atomicAdd(&w[WS_OFFER], (unsigned long long)ws.offer);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1d for small plans: k_daat_small - the same exact dynamic pruning as k_daat for batches whose queries
+// have one list per query term and at most 4 lists (BASELINE C2 / C4: 3), with the dependent-load chain of a
+// trip cut from ~15 levels to ~4.  k_daat walks the other lists one after the other, twice (pass 1 prunes,
+// pass 2 re-looks the hits up in plan order), every lookup hanging on the previous one's outcome; its
+// launch time is the number of trips per wave slot times that chain (the kernel moves ~0.6 GB: no
+// throughput roof is near).  Here a trip issues, as soon as its doc ids are known, the FIRST-level load of
+// every other list together - dense-row value, {bits, rank} bitmap cell, or the two table words of a sparse
+// list's slot - next to the own postings' packed words; bounds are then tightened with what is already
+// exact (row values, bitmap membership), the survivors fetch what is left (packed words of bitmap hits; up
+// to 4 doc ids of a sparse slot at once, then the packed words of a match), and the contributions are
+// summed in PLAN order as they complete: same operands, same order of additions, same bits as k_daat / k_score.
+// ------------------------------------------------------------------------------------------
+#ifndef PS_DAAT_US
+#define PS_DAAT_US 4   // postings per lane in flight
+#endif
+constexpr int DAAT_SMALL_MAX = 4;  // most lists per query
+
+template <int F_>
+__global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int U = PS_DAAT_US;
+  constexpr int NO = DAAT_SMALL_MAX - 1;  // other lists of a query
+  constexpr int FA = F_ ? F_ : MAX_F;
+  constexpr double SLACK = 1.0 + 1e-9;    // bounds are summed in another order than the scores
+  const int lane = threadIdx.x & (WAVE - 1);
+  const double* lut = reinterpret_cast<const double*>(smem);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
+  const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
+  {
+    // most workgroups of a launch only hold chunks of lists that are already non-essential: they leave
+    // before they stage the LUT
+    int need = 0;
+    if (id < n_ditems) {
+      const DEntry de = p.dentry[p.ditems[id].entry];
+      const double theta = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      need = !(de.skip_thr < theta);
+    }
+    if (!__syncthreads_or(need)) {
+      if (id < n_ditems && lane == 0) p.cand_cnt[p.ditems[id].slot] = 0u;
+      return;
+    }
+  }
+  {
+    double* l = reinterpret_cast<double*>(smem);
+    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * DAAT_WGW) l[i] = p.lut[i];
+    __syncthreads();  // the last workgroup-level synchronisation
+  }
+  if (id >= n_ditems) return;
+  const DItem it = p.ditems[id];
+  const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
+  const ps_plan_entry& own = p.plan[e_own];
+  const DEntry de = p.dentry[e_own];
+  const uint32_t q = __builtin_amdgcn_readfirstlane(de.q);
+  const uint32_t e0 = p.qbeg[q], ne = p.qbeg[q + 1] - e0;  // ne <= DAAT_SMALL_MAX (host)
+  const uint32_t own_pos = e_own - e0;
+  const double own_idf = own.idf, own_eb = own.boost;
+  const uint64_t own_off = own.post_off;
+  const uint32_t own_rank = de.rank;
+  const double skip_thr = de.skip_thr, others = de.others;
+  // the other lists, in plan order (wave-uniform: scalar registers)
+  uint64_t o_off[NO];
+  uint32_t o_shift[NO], o_bm[NO], o_tbl[NO], o_row[NO], o_rank[NO];
+  double o_idf[NO], o_eb[NO], o_ub[NO];
+#pragma unroll
+  for (int k = 0; k < NO; ++k) {
+    o_off[k] = 0; o_shift[k] = 0; o_bm[k] = 0xFFFFFFFFu; o_tbl[k] = 0; o_row[k] = 0; o_rank[k] = 0xFFFFFFFFu;
+    o_idf[k] = 0.0; o_eb[k] = 0.0; o_ub[k] = 0.0;
+    if ((uint32_t)k + 1u < ne) {
+      const uint32_t j = e0 + (uint32_t)k + ((uint32_t)k >= own_pos ? 1u : 0u);
+      const ps_plan_entry& en = p.plan[j];
+      const DEntry dj = p.dentry[j];
+      o_off[k] = en.post_off; o_shift[k] = en.shift; o_bm[k] = en.bm_off; o_tbl[k] = en.tbl_off; o_row[k] = en.node;
+      o_idf[k] = en.idf; o_eb[k] = en.boost; o_ub[k] = dj.ub; o_rank[k] = dj.rank;
+    }
+  }
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+  double published = 0.0;
+  const uint32_t end = it.begin + it.count;
+  bool essential = true;  // wave-uniform
+  WorkStats ws;
+#ifdef PS_ITEM_TRACE
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  uint32_t n_trips = 0;
+#endif
+  for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
+#ifdef PS_ITEM_TRACE
+    ++n_trips;
+#endif
+    const unsigned long long tbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t d[U];
+    uint64_t pi[U];
+    uint32_t wv[U][FA];
+    bool inr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + u * WAVE + lane;
+      inr[u] = i < end;
+      pi[u] = own_off + (i < end ? i : end - 1);
+      d[u] = p.doc[pi[u]];
+#pragma unroll
+      for (int x = 0; x < FA; ++x) wv[u][x] = 0;
+      tfl_load<F_>(p, pi[u], wv[u]);
+    }
+    const double theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)),
+                                          __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits));
+    essential = !(skip_thr < theta);  // false: the whole list has become non-essential
+    if (!essential) {  // (its doc ids and packed words were requested with the threshold: booked, then out)
+      ws.probe += min(end - i0, (uint32_t)(WAVE * U)) * (1u + (F_ ? (uint32_t)F_ : p.F));
+      break;
+    }
+    // ---- first level of every other list, all in flight together ----
+    uint2 fl[NO][U];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) fl[k][u] = make_uint2(0u, 0u);
+      if ((uint32_t)k + 1u < ne) {
+        if (o_shift[k] & DENSE_FLAG) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (inr[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.rows + (uint64_t)o_row[k] * p.row_stride + d[u]);
+        } else if (o_bm[k] != 0xFFFFFFFFu) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (inr[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(d[u] >> 5));
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (inr[u]) {
+              const uint32_t slot = (d[u] >> p.t_log2) >> (o_shift[k] & 0xFFu);
+              fl[k][u].x = p.table[o_tbl[k] + slot];
+              fl[k][u].y = p.table[o_tbl[k] + slot + 1];
+            }
+        }
+      }
+    }
+    if (p.alive != nullptr) {  // delta removals
+#pragma unroll
+      for (int u = 0; u < U; ++u) inr[u] = inr[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
+    }
+    ws.scanned += min(end - i0, (uint32_t)(WAVE * U));
+    // ---- own scores; first bound test ----
+    double s_own[U];
+    scores_from_words<F_, U>(p, lut, pi, inr, wv, own_idf, own_eb, s_own);
+    bool alive[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // everything the other entries could add, at most: below theta the document is out
+      alive[u] = inr[u] && (s_own[u] + others >= theta);
+      ws.reached += lanes_on(alive[u]);
+    }
+    // ---- what the first level already tells: exact row values, bitmap membership, empty table slots ----
+    double bound[U];
+    bool hit[NO][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) bound[u] = s_own[u];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) hit[k][u] = false;
+      if ((uint32_t)k + 1u < ne) {
+        const bool dense = (o_shift[k] & DENSE_FLAG) != 0, bitmap = !dense && o_bm[k] != 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          double c;
+          if (dense) {
+            c = __hiloint2double((int)fl[k][u].y, (int)fl[k][u].x);
+            hit[k][u] = alive[u] && c > 0.0;
+            ws.row += lanes_on(inr[u]);
+          } else if (bitmap) {
+            hit[k][u] = alive[u] && ((fl[k][u].x >> (d[u] & 31u)) & 1u);
+            c = hit[k][u] ? o_ub[k] : 0.0;
+            ws.cell += lanes_on(inr[u]);
+          } else {
+            hit[k][u] = alive[u] && fl[k][u].x < fl[k][u].y;  // the slot holds postings: maybe
+            c = hit[k][u] ? o_ub[k] : 0.0;
+            ws.probe += 2u * lanes_on(inr[u]);
+          }
+          bound[u] += alive[u] ? c : 0.0;
+          // (a document is evaluated from its highest-bound list only: known here for rows and bitmaps)
+          if ((dense || bitmap) && hit[k][u] && o_rank[k] < own_rank) alive[u] = false;
+        }
+      }
+    }
+    bool any_alive = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      alive[u] = alive[u] && (bound[u] * SLACK >= theta);
+      any_alive |= alive[u];
+    }
+    if (!__any(any_alive)) continue;
+    // ---- second level + the sum in PLAN order (query.rs:33-89; one list per query term: always the `+` / assign arm) ----
+    double P[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) P[u] = 0.0;
+#pragma unroll
+    for (int k = 0; k <= NO; ++k) {
+      if ((uint32_t)k == own_pos) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (alive[u] && s_own[u] > 0.0) P[u] += s_own[u];
+      }
+      if (k < NO && (uint32_t)k + 1u < ne) {
+        const bool dense = (o_shift[k] & DENSE_FLAG) != 0, bitmap = !dense && o_bm[k] != 0xFFFFFFFFu;
+        double sk[U];
+        if (dense) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) sk[u] = (alive[u] && hit[k][u]) ? __hiloint2double((int)fl[k][u].y, (int)fl[k][u].x) : 0.0;
+        } else {
+          bool found[U];
+          uint64_t pk[U];
+          bool any_f = false;
+          if (bitmap) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              found[u] = alive[u] && hit[k][u];
+              const uint32_t bit = d[u] & 31u;
+              pk[u] = o_off[k] + fl[k][u].y + (uint32_t)__popc(fl[k][u].x & ((1u << bit) - 1u));
+              any_f |= found[u];
+            }
+          } else {
+            // a sparse list's table slot holds a handful of postings: up to 4 doc ids per step, all requested at once
+            const uint32_t* docs = p.doc + o_off[k];
+            uint32_t lo[U];
+            bool open[U];
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              found[u] = false; pk[u] = o_off[k];
+              lo[u] = fl[k][u].x;
+              open[u] = alive[u] && hit[k][u];
+              more |= open[u];
+            }
+            more = __any(more);
+            while (more) {
+              uint32_t v[U][4];
+#pragma unroll
+              for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                  const bool rd = open[u] && lo[u] + t < fl[k][u].y;
+                  v[u][t] = rd ? docs[lo[u] + t] : 0xFFFFFFFFu;
+                  ws.probe += lanes_on(rd);
+                }
+              bool again = false;
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                if (open[u]) {
+#pragma unroll
+                  for (int t = 0; t < 4; ++t)
+                    if (v[u][t] == d[u]) { found[u] = true; pk[u] = o_off[k] + lo[u] + t; }
+                  // ascending doc ids: past the document, or past the slot, the search is over
+                  open[u] = !found[u] && v[u][3] < d[u] && lo[u] + 4 < fl[k][u].y;
+                  lo[u] += 4;
+                }
+                again |= open[u];
+              }
+              more = __any(again);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) any_f |= found[u];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) { sk[u] = 0.0; ws.hit += lanes_on(found[u]); }
+          if (__any(any_f)) posting_scores<F_, U>(p, lut, pk, found, o_idf[k], o_eb[k], sk);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (alive[u] && sk[u] > 0.0) {
+            if (o_rank[k] < own_rank) alive[u] = false;  // evaluated from its highest-bound list only
+            P[u] += sk[u];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool offer = alive[u] && P[u] >= theta;
+      ws.offer += lanes_on(offer);
+      if (__any(offer)) topk_offer(tk, p.K, lane, alive[u], P[u], d[u], theta);
+    }
+    if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta) {
+      // this wave's K-th best so far: the final K-th best of the query can only be higher
+      published = tk.thr_s;
+      if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+    }
+  }
+  if ((uint32_t)lane < p.K) {
+    const uint64_t o = (uint64_t)it.slot * p.K + lane;
+    const bool ok = (uint32_t)lane < tk.n;
+    p.cand_score[o] = ok ? tk.s : 0.0;
+    p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
+    if (lane == 0) p.cand_cnt[it.slot] = tk.n;
+  }
+#ifdef PS_ITEM_TRACE
+  if (p.item_trace != nullptr && lane == 0) {
+    unsigned long long* tr = p.item_trace + (size_t)id * 4;
+    tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = (unsigned long long)n_trips | ((unsigned long long)own_rank << 32);
+    tr[3] = ws.scanned | ((unsigned long long)ws.reached << 32);
+  }
+#endif
+  if (PS_WORK_COUNTERS && lane == 0) {
+    unsigned long long* w = p.wstats + (size_t)(blockIdx.x & (WS_SLOTS - 1u)) * WS_WORDS;
+    atomicAdd(&w[WS_ITEMS_RUN], 1ull);
+    if (ws.scanned) atomicAdd(&w[WS_SCANNED], (unsigned long long)ws.scanned);
+    if (ws.reached) atomicAdd(&w[WS_REACHED], (unsigned long long)ws.reached);
+    if (ws.row) atomicAdd(&w[WS_ROW], (unsigned long long)ws.row);
+    if (ws.cell) atomicAdd(&w[WS_CELL], (unsigned long long)ws.cell);
+    if (ws.probe) atomicAdd(&w[WS_PROBE], (unsigned long long)ws.probe);
+    if (ws.hit) atomicAdd(&w[WS_HIT], (unsigned long long)ws.hit);
+    if (ws.offer) atomicAdd(&w[WS_OFFER], (unsigned long long)ws.offer);
   }
 }
 
