@@ -423,9 +423,9 @@ def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layo
               "results": w["results"]})
     out = {"bound": "hbm", "achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS,
            "bytes_touched": touched, "units_processed": units, "counted_launches": int(wc["launches"]),
-           "bytes_touched_formula": "scanned x (4+4F) + row lookups x 8 + bitmap-cell lookups x 8 + search probes x 4 + "
-                                    "lookup hits x 4F + candidate slots written x 12 + results x 16  (F = %d; K1: postings "
-                                    "streamed x (4+4F) + row tile slices x tile_docs x 8)" % F,
+           "bytes_touched_formula": "scanned x (4+8F) + row lookups x 8 + bitmap-cell lookups x 8 + search probes x 4 + "
+                                    "lookup hits x 8F + candidate slots written x 12 + results x 16  (F = %d: doc id + score-plane "
+                                    "values per posting; K1: postings streamed x (4+4F) + row tile slices x tile_docs x 8)" % F,
            "fraction_of_reference_postings_scanned": (w["postings_scanned"] * (4 + 8 * F) / alg_bytes) if daat and alg_bytes else None,
            "kernel": kernel, "kernel_avg_ms": k_avg_ms, "rows_kernels_avg_ms": rows_avg_ms, "launches": launches,
            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_rate_GBps": alg_rate,

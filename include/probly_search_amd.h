@@ -378,11 +378,11 @@ ps_status ps_snapshot_kernel_breakdown(ps_snapshot* snap, ps_kernel_times* out, 
  * outstanding work.  This is what bench.py's roofline (`bytes_touched`) is computed from: the exact
  * pruning kernel K1d k_daat skips most of the postings the reference walks (src/query.rs:61-89), so
  * the bytes it moves have to be counted, not derived from the plan.
- *   K1d k_daat: a posting of the item's own list is "scanned" (doc id + packed {tf, field length} words:
- *   4 + 4F bytes); one that passes the first bound test "reaches the lookups"; a lookup into another
- *   list is one 8-byte dense-row read, one 8-byte {bits, rank} bitmap-cell read, or 4-byte probes of a
- *   binary search (two table words, the probed doc ids, the final check); a lookup that finds the
- *   document reads its packed words (4F bytes).
+ *   K1d k_daat / k_daat_small: a posting of the item's own list is "scanned" (doc id + its score-plane
+ *   values: 4 + 8F bytes); one that passes the first bound test "reaches the lookups"; a lookup into
+ *   another list is one 8-byte dense-row read, one 8-byte {bits, rank} bitmap-cell read, or 4-byte probes
+ *   of a sparse list's table slot (two table words, the probed doc ids); a lookup that finds the document
+ *   reads its score-plane values (8F bytes).
  *   K1 k_score: every posting of every (query, list) is streamed (4 + 4F bytes), a dense-row use reads
  *   8 bytes per document and plane of the tile slice. */
 typedef struct ps_work_counters {

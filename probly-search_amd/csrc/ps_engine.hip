@@ -190,9 +190,9 @@ struct EngineImpl {
     std::vector<double> avg;
     size_t n_layers = 0;
     DevBuf<unsigned long long> M;
-    struct JSet { std::vector<double> boosts; DevBuf<unsigned long long> J; uint64_t last_use = 0; bool valid = false; hipEvent_t ready = nullptr; };
+    struct JSet { std::vector<double> boosts; DevBuf<unsigned long long> J; DevBuf<double> plane; uint64_t last_use = 0; bool valid = false; hipEvent_t ready = nullptr; };
     hipEvent_t m_ready = nullptr;  // behind the kernel that last wrote M (batches on other streams wait for it)
-    JSet j[4];
+    JSet j[2];  // (each carries a score plane of 8F bytes per posting)
     uint64_t epoch = 0;
     DevBuf<BoundUnit> units;
     uint32_t n_units = 0;
@@ -229,7 +229,7 @@ struct EngineImpl {
   DevBuf<uint4> d_fnodes, d_layer_a, d_layer_b;
   DevBuf<uint32_t> d_fchar, d_fchild, d_term_meta, d_term_delta;
   DevBuf<uint64_t> d_term_df;
-  DevBuf<double> d_term_idf, d_eb_table;
+  DevBuf<double> d_term_idf, d_eb_table, d_layer_idf;
   uint32_t eb_n = 0;
   // A device-built plan (k_plan): the batch's text, the per-query counts of the count pass, the entries.
   struct PlanSet {
@@ -414,7 +414,7 @@ Engine::~Engine() {
   m.d_gthr.release(); m.d_rows.release(); m.d_removed_df.release();
   m.bounds.M.release(); m.bounds.units.release();
   if (m.bounds.m_ready) (void)hipEventDestroy(m.bounds.m_ready);
-  for (auto& js : m.bounds.j) { js.J.release(); if (js.ready) (void)hipEventDestroy(js.ready); }
+  for (auto& js : m.bounds.j) { js.J.release(); js.plane.release(); if (js.ready) (void)hipEventDestroy(js.ready); }
   if (m.lut_ready) (void)hipEventDestroy(m.lut_ready);
   m.cands.of_layer.release();
   for (auto& c : m.dctx) {
@@ -429,7 +429,7 @@ Engine::~Engine() {
   if (m.prep_stream) (void)hipStreamDestroy(m.prep_stream);
   if (m.score_stream) (void)hipStreamDestroy(m.score_stream);
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fchar.release(); m.d_fchild.release();
-  m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release();
+  m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release(); m.d_layer_idf.release();
   if (m.h_totals) (void)hipHostFree(m.h_totals);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
   m.d_sort_tmp.release(); m.d_pack.release();
@@ -570,9 +570,9 @@ void Engine::work_counters(ps_work_counters& out, bool reset) {
   out.results = m.wc_results;
   out.rows_built = sum[WS_ROWS_BUILT];
   out.rows_used = sum[WS_ROWS_USED];
-  const uint64_t F = m.snap->F, pw = 4 + 4 * F;
-  out.bytes_touched = out.postings_scanned * pw + out.lookups_row * 8 + out.lookups_cell * 8 + out.lookups_probe * 4 +
-                      out.lookup_hits * 4 * F + out.k1_postings * pw + out.k1_row_slices * (uint64_t)m.snap->T * 8 +
+  const uint64_t F = m.snap->F, pw = 4 + 4 * F;  // K1: doc id + packed words; K1d: doc id + score plane (8 bytes per field)
+  out.bytes_touched = out.postings_scanned * (4 + 8 * F) + out.lookups_row * 8 + out.lookups_cell * 8 + out.lookups_probe * 4 +
+                      out.lookup_hits * 8 * F + out.k1_postings * pw + out.k1_row_slices * (uint64_t)m.snap->T * 8 +
                       (m.wc_cand_slots + out.items_run * m.wc_k) * 12 + out.results * 16;
   if (reset) {
     PS_HIP(hipMemset(m.d_wstats, 0, w.size() * 8));
@@ -778,7 +778,7 @@ void ensure_dev_trie(EngineImpl& m);  // (defined with the device planner below)
 // Per-list score bounds on the device (k_list_bounds) for the current (k1, b, avg) and boosts; see
 // EngineImpl::ListBounds.  Enqueued on `st` in front of the batch that needs them; nothing is recomputed
 // while the parameters stay what they were, and a boost vector seen recently finds its J array resident.
-struct BoundsRef { const double* M; const double* J; };
+struct BoundsRef { const double* M; const double* J; const double* plane; };
 BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const KParams& kp, hipStream_t st) {
   const Snapshot& s = *m.snap;
   EngineImpl::ListBounds& lb = m.bounds;
@@ -797,7 +797,7 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
     // (they may have been computed on another context's stream a moment ago)
     PS_HIP(hipStreamWaitEvent(st, lb.m_ready, 0));
     PS_HIP(hipStreamWaitEvent(st, tgt->ready, 0));
-    return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p)};
+    return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p), tgt->plane.p};
   }
   // (M is rewritten in place and a J array may be recycled: their only readers are the preparation kernels,
   // which run on this same stream, in order)
@@ -820,11 +820,12 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
   }
   lb.M.ensure(nl * F + 1);
   tgt->J.ensure(nl + 1);
+  tgt->plane.ensure((size_t)s.P * F + 2);
   if (!m_ok) PS_HIP(hipMemsetAsync(lb.M.p, 0, (nl * F + 1) * 8, st));
   PS_HIP(hipMemsetAsync(tgt->J.p, 0, (nl + 1) * 8, st));
   if (lb.n_units) {
     hipLaunchKernelGGL(k_list_bounds, dim3((lb.n_units + 3) / 4), dim3(256), 0, st, kp, lb.units.p, lb.n_units, m.d_layer_a.p, lb.M.p,
-                       tgt->J.p, m_ok ? 0 : 1);
+                       tgt->J.p, m_ok ? 0 : 1, tgt->plane.p, m.d_layer_idf.p);
     PS_HIP(hipGetLastError());
   }
   if (!m_ok) PS_HIP(hipEventRecord(lb.m_ready, st)); else PS_HIP(hipStreamWaitEvent(st, lb.m_ready, 0));
@@ -833,7 +834,7 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
   tgt->valid = true; tgt->boosts = bv; tgt->last_use = lb.epoch;
   lb.last_ms = now_ms() - t0;
   ++lb.recomputed;
-  return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p)};
+  return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p), tgt->plane.p};
 }
 
 // K1d dense-row candidates: the snapshot's densest lists with one table slot per tile, longest first,
@@ -904,6 +905,7 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div;
   for (uint32_t x = 0; x < s.F; ++x) pp.boost[x] = boosts[x];
   pp.bound_m = br.M; pp.bound_j = br.J;
+  kp.splane = br.plane;
   pp.dentry = c.dentry.p; pp.rorder = c.rorder.p; pp.dgroup = multi ? c.dgroup.p : nullptr; pp.gord = c.gord.p;
   pp.gen = c.gen.p; pp.qslot = c.qslot.p; pp.qslot_n = c.qslot_n.p;
   pp.items = c.ditems.p; pp.items_cap = (uint32_t)items_bound;
@@ -1563,7 +1565,7 @@ void launch_k_score(EngineImpl& m, KParams& kp, bool tags, int n_cu, hipStream_t
 void launch_daat(EngineImpl& m, KParams& kp, bool multi, bool small, int n_cu, hipStream_t st) {
   // (PS_DAAT_PAD_LDS: extra dynamic LDS per workgroup - an occupancy cap for experiments; 24000 = 3 waves per SIMD)
   static const size_t pad_lds = env_u32("PS_DAAT_PAD_LDS", 0);
-  const size_t lds = std::max((size_t)kp.lut_stride * LUT_TF * 8, pad_lds);
+  const size_t lds = pad_lds;  // (K1d reads score planes: no table to stage)
 #define PS_DAAT(FV, MU)                                                                                  \
   do {                                                                                                   \
     const void* fn = reinterpret_cast<const void*>(&k_daat<FV, MU>);                                     \
@@ -1752,15 +1754,6 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     PS_HIP(hipEventRecord(c.prepared, P));
     // ---- scoring stream ----
     PS_HIP(hipStreamWaitEvent(S, c.prepared, 0));
-    // K0 (the saturated-tf table k_daat stages in LDS) runs when (k1, b) change; it is shared by every stream
-    if (kp.lut_rows && !(m.lut_valid && m.lut_k1 == sc.bm25_k1 && m.lut_b == sc.bm25_b && m.tune.lut_cache)) {
-      if (m.tail_pending && m.tail_stream != S) PS_HIP(hipStreamWaitEvent(S, m.ev[0], 0));
-      hipLaunchKernelGGL(k_bm25_lut, dim3(4), dim3(256), 0, S, kp, const_cast<double*>(kp.lut));
-      PS_HIP(hipEventRecord(m.lut_ready, S));
-      m.lut_valid = true; m.lut_k1 = sc.bm25_k1; m.lut_b = sc.bm25_b; m.lut_stream = S;
-    } else if (kp.lut_rows && m.lut_stream != S) {
-      PS_HIP(hipStreamWaitEvent(S, m.lut_ready, 0));
-    }
     m.wc_launches++;
     m.wc_k = kp.K;
     m.wc_results += (uint64_t)kp.B * kp.K;
@@ -2001,6 +1994,15 @@ void ensure_dev_trie(EngineImpl& m) {
   };
   up(m.d_fnodes, fn); up(m.d_layer_a, la); up(m.d_layer_b, lb); up(m.d_term_meta, meta); up(m.d_term_delta, delta);
   up(m.d_term_df, df); up(m.d_term_idf, idf); up(m.d_eb_table, eb);
+  {  // per list (layer) the idf of its term: what the score planes are built with
+    std::vector<double> lidf(std::max<size_t>(nl, 1), 0.0);
+    for (size_t o = 0; o < nt; ++o) {
+      const TermInfo& t = s.terms[o];
+      for (uint32_t l = 0; l < t.n_layers; ++l) lidf[t.first_layer + l] = idf[o];
+      for (uint32_t l = t.delta_head; l != 0xFFFFFFFFu && l < nl; l = s.layers[l].next) lidf[l] = idf[o];
+    }
+    up(m.d_layer_idf, lidf);
+  }
   std::vector<uint32_t> fc(s.fchar.begin(), s.fchar.end()), fd(s.fchild.begin(), s.fchild.end());
   if (fc.empty()) { fc.push_back(0); fd.push_back(0); }
   up(m.d_fchar, fc); up(m.d_fchild, fd);

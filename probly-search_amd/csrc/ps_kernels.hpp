@@ -144,6 +144,7 @@ struct KParams {
   uint32_t prep_ctl_words;
   const uint32_t* rorder;       // [n_plan_entries] per query: its entries in rank order (highest bound first)
   const struct DGroup* dgroup;  // [n_plan_entries] (multi-expansion batches)
+  const double* splane;         // [P][F] score plane (k_list_bounds): (tfn * idf) * boost_x of every (posting, field), 0.0 where tf_x == 0 - what K1d reads instead of re-deriving it per visit
   const uint32_t* tfl;          // [P][F] packed {tf (8 bits, 255 = see the tf plane), field length (24 bits, all ones = see the fl plane)}: what the hot loops read
   const uint32_t* bits;         // membership bitmaps of the denser lists (ps_plan_entry::bm_off)
   const uint32_t* alive;        // one bit per doc id, cleared by a delta removal; null = every document alive
@@ -1307,6 +1308,53 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
 // word k_score uses; items are handed out highest-bound lists first, so by the time the long
 // low-idf lists come up most of them are skipped whole.  No LDS tiles, no harvest over N documents.
 // ------------------------------------------------------------------------------------------
+// ---- score planes --------------------------------------------------------------------------------
+// ((tfn * idf) * boost_x) of a (posting, field) depends on the list (idf), the scorer parameters and the
+// boosts, not on the query: k_list_bounds evaluates it ONCE per posting - the same f64 expression, left to
+// right (bm25.rs:78-86) - into a plane next to the postings, and K1d's per-visit work shrinks to
+// `sum_x plane_x * expansion_boost` (the last multiplication and the additions of the same expression, in
+// the same order: bit-identical).  item traces showed k_daat bound by VALU issue - ~800 wave instructions
+// per 256 postings, most of them unpacking words and gathering the saturated-tf table - not by latency.
+template <int F_>
+__device__ __forceinline__ void plane_load(const KParams& p, const uint64_t pi, double (&t)[F_ ? F_ : MAX_F]) {
+  if (F_ == 1) {
+    t[0] = p.splane[pi];
+  } else if (F_ == 2) {
+    const double2 v = reinterpret_cast<const double2*>(p.splane)[pi];
+    t[0] = v.x; t[1] = v.y;
+  } else {
+#pragma unroll
+    for (int x = 0; x < (F_ ? F_ : MAX_F); ++x)
+      if ((uint32_t)x < p.F) t[x] = p.splane[pi * p.F + x];
+  }
+}
+template <int F_, int U>
+__device__ __forceinline__ void scores_from_plane(const KParams& p, const double (&t)[U][F_ ? F_ : MAX_F], const bool (&on)[U],
+                                                  const double eb, double (&s)[U]) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  const uint32_t F = F_ ? (uint32_t)F_ : p.F;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    double acc = 0.0;
+#pragma unroll
+    for (int x = 0; x < FA; ++x)
+      if ((uint32_t)x < F) acc += t[u][x] * eb;  // ((tfn*idf)*boost)*expansion_boost; a field with tf == 0 adds +0.0
+    s[u] = on[u] ? acc : 0.0;
+  }
+}
+template <int F_, int U>
+__device__ __forceinline__ void plane_scores(const KParams& p, const uint64_t (&pi)[U], const bool (&on)[U], const double eb, double (&s)[U]) {
+  constexpr int FA = F_ ? F_ : MAX_F;
+  double t[U][FA];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int x = 0; x < FA; ++x) t[u][x] = 0.0;
+    if (on[u]) plane_load<F_>(p, pi[u], t[u]);
+  }
+  scores_from_plane<F_, U>(p, t, on, eb, s);
+}
+
 // BM25 scores of U postings per lane from their packed {tf, field length} words (already loaded).
 template <int F_, int U>
 __device__ __forceinline__ void scores_from_words(const KParams& p, const double* lut, const uint64_t (&pi)[U], const bool (&on)[U],
@@ -1435,7 +1483,7 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
   bool any_found = false;
 #pragma unroll
   for (int u = 0; u < U; ++u) { any_found |= found[u]; ws.hit += lanes_on(found[u]); }
-  if (__any(any_found)) posting_scores<F_, U>(p, lut, pi, found, en.idf, en.boost, s);
+  if (__any(any_found)) plane_scores<F_, U>(p, pi, found, en.boost, s);
 }
 
 template <int F_, bool MULTI>
@@ -1466,11 +1514,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
       return;
     }
   }
-  {
-    double* l = reinterpret_cast<double*>(smem);
-    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * DAAT_WGW) l[i] = p.lut[i];
-    __syncthreads();  // the last workgroup-level synchronisation
-  }
   bool first = true;
   for (;;) {
     uint32_t id = 0;
@@ -1489,7 +1532,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
     const DEntry de = p.dentry[e_own];
     const uint32_t q = __builtin_amdgcn_readfirstlane(de.q);
     const uint32_t e0 = p.qbeg[q], e1 = p.qbeg[q + 1];
-    const double own_idf = own.idf, own_eb = own.boost;
+    const double own_eb = own.boost;
     const uint64_t own_off = own.post_off;
     const uint32_t own_rank = de.rank;
     const double skip_thr = de.skip_thr, others = de.others;
@@ -1538,7 +1581,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) alive[u] = alive[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
       }
-      posting_scores<F_, U>(p, lut, pi, alive, own_idf, own_eb, s_own);
+      plane_scores<F_, U>(p, pi, alive, own_eb, s_own);
       bool any_alive = false;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1786,7 +1829,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   constexpr int FA = F_ ? F_ : MAX_F;
   constexpr double SLACK = 1.0 + 1e-9;    // bounds are summed in another order than the scores
   const int lane = threadIdx.x & (WAVE - 1);
-  const double* lut = reinterpret_cast<const double*>(smem);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
   const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
@@ -1804,11 +1846,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       return;
     }
   }
-  {
-    double* l = reinterpret_cast<double*>(smem);
-    for (uint32_t i = threadIdx.x; i < p.lut_stride * LUT_TF; i += WAVE * DAAT_WGW) l[i] = p.lut[i];
-    __syncthreads();  // the last workgroup-level synchronisation
-  }
   if (id >= n_ditems) return;
   const DItem it = p.ditems[id];
   const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
@@ -1817,24 +1854,24 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   const uint32_t q = __builtin_amdgcn_readfirstlane(de.q);
   const uint32_t e0 = p.qbeg[q], ne = p.qbeg[q + 1] - e0;  // ne <= DAAT_SMALL_MAX (host)
   const uint32_t own_pos = e_own - e0;
-  const double own_idf = own.idf, own_eb = own.boost;
+  const double own_eb = own.boost;
   const uint64_t own_off = own.post_off;
   const uint32_t own_rank = de.rank;
   const double skip_thr = de.skip_thr, others = de.others;
   // the other lists, in plan order (wave-uniform: scalar registers)
   uint64_t o_off[NO];
   uint32_t o_shift[NO], o_bm[NO], o_tbl[NO], o_row[NO], o_rank[NO];
-  double o_idf[NO], o_eb[NO], o_ub[NO];
+  double o_eb[NO], o_ub[NO];
 #pragma unroll
   for (int k = 0; k < NO; ++k) {
     o_off[k] = 0; o_shift[k] = 0; o_bm[k] = 0xFFFFFFFFu; o_tbl[k] = 0; o_row[k] = 0; o_rank[k] = 0xFFFFFFFFu;
-    o_idf[k] = 0.0; o_eb[k] = 0.0; o_ub[k] = 0.0;
+    o_eb[k] = 0.0; o_ub[k] = 0.0;
     if ((uint32_t)k + 1u < ne) {
       const uint32_t j = e0 + (uint32_t)k + ((uint32_t)k >= own_pos ? 1u : 0u);
       const ps_plan_entry& en = p.plan[j];
       const DEntry dj = p.dentry[j];
       o_off[k] = en.post_off; o_shift[k] = en.shift; o_bm[k] = en.bm_off; o_tbl[k] = en.tbl_off; o_row[k] = en.node;
-      o_idf[k] = en.idf; o_eb[k] = en.boost; o_ub[k] = dj.ub; o_rank[k] = dj.rank;
+      o_eb[k] = en.boost; o_ub[k] = dj.ub; o_rank[k] = dj.rank;
     }
   }
   TopK tk;
@@ -1854,7 +1891,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
     const unsigned long long tbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t d[U];
     uint64_t pi[U];
-    uint32_t wv[U][FA];
+    double tw[U][FA];
     bool inr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1863,14 +1900,14 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       pi[u] = own_off + (i < end ? i : end - 1);
       d[u] = p.doc[pi[u]];
 #pragma unroll
-      for (int x = 0; x < FA; ++x) wv[u][x] = 0;
-      tfl_load<F_>(p, pi[u], wv[u]);
+      for (int x = 0; x < FA; ++x) tw[u][x] = 0.0;
+      plane_load<F_>(p, pi[u], tw[u]);
     }
     const double theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)),
                                           __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits));
     essential = !(skip_thr < theta);  // false: the whole list has become non-essential
     if (!essential) {  // (its doc ids and packed words were requested with the threshold: booked, then out)
-      ws.probe += min(end - i0, (uint32_t)(WAVE * U)) * (1u + (F_ ? (uint32_t)F_ : p.F));
+      ws.probe += min(end - i0, (uint32_t)(WAVE * U)) * (1u + 2u * (F_ ? (uint32_t)F_ : p.F));
       break;
     }
     // ---- first level of every other list, all in flight together ----
@@ -1906,7 +1943,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
     ws.scanned += min(end - i0, (uint32_t)(WAVE * U));
     // ---- own scores; first bound test ----
     double s_own[U];
-    scores_from_words<F_, U>(p, lut, pi, inr, wv, own_idf, own_eb, s_own);
+    scores_from_plane<F_, U>(p, tw, inr, own_eb, s_own);
     bool alive[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -2027,7 +2064,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) { sk[u] = 0.0; ws.hit += lanes_on(found[u]); }
-          if (__any(any_f)) posting_scores<F_, U>(p, lut, pk, found, o_idf[k], o_eb[k], sk);
+          if (__any(any_f)) plane_scores<F_, U>(p, pk, found, o_eb[k], sk);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

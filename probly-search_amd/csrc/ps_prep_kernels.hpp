@@ -82,15 +82,18 @@ struct BoundUnit { uint32_t layer, begin, count; };  // a segment of one list
 // postings of tfn_x, J[l] = max of sum_x boost_x * tfn_x; both through bm25_tfn, the expression the scoring
 // kernels evaluate, so they bound the COMPUTED values.  Positive doubles order like their bit patterns:
 // the segments of a list meet through 64-bit atomicMax.
+// The same pass writes the score plane the K1d kernels read (ps_kernels.hpp, "score planes"): per (posting,
+// field) the value (tfn * idf) * boost_x, the list's idf from `layer_idf` (the planner's own number).
 __global__ __launch_bounds__(256) void k_list_bounds(const KParams p, const BoundUnit* units, const uint32_t n_units,
                                                      const uint4* layer_a, unsigned long long* M, unsigned long long* J,
-                                                     const int with_m) {
+                                                     const int with_m, double* plane, const double* layer_idf) {
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   const int lane = threadIdx.x & (WAVE - 1);
   if (wave >= n_units) return;
   const BoundUnit u = units[wave];
   const uint4 la = layer_a[u.layer];
   const uint64_t off = ((uint64_t)la.x | ((uint64_t)la.y << 32)) + u.begin;
+  const double idf = layer_idf[u.layer];
   double mj = 0.0, mm[MAX_F];
   for (uint32_t x = 0; x < p.F; ++x) mm[x] = 0.0;
   for (uint32_t i = lane; i < u.count; i += WAVE) {
@@ -99,9 +102,10 @@ __global__ __launch_bounds__(256) void k_list_bounds(const KParams p, const Boun
     for (uint32_t x = 0; x < p.F; ++x) {
       const uint32_t w = p.tfl[pi * p.F + x];
       uint32_t tfu = w >> 24, flu = w & TFL_FL_ESC;
-      if (tfu == 0) continue;
+      if (tfu == 0) { plane[pi * p.F + x] = 0.0; continue; }
       tfl_exact(p, x, pi, tfu, flu);
       const double t = bm25_tfn(p, x, tfu, flu);
+      plane[pi * p.F + x] = (t * idf) * p.boost[x];  // bm25.rs:83-85, left to right; expansion_boost is the reader's
       if (t > mm[x]) mm[x] = t;
       sum += p.boost[x] * t;
     }
