@@ -1819,22 +1819,31 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
 #ifndef PS_DAAT_US
 #define PS_DAAT_US 4   // postings per lane in flight
 #endif
+#ifndef PS_EXP
+#define PS_EXP 0       // profiling builds only (wrong results): 1 = no top-K offers, 2 = no second level, 4 = no first-level loads
+#endif
 constexpr int DAAT_SMALL_MAX = 4;  // most lists per query
 
 template <int F_>
 __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int U = PS_DAAT_US;
   constexpr int NO = DAAT_SMALL_MAX - 1;  // other lists of a query
   constexpr int FA = F_ ? F_ : MAX_F;
+  constexpr uint32_t QCAP = 128;          // survivor queue entries per wave (a push adds <= 64 to < 64)
   constexpr double SLACK = 1.0 + 1e-9;    // bounds are summed in another order than the scores
+  // Survivor queue (wave-private LDS ring): the documents of a trip that are still alive after the first
+  // level - a few percent of the lanes - wait here until 64 of them are together; their second level
+  // (packed / plane words of bitmap hits, the doc ids of a sparse slot, the plan-order sum, the top-K offer)
+  // then runs with every lane busy instead of once per trip for a handful of lanes.
+  __shared__ uint32_t q_d[DAAT_WGW][QCAP];
+  __shared__ double q_s[DAAT_WGW][QCAP];
+  __shared__ unsigned long long q_loc[NO][DAAT_WGW][QCAP];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
   const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
   {
-    // most workgroups of a launch only hold chunks of lists that are already non-essential: they leave
-    // before they stage the LUT
+    // most workgroups of a launch only hold chunks of lists that are already non-essential: they leave at once
     int need = 0;
     if (id < n_ditems) {
       const DEntry de = p.dentry[p.ditems[id].entry];
@@ -1862,6 +1871,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   uint64_t o_off[NO];
   uint32_t o_shift[NO], o_bm[NO], o_tbl[NO], o_row[NO], o_rank[NO];
   double o_eb[NO], o_ub[NO];
+  uint32_t n_dense = 0, n_bitmap = 0, n_sparse = 0;
 #pragma unroll
   for (int k = 0; k < NO; ++k) {
     o_off[k] = 0; o_shift[k] = 0; o_bm[k] = 0xFFFFFFFFu; o_tbl[k] = 0; o_row[k] = 0; o_rank[k] = 0xFFFFFFFFu;
@@ -1872,6 +1882,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       const DEntry dj = p.dentry[j];
       o_off[k] = en.post_off; o_shift[k] = en.shift; o_bm[k] = en.bm_off; o_tbl[k] = en.tbl_off; o_row[k] = en.node;
       o_eb[k] = en.boost; o_ub[k] = dj.ub; o_rank[k] = dj.rank;
+      if (en.shift & DENSE_FLAG) ++n_dense; else if (en.bm_off != 0xFFFFFFFFu) ++n_bitmap; else ++n_sparse;
     }
   }
   TopK tk;
@@ -1880,10 +1891,91 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   const uint32_t end = it.begin + it.count;
   bool essential = true;  // wave-uniform
   WorkStats ws;
+  uint32_t q_head = 0, q_n = 0;  // wave-uniform
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
 #ifdef PS_ITEM_TRACE
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
   uint32_t n_trips = 0;
 #endif
+
+  // Second level + the sum in PLAN order (query.rs:33-89; one list per query term: always the `+` / assign
+  // arm) + the top-K offer for the first `count` (<= 64) queued documents, one per lane.
+  auto process = [&](const uint32_t count, const double theta) {
+    const uint32_t at = (q_head + (uint32_t)lane) & (QCAP - 1u);
+    bool ok = (uint32_t)lane < count;
+    const uint32_t d = ok ? q_d[wave][at] : 0u;
+    const double s_own = ok ? q_s[wave][at] : 0.0;
+    double P = 0.0;
+#pragma unroll
+    for (int k = 0; k <= NO; ++k) {
+      if ((uint32_t)k == own_pos && ok && s_own > 0.0) P += s_own;
+      if (k < NO && (uint32_t)k + 1u < ne && !(PS_EXP & 2)) {
+        const unsigned long long loc = ok ? q_loc[k < NO ? k : 0][wave][at] : ~0ull;
+        double sk = 0.0;
+        if (o_shift[k] & DENSE_FLAG) {
+          sk = ok ? __longlong_as_double((long long)loc) : 0.0;
+        } else {
+          bool found = false;
+          uint64_t pk = o_off[k];
+          if (o_bm[k] != 0xFFFFFFFFu) {
+            found = ok && loc != ~0ull;
+            if (found) pk = loc;
+          } else {
+            // a sparse list's table slot holds a handful of postings: up to 4 doc ids per step, all requested at once
+            const uint32_t* docs = p.doc + o_off[k];
+            uint32_t lo = (uint32_t)loc;
+            const uint32_t hi = (uint32_t)(loc >> 32);
+            bool open = ok && loc != ~0ull;
+            while (__any(open)) {
+              uint32_t v[4];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const bool rd = open && lo + t < hi;
+                v[t] = rd ? docs[lo + t] : 0xFFFFFFFFu;
+                ws.probe += lanes_on(rd);
+              }
+              if (open) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  if (v[t] == d) { found = true; pk = o_off[k] + lo + t; }
+                // ascending doc ids: past the document, or past the slot, the search is over
+                open = !found && v[3] < d && lo + 4 < hi;
+                lo += 4;
+              }
+            }
+          }
+          ws.hit += lanes_on(found);
+          if (__any(found)) {
+            double t[FA];
+#pragma unroll
+            for (int x = 0; x < FA; ++x) t[x] = 0.0;
+            if (found) plane_load<F_>(p, pk, t);
+            double acc = 0.0;
+#pragma unroll
+            for (int x = 0; x < FA; ++x)
+              if ((uint32_t)x < (F_ ? (uint32_t)F_ : p.F)) acc += t[x] * o_eb[k];
+            sk = found ? acc : 0.0;
+          }
+        }
+        if (ok && sk > 0.0) {
+          if (o_rank[k] < own_rank) ok = false;  // evaluated from its highest-bound list only
+          P += sk;
+        }
+      }
+    }
+    const bool offer = ok && P >= theta;
+    ws.offer += lanes_on(offer);
+    if (!(PS_EXP & 1) && __any(offer)) topk_offer(tk, p.K, lane, ok, P, d, theta);
+    q_head = (q_head + count) & (QCAP - 1u);
+    q_n -= count;
+    if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta) {
+      // this wave's K-th best so far: the final K-th best of the query can only be higher
+      published = tk.thr_s;
+      if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+    }
+  };
+
+  double theta = 0.0;
   for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
 #ifdef PS_ITEM_TRACE
     ++n_trips;
@@ -1903,11 +1995,11 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       for (int x = 0; x < FA; ++x) tw[u][x] = 0.0;
       plane_load<F_>(p, pi[u], tw[u]);
     }
-    const double theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)),
-                                          __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits));
+    theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)), __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits));
     essential = !(skip_thr < theta);  // false: the whole list has become non-essential
-    if (!essential) {  // (its doc ids and packed words were requested with the threshold: booked, then out)
-      ws.probe += min(end - i0, (uint32_t)(WAVE * U)) * (1u + 2u * (F_ ? (uint32_t)F_ : p.F));
+    const uint32_t n_in = min(end - i0, (uint32_t)(WAVE * U));
+    if (!essential) {  // (its doc ids and plane values were requested with the threshold: booked, then out)
+      ws.probe += n_in * (1u + 2u * (F_ ? (uint32_t)F_ : p.F));
       break;
     }
     // ---- first level of every other list, all in flight together ----
@@ -1916,7 +2008,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
     for (int k = 0; k < NO; ++k) {
 #pragma unroll
       for (int u = 0; u < U; ++u) fl[k][u] = make_uint2(0u, 0u);
-      if ((uint32_t)k + 1u < ne) {
+      if ((uint32_t)k + 1u < ne && !(PS_EXP & 4)) {
         if (o_shift[k] & DENSE_FLAG) {
 #pragma unroll
           for (int u = 0; u < U; ++u)
@@ -1940,153 +2032,64 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
 #pragma unroll
       for (int u = 0; u < U; ++u) inr[u] = inr[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
     }
-    ws.scanned += min(end - i0, (uint32_t)(WAVE * U));
+    // (work counters: every posting of the trip asked every other list's first level)
+    ws.scanned += n_in;
+    ws.row += n_in * n_dense; ws.cell += n_in * n_bitmap; ws.probe += 2u * n_in * n_sparse;
     // ---- own scores; first bound test ----
     double s_own[U];
     scores_from_plane<F_, U>(p, tw, inr, own_eb, s_own);
-    bool alive[U];
+    // ---- what the first level already tells: exact row values, bitmap membership, empty table slots ----
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // everything the other entries could add, at most: below theta the document is out
-      alive[u] = inr[u] && (s_own[u] + others >= theta);
-      ws.reached += lanes_on(alive[u]);
-    }
-    // ---- what the first level already tells: exact row values, bitmap membership, empty table slots ----
-    double bound[U];
-    bool hit[NO][U];
+      bool alive = inr[u] && (s_own[u] + others >= theta);
+      ws.reached += lanes_on(alive);
+      double bound = s_own[u];
+      unsigned long long loc[NO];
 #pragma unroll
-    for (int u = 0; u < U; ++u) bound[u] = s_own[u];
-#pragma unroll
-    for (int k = 0; k < NO; ++k) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) hit[k][u] = false;
-      if ((uint32_t)k + 1u < ne) {
-        const bool dense = (o_shift[k] & DENSE_FLAG) != 0, bitmap = !dense && o_bm[k] != 0xFFFFFFFFu;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+      for (int k = 0; k < NO; ++k) {
+        loc[k] = ~0ull;
+        if ((uint32_t)k + 1u < ne) {
+          const bool dense = (o_shift[k] & DENSE_FLAG) != 0, bitmap = !dense && o_bm[k] != 0xFFFFFFFFu;
           double c;
+          bool hit;
           if (dense) {
             c = __hiloint2double((int)fl[k][u].y, (int)fl[k][u].x);
-            hit[k][u] = alive[u] && c > 0.0;
-            ws.row += lanes_on(inr[u]);
+            hit = c > 0.0;
+            loc[k] = (unsigned long long)fl[k][u].x | ((unsigned long long)fl[k][u].y << 32);
           } else if (bitmap) {
-            hit[k][u] = alive[u] && ((fl[k][u].x >> (d[u] & 31u)) & 1u);
-            c = hit[k][u] ? o_ub[k] : 0.0;
-            ws.cell += lanes_on(inr[u]);
+            const uint32_t bit = d[u] & 31u;
+            hit = (fl[k][u].x >> bit) & 1u;
+            c = hit ? o_ub[k] : 0.0;
+            if (hit) loc[k] = o_off[k] + fl[k][u].y + (uint32_t)__popc(fl[k][u].x & ((1u << bit) - 1u));
           } else {
-            hit[k][u] = alive[u] && fl[k][u].x < fl[k][u].y;  // the slot holds postings: maybe
-            c = hit[k][u] ? o_ub[k] : 0.0;
-            ws.probe += 2u * lanes_on(inr[u]);
+            hit = fl[k][u].x < fl[k][u].y;  // the slot holds postings: maybe
+            c = hit ? o_ub[k] : 0.0;
+            if (hit) loc[k] = (unsigned long long)fl[k][u].x | ((unsigned long long)fl[k][u].y << 32);
           }
-          bound[u] += alive[u] ? c : 0.0;
+          bound += c;
           // (a document is evaluated from its highest-bound list only: known here for rows and bitmaps)
-          if ((dense || bitmap) && hit[k][u] && o_rank[k] < own_rank) alive[u] = false;
+          if ((dense || bitmap) && hit && o_rank[k] < own_rank) alive = false;
         }
       }
-    }
-    bool any_alive = false;
+      alive = alive && (bound * SLACK >= theta);
+      // ---- survivors wait in the queue until 64 are together ----
+      const unsigned long long m = __ballot(alive);
+      if (m) {
+        if (alive) {
+          const uint32_t at = (q_head + q_n + (uint32_t)__popcll(m & lt)) & (QCAP - 1u);
+          q_d[wave][at] = d[u];
+          q_s[wave][at] = s_own[u];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      alive[u] = alive[u] && (bound[u] * SLACK >= theta);
-      any_alive |= alive[u];
-    }
-    if (!__any(any_alive)) continue;
-    // ---- second level + the sum in PLAN order (query.rs:33-89; one list per query term: always the `+` / assign arm) ----
-    double P[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) P[u] = 0.0;
-#pragma unroll
-    for (int k = 0; k <= NO; ++k) {
-      if ((uint32_t)k == own_pos) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (alive[u] && s_own[u] > 0.0) P[u] += s_own[u];
-      }
-      if (k < NO && (uint32_t)k + 1u < ne) {
-        const bool dense = (o_shift[k] & DENSE_FLAG) != 0, bitmap = !dense && o_bm[k] != 0xFFFFFFFFu;
-        double sk[U];
-        if (dense) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) sk[u] = (alive[u] && hit[k][u]) ? __hiloint2double((int)fl[k][u].y, (int)fl[k][u].x) : 0.0;
-        } else {
-          bool found[U];
-          uint64_t pk[U];
-          bool any_f = false;
-          if (bitmap) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              found[u] = alive[u] && hit[k][u];
-              const uint32_t bit = d[u] & 31u;
-              pk[u] = o_off[k] + fl[k][u].y + (uint32_t)__popc(fl[k][u].x & ((1u << bit) - 1u));
-              any_f |= found[u];
-            }
-          } else {
-            // a sparse list's table slot holds a handful of postings: up to 4 doc ids per step, all requested at once
-            const uint32_t* docs = p.doc + o_off[k];
-            uint32_t lo[U];
-            bool open[U];
-            bool more = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              found[u] = false; pk[u] = o_off[k];
-              lo[u] = fl[k][u].x;
-              open[u] = alive[u] && hit[k][u];
-              more |= open[u];
-            }
-            more = __any(more);
-            while (more) {
-              uint32_t v[U][4];
-#pragma unroll
-              for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                  const bool rd = open[u] && lo[u] + t < fl[k][u].y;
-                  v[u][t] = rd ? docs[lo[u] + t] : 0xFFFFFFFFu;
-                  ws.probe += lanes_on(rd);
-                }
-              bool again = false;
-#pragma unroll
-              for (int u = 0; u < U; ++u) {
-                if (open[u]) {
-#pragma unroll
-                  for (int t = 0; t < 4; ++t)
-                    if (v[u][t] == d[u]) { found[u] = true; pk[u] = o_off[k] + lo[u] + t; }
-                  // ascending doc ids: past the document, or past the slot, the search is over
-                  open[u] = !found[u] && v[u][3] < d[u] && lo[u] + 4 < fl[k][u].y;
-                  lo[u] += 4;
-                }
-                again |= open[u];
-              }
-              more = __any(again);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) any_f |= found[u];
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) { sk[u] = 0.0; ws.hit += lanes_on(found[u]); }
-          if (__any(any_f)) plane_scores<F_, U>(p, pk, found, o_eb[k], sk);
+          for (int k = 0; k < NO; ++k)
+            if ((uint32_t)k + 1u < ne) q_loc[k][wave][at] = loc[k];
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (alive[u] && sk[u] > 0.0) {
-            if (o_rank[k] < own_rank) alive[u] = false;  // evaluated from its highest-bound list only
-            P[u] += sk[u];
-          }
-        }
+        q_n += (uint32_t)__popcll(m);
+        if (q_n >= (uint32_t)WAVE) process((uint32_t)WAVE, theta);
       }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool offer = alive[u] && P[u] >= theta;
-      ws.offer += lanes_on(offer);
-      if (__any(offer)) topk_offer(tk, p.K, lane, alive[u], P[u], d[u], theta);
-    }
-    if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta) {
-      // this wave's K-th best so far: the final K-th best of the query can only be higher
-      published = tk.thr_s;
-      if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
     }
   }
+  while (q_n) process(min(q_n, (uint32_t)WAVE), theta);
   if ((uint32_t)lane < p.K) {
     const uint64_t o = (uint64_t)it.slot * p.K + lane;
     const bool ok = (uint32_t)lane < tk.n;
