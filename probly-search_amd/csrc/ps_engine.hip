@@ -230,6 +230,10 @@ struct EngineImpl {
   DevBuf<uint32_t> d_fchar, d_fchild, d_term_meta, d_term_delta;
   DevBuf<uint64_t> d_term_df;
   DevBuf<double> d_term_idf, d_eb_table, d_layer_idf;
+  // Bloom filters of the lists without a bitmap (K1d lookups): built on the device per snapshot state
+  DevBuf<unsigned long long> d_bloom, d_layer_bloom;
+  bool bloom_valid = false;
+  uint64_t bloom_words = 0;
   uint32_t eb_n = 0;
   // A device-built plan (k_plan): the batch's text, the per-query counts of the count pass, the entries.
   struct PlanSet {
@@ -429,7 +433,7 @@ Engine::~Engine() {
   if (m.prep_stream) (void)hipStreamDestroy(m.prep_stream);
   if (m.score_stream) (void)hipStreamDestroy(m.score_stream);
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fchar.release(); m.d_fchild.release();
-  m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release(); m.d_layer_idf.release();
+  m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release(); m.d_layer_idf.release(); m.d_bloom.release(); m.d_layer_bloom.release();
   if (m.h_totals) (void)hipHostFree(m.h_totals);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
   m.d_sort_tmp.release(); m.d_pack.release();
@@ -837,6 +841,39 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
   return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p), tgt->plane.p};
 }
 
+// Bloom filters of the lists that have no membership bitmap (fewer than N / 128 postings): 16 bits per posting,
+// three bits per document in one 64-bit word, a power-of-two number of words per list.  K1d asks them before it
+// touches a sparse list's table: a filter of a few KB stays in L2, and nearly every answer is "no".
+void ensure_bloom(EngineImpl& m, hipStream_t st) {
+  if (m.bloom_valid) return;
+  const Snapshot& s = *m.snap;
+  ensure_dev_trie(m);
+  const size_t nl = s.layers.size();
+  std::vector<unsigned long long> desc(std::max<size_t>(nl, 1), NO_BLOOM);
+  uint64_t words = 0;
+  for (size_t l = 0; l < nl; ++l) {
+    const LayerInfo& L = s.layers[l];
+    if (L.bm_off != NO_BITMAP || L.len == 0) continue;
+    uint64_t nw = 1;
+    uint32_t lg = 0;
+    while (nw * 64 < (uint64_t)L.len * BLOOM_BITS_PER_KEY) { nw <<= 1; ++lg; }
+    desc[l] = words | ((unsigned long long)lg << 58);
+    words += nw;
+  }
+  if (words >= (1ull << 40)) throw std::length_error("Bloom filters: more than 2^40 words");
+  m.d_layer_bloom.ensure(desc.size() + 1);
+  m.d_bloom.ensure(words + 2);
+  PS_HIP(hipMemcpy(m.d_layer_bloom.p, desc.data(), desc.size() * 8, hipMemcpyHostToDevice));
+  PS_HIP(hipMemsetAsync(m.d_bloom.p, 0, (words + 1) * 8, st));
+  if (nl) {
+    hipLaunchKernelGGL(k_build_bloom, dim3((uint32_t)((nl + 3) / 4)), dim3(256), 0, st, m.d_doc, m.d_layer_a.p, m.d_layer_bloom.p, (uint32_t)nl,
+                       m.d_bloom.p);
+    PS_HIP(hipGetLastError());
+  }
+  m.bloom_words = words;
+  m.bloom_valid = true;
+}
+
 // K1d dense-row candidates: the snapshot's densest lists with one table slot per tile, longest first,
 // each with a fixed row slot.  Chosen on the host when the snapshot's layers or the knobs change; which
 // candidates a batch reads, and with which weights, is decided on the device (k_prep_finish).
@@ -882,6 +919,9 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   const BoundsRef br = ensure_list_bounds(m, sc, boosts, kp, st);
   m.last_bounds_recomputed = m.bounds.recomputed != rc0;
   ensure_row_candidates(m, st);
+  ensure_bloom(m, st);
+  kp.bloom = m.d_bloom.p;
+  kp.layer_bloom = m.d_layer_bloom.p;
   // the context's resident rows are only valid for the candidates and parameters they were scored with
   {
     std::vector<double> sig{sc.bm25_k1, sc.bm25_b};
@@ -1681,6 +1721,7 @@ void forget_rows(EngineImpl& m) {
   m.bounds.n_units = 0;
   for (auto& js : m.bounds.j) js.valid = false;
   m.cands.valid = false;
+  m.bloom_valid = false;
   for (auto& c : m.dctx) { c.row_sig.clear(); c.ctl_clean = false; }
 }
 

@@ -144,6 +144,11 @@ struct KParams {
   uint32_t prep_ctl_words;
   const uint32_t* rorder;       // [n_plan_entries] per query: its entries in rank order (highest bound first)
   const struct DGroup* dgroup;  // [n_plan_entries] (multi-expansion batches)
+  // Bloom filters of the lists without a bitmap (k_build_bloom): "is document d in this sparse list" is
+  // one 8-byte load of a few-KB filter - and the answer is no for > 98 % of the documents asked - instead
+  // of two table words and a handful of doc ids
+  const unsigned long long* bloom;        // filter words
+  const unsigned long long* layer_bloom;  // [n_layers] first word (low 40 bits) | log2(words) << 58; ~0 = none
   const double* splane;         // [P][F] score plane (k_list_bounds): (tfn * idf) * boost_x of every (posting, field), 0.0 where tf_x == 0 - what K1d reads instead of re-deriving it per visit
   const uint32_t* tfl;          // [P][F] packed {tf (8 bits, 255 = see the tf plane), field length (24 bits, all ones = see the fl plane)}: what the hot loops read
   const uint32_t* bits;         // membership bitmaps of the denser lists (ps_plan_entry::bm_off)
@@ -1308,6 +1313,33 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
 // word k_score uses; items are handed out highest-bound lists first, so by the time the long
 // low-idf lists come up most of them are skipped whole.  No LDS tiles, no harvest over N documents.
 // ------------------------------------------------------------------------------------------
+// ---- Bloom filters of the sparse lists --------------------------------------------------------------
+constexpr unsigned long long NO_BLOOM = ~0ull;
+constexpr uint32_t BLOOM_BITS_PER_KEY = 16;
+__device__ __forceinline__ void bloom_probe(const uint32_t d, const unsigned long long desc, uint64_t& word, unsigned long long& mask) {
+  const unsigned long long h = (unsigned long long)d * 0x9E3779B97F4A7C15ull;
+  const uint32_t lg = (uint32_t)(desc >> 58);
+  word = (desc & ((1ull << 40) - 1ull)) + ((h >> 36) & ((1ull << lg) - 1ull));
+  mask = (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u)) | (1ull << ((h >> 12) & 63u));
+}
+// one wave per sparse list: every posting sets its three bits (blocked filter: all three in one 64-bit word)
+__global__ __launch_bounds__(256) void k_build_bloom(const uint32_t* doc, const uint4* layer_a, const unsigned long long* layer_bloom,
+                                                     const uint32_t n_layers, unsigned long long* bloom) {
+  const uint32_t l = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (l >= n_layers) return;
+  const unsigned long long desc = layer_bloom[l];
+  if (desc == NO_BLOOM) return;
+  const uint4 la = layer_a[l];
+  const uint64_t off = (uint64_t)la.x | ((uint64_t)la.y << 32);
+  for (uint32_t i = lane; i < la.z; i += WAVE) {
+    uint64_t w;
+    unsigned long long m;
+    bloom_probe(doc[off + i], desc, w, m);
+    atomicOr(&bloom[w], m);
+  }
+}
+
 // ---- score planes --------------------------------------------------------------------------------
 // ((tfn * idf) * boost_x) of a (posting, field) depends on the list (idf), the scorer parameters and the
 // boosts, not on the query: k_list_bounds evaluates it ONCE per posting - the same f64 expression, left to
@@ -1441,19 +1473,41 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
       pi[u] = en.post_off + cell[u].y + (uint32_t)__popc(cell[u].x & ((1u << bit) - 1u));
     }
   } else {
-    // sparse lists: the tile-offset table slot holds a handful of postings - short binary search
+    // sparse lists: first the list's Bloom filter (one 8-byte load; nearly every document asked is not in
+    // the list), then, for a "maybe", the tile-offset table slot - a handful of postings - short binary search
+    bool may[U];
+    {
+      const unsigned long long desc = p.layer_bloom ? p.layer_bloom[en.node] : NO_BLOOM;
+      bool any_may = false;
+      if (desc != NO_BLOOM) {
+        unsigned long long w[U], mk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          uint64_t wi;
+          bloom_probe(d[u], desc, wi, mk[u]);
+          w[u] = on[u] ? p.bloom[wi] : 0ull;
+          ws.cell += lanes_on(on[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { may[u] = on[u] && (w[u] & mk[u]) == mk[u]; any_may |= may[u]; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { may[u] = on[u]; any_may |= may[u]; }
+      }
+      if (!__any(any_may)) return;
+    }
     const uint32_t* docs = p.doc + en.post_off;
     uint32_t lo[U], hi[U], end[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       lo[u] = 0; hi[u] = 0; end[u] = 0;
-      if (on[u]) {
+      if (may[u]) {
         const uint32_t slot = (d[u] >> p.t_log2) >> (en.shift & 0xFFu);
         lo[u] = p.table[en.tbl_off + slot];
         end[u] = p.table[en.tbl_off + slot + 1];
         hi[u] = end[u];
       }
-      ws.probe += 2u * lanes_on(on[u]);
+      ws.probe += 2u * lanes_on(may[u]);
     }
     bool more = true;  // wave-uniform
     while (more) {
@@ -1476,9 +1530,9 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
     }
     uint32_t chk[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { chk[u] = (on[u] && lo[u] < end[u]) ? docs[lo[u]] : 0xFFFFFFFFu; ws.probe += lanes_on(on[u] && lo[u] < end[u]); }
+    for (int u = 0; u < U; ++u) { chk[u] = (may[u] && lo[u] < end[u]) ? docs[lo[u]] : 0xFFFFFFFFu; ws.probe += lanes_on(may[u] && lo[u] < end[u]); }
 #pragma unroll
-    for (int u = 0; u < U; ++u) { found[u] = on[u] && lo[u] < end[u] && chk[u] == d[u]; pi[u] = en.post_off + (found[u] ? lo[u] : 0u); }
+    for (int u = 0; u < U; ++u) { found[u] = may[u] && lo[u] < end[u] && chk[u] == d[u]; pi[u] = en.post_off + (found[u] ? lo[u] : 0u); }
   }
   bool any_found = false;
 #pragma unroll
@@ -1870,19 +1924,19 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   // the other lists, in plan order (wave-uniform: scalar registers)
   uint64_t o_off[NO];
   uint32_t o_shift[NO], o_bm[NO], o_tbl[NO], o_row[NO], o_rank[NO];
+  unsigned long long o_bloom[NO];
   double o_eb[NO], o_ub[NO];
-  uint32_t n_dense = 0, n_bitmap = 0, n_sparse = 0;
 #pragma unroll
   for (int k = 0; k < NO; ++k) {
     o_off[k] = 0; o_shift[k] = 0; o_bm[k] = 0xFFFFFFFFu; o_tbl[k] = 0; o_row[k] = 0; o_rank[k] = 0xFFFFFFFFu;
-    o_eb[k] = 0.0; o_ub[k] = 0.0;
+    o_eb[k] = 0.0; o_ub[k] = 0.0; o_bloom[k] = NO_BLOOM;
     if ((uint32_t)k + 1u < ne) {
       const uint32_t j = e0 + (uint32_t)k + ((uint32_t)k >= own_pos ? 1u : 0u);
       const ps_plan_entry& en = p.plan[j];
       const DEntry dj = p.dentry[j];
       o_off[k] = en.post_off; o_shift[k] = en.shift; o_bm[k] = en.bm_off; o_tbl[k] = en.tbl_off; o_row[k] = en.node;
       o_eb[k] = en.boost; o_ub[k] = dj.ub; o_rank[k] = dj.rank;
-      if (en.shift & DENSE_FLAG) ++n_dense; else if (en.bm_off != 0xFFFFFFFFu) ++n_bitmap; else ++n_sparse;
+      if (!(en.shift & DENSE_FLAG) && en.bm_off == 0xFFFFFFFFu && p.layer_bloom) o_bloom[k] = p.layer_bloom[en.node];
     }
   }
   TopK tk;
@@ -1921,11 +1975,18 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
             found = ok && loc != ~0ull;
             if (found) pk = loc;
           } else {
-            // a sparse list's table slot holds a handful of postings: up to 4 doc ids per step, all requested at once
+            // a sparse list whose filter said "maybe": its table slot holds a handful of postings - up to 4 doc ids
+            // per step, all requested at once
             const uint32_t* docs = p.doc + o_off[k];
-            uint32_t lo = (uint32_t)loc;
-            const uint32_t hi = (uint32_t)(loc >> 32);
             bool open = ok && loc != ~0ull;
+            uint32_t lo = 0, hi = 0;
+            if (open) {
+              const uint32_t slot = (d >> p.t_log2) >> (o_shift[k] & 0xFFu);
+              lo = p.table[o_tbl[k] + slot];
+              hi = p.table[o_tbl[k] + slot + 1];
+            }
+            ws.probe += 2u * lanes_on(open);
+            open = open && lo < hi;
             while (__any(open)) {
               uint32_t v[4];
 #pragma unroll
@@ -2002,7 +2063,23 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       ws.probe += n_in * (1u + 2u * (F_ ? (uint32_t)F_ : p.F));
       break;
     }
-    // ---- first level of every other list, all in flight together ----
+    // ---- own scores; first bound test: everything the other entries could add, at most - below theta the
+    // document is out before anything is asked of another list ----
+    if (p.alive != nullptr) {  // delta removals
+#pragma unroll
+      for (int u = 0; u < U; ++u) inr[u] = inr[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
+    }
+    double s_own[U];
+    scores_from_plane<F_, U>(p, tw, inr, own_eb, s_own);
+    bool rch[U];
+    ws.scanned += n_in;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rch[u] = inr[u] && (s_own[u] + others >= theta);
+      ws.reached += lanes_on(rch[u]);
+    }
+    // ---- first level of every other list for the documents that passed, all in flight together: dense-row
+    // value, {bits, rank} bitmap cell, or the sparse list's Bloom-filter word ----
     uint2 fl[NO][U];
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
@@ -2011,39 +2088,36 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       if ((uint32_t)k + 1u < ne && !(PS_EXP & 4)) {
         if (o_shift[k] & DENSE_FLAG) {
 #pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (inr[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.rows + (uint64_t)o_row[k] * p.row_stride + d[u]);
+          for (int u = 0; u < U; ++u) {
+            if (rch[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.rows + (uint64_t)o_row[k] * p.row_stride + d[u]);
+            ws.row += lanes_on(rch[u]);
+          }
         } else if (o_bm[k] != 0xFFFFFFFFu) {
 #pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (inr[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(d[u] >> 5));
+          for (int u = 0; u < U; ++u) {
+            if (rch[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(d[u] >> 5));
+            ws.cell += lanes_on(rch[u]);
+          }
+        } else if (o_bloom[k] != NO_BLOOM) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            uint64_t wi;
+            unsigned long long mk;
+            bloom_probe(d[u], o_bloom[k], wi, mk);
+            const unsigned long long w = rch[u] ? p.bloom[wi] : 0ull;
+            fl[k][u].x = (rch[u] && (w & mk) == mk) ? 1u : 0u;  // maybe
+            ws.cell += lanes_on(rch[u]);
+          }
         } else {
 #pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (inr[u]) {
-              const uint32_t slot = (d[u] >> p.t_log2) >> (o_shift[k] & 0xFFu);
-              fl[k][u].x = p.table[o_tbl[k] + slot];
-              fl[k][u].y = p.table[o_tbl[k] + slot + 1];
-            }
+          for (int u = 0; u < U; ++u) fl[k][u].x = rch[u] ? 1u : 0u;  // no filter: ask the table
         }
       }
     }
-    if (p.alive != nullptr) {  // delta removals
-#pragma unroll
-      for (int u = 0; u < U; ++u) inr[u] = inr[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
-    }
-    // (work counters: every posting of the trip asked every other list's first level)
-    ws.scanned += n_in;
-    ws.row += n_in * n_dense; ws.cell += n_in * n_bitmap; ws.probe += 2u * n_in * n_sparse;
-    // ---- own scores; first bound test ----
-    double s_own[U];
-    scores_from_plane<F_, U>(p, tw, inr, own_eb, s_own);
-    // ---- what the first level already tells: exact row values, bitmap membership, empty table slots ----
+    // ---- what the first level already tells: exact row values, bitmap membership, filter misses ----
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      // everything the other entries could add, at most: below theta the document is out
-      bool alive = inr[u] && (s_own[u] + others >= theta);
-      ws.reached += lanes_on(alive);
+      bool alive = rch[u];
       double bound = s_own[u];
       unsigned long long loc[NO];
 #pragma unroll
@@ -2063,9 +2137,9 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
             c = hit ? o_ub[k] : 0.0;
             if (hit) loc[k] = o_off[k] + fl[k][u].y + (uint32_t)__popc(fl[k][u].x & ((1u << bit) - 1u));
           } else {
-            hit = fl[k][u].x < fl[k][u].y;  // the slot holds postings: maybe
+            hit = fl[k][u].x != 0u;  // the filter (or its absence) says maybe
             c = hit ? o_ub[k] : 0.0;
-            if (hit) loc[k] = (unsigned long long)fl[k][u].x | ((unsigned long long)fl[k][u].y << 32);
+            if (hit) loc[k] = 0ull;
           }
           bound += c;
           // (a document is evaluated from its highest-bound list only: known here for rows and bitmaps)
