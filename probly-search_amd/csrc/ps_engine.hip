@@ -9,7 +9,7 @@
 //
 //       k_pack_tfl   per snapshot (and per delta): the packed {tf, field length} posting words the hot kernels stream
 //       k_upload     per batch: the staged plan, read from the device-mapped pinned slot
-//       k_list_bounds / k_prep_batch / k_prep_items  per K1d batch (ps_prep_kernels.hpp): per-list score
+//       k_list_bounds / k_prep_query / k_prep_finish / k_prep_items  per K1d batch (ps_prep_kernels.hpp): per-list score
 //                    bounds, work descriptors, item order, candidate slots and dense-row choice, all on the device
 //   K0  k_bm25_lut   per (k1, b): saturated-tf table tfn(field, tf < 16, field length), same f64 expression
 //   K0b k_dense_rows per-document score rows of the hot (list, idf, boost) combinations not yet resident
@@ -954,8 +954,9 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   pp.rows_resident = m.tune.row_cache_mb != 0;
   pp.layer_a = m.d_layer_a.p; pp.row_state = c.row_state; pp.row_desc = c.row_desc; pp.wstats = m.d_wstats;
   if (B) {
-    hipLaunchKernelGGL(k_prep_batch, dim3(1), dim3(1024), 0, st, pp);
-    if (ne) hipLaunchKernelGGL(k_prep_items, dim3((uint32_t)((ne + 3) / 4)), dim3(256), 0, st, pp);
+    hipLaunchKernelGGL(k_prep_query, dim3((uint32_t)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, pp);
+    hipLaunchKernelGGL(k_prep_finish, dim3(1), dim3(WAVE), 0, st, pp);
+    if (ne) hipLaunchKernelGGL(k_prep_items, dim3((uint32_t)((ne + 2 * WAVE - 1) / (2 * WAVE))), dim3(2 * WAVE), 0, st, pp);
     PS_HIP(hipGetLastError());
   }
   kp.dentry = c.dentry.p; kp.ditems = c.ditems.p; kp.qslot = c.qslot.p; kp.qslot_n = c.qslot_n.p;
@@ -2085,7 +2086,7 @@ PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
                      nullptr, ps_.cnt.p, ps_.qtl.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, nullptr, ps_.items.p, m.tune.daat_chunk,
                      m.tune.daat_split_div, ps_.tok_node.p);
   // (the totals are written straight into pinned, device-mapped host memory: no copy-engine transfer to wait for)
-  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
+  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(WAVE), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
                      ps_.qbeg.p, m.d_totals_mapped);
   PS_HIP(hipGetLastError());
   sync_stream(st);

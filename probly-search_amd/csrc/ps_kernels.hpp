@@ -2397,7 +2397,7 @@ __device__ __noinline__ void plan_query_seq(const DevTrie& t, const char* s, con
 // bytes of text), then lane i plans token i - the trie walks of a query's terms, which are chains of
 // dependent loads, run side by side instead of one after the other.  The count pass leaves every token's
 // trie node in `tok_node` ([B][64]; -2 = empty token), so the fill pass walks nothing.
-constexpr int PLAN_WAVES = 16;  // queries per workgroup (few fat workgroups: while a k_daat launch floods the dispatcher, every extra workgroup of another queue waits its turn)
+constexpr int PLAN_WAVES = 1;  // queries per workgroup (one-wave workgroups slip into the wave slots a running k_daat launch frees; fat ones wait)
 template <bool FILL>
 __global__ __launch_bounds__(WAVE * PLAN_WAVES) void k_plan(const DevTrie t, const char* text, const uint64_t* offsets, const uint32_t B,
                                                           const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt,
@@ -2485,38 +2485,28 @@ __global__ __launch_bounds__(WAVE * PLAN_WAVES) void k_plan(const DevTrie t, con
   }
 }
 
-// one workgroup: exclusive scan of the per-query entry counts + the batch totals (wave shuffles + one
-// LDS hop: a few microseconds even while a k_daat launch owns the rest of the chip)
-__global__ __launch_bounds__(1024) void k_plan_scan(const uint32_t* q_cnt, const uint32_t* q_nterms, const uint32_t* q_multi,
+// one wave: exclusive scan of the per-query entry counts + the batch totals (a lane takes B / 64 consecutive
+// queries; one shuffle scan; a single wave finds a slot at once even while a k_daat launch owns the chip)
+__global__ __launch_bounds__(WAVE) void k_plan_scan(const uint32_t* q_cnt, const uint32_t* q_nterms, const uint32_t* q_multi,
                                                      const unsigned long long* q_postings, const uint32_t* q_items, const uint32_t B,
                                                      uint32_t* qbeg, PlanTotals* tot) {
-  __shared__ uint32_t w_sum[16], w_me[16], w_mt[16], w_mm[16];
-  __shared__ unsigned long long w_post[16], w_itm[16];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, per = (B + 1023) / 1024;
-  const uint32_t b = min(B, tid * per), e = min(B, b + per);
+  const uint32_t lane = threadIdx.x, per = (B + WAVE - 1) / WAVE;
+  const uint32_t b = min(B, lane * per), e = min(B, b + per);
   uint32_t sum = 0, me = 0, mt = 0, mm = 0;
   unsigned long long ps = 0, it = 0;
   for (uint32_t i = b; i < e; ++i) { sum += q_cnt[i]; me = max(me, q_cnt[i]); mt = max(mt, q_nterms[i]); mm |= q_multi[i]; ps += q_postings[i]; it += q_items[i]; }
-  // inclusive scan of `sum` within the wave; reductions of the rest
   uint32_t inc = sum;
   for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
   for (int o = 32; o > 0; o >>= 1) {
-    me = max(me, __shfl_xor(me, o)); mt = max(mt, __shfl_xor(mt, o)); mm |= __shfl_xor(mm, o);
+    me = max(me, (uint32_t)__shfl_xor((int)me, o)); mt = max(mt, (uint32_t)__shfl_xor((int)mt, o)); mm |= (uint32_t)__shfl_xor((int)mm, o);
     ps += __shfl_xor(ps, o); it += __shfl_xor(it, o);
   }
-  if (lane == 63) w_sum[wave] = inc;
-  if (lane == 0) { w_me[wave] = me; w_mt[wave] = mt; w_mm[wave] = mm; w_post[wave] = ps; w_itm[wave] = it; }
-  __syncthreads();
-  uint32_t base = 0;
-  for (uint32_t w = 0; w < wave; ++w) base += w_sum[w];
-  uint32_t run = base + inc - sum;  // exclusive prefix of this thread's first query
+  uint32_t run = inc - sum;  // exclusive prefix of this lane's first query
   for (uint32_t i = b; i < e; ++i) { qbeg[i] = run; run += q_cnt[i]; }
-  if (tid == 0) {
-    uint32_t total = 0, a = 0, c = 0, d = 0;
-    unsigned long long pp = 0, ii = 0;
-    for (uint32_t w = 0; w < 16; ++w) { total += w_sum[w]; a = max(a, w_me[w]); c = max(c, w_mt[w]); d |= w_mm[w]; pp += w_post[w]; ii += w_itm[w]; }
+  if (lane == 0) {
     qbeg[B] = total;
-    tot->max_entries = a; tot->max_qterms = c; tot->multi = d; tot->postings = pp; tot->n_items = ii;
+    tot->max_entries = me; tot->max_qterms = mt; tot->multi = mm; tot->postings = ps; tot->n_items = it;
     __threadfence_system();
     tot->n_entries = total;
   }

@@ -5,12 +5,14 @@
 //   k_list_bounds  per (k1, b, avg[, boosts]): exact per-list maxima of the saturated term frequency
 //                  per field (M) and of the boosted per-posting sum (J), by the kernels' own f64
 //                  expression (bm25.rs:78-86)
-//   k_prep_batch   one workgroup, a thread per query: upper bound of every entry, the query's processing
-//                  order (rank), what the other entries can add (`others`), the whole-list skip thresholds,
-//                  per-query-term data of multi-expansion queries, chunking, candidate slots; with its
-//                  counters in LDS: item buckets (rank-major: every query's highest-bound list first, longest
-//                  lists first), the batch's item count, which dense rows are read / have to be scored
-//   k_prep_items   one wave per list: its work items and its dense-row flag
+//   k_prep_query   a thread per query: upper bound of every entry, the query's processing order (rank), what
+//                  the other entries can add (`others`), the whole-list skip thresholds, per-query-term data of
+//                  multi-expansion queries, chunking, candidate slots, item-bucket totals, dense-row uses
+//                  (wave-aggregated atomics)
+//   k_prep_finish  one wave: bucket starts (rank-major: every query's highest-bound list first, longest lists
+//                  first), the batch's item count, which dense rows are read / have to be scored
+//   k_prep_items   a thread per list: its place in the item order and its dense-row flag; then a lane per
+//                  chunk: the work items
 //
 // What used to be Engine::plan_daat + select_dense_rows on the host (≈0.2 ms per 1024 queries on the
 // critical path of a 0.5 ms step).  Orders within a bucket and the placement of candidate slots come
@@ -338,63 +340,85 @@ __device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const 
   return slots;
 }
 
-// One workgroup prepares the whole batch (thread t: queries t, t + 1024, ...; plans of <= 64 entries - the
-// host routes wider batches to k_score): descriptors per query, then - the counters live in LDS, so the
-// thousands of increments of a batch do not queue up on a few L2 lines - candidate slots, item buckets and
-// dense-row uses; after one barrier the bucket starts and the dense rows of this batch; after another every
-// list's place in the item order.  k_prep_items expands the lists into items in parallel.
-__global__ __launch_bounds__(1024) void k_prep_batch(const PrepParams pp) {
-  __shared__ uint32_t sh_total_slots, sh_bucket_total[PREP_BUCKETS], sh_bucket_start[PREP_BUCKETS], sh_bucket_fill[PREP_BUCKETS];
-  __shared__ uint32_t sh_row_use[PREP_MAX_ROWS];
-  __shared__ unsigned long long sh_row_first[PREP_MAX_ROWS];  // ~(lowest plan-entry index that uses the candidate), 0 = none
-  const uint32_t tid = threadIdx.x;
-  if (tid == 0) sh_total_slots = 0;
-  for (uint32_t k = tid; k < PREP_BUCKETS; k += blockDim.x) { sh_bucket_total[k] = 0; sh_bucket_fill[k] = 0; }
-  for (uint32_t k = tid; k < PREP_MAX_ROWS; k += blockDim.x) { sh_row_use[k] = 0; sh_row_first[k] = 0ull; }
-  __syncthreads();
-  for (uint32_t q = tid; q < pp.B; q += blockDim.x) {
-    const uint32_t b = pp.qbeg[q], e = pp.qbeg[q + 1], n = e - b;
-    if (n == 0) { pp.qslot[q] = 0; pp.qslot_n[q] = 0; continue; }
-    const uint32_t slots = n <= 4 ? prep_query_small<4>(pp, q, b, n) : n <= 8 ? prep_query_small<8>(pp, q, b, n) : prep_query_general(pp, q, b, n);
-    // candidate slots: query-major within the query, the query's block placed by one (LDS) atomic
-    const uint32_t s0 = atomicAdd(&sh_total_slots, slots);
-    pp.qslot[q] = s0;
-    pp.qslot_n[q] = slots;
-    uint32_t sl = s0;
-    for (uint32_t i = 0; i < n; ++i) {
+// ---- wave-aggregated atomics ------------------------------------------------------------------------
+// Thousands of increments per batch go to a few dozen counters (item buckets, candidate slots, row uses): lanes
+// of a wave that hit the same counter are summed first and one lane adds the sum, so a counter sees one
+// atomic per wave instead of one per entry.  Returns the value the counter had before this lane's share.
+__device__ __forceinline__ uint32_t wave_add_by_key(uint32_t* counters, const uint32_t key, const uint32_t val, bool active) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  uint32_t result = 0;
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+    const bool same = active && key == k;
+    const uint32_t v = same ? val : 0u;
+    uint32_t inc = v;  // inclusive scan over the lanes
+    for (int o = 1; o < WAVE; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(&counters[k], total);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+    if (same) result = base + inc - v;
+    todo &= ~__ballot(same);
+    active = active && !same;
+  }
+  return result;
+}
+
+// Thread per query (small workgroups: while a k_daat launch owns the chip, a workgroup of another queue only
+// gets the wave slots two finishing k_daat waves leave behind - a 1024-thread workgroup can wait 200 us for
+// a compute unit to have room): descriptors, candidate slots, item-bucket totals, dense-row uses.
+__global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have = q < pp.B;
+  const uint32_t b = have ? pp.qbeg[q] : 0u, n = have ? pp.qbeg[q + 1] - b : 0u;
+  uint32_t slots = 0;
+  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n) : n <= 8 ? prep_query_small<8>(pp, q, b, n) : prep_query_general(pp, q, b, n);
+  // candidate slots: query-major within the query; the wave's queries take one block of the batch's slots
+  const uint32_t s0 = wave_add_by_key(&pp.ctl->total_slots, 0u, slots, have && n != 0);
+  if (have) { pp.qslot[q] = n ? s0 : 0u; pp.qslot_n[q] = slots; }
+  uint32_t n_max = n;
+  for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, o));
+  uint32_t sl = s0;
+  for (uint32_t i = 0; i < n_max; ++i) {  // (wave-uniform trip count: the aggregated atomics need every lane)
+    const bool on = i < n;
+    uint32_t bk = 0, nc = 0, cd = NO_CAND;
+    if (on) {
       const ps_plan_entry& en = pp.plan[b + i];
       const uint32_t c = prep_chunk(pp, en.len);
-      const uint32_t nc = (en.len + c - 1) / c;
+      nc = (en.len + c - 1) / c;
       pp.gen[b + i] = DItemGen{b + i, 0u, c, sl};
       sl += nc;
-      if (nc) atomicAdd(&sh_bucket_total[prep_bucket(pp.dentry[b + i].rank, en.len)], nc);
-      if (pp.n_cand) {
-        const uint32_t cd = pp.cand_of_layer[en.node];
-        if (cd != NO_CAND) {
-          atomicAdd(&sh_row_use[cd], 1u);
-          atomicMax(&sh_row_first[cd], ~(unsigned long long)(b + i));
-        }
-      }
+      bk = prep_bucket(pp.dentry[b + i].rank, en.len);
+      if (pp.n_cand) cd = pp.cand_of_layer[en.node];
+    }
+    (void)wave_add_by_key(pp.ctl->bucket_total, bk, nc, on && nc != 0);
+    if (pp.n_cand) {
+      (void)wave_add_by_key(pp.ctl->row_use, cd == NO_CAND ? 0u : cd, 1u, on && cd != NO_CAND);
+      if (on && cd != NO_CAND) atomicMax(&pp.ctl->row_first[cd], ~(unsigned long long)(b + i));
     }
   }
-  __syncthreads();
-  // bucket starts (rank-major, longest rank-0 lists first) and the item count
-  if (tid == 0) {
+}
+
+// One wave: bucket starts (rank-major, longest rank-0 lists first), the item count, and the dense rows of this
+// batch: a candidate used >= min_uses times is read as a row, scored with the (idf, expansion_boost) of its
+// FIRST user in plan order (deterministic); entries with other weights keep their bitmap lookups.  A resident
+// row with the same weights is not scored again.
+__global__ __launch_bounds__(WAVE) void k_prep_finish(const PrepParams pp) {
+  PrepCtl& c = *pp.ctl;
+  if (threadIdx.x == 0) {
     uint32_t at = 0;
-    for (uint32_t k = 0; k < PREP_BUCKETS; ++k) { sh_bucket_start[k] = at; at += sh_bucket_total[k]; }
-    pp.ctl->n_items = at;
-    pp.ctl->total_slots = sh_total_slots;
+    for (uint32_t k = 0; k < PREP_BUCKETS; ++k) { c.bucket_start[k] = at; at += c.bucket_total[k]; }
+    c.n_items = at;
   }
-  // the dense rows of this batch: a candidate used >= min_uses times is read as a row, scored with the (idf,
-  // expansion_boost) of its FIRST user in plan order (deterministic); entries with other weights keep their
-  // bitmap lookups.  A resident row with the same weights is not scored again.
-  if (tid == 64) {
+  if (threadIdx.x == 1) {
     uint32_t n_build = 0, n_used = 0;
     for (uint32_t cd = 0; cd < pp.n_cand; ++cd) {
       RowState& rs = pp.row_state[cd];
       rs.use_now = 0;
-      if (sh_row_use[cd] < pp.min_uses || sh_row_first[cd] == 0ull) continue;
-      const ps_plan_entry& en = pp.plan[~sh_row_first[cd]];
+      if (c.row_use[cd] < pp.min_uses || c.row_first[cd] == 0ull) continue;
+      const ps_plan_entry& en = pp.plan[~c.row_first[cd]];
       const unsigned long long ib = (unsigned long long)__double_as_longlong(en.idf), eb = (unsigned long long)__double_as_longlong(en.boost);
       rs.use_now = 1;
       ++n_used;
@@ -411,51 +435,56 @@ __global__ __launch_bounds__(1024) void k_prep_batch(const PrepParams pp) {
       rd.tbl_off = la.w;  // candidates are lists with one table slot per tile (host: shift == 0)
       pp.row_desc[n_build++] = rd;
     }
-    pp.ctl->n_rows_build = n_build;
-    pp.ctl->n_rows_used = n_used;
+    c.n_rows_build = n_build;
+    c.n_rows_used = n_used;
     if (PS_WORK_COUNTERS && (n_build | n_used)) {
       atomicAdd(&pp.wstats[WS_ROWS_BUILT], (unsigned long long)n_build);
       atomicAdd(&pp.wstats[WS_ROWS_USED], (unsigned long long)n_used);
     }
   }
-  __syncthreads();
-  // every list's place in the item order: the next free items of its bucket
-  for (uint32_t q = tid; q < pp.B; q += blockDim.x) {
-    const uint32_t b = pp.qbeg[q], e = pp.qbeg[q + 1];
-    for (uint32_t i = b; i < e; ++i) {
-      const uint32_t len = pp.plan[i].len, c = pp.gen[i].chunk;
-      const uint32_t nc = (len + c - 1) / c;
-      if (!nc) continue;
-      const uint32_t bk = prep_bucket(pp.dentry[i].rank, len);
-      pp.gen[i].item_at = sh_bucket_start[bk] + atomicAdd(&sh_bucket_fill[bk], nc);
-    }
-  }
 }
 
-// One wave per list: its items at the place k_prep_batch gave it; an entry whose list is read as a dense
-// row this batch (same weights as the row was scored with) gets the flag and the row slot.
-__global__ __launch_bounds__(256) void k_prep_items(const PrepParams pp) {
-  const uint32_t i = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-  const uint32_t lane = threadIdx.x % WAVE;
-  if (i >= pp.ne) return;
-  ps_plan_entry& en = pp.plan[i];
-  const DItemGen g = pp.gen[i];
-  const uint32_t len = en.len;
-  const uint32_t n = (len + g.chunk - 1) / g.chunk;
-  if (lane == 0 && pp.n_cand) {
-    const uint32_t cd = pp.cand_of_layer[en.node];
-    if (cd != NO_CAND) {
-      const RowState rs = pp.row_state[cd];
-      if (rs.use_now && rs.idf_bits == (unsigned long long)__double_as_longlong(en.idf) &&
-          rs.eb_bits == (unsigned long long)__double_as_longlong(en.boost)) {
-        en.shift |= DENSE_FLAG;
-        en.node = cd;
+// 128 lists per workgroup: a thread per list takes the list's place in the item order (the next free items of
+// its bucket: one aggregated atomic per bucket and wave) and sets its dense-row flag; then each wave expands
+// its 64 lists into items, a lane per chunk.
+__global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
+  __shared__ uint32_t sh_at[2 * WAVE];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x % WAVE, wv = threadIdx.x / WAVE;
+  const bool have = i < pp.ne;
+  uint32_t nc = 0, bk = 0;
+  if (have) {
+    ps_plan_entry& en = pp.plan[i];
+    const uint32_t len = en.len, c = pp.gen[i].chunk;
+    nc = (len + c - 1) / c;
+    bk = prep_bucket(pp.dentry[i].rank, len);
+    if (pp.n_cand) {
+      const uint32_t cd = pp.cand_of_layer[en.node];
+      if (cd != NO_CAND) {
+        const RowState rs = pp.row_state[cd];
+        if (rs.use_now && rs.idf_bits == (unsigned long long)__double_as_longlong(en.idf) &&
+            rs.eb_bits == (unsigned long long)__double_as_longlong(en.boost)) {
+          en.shift |= DENSE_FLAG;
+          en.node = cd;
+        }
       }
     }
   }
-  for (uint32_t j = lane; j < n; j += WAVE) {
-    const uint32_t pb = j * g.chunk;
-    if (g.item_at + j < pp.items_cap) pp.items[g.item_at + j] = DItem{i, pb, min(g.chunk, len - pb), g.first_slot + j};
+  const uint32_t off = wave_add_by_key(pp.ctl->bucket_fill, bk, nc, have && nc != 0);
+  const uint32_t at = have && nc ? pp.ctl->bucket_start[bk] + off : 0u;
+  if (have) pp.gen[i].item_at = at;
+  sh_at[threadIdx.x] = at;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * blockDim.x + wv * WAVE;
+  for (uint32_t k = 0; k < (uint32_t)WAVE && base + k < pp.ne; ++k) {
+    const uint32_t e = base + k;
+    const DItemGen g = pp.gen[e];
+    const uint32_t len = pp.plan[e].len;
+    const uint32_t n = (len + g.chunk - 1) / g.chunk, a0 = sh_at[wv * WAVE + k];
+    for (uint32_t j = lane; j < n; j += WAVE) {
+      const uint32_t pb = j * g.chunk;
+      if (a0 + j < pp.items_cap) pp.items[a0 + j] = DItem{e, pb, min(g.chunk, len - pb), g.first_slot + j};
+    }
   }
 }
 
