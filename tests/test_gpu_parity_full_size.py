@@ -117,28 +117,34 @@ def test_c3_full_size_against_oracle():
 
 
 def test_c5_full_size_against_oracle():
-    """C5 + queries that leave K1d's register arm: more than 4 query terms and more than 64 expanded
-    lists per query (short prefixes expand to hundreds of terms), at C5's full scale."""
+    """C5 + queries that leave K1d's register arm, at C5's full scale: (a) more than 4 query terms (5-6 terms x
+    4 variants = 20-24 lists: k_daat's single-pass arm), (b) more than 64 expanded lists per query (a short
+    prefix expands to hundreds of terms): such batches are routed to the streaming kernel k_score, exactly."""
     snap, corpus, queries, top, o = _full_size("C5", 4, 1024)
     sc, osc = psa.bm25.new(), orc.bm25()
     stems = [q.split(" ")[0] for q in queries[:64]]
-    wide = []
+    many_terms, wide = [], []
     for i in range(16):
-        t = [stems[(5 * i + j) % 64] for j in range(5)]        # 5 query terms x 4 variants = 20 lists
+        t = [stems[(5 * i + j) % 64] for j in range(5 + i % 2)]  # 5 or 6 query terms x 4 variants
+        many_terms.append(" ".join(t))
+        t = list(t)
         t[i % 5] = t[i % 5][:2]                                   # one 2-letter prefix: hundreds of lists
-        if i % 3 == 0:
-            t.append(t[0][:3])                                    # a 6th term, 3-letter prefix
         wide.append(" ".join(t))
+    n_lists = [len(snap.plan(q, sc)[0]) for q in many_terms]
+    assert max(n_lists) <= 64 and min(n_lists) >= 20
     assert max(len(snap.plan(q, sc)[0]) for q in wide) > 64
-    _set("PS_DAAT", 1)
-    a = snap.query_batch(wide, sc, None, [1.0, 1.0], top_k=10)
-    assert snap.kernel_breakdown(reset=True)["score_kernel"].startswith("ps::k_daat")
-    _set("PS_DAAT", 0)
-    b = snap.query_batch(wide, sc, None, [1.0, 1.0], top_k=10)
-    assert _tuples(a) == _tuples(b)
-    _, _, _, exp = o.bench_queries(wide, osc, [1.0, 1.0], threads=16, top_k=10)
-    for qi in range(len(wide)):
-        assert_same([tuple(r) for r in a[qi]], exp[qi], ("C5 wide", qi))
+    for batch, kernel, tag in ((many_terms, "ps::k_daat", "C5 many terms"), (wide, "ps::k_score", "C5 wide")):
+        _set("PS_DAAT", 1)
+        a = snap.query_batch(batch, sc, None, [1.0, 1.0], top_k=10)
+        assert snap.kernel_breakdown(reset=True)["score_kernel"].startswith(kernel), tag
+        dev = run_device_planned(snap, batch, [1.0, 1.0], 10)
+        assert [[(k, bits(s_)) for k, s_ in rs] for rs in dev] == _tuples(a), tag
+        _set("PS_DAAT", 0)
+        b = snap.query_batch(batch, sc, None, [1.0, 1.0], top_k=10)
+        assert _tuples(a) == _tuples(b), tag
+        _, _, _, exp = o.bench_queries(batch, osc, [1.0, 1.0], threads=16, top_k=10)
+        for qi in range(len(batch)):
+            assert_same([tuple(r) for r in a[qi]], exp[qi], (tag, qi))
 
 
 def test_c4_full_size_against_oracle():
