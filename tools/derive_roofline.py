@@ -106,7 +106,15 @@ def main():
         scorer = args[args.index("--scorer") + 1]
     elif cfg == "C3":
         scorer = "zero_to_one"
-    out = {"config": cfg, "scorer": scorer, "head": head, "kernel": demangle(dom), "kernel_symbol": dom,
+    work = None  # the kernel's own work counters, as the traced run's bench line reports them (per launch)
+    try:
+        line = [l for l in open(os.path.join(d, "kt.bench.json")) if l.startswith("{")][-1]
+        rl = json.loads(line)["roofline"]
+        work = {"units_processed": rl.get("units_processed"), "bytes_touched": rl.get("bytes_touched"),
+                "kernel_avg_ms_live": rl.get("kernel_avg_ms")}
+    except Exception:  # noqa: BLE001
+        pass
+    out = {"config": cfg, "scorer": scorer, "head": head, "kernel": demangle(dom), "kernel_symbol": dom, "work_counters": work,
            "resident_rows": "--resident-rows" in args, "bench_args": args,
            "kernel_avg_us_in_trace": score[dom]["avg_us"], "registers": {k: score[dom][k] for k in ("vgpr", "sgpr", "lds")},
            "measured_clock_GHz": clock / 1e9, "counters_per_launch": ctr,
