@@ -43,3 +43,18 @@ def test_two_ranks_debug_one_gpu_end_to_end():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0
     assert "DEBUG" in d["data"]
+
+
+@pytest.mark.gpu
+def test_eight_ranks_debug_one_gpu_end_to_end():
+    """The launch shape of the driver's 8-GPU scaling run - `bench.py --gpus 8`, eight self-spawned ranks, one
+    snapshot file mmap-loaded by seven of them, 8 x 1024-query shards of C4's 8192-query batch, the library-side
+    exchange of the top-k blocks every step - on the box's single GPU through the debug transport, so that the
+    first real 8-GPU run does not fail on plumbing.  (Not a measurement.)"""
+    r = _run(["--gpus", "8", "--config", "C4", "--n-docs", "30000", "--steps", "3", "--warmup", "1",
+              "--no-cpu-baseline", "--no-single-latency"], env={"PS_BENCH_DEBUG_ONE_GPU": "1"}, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8192 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "DEBUG" in d["data"]
