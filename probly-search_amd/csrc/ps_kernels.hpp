@@ -1926,6 +1926,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   uint32_t o_shift[NO], o_bm[NO], o_tbl[NO], o_row[NO], o_rank[NO];
   unsigned long long o_bloom[NO];
   double o_eb[NO], o_ub[NO];
+  uint32_t n_row_lists = 0, n_cell_lists = 0;  // (work counters: lists asked with one 8-byte load per document)
 #pragma unroll
   for (int k = 0; k < NO; ++k) {
     o_off[k] = 0; o_shift[k] = 0; o_bm[k] = 0xFFFFFFFFu; o_tbl[k] = 0; o_row[k] = 0; o_rank[k] = 0xFFFFFFFFu;
@@ -1937,6 +1938,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       o_off[k] = en.post_off; o_shift[k] = en.shift; o_bm[k] = en.bm_off; o_tbl[k] = en.tbl_off; o_row[k] = en.node;
       o_eb[k] = en.boost; o_ub[k] = dj.ub; o_rank[k] = dj.rank;
       if (!(en.shift & DENSE_FLAG) && en.bm_off == 0xFFFFFFFFu && p.layer_bloom) o_bloom[k] = p.layer_bloom[en.node];
+      if (en.shift & DENSE_FLAG) ++n_row_lists; else if (en.bm_off != 0xFFFFFFFFu || o_bloom[k] != NO_BLOOM) ++n_cell_lists;
     }
   }
   TopK tk;
@@ -2076,7 +2078,8 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       rch[u] = inr[u] && (s_own[u] + others >= theta);
-      ws.reached += lanes_on(rch[u]);
+      const uint32_t nr = lanes_on(rch[u]);  // every document that passed asks every other list's first level
+      ws.reached += nr; ws.row += nr * n_row_lists; ws.cell += nr * n_cell_lists;
     }
     // ---- first level of every other list for the documents that passed, all in flight together: dense-row
     // value, {bits, rank} bitmap cell, or the sparse list's Bloom-filter word ----
@@ -2088,16 +2091,12 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       if ((uint32_t)k + 1u < ne && !(PS_EXP & 4)) {
         if (o_shift[k] & DENSE_FLAG) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
+          for (int u = 0; u < U; ++u)
             if (rch[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.rows + (uint64_t)o_row[k] * p.row_stride + d[u]);
-            ws.row += lanes_on(rch[u]);
-          }
         } else if (o_bm[k] != 0xFFFFFFFFu) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
+          for (int u = 0; u < U; ++u)
             if (rch[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(d[u] >> 5));
-            ws.cell += lanes_on(rch[u]);
-          }
         } else if (o_bloom[k] != NO_BLOOM) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
@@ -2106,7 +2105,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
             bloom_probe(d[u], o_bloom[k], wi, mk);
             const unsigned long long w = rch[u] ? p.bloom[wi] : 0ull;
             fl[k][u].x = (rch[u] && (w & mk) == mk) ? 1u : 0u;  // maybe
-            ws.cell += lanes_on(rch[u]);
           }
         } else {
 #pragma unroll
