@@ -9,7 +9,7 @@
 //
 //       k_pack_tfl   per snapshot (and per delta): the packed {tf, field length} posting words the hot kernels stream
 //       k_upload     per batch: the staged plan, read from the device-mapped pinned slot
-//       k_list_bounds / k_prep_query / k_prep_finish / k_prep_items  per K1d batch (ps_prep_kernels.hpp): per-list score
+//       k_list_bounds / k_prep_query / k_prep_items  per K1d batch (ps_prep_kernels.hpp): per-list score
 //                    bounds, work descriptors, item order, candidate slots and dense-row choice, all on the device
 //   K0  k_bm25_lut   per (k1, b): saturated-tf table tfn(field, tf < 16, field length), same f64 expression
 //   K0b k_dense_rows per-document score rows of the hot (list, idf, boost) combinations not yet resident
@@ -226,7 +226,7 @@ struct EngineImpl {
   // N2 device-side planner: the frozen trie + per-term / per-layer tables in HBM (uploaded on first
   // use, again after a delta changed them), per-batch scratch
   bool dev_trie_valid = false;
-  DevBuf<uint4> d_fnodes, d_layer_a, d_layer_b;
+  DevBuf<uint4> d_fnodes, d_layer_a, d_layer_b, d_fbits;
   DevBuf<uint32_t> d_fchar, d_fchild, d_term_meta, d_term_delta;
   DevBuf<uint64_t> d_term_df;
   DevBuf<double> d_term_idf, d_eb_table, d_layer_idf;
@@ -432,7 +432,7 @@ Engine::~Engine() {
   }
   if (m.prep_stream) (void)hipStreamDestroy(m.prep_stream);
   if (m.score_stream) (void)hipStreamDestroy(m.score_stream);
-  m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fchar.release(); m.d_fchild.release();
+  m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fbits.release(); m.d_fchar.release(); m.d_fchild.release();
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release(); m.d_layer_idf.release(); m.d_bloom.release(); m.d_layer_bloom.release();
   if (m.h_totals) (void)hipHostFree(m.h_totals);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
@@ -955,7 +955,6 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   pp.layer_a = m.d_layer_a.p; pp.row_state = c.row_state; pp.row_desc = c.row_desc; pp.wstats = m.d_wstats;
   if (B) {
     hipLaunchKernelGGL(k_prep_query, dim3((uint32_t)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, pp);
-    hipLaunchKernelGGL(k_prep_finish, dim3(1), dim3(WAVE), 0, st, pp);
     if (ne) hipLaunchKernelGGL(k_prep_items, dim3((uint32_t)((ne + 2 * WAVE - 1) / (2 * WAVE))), dim3(2 * WAVE), 0, st, pp);
     PS_HIP(hipGetLastError());
   }
@@ -2048,6 +2047,19 @@ void ensure_dev_trie(EngineImpl& m) {
   std::vector<uint32_t> fc(s.fchar.begin(), s.fchar.end()), fd(s.fchild.begin(), s.fchild.end());
   if (fc.empty()) { fc.push_back(0); fd.push_back(0); }
   up(m.d_fchar, fc); up(m.d_fchild, fd);
+  {  // per node the set of its child characters below U+0100 (children are sorted by character: position = bits below)
+    std::vector<uint4> fb(std::max<size_t>(nn, 1) * 2, make_uint4(0, 0, 0, 0));
+    for (size_t i = 0; i < nn; ++i) {
+      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t k = 0; k < s.fnodes[i].child_count; ++k) {
+        const uint32_t ch = s.fchar[s.fnodes[i].child_begin + k];
+        if (ch < 256u) w[ch >> 5] |= 1u << (ch & 31u);
+      }
+      fb[2 * i] = make_uint4(w[0], w[1], w[2], w[3]);
+      fb[2 * i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    up(m.d_fbits, fb);
+  }
   if (!m.h_totals) {
     PS_HIP(hipHostMalloc((void**)&m.h_totals, sizeof(PlanTotals), hipHostMallocMapped | hipHostMallocCoherent));
     PS_HIP(hipHostGetDevicePointer((void**)&m.d_totals_mapped, m.h_totals, 0));
@@ -2079,7 +2091,7 @@ PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
   ps_.cnt.ensure(B + 1); ps_.qtl.ensure(B + 1); ps_.nterms.ensure(B + 1); ps_.multi.ensure(B + 1); ps_.items.ensure(B + 1);
   ps_.post.ensure(B + 1); ps_.qbeg.ensure(B + 2); ps_.qorder.ensure(B + 1);
   DevTrie t{m.d_fnodes.p, m.d_fchar.p, m.d_fchild.p, m.d_term_df.p, m.d_term_meta.p, m.d_term_delta.p, m.d_term_idf.p,
-            m.d_layer_a.p, m.d_layer_b.p, m.d_eb_table.p, m.eb_n};
+            m.d_layer_a.p, m.d_layer_b.p, m.d_eb_table.p, m.eb_n, m.d_fbits.p};
   const uint32_t blocks = (uint32_t)((B + PLAN_WAVES - 1) / PLAN_WAVES);
   ps_.tok_node.ensure(B * (size_t)WAVE + 1);
   hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, nullptr,

@@ -2271,6 +2271,7 @@ struct DevTrie {
   const uint4* layer_b;      // {shift, bm_off, next, -}
   const double* eb_table;    // [EB_TABLE] expansion_boost by (len_expanded - len_query)
   uint32_t eb_n;
+  const uint4* fbits;        // [2 per node] 256-bit set of the node's child characters below U+0100 (null: binary search only)
 };
 
 struct PlanTotals {  // written by k_plan_scan
@@ -2294,6 +2295,22 @@ __device__ __forceinline__ int64_t dev_find_node(const DevTrie& t, const char* s
   while (b < e) {
     const uint32_t ch = utf8_next(s, b, e);
     const uint4 fn = t.fnodes[n];
+    if (t.fbits != nullptr && ch < 256u) {
+      // children are sorted by character: the child's position is the number of set bits below it - three
+      // independent loads and one dependent one per level instead of a binary search's chain
+      const uint4 lo = t.fbits[2 * (size_t)n], hi = t.fbits[2 * (size_t)n + 1];
+      const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const uint32_t wi = ch >> 5, bit = ch & 31u;
+      uint32_t below = 0, mine = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        below += k < wi ? (uint32_t)__popc(w[k]) : 0u;
+        mine = k == wi ? w[k] : mine;
+      }
+      if (!((mine >> bit) & 1u)) return -1;
+      n = t.fchild[fn.x + below + (uint32_t)__popc(mine & ((1u << bit) - 1u))];
+      continue;
+    }
     uint32_t lo = 0, hi = fn.y;
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
@@ -2397,11 +2414,11 @@ __device__ __noinline__ void plan_query_seq(const DevTrie& t, const char* s, con
 // trie node in `tok_node` ([B][64]; -2 = empty token), so the fill pass walks nothing.
 constexpr int PLAN_WAVES = 1;  // queries per workgroup (one-wave workgroups slip into the wave slots a running k_daat launch frees; fat ones wait)
 template <bool FILL>
-__global__ __launch_bounds__(WAVE * PLAN_WAVES) void k_plan(const DevTrie t, const char* text, const uint64_t* offsets, const uint32_t B,
-                                                          const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt,
-                                                          uint32_t* q_terms_len, uint32_t* q_nterms, uint32_t* q_multi,
-                                                          unsigned long long* q_postings, uint32_t* qorder, uint32_t* q_items,
-                                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node) {
+__device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, const uint64_t* offsets, const uint32_t B,
+                                          const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt,
+                                          uint32_t* q_terms_len, uint32_t* q_nterms, uint32_t* q_multi,
+                                          unsigned long long* q_postings, uint32_t* qorder, uint32_t* q_items,
+                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node) {
   __shared__ uint32_t sh_tb[PLAN_WAVES][WAVE], sh_te[PLAN_WAVES][WAVE];
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const uint32_t q = blockIdx.x * PLAN_WAVES + wv;
@@ -2484,11 +2501,13 @@ __global__ __launch_bounds__(WAVE * PLAN_WAVES) void k_plan(const DevTrie t, con
 }
 
 // one wave: exclusive scan of the per-query entry counts + the batch totals (a lane takes B / 64 consecutive
-// queries; one shuffle scan; a single wave finds a slot at once even while a k_daat launch owns the chip)
+// queries; one shuffle scan; a single wave finds a slot at once even while a k_daat launch owns the chip).
+// (Folding it into the count pass behind a last-wave ticket was tried: 1024 fences + atomics on one word made the
+// count pass 224 us instead of 30-160.)
 __global__ __launch_bounds__(WAVE) void k_plan_scan(const uint32_t* q_cnt, const uint32_t* q_nterms, const uint32_t* q_multi,
                                                      const unsigned long long* q_postings, const uint32_t* q_items, const uint32_t B,
                                                      uint32_t* qbeg, PlanTotals* tot) {
-  const uint32_t lane = threadIdx.x, per = (B + WAVE - 1) / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE, per = (B + WAVE - 1) / WAVE;
   const uint32_t b = min(B, lane * per), e = min(B, b + per);
   uint32_t sum = 0, me = 0, mt = 0, mm = 0;
   unsigned long long ps = 0, it = 0;
@@ -2508,6 +2527,16 @@ __global__ __launch_bounds__(WAVE) void k_plan_scan(const uint32_t* q_cnt, const
     __threadfence_system();
     tot->n_entries = total;
   }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(WAVE * PLAN_WAVES) void k_plan(const DevTrie t, const char* text, const uint64_t* offsets, const uint32_t B,
+                                                          const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt,
+                                                          uint32_t* q_terms_len, uint32_t* q_nterms, uint32_t* q_multi,
+                                                          unsigned long long* q_postings, uint32_t* qorder, uint32_t* q_items,
+                                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node) {
+  plan_wave<FILL>(t, text, offsets, B, qbeg, entries, q_cnt, q_terms_len, q_nterms, q_multi, q_postings, qorder, q_items, chunk_min,
+                  split_div, tok_node);
 }
 
 // Plan upload without the copy engine: the staged batch is read from the pinned, device-mapped

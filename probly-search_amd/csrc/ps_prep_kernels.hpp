@@ -9,10 +9,9 @@
 //                  the other entries can add (`others`), the whole-list skip thresholds, per-query-term data of
 //                  multi-expansion queries, chunking, candidate slots, item-bucket totals, dense-row uses
 //                  (wave-aggregated atomics)
-//   k_prep_finish  one wave: bucket starts (rank-major: every query's highest-bound list first, longest lists
-//                  first), the batch's item count, which dense rows are read / have to be scored
-//   k_prep_items   a thread per list: its place in the item order and its dense-row flag; then a lane per
-//                  chunk: the work items
+//                  ; its last wave closes the counters: bucket starts (rank-major: every query's highest-bound
+//                  list first, longest lists first), the batch's item count, which dense rows are read / scored
+//   k_prep_items   a thread per list: its place in the item order, its dense-row flag, its work items
 //
 // What used to be Engine::plan_daat + select_dense_rows on the host (≈0.2 ms per 1024 queries on the
 // critical path of a 0.5 ms step).  Orders within a bucket and the placement of candidate slots come
@@ -34,6 +33,8 @@ struct PrepCtl {  // per-batch control words; zeroed again behind k_merge_items
   uint32_t n_items;
   uint32_t n_rows_build;   // rows k_dense_rows_dyn has to score for this batch
   uint32_t n_rows_used;    // rows the batch reads
+  uint32_t ticket;         // k_prep_query workgroups that are through (the last one closes the counters)
+  uint32_t _pad;
   uint32_t bucket_total[PREP_BUCKETS];
   uint32_t bucket_start[PREP_BUCKETS];
   uint32_t bucket_fill[PREP_BUCKETS];
@@ -366,6 +367,71 @@ __device__ __forceinline__ uint32_t wave_add_by_key(uint32_t* counters, const ui
   return result;
 }
 
+// The same without a result: nobody waits for the atomic's round trip.
+__device__ __forceinline__ void wave_add_by_key_noret(uint32_t* counters, const uint32_t key, const uint32_t val, bool active) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+    const bool same = active && key == k;
+    uint32_t v = same ? val : 0u;
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    if (lane == first) atomicAdd(&counters[k], v);
+    todo &= ~__ballot(same);
+    active = active && !same;
+  }
+}
+
+// (run by the last wave of k_prep_query) bucket starts (rank-major, longest rank-0 lists first), the item count, and the dense rows of this
+// batch: a candidate used >= min_uses times is read as a row, scored with the (idf, expansion_boost) of its
+// FIRST user in plan order (deterministic); entries with other weights keep their bitmap lookups.  A resident
+// row with the same weights is not scored again.
+__device__ __forceinline__ void prep_finish(const PrepParams& pp) {
+  PrepCtl& c = *pp.ctl;
+  if (threadIdx.x == 0) {
+    uint32_t at = 0;
+    for (uint32_t k = 0; k < PREP_BUCKETS; ++k) {
+      const uint32_t tot = __hip_atomic_load(&c.bucket_total[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c.bucket_start[k] = at;
+      at += tot;
+    }
+    c.n_items = at;
+  }
+  if (threadIdx.x == 1) {
+    uint32_t n_build = 0, n_used = 0;
+    for (uint32_t cd = 0; cd < pp.n_cand; ++cd) {
+      RowState& rs = pp.row_state[cd];
+      rs.use_now = 0;
+      const uint32_t uses = __hip_atomic_load(&c.row_use[cd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long first = __hip_atomic_load(&c.row_first[cd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (uses < pp.min_uses || first == 0ull) continue;
+      const ps_plan_entry& en = pp.plan[~first];
+      const unsigned long long ib = (unsigned long long)__double_as_longlong(en.idf), eb = (unsigned long long)__double_as_longlong(en.boost);
+      rs.use_now = 1;
+      ++n_used;
+      if (pp.rows_resident && rs.valid && rs.idf_bits == ib && rs.eb_bits == eb) continue;
+      rs.valid = 1; rs.idf_bits = ib; rs.eb_bits = eb;
+      const uint4 la = pp.layer_a[en.node];
+      RowDesc rd;
+      rd.post_off = (uint64_t)la.x | ((uint64_t)la.y << 32);
+      rd.len = la.z;
+      rd._pad = 0;
+      rd.idf = en.idf;
+      rd.eb = en.boost;
+      rd.slot = cd;
+      rd.tbl_off = la.w;  // candidates are lists with one table slot per tile (host: shift == 0)
+      pp.row_desc[n_build++] = rd;
+    }
+    c.n_rows_build = n_build;
+    c.n_rows_used = n_used;
+    if (PS_WORK_COUNTERS && (n_build | n_used)) {
+      atomicAdd(&pp.wstats[WS_ROWS_BUILT], (unsigned long long)n_build);
+      atomicAdd(&pp.wstats[WS_ROWS_USED], (unsigned long long)n_used);
+    }
+  }
+}
+
 // Thread per query (small workgroups: while a k_daat launch owns the chip, a workgroup of another queue only
 // gets the wave slots two finishing k_daat waves leave behind - a 1024-thread workgroup can wait 200 us for
 // a compute unit to have room): descriptors, candidate slots, item-bucket totals, dense-row uses.
@@ -393,69 +459,34 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
       bk = prep_bucket(pp.dentry[b + i].rank, en.len);
       if (pp.n_cand) cd = pp.cand_of_layer[en.node];
     }
-    (void)wave_add_by_key(pp.ctl->bucket_total, bk, nc, on && nc != 0);
+    wave_add_by_key_noret(pp.ctl->bucket_total, bk, nc, on && nc != 0);
     if (pp.n_cand) {
-      (void)wave_add_by_key(pp.ctl->row_use, cd == NO_CAND ? 0u : cd, 1u, on && cd != NO_CAND);
+      wave_add_by_key_noret(pp.ctl->row_use, cd == NO_CAND ? 0u : cd, 1u, on && cd != NO_CAND);
       if (on && cd != NO_CAND) atomicMax(&pp.ctl->row_first[cd], ~(unsigned long long)(b + i));
     }
   }
-}
-
-// One wave: bucket starts (rank-major, longest rank-0 lists first), the item count, and the dense rows of this
-// batch: a candidate used >= min_uses times is read as a row, scored with the (idf, expansion_boost) of its
-// FIRST user in plan order (deterministic); entries with other weights keep their bitmap lookups.  A resident
-// row with the same weights is not scored again.
-__global__ __launch_bounds__(WAVE) void k_prep_finish(const PrepParams pp) {
-  PrepCtl& c = *pp.ctl;
-  if (threadIdx.x == 0) {
-    uint32_t at = 0;
-    for (uint32_t k = 0; k < PREP_BUCKETS; ++k) { c.bucket_start[k] = at; at += c.bucket_total[k]; }
-    c.n_items = at;
-  }
-  if (threadIdx.x == 1) {
-    uint32_t n_build = 0, n_used = 0;
-    for (uint32_t cd = 0; cd < pp.n_cand; ++cd) {
-      RowState& rs = pp.row_state[cd];
-      rs.use_now = 0;
-      if (c.row_use[cd] < pp.min_uses || c.row_first[cd] == 0ull) continue;
-      const ps_plan_entry& en = pp.plan[~c.row_first[cd]];
-      const unsigned long long ib = (unsigned long long)__double_as_longlong(en.idf), eb = (unsigned long long)__double_as_longlong(en.boost);
-      rs.use_now = 1;
-      ++n_used;
-      if (pp.rows_resident && rs.valid && rs.idf_bits == ib && rs.eb_bits == eb) continue;
-      rs.valid = 1; rs.idf_bits = ib; rs.eb_bits = eb;
-      const uint4 la = pp.layer_a[en.node];
-      RowDesc rd;
-      rd.post_off = (uint64_t)la.x | ((uint64_t)la.y << 32);
-      rd.len = la.z;
-      rd._pad = 0;
-      rd.idf = en.idf;
-      rd.eb = en.boost;
-      rd.slot = cd;
-      rd.tbl_off = la.w;  // candidates are lists with one table slot per tile (host: shift == 0)
-      pp.row_desc[n_build++] = rd;
-    }
-    c.n_rows_build = n_build;
-    c.n_rows_used = n_used;
-    if (PS_WORK_COUNTERS && (n_build | n_used)) {
-      atomicAdd(&pp.wstats[WS_ROWS_BUILT], (unsigned long long)n_build);
-      atomicAdd(&pp.wstats[WS_ROWS_USED], (unsigned long long)n_used);
-    }
+  // the wave that finishes last closes the batch's counters (k_prep_finish's work, without its launch)
+  __threadfence();
+  uint32_t t = 0;
+  if (threadIdx.x == 0) t = atomicAdd(&pp.ctl->ticket, 1u);
+  t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  if (t + 1u == gridDim.x) {
+    __threadfence();
+    prep_finish(pp);
   }
 }
 
-// 128 lists per workgroup: a thread per list takes the list's place in the item order (the next free items of
-// its bucket: one aggregated atomic per bucket and wave) and sets its dense-row flag; then each wave expands
-// its 64 lists into items, a lane per chunk.
+// A thread per list: the list's place in the item order (the next free items of its bucket: one aggregated
+// atomic per bucket and wave), its dense-row flag, its items.
 __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
-  __shared__ uint32_t sh_at[2 * WAVE];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lane = threadIdx.x % WAVE, wv = threadIdx.x / WAVE;
   const bool have = i < pp.ne;
-  uint32_t nc = 0, bk = 0;
+  uint32_t nc = 0, bk = 0, len_i = 0, chunk = 1, first_slot = 0;
   if (have) {
     ps_plan_entry& en = pp.plan[i];
-    const uint32_t len = en.len, c = pp.gen[i].chunk;
+    const DItemGen g = pp.gen[i];
+    const uint32_t len = en.len, c = g.chunk;
+    len_i = len; chunk = c; first_slot = g.first_slot;
     nc = (len + c - 1) / c;
     bk = prep_bucket(pp.dentry[i].rank, len);
     if (pp.n_cand) {
@@ -472,18 +503,12 @@ __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
   }
   const uint32_t off = wave_add_by_key(pp.ctl->bucket_fill, bk, nc, have && nc != 0);
   const uint32_t at = have && nc ? pp.ctl->bucket_start[bk] + off : 0u;
-  if (have) pp.gen[i].item_at = at;
-  sh_at[threadIdx.x] = at;
-  __syncthreads();
-  const uint32_t base = blockIdx.x * blockDim.x + wv * WAVE;
-  for (uint32_t k = 0; k < (uint32_t)WAVE && base + k < pp.ne; ++k) {
-    const uint32_t e = base + k;
-    const DItemGen g = pp.gen[e];
-    const uint32_t len = pp.plan[e].len;
-    const uint32_t n = (len + g.chunk - 1) / g.chunk, a0 = sh_at[wv * WAVE + k];
-    for (uint32_t j = lane; j < n; j += WAVE) {
-      const uint32_t pb = j * g.chunk;
-      if (a0 + j < pp.items_cap) pp.items[a0 + j] = DItem{e, pb, min(g.chunk, len - pb), g.first_slot + j};
+  if (have) {
+    // the list's items (<= 64, ~20 on average): stores nobody waits for
+    pp.gen[i].item_at = at;
+    for (uint32_t j = 0; j < nc; ++j) {
+      const uint32_t pb = j * chunk;
+      if (at + j < pp.items_cap) pp.items[at + j] = DItem{i, pb, min(chunk, len_i - pb), first_slot + j};
     }
   }
 }
