@@ -260,6 +260,8 @@ struct EngineImpl {
     hipEvent_t done = nullptr;     // behind the batch's merge (scoring stream)
     hipEvent_t entry = nullptr;    // the caller stream's position when the batch was submitted
     hipEvent_t prepared = nullptr; // behind the batch's preparation (preparation stream)
+    hipEvent_t counted = nullptr;  // behind the planner's count pass (planning stream)
+    hipEvent_t scored = nullptr;   // behind the batch's k_daat (scoring stream)
     bool busy = false;
     PlanSet plan;                  // device-planned batches
     DevBuf<unsigned char> stage;   // host-planned batches: entries | qbeg | qterms_len as uploaded
@@ -279,9 +281,9 @@ struct EngineImpl {
     uint64_t cands_gen = 0;        // RowCands::gen its rows belong to
     bool ctl_clean = false;        // k_merge_items left the control words zeroed
   };
-  DaatCtx dctx[2];
+  DaatCtx dctx[3];  // (three: the count pass of batch s + 1 must not wait for batch s - 1, whose k_daat may still be running)
   int next_dctx = 0;
-  hipStream_t prep_stream = nullptr, score_stream = nullptr;
+  hipStream_t prep_stream = nullptr, score_stream = nullptr, plan_stream = nullptr, merge_stream = nullptr;
   hipEvent_t lut_ready = nullptr;  // behind the most recent k_bm25_lut
   PlanTotals* h_totals = nullptr;  // pinned, device-mapped: k_plan_scan writes the totals where the host reads them
   PlanTotals* d_totals_mapped = nullptr;
@@ -427,10 +429,12 @@ Engine::~Engine() {
     c.cand_score.release(); c.rows.release(); c.gthr.release();
     for (void* p : {(void*)c.ctl, (void*)c.work, (void*)c.row_state, (void*)c.row_desc})
       if (p) (void)hipFree(p);
-    for (hipEvent_t e : {c.done, c.entry, c.prepared})
+    for (hipEvent_t e : {c.done, c.entry, c.prepared, c.counted, c.scored})
       if (e) (void)hipEventDestroy(e);
   }
   if (m.prep_stream) (void)hipStreamDestroy(m.prep_stream);
+  if (m.plan_stream) (void)hipStreamDestroy(m.plan_stream);
+  if (m.merge_stream) (void)hipStreamDestroy(m.merge_stream);
   if (m.score_stream) (void)hipStreamDestroy(m.score_stream);
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fbits.release(); m.d_fchar.release(); m.d_fchild.release();
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release(); m.d_layer_idf.release(); m.d_bloom.release(); m.d_layer_bloom.release();
@@ -977,14 +981,22 @@ EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
     int lo = 0, hi = 0;
     PS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     PS_HIP(hipStreamCreateWithPriority(&m.prep_stream, hipStreamNonBlocking, hi));
+    // the planner's count pass (text upload, k_plan count, k_plan_scan) has a stream of its own: the host waits
+    // for its totals, and that wait should not sit behind the previous batch's preparation kernels
+    PS_HIP(hipStreamCreateWithPriority(&m.plan_stream, hipStreamNonBlocking, hi));
     PS_HIP(hipStreamCreateWithFlags(&m.score_stream, hipStreamNonBlocking));
+    // the merge of batch s (the kernel that waits for the caller's stream) off the scoring stream: k_daat of
+    // batch s + 1 starts the moment k_daat of batch s ends
+    PS_HIP(hipStreamCreateWithPriority(&m.merge_stream, hipStreamNonBlocking, hi));
   }
   EngineImpl::DaatCtx& c = m.dctx[m.next_dctx];
-  m.next_dctx ^= 1;
+  m.next_dctx = (m.next_dctx + 1) % 3;
   if (!c.done) {
     PS_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.entry, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.prepared, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&c.counted, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&c.scored, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.plan.h.done, hipEventDisableTiming));
     PS_HIP(hipMalloc((void**)&c.ctl, sizeof(PrepCtl)));
     PS_HIP(hipMalloc((void**)&c.work, 256));
@@ -994,8 +1006,11 @@ EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
     c.ctl_clean = false;
   }
   // the batch that used this context last must be through before its buffers are written again
-  if (c.busy) PS_HIP(hipStreamWaitEvent(m.prep_stream, c.done, 0));
-  if (m.tail_pending) PS_HIP(hipStreamWaitEvent(m.prep_stream, m.ev[0], 0));  // (a k_score / full-result batch still in flight)
+  if (c.busy) { PS_HIP(hipStreamWaitEvent(m.prep_stream, c.done, 0)); PS_HIP(hipStreamWaitEvent(m.plan_stream, c.done, 0)); }
+  if (m.tail_pending) {  // (a k_score / full-result batch still in flight)
+    PS_HIP(hipStreamWaitEvent(m.prep_stream, m.ev[0], 0));
+    PS_HIP(hipStreamWaitEvent(m.plan_stream, m.ev[0], 0));
+  }
   return c;
 }
 
@@ -1820,6 +1835,9 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     PS_HIP(hipEventRecord(kt->b, S));
     kt->pending = true;
     m.last_kt = kt;
+    PS_HIP(hipEventRecord(c.scored, S));
+    S = m.merge_stream;
+    PS_HIP(hipStreamWaitEvent(S, c.scored, 0));
     if (caller && caller != S) {  // the merge overwrites the caller's output buffers: not before the caller's earlier work is through
       PS_HIP(hipEventRecord(c.entry, caller));
       PS_HIP(hipStreamWaitEvent(S, c.entry, 0));
@@ -2073,7 +2091,7 @@ void ensure_dev_trie(EngineImpl& m) {
 PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, const uint64_t* offsets, size_t B) {
   ensure_dev_trie(m);
   EngineImpl::PlanSet& ps_ = c.plan;
-  hipStream_t st = m.prep_stream;
+  hipStream_t st = m.plan_stream;
   const size_t n_bytes = B ? (size_t)offsets[B] : 0;
   if (n_bytes >= 0xFFFFFFF0ull) throw std::length_error("device planner: more than 4 GiB of query text");
   const size_t off_bytes = (B + 1) * 8, text_at = (off_bytes + 15) & ~(size_t)15;
@@ -2101,9 +2119,12 @@ PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
   hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(WAVE), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
                      ps_.qbeg.p, m.d_totals_mapped);
   PS_HIP(hipGetLastError());
+  PS_HIP(hipEventRecord(c.counted, st));
   sync_stream(st);
   const PlanTotals tot = *m.h_totals;
   ps_.entries.ensure((size_t)tot.n_entries + 1);
+  st = m.prep_stream;  // the fill pass and everything behind it: preparation stream
+  PS_HIP(hipStreamWaitEvent(st, c.counted, 0));
   hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, ps_.qbeg.p,
                      ps_.entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, ps_.qorder.p, nullptr, m.tune.daat_chunk,
                      m.tune.daat_split_div, ps_.tok_node.p);
@@ -2151,6 +2172,7 @@ void Engine::plan_device(const char* text, const uint64_t* offsets, size_t B, Pl
   out.qterms_len.resize(B);
   out.n_nodes.assign(B, 0);
   PS_HIP(hipStreamSynchronize(m.prep_stream));
+  PS_HIP(hipStreamSynchronize(m.plan_stream));
   if (tot.n_entries) PS_HIP(hipMemcpy(out.entries.data(), c.plan.entries.p, (size_t)tot.n_entries * sizeof(ps_plan_entry), hipMemcpyDeviceToHost));
   PS_HIP(hipMemcpy(out.qbeg.data(), c.plan.qbeg.p, (B + 1) * 4, hipMemcpyDeviceToHost));
   if (B) PS_HIP(hipMemcpy(out.qterms_len.data(), c.plan.qtl.p, B * 4, hipMemcpyDeviceToHost));
