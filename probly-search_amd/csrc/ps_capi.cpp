@@ -496,19 +496,17 @@ static ps_status run_batch(ps_snapshot* snap, const ps_scorer_desc* scorer, cons
     ps::Plan plan;
     plan_batch(snap, *scorer, views_of(queries, n), tokenizer, user, plan);
     const double t1 = wall_ms();
-    std::vector<ps_result> res;
+    ps::ResultBuf res;  // (a malloc'd block, handed to the caller as it is)
     std::vector<size_t> offs;
     ps_batch_stats stats;
     snap->engine->run_host(*scorer, fields_boost, plan, top_k, res, offs, stats);
     stats.plan_ms = t1 - t0;
     stats.total_ms = wall_ms() - t0;
     set_stats(snap, stats);
-    ps_result* r = (ps_result*)malloc(sizeof(ps_result) * (res.size() ? res.size() : 1));
     size_t* o = (size_t*)malloc(sizeof(size_t) * (n + 1));
-    if (!r || !o) { free(r); free(o); return fail(PS_ENOMEM, "out of memory"); }
-    if (!res.empty()) memcpy(r, res.data(), sizeof(ps_result) * res.size());
+    if (!o) return fail(PS_ENOMEM, "out of memory");
     memcpy(o, offs.data(), sizeof(size_t) * (n + 1));
-    *out = r;
+    *out = res.release();
     *out_offsets = o;
     return PS_OK;
   });

@@ -2316,7 +2316,7 @@ void Engine::run_device(const ps_scorer_desc& sc, const double* boosts, const Pl
 }
 
 void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k,
-                      std::vector<ps_result>& out, std::vector<size_t>& offsets, ps_batch_stats& stats) {
+                      ResultBuf& out, std::vector<size_t>& offsets, ps_batch_stats& stats) {
   EngineImpl& m = *impl_;
   const Snapshot& s = *m.snap;
   const size_t B = plan.qbeg.size() - 1;
@@ -2381,13 +2381,12 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   if ((total_cap * 12 > budget || total_cap >= 0xFFFFFFF0ull) && B > 1) {
     // keep the result buffers bounded: run the two halves of the batch one after the other
     const size_t half = B / 2;
-    std::vector<ps_result> o1, o2;
+    ResultBuf o2;
     std::vector<size_t> f1, f2;
     ps_batch_stats s1, s2;
-    run_host(sc, boosts, sub_plan(plan, 0, half), top_k, o1, f1, s1);
+    run_host(sc, boosts, sub_plan(plan, 0, half), top_k, out, f1, s1);
     run_host(sc, boosts, sub_plan(plan, half, B), top_k, o2, f2, s2);
-    out = std::move(o1);
-    out.insert(out.end(), o2.begin(), o2.end());
+    out.append(o2);
     for (size_t q = 0; q <= half; ++q) offsets[q] = f1[q];
     for (size_t q = half; q <= B; ++q) offsets[q] = f1[half] + f2[q - half];
     fill_stats(m, stats, s, plan, out.size());
@@ -2490,7 +2489,20 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
     sync_stream(st);  // h_po (pinned) is reused as the download target
     PS_HIP(hipMemcpyAsync(m.result.p, m.d_pack.p, total * sizeof(ps_result), hipMemcpyDeviceToHost, st));
     sync_stream(st);
-    memcpy(out.data(), m.result.p, total * sizeof(ps_result));
+    // pinned -> the caller's block: a few threads for the large ones (one core copies ~10 GB/s)
+    const size_t bytes = total * sizeof(ps_result);
+    const unsigned nt = bytes > (32u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (nt <= 1) {
+      memcpy(out.data(), m.result.p, bytes);
+    } else {
+      std::vector<std::thread> th;
+      const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+      for (unsigned t = 0; t < nt; ++t) {
+        const size_t b0 = std::min(bytes, (size_t)t * per), b1 = std::min(bytes, b0 + per);
+        if (b1 > b0) th.emplace_back([&, b0, b1]() { memcpy(reinterpret_cast<char*>(out.data()) + b0, m.result.p + b0, b1 - b0); });
+      }
+      for (auto& x : th) x.join();
+    }
   }
   m.wc_results += total;
   fill_stats(m, stats, s, plan, total);

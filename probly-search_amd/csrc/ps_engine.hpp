@@ -2,6 +2,9 @@
 // the scoring kernels and result download.  Implemented in ps_engine.hip (HIP, gfx950 only).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -10,6 +13,39 @@
 namespace ps {
 
 struct EngineImpl;
+
+// Result records on their way to the C caller: a malloc'd block that grows without value-initialising
+// (a full-result batch is hundreds of MB: every avoidable pass over it shows) and is handed over as it is.
+struct ResultBuf {
+  ps_result* p = nullptr;
+  size_t n = 0;
+  ResultBuf() = default;
+  ResultBuf(const ResultBuf&) = delete;
+  ResultBuf& operator=(const ResultBuf&) = delete;
+  ~ResultBuf() { free(p); }
+  void resize(size_t k) {
+    void* q = realloc(p, (k ? k : 1) * sizeof(ps_result));
+    if (!q) throw std::bad_alloc();
+    p = static_cast<ps_result*>(q);
+    n = k;
+  }
+  void clear() { n = 0; }
+  size_t size() const { return n; }
+  ps_result* data() { return p; }
+  ps_result& operator[](size_t i) { return p[i]; }
+  void append(const ResultBuf& o) {
+    const size_t at = n;
+    resize(n + o.n);
+    if (o.n) memcpy(p + at, o.p, o.n * sizeof(ps_result));
+  }
+  ps_result* release() {
+    if (!p) resize(0);
+    ps_result* r = p;
+    p = nullptr;
+    n = 0;
+    return r;
+  }
+};
 
 class Engine {
  public:
@@ -22,7 +58,7 @@ class Engine {
   // Runs one planned batch.  top_k == 0: every match (canonical order) into out/offsets.
   // top_k  > 0: the first top_k of the canonical order per query.
   void run_host(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k,
-                std::vector<ps_result>& out, std::vector<size_t>& offsets, ps_batch_stats& stats);
+                ResultBuf& out, std::vector<size_t>& offsets, ps_batch_stats& stats);
   // Device-resident top-k (1..PS_MAX_DEVICE_TOPK) into caller buffers, ordered on `stream`
   // (nullptr = engine stream, synchronous).
   void run_device(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,

@@ -276,10 +276,12 @@ class Snapshot:
             _raise(e)
         o = np.ctypeslib.as_array(offs, shape=(len(qb) + 1,)).copy()
         n = int(o[-1])
-        rec = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(max(n, 1), 2))[:n].copy()
+        rec = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(max(n, 1), 2))[:n]  # a view of the library's block
+        keys, scores = np.ascontiguousarray(rec[:, 0]), np.ascontiguousarray(rec[:, 1]).view(np.float64)
+        del rec
         self._L.ps_free(out)
         self._L.ps_free(offs)
-        return rec[:, 0].copy(), rec[:, 1].copy().view(np.float64), o
+        return keys, scores, o
 
     def query_batch_device(self, queries, score_calculator, tokenizer, fields_boost, top_k, d_keys, d_scores,
                            d_counts, stream=None):
