@@ -96,3 +96,68 @@ def _device_planned_batches(cfg_name, n_docs, kernel):
     for q, g in zip(qs, got):
         exp = o.query(q, orc.bm25(), [2.0, 0.5])[:7]
         assert [(k, bits(s)) for k, s in g] == [(k, bits(s)) for k, s in exp], q
+
+
+def test_batches_in_flight_keep_their_results_apart():
+    """The library overlaps consecutive K1d batches of one snapshot (three batch contexts, its own streams): nine
+    different batches submitted back to back on ONE caller stream into nine output blocks, then one synchronisation -
+    every block must hold its own batch's answer (the synchronous call's), device- and host-planned alike."""
+    hip = psd._DeviceBuffer.hip()
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    cfg = dict(synth.CONFIGS["C2"], n_docs=60_000, vocab=3_000)
+    corpus = synth.Corpus(**cfg)
+    snap = synth.fill(psa.Index(2), corpus).snapshot(device=0)
+    sc, K, B = psa.bm25.new(), 10, 96
+    batches = [corpus.queries(B, 3, salt=s) for s in range(9)]
+    want = [[[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(b, sc, None, [1.0, 1.0], top_k=K)] for b in batches]
+    for planner in (1, 0):
+        psa.load().ps_set_option(b"PS_DEVICE_PLAN", planner)
+        try:
+            st = C.c_void_p()
+            assert hip.hipStreamCreate(C.byref(st)) == 0
+            bufs = [psd._DeviceBuffer(psd.block_bytes(B, K)) for _ in batches]
+            packed = [synth.pack_queries(b) for b in batches]
+            for (text, offsets), buf in zip(packed, bufs):
+                snap.query_batch_allgather_flat(None, text, offsets, sc, [1.0, 1.0], K, buf.ptr.value, buf.ptr.value, stream=st.value)
+                assert snap.last_stats()["device_planned"] == planner
+            assert hip.hipStreamSynchronize(st) == 0
+            for i, buf in enumerate(bufs):
+                got = psd.unpack_blocks(buf.to_host(), 1, B, K, [B])
+                assert [[(k, bits(s)) for k, s in rs] for rs in got] == want[i], (planner, i)
+            hip.hipStreamDestroy(st)
+        finally:
+            psa.load().ps_set_option(b"PS_DEVICE_PLAN", 1)
+
+
+def test_work_counters_of_a_batch():
+    """ps_snapshot_work_counters: what the kernels counted is consistent with the plan (K1d scans a part of the
+    postings the reference walks; k_score streams all of them), bytes follow the documented formula, reset works."""
+    cfg = dict(synth.CONFIGS["C2"], n_docs=80_000, vocab=3_000)
+    corpus = synth.Corpus(**cfg)
+    snap = synth.fill(psa.Index(2), corpus).snapshot(device=0)
+    queries = corpus.queries(128, 3)
+    sc = psa.bm25.new()
+    F = 2
+    snap.work_counters(reset=True)
+    snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=10)
+    walked = snap.last_stats()["postings_visited"]
+    w = snap.work_counters(reset=True)
+    assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_daat")
+    assert w["launches"] == 1 and 0 < w["items_run"] <= w["items"]
+    assert 0 < w["postings_scanned"] < walked and w["postings_reached_lookups"] <= w["postings_scanned"]
+    assert w["results"] == 128 * 10 and w["k1_postings"] == 0
+    want = (w["postings_scanned"] * (4 + 8 * F) + (w["lookups_row"] + w["lookups_cell"]) * 8 + w["lookups_probe"] * 4 +
+            w["lookup_hits"] * 8 * F + w["items_run"] * 10 * 12 + w["results"] * 16)
+    assert w["bytes_touched"] == want
+    psa.load().ps_set_option(b"PS_DAAT", 0)
+    try:
+        snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=10)
+        w = snap.work_counters(reset=True)
+        assert w["postings_scanned"] == 0 and w["k1_items"] > 0
+        # every posting of every (query, list) is streamed, unless its list was read as a dense row
+        assert 0 < w["k1_postings"] <= walked and (w["k1_postings"] == walked or w["k1_row_slices"] > 0)
+    finally:
+        psa.load().ps_set_option(b"PS_DAAT", 1)
+    assert snap.work_counters()["launches"] == 0
