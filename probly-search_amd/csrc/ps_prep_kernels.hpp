@@ -22,9 +22,9 @@
 
 namespace ps {
 
-constexpr uint32_t PREP_CLASSES = 64;                 // length classes of the rank-0 lists (log2 with one fractional bit)
-constexpr uint32_t PREP_RANKS = 8;                    // ranks 1..7 get a bucket each, everything above shares the last
-constexpr uint32_t PREP_BUCKETS = PREP_CLASSES + PREP_RANKS;
+constexpr uint32_t PREP_CLASSES = 64;                 // length classes of the rank-0 and of the rank-1 lists (log2 with one fractional bit)
+constexpr uint32_t PREP_RANKS = 8;                    // ranks 2..7 get a bucket each, everything above shares the last
+constexpr uint32_t PREP_BUCKETS = 2 * PREP_CLASSES + PREP_RANKS;
 constexpr uint32_t PREP_MAX_ROWS = 64;                // dense-row candidates per snapshot
 constexpr uint32_t NO_CAND = 0xFFu;
 
@@ -145,12 +145,13 @@ __device__ __forceinline__ uint32_t prep_chunk(const PrepParams& pp, const uint3
   return c > pp.chunk_min ? c : pp.chunk_min;
 }
 __device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint32_t len) {
-  if (rank == 0) {  // longest lists first: 64 classes, log2 with one fractional bit
+  if (rank <= 1) {  // longest lists first: 64 classes, log2 with one fractional bit (the rank-1 lists that stay
+                    // essential are what a launch ends on: the long ones must not start last)
     const uint32_t l = len ? len : 1u;
     const uint32_t lg = 31u - (uint32_t)__clz((int)l);
-    return 63u - (2u * lg + (lg ? ((l >> (lg - 1)) & 1u) : 0u));
+    return rank * PREP_CLASSES + 63u - (2u * lg + (lg ? ((l >> (lg - 1)) & 1u) : 0u));
   }
-  return PREP_CLASSES + (rank < PREP_RANKS ? rank : PREP_RANKS) - 1u;
+  return 2 * PREP_CLASSES + (rank < PREP_RANKS ? rank : PREP_RANKS) - 1u;
 }
 
 // ---- descriptors of one query ---------------------------------------------------------------------
