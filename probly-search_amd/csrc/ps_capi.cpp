@@ -192,7 +192,9 @@ ps_status run_device_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const
 extern "C" {
 
 const char* ps_last_error(void) { return g_err.c_str(); }
-void ps_free(void* p) { free(p); }
+void ps_free(void* p) {
+  if (!ps::result_block_release(p)) free(p);  // large result blocks are pinned pool blocks (ps_engine.hpp)
+}
 int ps_device_count(void) { return ps::device_count(); }
 ps_status ps_set_option(const char* name, uint32_t value) {
   if (!name || strncmp(name, "PS_", 3) != 0) return fail(PS_EINVAL, "option names are the PS_* knob names");

@@ -130,6 +130,7 @@ struct Tuning {
   uint32_t lut_cache = 1;  // PS_LUT_CACHE
   uint32_t z21_lds = 20480;  // PS_Z21_LDS
   uint32_t full_budget_mb = 4096;  // PS_FULL_BUDGET_MB
+  uint32_t result_pinned_min_kb = 4096;  // PS_RESULT_PINNED_MIN_KB: result blocks from this size on are pinned pool blocks (ps_free recycles them)
   uint32_t daat = 1;             // PS_DAAT: BM25 top-k batches take K1d k_daat (exact dynamic pruning)
   uint32_t daat_min_batch = 8;   // PS_DAAT_MIN_BATCH: smaller batches keep the k_score latency path
   uint32_t daat_chunk = 4096;    // PS_DAAT_CHUNK: smallest chunk of a list one item covers
@@ -210,8 +211,8 @@ struct EngineImpl {
   } cands;
   std::vector<uint32_t> z_minfl;  // zero_to_one field pruning: [layer][field] shortest field length holding the term (compute_z_bounds)
   std::unordered_map<uint64_t, uint32_t> z_layer_of;  // post_off -> layer (zero_to_one plan entries do not carry it)
-  DevBuf<uint32_t> d_sort_doc, d_seg;  // K4 scratch
-  DevBuf<uint64_t> d_sort_score, d_pack_off;
+  DevBuf<uint32_t> d_sort_doc, d_seg, d_gs_u32;  // K4 scratch
+  DevBuf<uint64_t> d_sort_score, d_pack_off, d_gs_u64;
   DevBuf<unsigned char> d_sort_tmp;
   DevBuf<ps_result> d_pack;
   Stage stage[N_STAGE];
@@ -440,7 +441,7 @@ Engine::~Engine() {
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release(); m.d_layer_idf.release(); m.d_bloom.release(); m.d_layer_bloom.release();
   if (m.h_totals) (void)hipHostFree(m.h_totals);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
-  m.d_sort_tmp.release(); m.d_pack.release();
+  m.d_sort_tmp.release(); m.d_pack.release(); m.d_gs_u32.release(); m.d_gs_u64.release();
   for (auto& sg : m.stage) {
     if (sg.p) (void)hipHostFree(sg.p);
     if (sg.done) (void)hipEventDestroy(sg.done);
@@ -628,6 +629,70 @@ bool get_option(const char* name, uint32_t* value) {
   return true;
 }
 
+// ---- pinned result blocks (ps_engine.hpp: ResultBuf) -------------------------------------------------------------
+namespace {
+struct ResultPool {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> all;            // every live pool block -> bytes
+  std::vector<std::pair<void*, size_t>> idle;       // handed back, ready for reuse (oldest first)
+  size_t idle_bytes = 0;
+};
+ResultPool& result_pool() {
+  static ResultPool* p = new ResultPool();  // never destroyed: blocks may be freed after static destruction began
+  return *p;
+}
+}  // namespace
+
+void* result_block_acquire(size_t bytes, size_t* capacity) {
+  ResultPool& rp = result_pool();
+  {
+    std::lock_guard<std::mutex> l(rp.mu);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < rp.idle.size(); ++i)
+      if (rp.idle[i].second >= bytes && (best == SIZE_MAX || rp.idle[i].second < rp.idle[best].second)) best = i;
+    // (a block several times too large stays where it is for the batch it fits)
+    if (best != SIZE_MAX && rp.idle[best].second <= 2 * bytes + (64u << 20)) {
+      void* q = rp.idle[best].first;
+      *capacity = rp.idle[best].second;
+      rp.idle_bytes -= rp.idle[best].second;
+      rp.idle.erase(rp.idle.begin() + (ptrdiff_t)best);
+      return q;
+    }
+  }
+  const size_t cap = ((bytes + bytes / 8) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  void* q = nullptr;
+  if (hipHostMalloc(&q, cap, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> l(rp.mu);
+  rp.all[q] = cap;
+  *capacity = cap;
+  return q;
+}
+
+bool result_block_release(void* p) {
+  if (!p) return false;
+  ResultPool& rp = result_pool();
+  std::vector<void*> drop;
+  const size_t keep = (size_t)env_u32("PS_RESULT_POOL_MB", 1024) << 20;
+  {
+    std::lock_guard<std::mutex> l(rp.mu);
+    auto it = rp.all.find(p);
+    if (it == rp.all.end()) return false;
+    rp.idle.emplace_back(p, it->second);
+    rp.idle_bytes += it->second;
+    while (rp.idle_bytes > keep && !rp.idle.empty()) {  // oldest first
+      drop.push_back(rp.idle.front().first);
+      rp.idle_bytes -= rp.idle.front().second;
+      rp.all.erase(rp.idle.front().first);
+      rp.idle.erase(rp.idle.begin());
+    }
+  }
+  for (void* q : drop) (void)hipHostFree(q);
+  return true;
+}
+
 void Tuning::load() {
     dense_max_rows = env_u32("PS_DENSE_MAX_ROWS", dense_max_rows);
     row_cache_mb = env_u32("PS_ROW_CACHE_MB", row_cache_mb);
@@ -648,6 +713,7 @@ void Tuning::load() {
     lut_cache = env_u32("PS_LUT_CACHE", lut_cache);
     z21_lds = env_u32("PS_Z21_LDS", z21_lds);
     full_budget_mb = env_u32("PS_FULL_BUDGET_MB", full_budget_mb);
+    result_pinned_min_kb = env_u32("PS_RESULT_PINNED_MIN_KB", result_pinned_min_kb);
     daat = env_u32("PS_DAAT", daat);
     daat_min_batch = env_u32("PS_DAAT_MIN_BATCH", daat_min_batch);
     daat_chunk = std::max(256u, env_u32("PS_DAAT_CHUNK", daat_chunk));
@@ -2442,14 +2508,14 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   }
   // K4 (query.rs:97-105, "materialise + sort"): canonical order (score desc, doc id asc == key asc)
   // of every query's run, on the device (ps_sort.hip)
-  m.d_sort_doc.ensure(total_cap + 1);
-  m.d_sort_score.ensure(total_cap + 1);
-  m.d_seg.ensure(2 * (B + 1));
-  SortBuffers sb{m.d_full_doc.p, reinterpret_cast<uint64_t*>(m.d_full_score.p), m.d_sort_doc.p, m.d_sort_score.p,
-                 m.d_seg.p, m.d_seg.p + B + 1};
-  // few or huge runs: device-wide sort per run (needs the counts); many small runs: one segmented sort
+  // few or huge runs: one set of device-wide sorts over all runs (needs the counts); many small runs: one segmented sort
   const bool few_runs = B <= 8 || total_cap / B > 32768;
   if (total_cap && B && !few_runs) {
+    m.d_sort_doc.ensure(total_cap + 1);
+    m.d_sort_score.ensure(total_cap + 1);
+    m.d_seg.ensure(2 * (B + 1));
+    SortBuffers sb{m.d_full_doc.p, reinterpret_cast<uint64_t*>(m.d_full_score.p), m.d_sort_doc.p, m.d_sort_score.p,
+                   m.d_seg.p, m.d_seg.p + B + 1};
     size_t tb = 0;
     PS_HIP(sort_results(sb, (unsigned)total_cap, (unsigned)B, m.d_full_off.p, m.d_full_cnt.p, nullptr, tb, st));
     m.d_sort_tmp.ensure(tb + 256);
@@ -2459,50 +2525,74 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   sync_stream(st);
   std::vector<uint32_t> cnt(h_cnt, h_cnt + B);
   read_kernel_times(m, stats);
-  if (few_runs) {
-    for (size_t q = 0; q < B; ++q) {
-      if (cnt[q] < 2) continue;
-      size_t tb = 0;
-      PS_HIP(sort_run(sb, cap[q], cnt[q], nullptr, tb, st));
-      m.d_sort_tmp.ensure(tb + 256);
-      PS_HIP(sort_run(sb, cap[q], cnt[q], m.d_sort_tmp.p, tb, st));
-    }
-  }
-  // pack the first `keep` results of every run as {key, score} records, one D2H copy
-  size_t total = 0;
+  static const bool ftrace = getenv("PS_FULL_TRACE") != nullptr;
+  const double t_scored = now_ms();
+  // the first `keep` results of every run as {key, score} records
+  size_t total = 0, found = 0;
+  std::vector<uint64_t> cmp_off(B + 1, 0);
   for (size_t q = 0; q < B; ++q) {
     offsets[q] = total;
     total += (top_k ? std::min<size_t>(top_k, cnt[q]) : cnt[q]);
+    cmp_off[q] = found;
+    found += cnt[q];
   }
   offsets[B] = total;
-  out.resize(total);
+  cmp_off[B] = found;
+  if (found >= 0xFFFFFFF0ull) throw std::length_error("full-result batch too large for one pass");
+  const size_t bytes = total * sizeof(ps_result);
+  // large blocks: pinned, written by the device, handed to the caller as they are (ps_free recycles them)
+  const bool pinned = bytes >= ((size_t)m.tune.result_pinned_min_kb << 10) && out.resize_pinned(total);
+  if (!pinned) out.resize(total);
+  double t_packed = t_scored;
   if (total) {
-    m.d_pack_off.ensure(B + 1);
+    m.d_pack_off.ensure(2 * (B + 1));
     m.d_pack.ensure(total);
-    m.result.ensure(std::max<size_t>((B + 1) * 8, total * sizeof(ps_result)) + 64);
+    m.result.ensure(std::max<size_t>(2 * (B + 1) * 8, pinned ? 0 : bytes) + 64);
     uint64_t* h_po = reinterpret_cast<uint64_t*>(m.result.p);
-    for (size_t q = 0; q <= B; ++q) h_po[q] = offsets[q];
-    PS_HIP(hipMemcpyAsync(m.d_pack_off.p, h_po, (B + 1) * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_pack_results, dim3((uint32_t)B), dim3(256), 0, st, m.d_full_doc.p, m.d_full_score.p,
-                       m.d_full_off.p, m.d_pack_off.p, m.d_keys, m.d_pack.p);
-    PS_HIP(hipGetLastError());
-    sync_stream(st);  // h_po (pinned) is reused as the download target
-    PS_HIP(hipMemcpyAsync(m.result.p, m.d_pack.p, total * sizeof(ps_result), hipMemcpyDeviceToHost, st));
-    sync_stream(st);
-    // pinned -> the caller's block: a few threads for the large ones (one core copies ~10 GB/s)
-    const size_t bytes = total * sizeof(ps_result);
-    const unsigned nt = bytes > (32u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-    if (nt <= 1) {
-      memcpy(out.data(), m.result.p, bytes);
+    for (size_t q = 0; q <= B; ++q) { h_po[q] = offsets[q]; h_po[B + 1 + q] = cmp_off[q]; }
+    PS_HIP(hipMemcpyAsync(m.d_pack_off.p, h_po, 2 * (B + 1) * 8, hipMemcpyHostToDevice, st));
+    if (few_runs) {
+      m.d_gs_u32.ensure(4 * found + 4);
+      m.d_gs_u64.ensure(3 * found + 3);
+      GlobalSort gs{};
+      gs.doc = m.d_full_doc.p;
+      gs.score_bits = reinterpret_cast<const uint64_t*>(m.d_full_score.p);
+      gs.run_off = m.d_full_off.p;
+      gs.cmp_off = m.d_pack_off.p + B + 1;
+      gs.n_runs = (uint32_t)B;
+      gs.n = (uint32_t)found;
+      gs.n_docs = s.n_ids;
+      gs.kd = m.d_gs_u32.p;
+      gs.k32 = m.d_gs_u32.p + found;
+      gs.ia = m.d_gs_u32.p + 2 * found;
+      gs.ib = m.d_gs_u32.p + 3 * found;
+      gs.sc = m.d_gs_u64.p;
+      gs.ks = m.d_gs_u64.p + found;
+      gs.ks_out = m.d_gs_u64.p + 2 * found;
+      size_t tb = 0;
+      PS_HIP(sort_runs_global(gs, nullptr, tb, st));
+      m.d_sort_tmp.ensure(tb + 256);
+      PS_HIP(sort_runs_global(gs, m.d_sort_tmp.p, tb, st));
+      PS_HIP(pack_sorted(gs, m.d_pack_off.p, total, m.d_keys, m.d_pack.p, st));
     } else {
-      std::vector<std::thread> th;
-      const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
-      for (unsigned t = 0; t < nt; ++t) {
-        const size_t b0 = std::min(bytes, (size_t)t * per), b1 = std::min(bytes, b0 + per);
-        if (b1 > b0) th.emplace_back([&, b0, b1]() { memcpy(reinterpret_cast<char*>(out.data()) + b0, m.result.p + b0, b1 - b0); });
-      }
-      for (auto& x : th) x.join();
+      hipLaunchKernelGGL(k_pack_results, dim3(64, (uint32_t)B), dim3(256), 0, st, m.d_full_doc.p, m.d_full_score.p,
+                         m.d_full_off.p, m.d_pack_off.p, m.d_keys, m.d_pack.p);
+      PS_HIP(hipGetLastError());
     }
+    if (ftrace) { sync_stream(st); t_packed = now_ms(); }
+    if (pinned) {
+      PS_HIP(hipMemcpyAsync(out.data(), m.d_pack.p, bytes, hipMemcpyDeviceToHost, st));
+      sync_stream(st);
+    } else {
+      sync_stream(st);  // h_po (pinned) is reused as the download target
+      PS_HIP(hipMemcpyAsync(m.result.p, m.d_pack.p, bytes, hipMemcpyDeviceToHost, st));
+      sync_stream(st);
+      memcpy(out.data(), m.result.p, bytes);
+    }
+    if (ftrace)
+      fprintf(stderr, "[full] to scored+counts %.2f ms, sort+pack %.2f, d2h%s %.2f (%zu results, %s block)\n",
+              t_scored - t0, t_packed - t_scored, pinned ? "" : " + host copy", now_ms() - t_packed, total,
+              pinned ? "pinned pool" : "malloc'd");
   }
   m.wc_results += total;
   fill_stats(m, stats, s, plan, total);

@@ -16,18 +16,57 @@ struct EngineImpl;
 
 // Result records on their way to the C caller: a malloc'd block that grows without value-initialising
 // (a full-result batch is hundreds of MB: every avoidable pass over it shows) and is handed over as it is.
+// Large result blocks are PINNED host memory the device writes into directly (no pageable copy, whose first-touch
+// page faults cost 17 ms for the 213 MB of a 24-query C2 batch); ps_free() hands such a block back to a process-wide
+// pool instead of the allocator, the next batch reuses it (PS_RESULT_POOL_MB of idle blocks are kept, default 1024).
+// result_block_release returns false for a pointer the pool does not know (then it is a malloc'd block).
+void* result_block_acquire(size_t bytes, size_t* capacity);  // nullptr: no pinned memory to be had
+bool result_block_release(void* p);
+
 struct ResultBuf {
   ps_result* p = nullptr;
   size_t n = 0;
+  size_t pinned_cap = 0;  // bytes of the pool block p points to, 0 = malloc'd
   ResultBuf() = default;
   ResultBuf(const ResultBuf&) = delete;
   ResultBuf& operator=(const ResultBuf&) = delete;
-  ~ResultBuf() { free(p); }
+  ~ResultBuf() { drop(); }
+  void drop() {
+    if (pinned_cap) result_block_release(p); else free(p);
+    p = nullptr;
+    n = pinned_cap = 0;
+  }
   void resize(size_t k) {
-    void* q = realloc(p, (k ? k : 1) * sizeof(ps_result));
+    const size_t bytes = (k ? k : 1) * sizeof(ps_result);
+    if (pinned_cap) {
+      if (bytes > pinned_cap) {  // grow: a larger pool block, or back to the allocator
+        size_t cap = 0;
+        void* q = result_block_acquire(bytes, &cap);
+        if (!q) { q = malloc(bytes); cap = 0; }
+        if (!q) throw std::bad_alloc();
+        memcpy(q, p, n * sizeof(ps_result));
+        result_block_release(p);
+        p = static_cast<ps_result*>(q);
+        pinned_cap = cap;
+      }
+      n = k;
+      return;
+    }
+    void* q = realloc(p, bytes);
     if (!q) throw std::bad_alloc();
     p = static_cast<ps_result*>(q);
     n = k;
+  }
+  // k results in a pinned pool block when there is one to be had (contents undefined); false: malloc'd as resize()
+  bool resize_pinned(size_t k) {
+    drop();
+    size_t cap = 0;
+    void* q = result_block_acquire((k ? k : 1) * sizeof(ps_result), &cap);
+    if (!q) { resize(k); return false; }
+    p = static_cast<ps_result*>(q);
+    pinned_cap = cap;
+    n = k;
+    return true;
   }
   void clear() { n = 0; }
   size_t size() const { return n; }
@@ -38,11 +77,11 @@ struct ResultBuf {
     resize(n + o.n);
     if (o.n) memcpy(p + at, o.p, o.n * sizeof(ps_result));
   }
-  ps_result* release() {
+  ps_result* release() {  // the caller's block now: ps_free() knows both kinds
     if (!p) resize(0);
     ps_result* r = p;
     p = nullptr;
-    n = 0;
+    n = pinned_cap = 0;
     return r;
   }
 };

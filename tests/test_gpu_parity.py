@@ -595,3 +595,45 @@ def test_field_longer_than_the_packed_posting_word_holds():
             exp = o.query(q, oracle_scorer(name), [1.0, 1.5])
             assert_same([tuple(r) for r in f], exp, (name, q))
             assert_same([tuple(r) for r in t2], exp[:2], (name, q, "top2"))
+
+
+def test_full_result_blocks_from_the_pinned_pool():
+    """Large result blocks are pinned pool blocks the device writes into (ps_engine.hpp: ResultBuf): forced for
+    every size here.  Full lists of 1 / 5 / 12 queries (one set of device-wide sorts over all runs) and the
+    truncated full mode (top_k = 100) against the oracle; a block handed back with ps_free is the next call's block."""
+    import ctypes as C
+    from probly_search_amd import _lib
+    L = psa.load()
+    cfg = dict(synth.CONFIGS["C2"], n_docs=60_000, vocab=5_000)
+    corpus = synth.Corpus(**cfg)
+    p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
+    snap = p.snapshot(device=0)
+    queries = corpus.queries(12, 3) + ["", "zzzzzz"]
+    boosts = [1.0, 1.5]
+    L.ps_set_option(b"PS_RESULT_PINNED_MIN_KB", 0)
+    try:
+        for name in ("bm25", "zero_to_one"):
+            sc = product_scorer(name)
+            exp = [o.query(q, oracle_scorer(name), boosts) for q in queries]
+            assert sum(len(e) for e in exp[:12]) > 12 * 32768  # the runs are of the size that takes the device-wide sorts
+            for sel in (slice(0, 1), slice(3, 8), slice(0, 14)):
+                for k in (0, 100):
+                    got = snap.query_batch(queries[sel], sc, None, boosts, top_k=k)
+                    for q, g, e in zip(queries[sel], got, exp[sel]):
+                        assert_same([tuple(r) for r in g], e[:k] if k else e, (name, q, k))
+        # the block of one call, freed, is the block of the next call of the same size
+        qb, arr = snap._pack_queries(queries[:4])
+        desc = psa.index._scorer_desc(product_scorer("bm25"))
+        b, nb = psa.index._boosts(boosts)
+        seen = []
+        for _ in range(3):
+            out, offs = C.POINTER(_lib.Result)(), C.POINTER(C.c_size_t)()
+            _lib.check(L.ps_snapshot_query_batch(snap._h, C.byref(desc), arr, len(qb), b, nb, None, None, 0,
+                                                 C.byref(out), C.byref(offs)))
+            seen.append(C.cast(out, C.c_void_p).value)
+            assert offs[4] > 4 * 1000
+            L.ps_free(out)
+            L.ps_free(offs)
+        assert seen[0] == seen[1] == seen[2], seen
+    finally:
+        L.ps_set_option(b"PS_RESULT_PINNED_MIN_KB", 4096)
