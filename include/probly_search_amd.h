@@ -8,7 +8,10 @@
  * plain pointers and sizes, no C++ or torch types, never unwinds.
  *
  * Ownership: every handle is created and freed by the library.  Result arrays returned through
- * `ps_result**` / `size_t**` are malloc'd by the library and released with ps_free().
+ * `ps_result**` / `size_t**` are allocated by the library and released with ps_free() - and only with it: large
+ * result blocks (PS_RESULT_PINNED_MIN_KB, default 4 MiB) are pinned host memory the device wrote into directly;
+ * ps_free() hands them back to a pool for the next batch (PS_RESULT_POOL_MB of idle blocks are kept), libc free()
+ * on them is undefined.
  * Threading: a `ps_index` needs external exclusion for mutation (it is `&mut self` in the
  * reference); a `ps_snapshot` is immutable and its query entry points are thread-safe
  * (`query(&self)`, src/query.rs:21-27).
@@ -132,7 +135,11 @@ typedef struct ps_scorer_desc {
 } ps_scorer_desc;
 
 const char* ps_last_error(void);
+/* Releases a block a query / plan entry point returned (NULL is fine).  Thread-safe. */
 void ps_free(void* p);
+/* Convenience for bindings that want columns (numpy, Arrow): keys[i] = results[i].key, scores[i] = results[i].score
+ * for i < n; a few host threads for large blocks.  Either output may be NULL. */
+void ps_results_split(const ps_result* results, size_t n, uint64_t* keys, double* scores);
 /* Number of visible HIP devices (0 if none / HIP unusable). */
 int ps_device_count(void);
 /* Tuning knobs by name - the PS_* names listed in DESIGN.md section 11 (e.g. "PS_DAAT", "PS_ROW_CACHE_MB",

@@ -123,6 +123,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "ps_last_error": (C.c_char_p, []),
     "ps_free": (None, [_P]),
+    "ps_results_split": (None, [_P, C.c_size_t, _P, _P]),
     "ps_device_count": (C.c_int, []),
     "ps_set_option": (C.c_int, [C.c_char_p, C.c_uint32]),
     "ps_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32)]),

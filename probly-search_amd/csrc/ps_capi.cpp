@@ -195,6 +195,22 @@ const char* ps_last_error(void) { return g_err.c_str(); }
 void ps_free(void* p) {
   if (!ps::result_block_release(p)) free(p);  // large result blocks are pinned pool blocks (ps_engine.hpp)
 }
+void ps_results_split(const ps_result* r, size_t n, uint64_t* keys, double* scores) {
+  if (!r || !n) return;
+  auto part = [=](size_t a, size_t b) {
+    if (keys) for (size_t i = a; i < b; ++i) keys[i] = r[i].key;
+    if (scores) for (size_t i = a; i < b; ++i) scores[i] = r[i].score;
+  };
+  const unsigned nt = n >= (1u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+  if (nt <= 1) return part(0, n);
+  std::vector<std::thread> th;
+  const size_t per = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t a = std::min(n, (size_t)t * per), b = std::min(n, a + per);
+    if (b > a) th.emplace_back(part, a, b);
+  }
+  for (auto& x : th) x.join();
+}
 int ps_device_count(void) { return ps::device_count(); }
 ps_status ps_set_option(const char* name, uint32_t value) {
   if (!name || strncmp(name, "PS_", 3) != 0) return fail(PS_EINVAL, "option names are the PS_* knob names");

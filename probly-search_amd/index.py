@@ -276,9 +276,8 @@ class Snapshot:
             _raise(e)
         o = np.ctypeslib.as_array(offs, shape=(len(qb) + 1,)).copy()
         n = int(o[-1])
-        rec = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(max(n, 1), 2))[:n]  # a view of the library's block
-        keys, scores = np.ascontiguousarray(rec[:, 0]), np.ascontiguousarray(rec[:, 1]).view(np.float64)
-        del rec
+        keys, scores = np.empty(n, np.uint64), np.empty(n, np.float64)
+        self._L.ps_results_split(out, n, keys.ctypes.data, scores.ctypes.data)
         self._L.ps_free(out)
         self._L.ps_free(offs)
         return keys, scores, o
