@@ -36,6 +36,12 @@ constexpr int WAVE = 64;
 #ifndef PS_DAAT_UM
 #define PS_DAAT_UM 2             // K1d, multi-expansion arm: postings per lane in flight
 #endif
+#ifndef PS_DAAT_MQ
+#define PS_DAAT_MQ 1             // K1d, multi-expansion arm: survivors of the first lookup level wait in a wave-private LDS queue (0: the round-2 arm)
+#endif
+#ifndef PS_DAAT_UMQ
+#define PS_DAAT_UMQ 4            // ... postings per lane in flight in its scan stage
+#endif
 #ifndef PS_HARVEST_UNROLL
 #define PS_HARVEST_UNROLL 8  // 16-byte LDS reads in flight per lane while a tile is harvested
 #endif
@@ -1652,6 +1658,213 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
     const uint32_t end = (p.ablate & 16u) ? it.begin : it.begin + it.count;  // (debug: 16 = no postings)
     bool essential = true;  // wave-uniform
     WorkStats ws;
+    bool handled = false;
+    if constexpr (MULTI && PS_DAAT_MQ != 0) {
+      if (e1 - e0 <= 64u && own_grp < 4u) {
+        // Several expansions per query term (the expansions of one term merge by max, query.rs:150-164: a document
+        // scores at most the sum over query terms of the best of its lists of that term), in two stages.
+        // The walk over the other lists, highest bound first, is a chain of dependent lookups that a wave follows
+        // as long as ANY of its postings is alive - yet a posting survives 1.7 lookups on average (C5).  So the
+        // scan stage only does the FIRST lookup (the highest-bound other list) for the postings of a trip, UA per
+        // lane in flight; what is still alive - a fraction of the lanes - waits in a wave-private LDS queue until 64
+        // are together, and the rest of the walk (pass 1 from the second list on, pass 2 = the add / max state
+        // machine in plan order) runs with every lane busy.
+        handled = true;
+        constexpr int UA = F_ ? PS_DAAT_UMQ : 2;
+        constexpr uint32_t QCAP = 128;  // a push adds <= 64 to < 64
+        __shared__ uint32_t mq_d[DAAT_WGW][QCAP];
+        __shared__ double mq_so[DAAT_WGW][QCAP];
+        __shared__ double mq_s1[DAAT_WGW][QCAP];
+        uint32_t q_head = 0, q_n = 0;  // wave-uniform
+        const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+        uint32_t r1 = e1;
+        for (uint32_t r = e0; r < e1; ++r)
+          if (p.rorder[r] != e_own) { r1 = r; break; }
+        const bool has1 = r1 < e1;
+        const uint32_t j1 = has1 ? p.rorder[r1] : e_own;
+        const ps_plan_entry& en1 = p.plan[j1];
+        const uint32_t g1 = has1 ? p.dgroup[j1].grp : 0xFFFFFFFFu;
+        const uint32_t j1_rank = p.dentry[j1].rank;
+        double rem1[4] = {rem0[0], rem0[1], rem0[2], rem0[3]};  // per query term: the best list not looked at after level 1
+        if (has1) {
+          const double nxt = p.dgroup[j1].nxt_s;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if ((uint32_t)g == g1) rem1[g] = nxt;
+        }
+        double theta = 0.0;
+#ifdef PS_MQ_TIME
+        unsigned long long mq_tb1 = 0, mq_tb2 = 0, mq_cnt = 0;
+#endif
+        // the rest of the walk for the first `count` (<= 64) queued documents, one per lane
+        auto process = [&](const uint32_t count) {
+          const uint32_t at = (q_head + (uint32_t)lane) & (QCAP - 1u);
+          const bool ok = (uint32_t)lane < count;
+          const uint32_t d1[1] = {ok ? mq_d[wave][at] : 0u};
+          const double so = ok ? mq_so[wave][at] : 0.0, s1v = ok ? mq_s1[wave][at] : 0.0;
+          q_head = (q_head + count) & (QCAP - 1u);
+          q_n -= count;
+#ifdef PS_MQ_TIME  // profiling builds only: time in this stage -> the `probe` counter, survivors -> `offer`, 100 ns units of the whole arm -> `row`
+          const unsigned long long t_b0 = __builtin_amdgcn_s_memrealtime();
+          mq_cnt += count;
+#endif
+          bool alive1[1] = {ok};
+          double act[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            act[g] = (uint32_t)g == own_grp ? so : 0.0;
+            if ((uint32_t)g == g1 && s1v > 0.0) act[g] = fmax(act[g], s1v);
+          }
+          unsigned long long hits = s1v > 0.0 ? 1ull << (j1 - e0) : 0ull;
+          double rem[4] = {rem1[0], rem1[1], rem1[2], rem1[3]};
+          bool any_alive = true;
+          for (uint32_t r = r1 + 1; r < e1 && any_alive; ++r) {
+            const uint32_t j = p.rorder[r];
+            if (j != e_own) {
+              const ps_plan_entry& en = p.plan[j];
+              const DGroup gj = p.dgroup[j];
+              const uint32_t j_rank = p.dentry[j].rank;
+              double s[1];
+              lookup_scores<F_, 1>(p, lut, en, d1, alive1, s, ws);
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                if ((uint32_t)g == gj.grp) rem[g] = gj.nxt_s;
+              if (alive1[0]) {
+                if (s[0] > 0.0) {
+                  hits |= 1ull << (j - e0);
+#pragma unroll
+                  for (int g = 0; g < 4; ++g)
+                    if ((uint32_t)g == gj.grp) act[g] = fmax(act[g], s[0]);
+                }
+                double bound = 0.0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bound += fmax(act[g], rem[g]);
+                // (j_rank < own_rank: the document is evaluated from its highest-bound list only)
+                if (bound < theta || (s[0] > 0.0 && j_rank < own_rank)) alive1[0] = false;
+              }
+              any_alive = __any(alive1[0]);
+            }
+          }
+#ifdef PS_MQ_TIME
+          mq_tb1 += __builtin_amdgcn_s_memrealtime() - t_b0;
+#endif
+          if (!any_alive) return;
+          // pass 2, the survivors: the add / max state machine in PLAN order (query.rs:33-89,150-164)
+#ifdef PS_MQ_TIME
+          const unsigned long long t_b2 = __builtin_amdgcn_s_memrealtime();
+#endif
+          double P = 0.0;
+          bool present = false, visited = false;
+          uint32_t cur_qterm = 0xFFFFFFFFu;
+          for (uint32_t j = e0; j < e1; ++j) {
+            const ps_plan_entry& en = p.plan[j];
+            if (en.qterm != cur_qterm) {  // query.rs:37
+              cur_qterm = en.qterm;
+              visited = false;
+            }
+            double s[1] = {0.0};
+            if (j == e_own) {
+              s[0] = so;
+            } else if (has1 && j == j1) {
+              s[0] = s1v;  // (looked up by the scan stage)
+            } else {
+              // (keeping what pass 1 found in registers instead - 7 lists - cost 14 VGPRs and the fourth wave per
+              // SIMD: 2.64 ms against 2.44 on C5)
+              bool want[1] = {alive1[0] && ((hits >> (j - e0)) & 1ull)};
+              if (__any(want[0])) lookup_scores<F_, 1>(p, lut, en, d1, want, s, ws);
+            }
+            if (alive1[0] && s[0] > 0.0) {
+              P = present ? (visited ? fmax(P, s[0]) : P + s[0]) : s[0];
+              visited = true;
+              present = true;
+            }
+          }
+          const bool offer = alive1[0] && P >= theta;
+          ws.offer += lanes_on(offer);
+          if (__any(offer)) topk_offer(tk, p.K, lane, alive1[0], P, d1[0], theta);
+          if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta) {
+            // this wave's K-th best so far: the final K-th best of the query can only be higher
+            published = tk.thr_s;
+            if (lane == 0) atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+          }
+#ifdef PS_MQ_TIME
+          mq_tb2 += __builtin_amdgcn_s_memrealtime() - t_b2;
+#endif
+        };
+        uint32_t i0 = it.begin;
+#ifdef PS_MQ_TIME
+        const unsigned long long t_a0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        for (;;) {
+          const bool scanning = i0 < end && essential;
+          if (q_n >= (uint32_t)WAVE || (!scanning && q_n)) { process(min(q_n, (uint32_t)WAVE)); continue; }
+          if (!scanning) break;
+          const unsigned long long tbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)),
+                                   __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits));
+          essential = !(skip_thr < theta);  // false: the whole list has become non-essential
+          uint32_t d[UA];
+          uint64_t pi[UA];
+          bool alive[UA];
+          double s_own[UA];
+#pragma unroll
+          for (int u = 0; u < UA; ++u) {
+            const uint32_t i = i0 + u * WAVE + lane;
+            alive[u] = essential && i < end;
+            pi[u] = own_off + (i < end ? i : end - 1);
+            d[u] = p.doc[pi[u]];
+          }
+          if (p.alive != nullptr) {  // delta removals
+#pragma unroll
+            for (int u = 0; u < UA; ++u) alive[u] = alive[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
+          }
+          plane_scores<F_, UA>(p, pi, alive, own_eb, s_own);
+          bool any_alive = false;
+#pragma unroll
+          for (int u = 0; u < UA; ++u) {
+            // everything the other entries could add, at most: below theta the document is out
+            alive[u] = alive[u] && (s_own[u] + others >= theta) && !(p.ablate & 32u);  // (debug: 32 = no lookups)
+            any_alive |= alive[u];
+            ws.reached += lanes_on(alive[u]);
+          }
+          if (essential) ws.scanned += min(end - i0, (uint32_t)(WAVE * UA)); else ws.probe += min(end - i0, (uint32_t)(WAVE * UA));
+          i0 += WAVE * UA;
+          if (!__any(any_alive)) continue;
+          double s1[UA];
+#pragma unroll
+          for (int u = 0; u < UA; ++u) s1[u] = 0.0;
+          if (has1) lookup_scores<F_, UA>(p, lut, en1, d, alive, s1, ws);
+#pragma unroll
+          for (int u = 0; u < UA; ++u) {
+            if (alive[u]) {
+              double bound = 0.0;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                double a = (uint32_t)g == own_grp ? s_own[u] : 0.0;
+                if ((uint32_t)g == g1 && s1[u] > 0.0) a = fmax(a, s1[u]);
+                bound += fmax(a, rem1[g]);
+              }
+              if (bound < theta || (s1[u] > 0.0 && j1_rank < own_rank)) alive[u] = false;
+            }
+            const unsigned long long m = __ballot(alive[u]);
+            if (m) {
+              if (alive[u]) {
+                const uint32_t at = (q_head + q_n + (uint32_t)__popcll(m & lt)) & (QCAP - 1u);
+                mq_d[wave][at] = d[u];
+                mq_so[wave][at] = s_own[u];
+                mq_s1[wave][at] = s1[u];
+              }
+              q_n += (uint32_t)__popcll(m);
+              if (q_n >= (uint32_t)WAVE) process((uint32_t)WAVE);
+            }
+          }
+        }
+#ifdef PS_MQ_TIME
+        ws.probe = (uint32_t)mq_tb1; ws.offer = (uint32_t)mq_tb2; ws.row = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_a0); ws.hit = (uint32_t)mq_cnt;
+#endif
+      }
+    }
+    if (!handled)
     for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
       // the query's current threshold: a lower bound of its final K-th best score (0 = none yet).
       // One load instruction returns one value to the whole wave; readfirstlane tells the compiler.
@@ -1742,7 +1955,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
                 if (alive[u] && s[u] > 0.0) P[u] += s[u];
             }
           }
-        } else if (MULTI && ne <= 64u && own_grp < 4u) {
+        } else if (MULTI && PS_DAAT_MQ == 0 && ne <= 64u && own_grp < 4u) {
           // Several expansions per query term: the expansions of one term merge by max
           // (query.rs:150-164), so a document scores at most the sum over query terms of the best of
           // its lists of that term.  Pass 1 (highest-bound lists first) keeps, per query term, the best
