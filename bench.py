@@ -34,8 +34,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (a step is 0.05-2.7 ms: 100 of them keep the pipeline's fill and drain - the timed region is fenced on both
+    # sides, about 0.6 ms for the three batches in flight - at a percent of the measurement instead of 9 % at 20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--resident-rows", action="store_true",
                     help="keep dense score rows resident across steps (the library's default); without it "
                          "every step rebuilds its rows inside the timed region (the conservative, reported number)")
