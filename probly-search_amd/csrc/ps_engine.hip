@@ -130,6 +130,7 @@ struct Tuning {
   uint32_t lut_cache = 1;  // PS_LUT_CACHE
   uint32_t z21_lds = 20480;  // PS_Z21_LDS
   uint32_t full_budget_mb = 4096;  // PS_FULL_BUDGET_MB
+  uint32_t full_parts_min_kb = 32768;  // PS_FULL_PARTS_MIN_KB: pinned result blocks from this size on are sorted and downloaded in up to 4 parts (download of a part beside the sorts of the next)
   uint32_t result_pinned_min_kb = 4096;  // PS_RESULT_PINNED_MIN_KB: result blocks from this size on are pinned pool blocks (ps_free recycles them)
   uint32_t daat = 1;             // PS_DAAT: BM25 top-k batches take K1d k_daat (exact dynamic pruning)
   uint32_t daat_min_batch = 8;   // PS_DAAT_MIN_BATCH: smaller batches keep the k_score latency path
@@ -211,6 +212,8 @@ struct EngineImpl {
   } cands;
   std::vector<uint32_t> z_minfl;  // zero_to_one field pruning: [layer][field] shortest field length holding the term (compute_z_bounds)
   std::unordered_map<uint64_t, uint32_t> z_layer_of;  // post_off -> layer (zero_to_one plan entries do not carry it)
+  hipStream_t copy_stream = nullptr;  // full-result mode: downloads of sorted parts beside the sorts of the next
+  hipEvent_t part_done[4] = {nullptr, nullptr, nullptr, nullptr};
   DevBuf<uint32_t> d_sort_doc, d_seg, d_gs_u32;  // K4 scratch
   DevBuf<uint64_t> d_sort_score, d_pack_off, d_gs_u64;
   DevBuf<unsigned char> d_sort_tmp;
@@ -437,6 +440,8 @@ Engine::~Engine() {
   if (m.plan_stream) (void)hipStreamDestroy(m.plan_stream);
   if (m.merge_stream) (void)hipStreamDestroy(m.merge_stream);
   if (m.score_stream) (void)hipStreamDestroy(m.score_stream);
+  if (m.copy_stream) (void)hipStreamDestroy(m.copy_stream);
+  for (auto& e : m.part_done) if (e) (void)hipEventDestroy(e);
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fbits.release(); m.d_fchar.release(); m.d_fchild.release();
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release(); m.d_layer_idf.release(); m.d_bloom.release(); m.d_layer_bloom.release();
   if (m.h_totals) (void)hipHostFree(m.h_totals);
@@ -714,6 +719,7 @@ void Tuning::load() {
     z21_lds = env_u32("PS_Z21_LDS", z21_lds);
     full_budget_mb = env_u32("PS_FULL_BUDGET_MB", full_budget_mb);
     result_pinned_min_kb = env_u32("PS_RESULT_PINNED_MIN_KB", result_pinned_min_kb);
+    full_parts_min_kb = env_u32("PS_FULL_PARTS_MIN_KB", full_parts_min_kb);
     daat = env_u32("PS_DAAT", daat);
     daat_min_batch = env_u32("PS_DAAT_MIN_BATCH", daat_min_batch);
     daat_chunk = std::max(256u, env_u32("PS_DAAT_CHUNK", daat_chunk));
@@ -2544,6 +2550,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   const bool pinned = bytes >= ((size_t)m.tune.result_pinned_min_kb << 10) && out.resize_pinned(total);
   if (!pinned) out.resize(total);
   double t_packed = t_scored;
+  bool downloaded = false;
   if (total) {
     m.d_pack_off.ensure(2 * (B + 1));
     m.d_pack.ensure(total);
@@ -2559,8 +2566,6 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
       gs.score_bits = reinterpret_cast<const uint64_t*>(m.d_full_score.p);
       gs.run_off = m.d_full_off.p;
       gs.cmp_off = m.d_pack_off.p + B + 1;
-      gs.n_runs = (uint32_t)B;
-      gs.n = (uint32_t)found;
       gs.n_docs = s.n_ids;
       gs.kd = m.d_gs_u32.p;
       gs.k32 = m.d_gs_u32.p + found;
@@ -2569,22 +2574,72 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
       gs.sc = m.d_gs_u64.p;
       gs.ks = m.d_gs_u64.p + found;
       gs.ks_out = m.d_gs_u64.p + 2 * found;
-      size_t tb = 0;
-      PS_HIP(sort_runs_global(gs, nullptr, tb, st));
-      m.d_sort_tmp.ensure(tb + 256);
-      PS_HIP(sort_runs_global(gs, m.d_sort_tmp.p, tb, st));
-      PS_HIP(pack_sorted(gs, m.d_pack_off.p, total, m.d_keys, m.d_pack.p, st));
+      // Large batches in up to 4 parts of whole runs: the download of a part (the link: 57 GB/s, more than half of
+      // a large batch's time) runs on the copy stream while the next part is sorted.
+      const size_t n_parts = (pinned && bytes >= ((size_t)m.tune.full_parts_min_kb << 10)) ? std::min<size_t>(4, B) : 1;
+      if (n_parts > 1 && !m.copy_stream) {
+        PS_HIP(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
+        for (auto& e : m.part_done) PS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      }
+      {  // the sorts' temporary storage once, for the largest part there can be (no reallocation between parts)
+        gs.run0 = 0; gs.n_runs = (uint32_t)B; gs.first = 0; gs.n = (uint32_t)found;
+        size_t tb = 0;
+        PS_HIP(sort_runs_global(gs, nullptr, tb, st));
+        m.d_sort_tmp.ensure(tb + 256);
+      }
+      size_t qa = 0;
+      try {
+      for (size_t part = 0; part < n_parts; ++part) {
+        size_t qb = qa;
+        if (part + 1 == n_parts) {
+          qb = B;
+        } else {  // whole runs up to this part's share of the results
+          const uint64_t goal = (uint64_t)found * (part + 1) / n_parts;
+          while (qb < B && (cmp_off[qb + 1] <= goal || qb == qa)) ++qb;
+          qb = std::min(qb, B - (n_parts - 1 - part));
+          qb = std::max(qb, qa + 1);
+        }
+        gs.run0 = (uint32_t)qa;
+        gs.n_runs = (uint32_t)(qb - qa);
+        gs.first = (uint32_t)cmp_off[qa];
+        gs.n = (uint32_t)(cmp_off[qb] - cmp_off[qa]);
+        const size_t o0 = offsets[qa], o1 = offsets[qb];
+        if (gs.n) {
+          size_t tb = m.d_sort_tmp.cap;
+          PS_HIP(sort_runs_global(gs, m.d_sort_tmp.p, tb, st));
+          PS_HIP(pack_sorted(gs, m.d_pack_off.p, o0, o1 - o0, m.d_keys, m.d_pack.p, st));
+        }
+        if (n_parts > 1 && o1 > o0) {
+          PS_HIP(hipEventRecord(m.part_done[part], st));
+          PS_HIP(hipStreamWaitEvent(m.copy_stream, m.part_done[part], 0));
+          PS_HIP(hipMemcpyAsync(out.data() + o0, m.d_pack.p + o0, (o1 - o0) * sizeof(ps_result), hipMemcpyDeviceToHost, m.copy_stream));
+        }
+        qa = qb;
+      }
+      } catch (...) {  // nothing may still be writing into the caller's block when it goes back to the pool
+        if (m.copy_stream) (void)hipStreamSynchronize(m.copy_stream);
+        (void)hipStreamSynchronize(st);
+        throw;
+      }
+      if (n_parts > 1) {
+        downloaded = true;
+        if (ftrace) { sync_stream(st); t_packed = now_ms(); }
+        PS_HIP(hipStreamSynchronize(m.copy_stream));
+        sync_stream(st);
+      }
     } else {
       hipLaunchKernelGGL(k_pack_results, dim3(64, (uint32_t)B), dim3(256), 0, st, m.d_full_doc.p, m.d_full_score.p,
                          m.d_full_off.p, m.d_pack_off.p, m.d_keys, m.d_pack.p);
       PS_HIP(hipGetLastError());
     }
-    if (ftrace) { sync_stream(st); t_packed = now_ms(); }
-    if (pinned) {
+    if (downloaded) {
+    } else if (pinned) {
+      if (ftrace) { sync_stream(st); t_packed = now_ms(); }
       PS_HIP(hipMemcpyAsync(out.data(), m.d_pack.p, bytes, hipMemcpyDeviceToHost, st));
       sync_stream(st);
     } else {
       sync_stream(st);  // h_po (pinned) is reused as the download target
+      if (ftrace) t_packed = now_ms();
       PS_HIP(hipMemcpyAsync(m.result.p, m.d_pack.p, bytes, hipMemcpyDeviceToHost, st));
       sync_stream(st);
       memcpy(out.data(), m.result.p, bytes);

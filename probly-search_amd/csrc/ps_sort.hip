@@ -69,10 +69,11 @@ __device__ __forceinline__ uint32_t run_of(const uint64_t* off, uint32_t n_runs,
   return lo;
 }
 __global__ __launch_bounds__(256) void k_gs_compact(const uint32_t* doc, const uint64_t* score, const uint64_t* run_off,
-                                                    const uint64_t* cmp_off, uint32_t n_runs, uint32_t n, uint32_t* kd,
-                                                    uint64_t* sc, uint32_t* idx) {
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const uint32_t q = run_of(cmp_off, n_runs, j);
+                                                    const uint64_t* cmp_off, uint32_t run0, uint32_t n_runs,
+                                                    uint32_t first, uint32_t n, uint32_t* kd, uint64_t* sc, uint32_t* idx) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const uint32_t j = first + t;
+    const uint32_t q = run0 + run_of(cmp_off + run0, n_runs, j);
     const uint64_t src = run_off[q] + (j - cmp_off[q]);
     kd[j] = doc[src];
     sc[j] = score[src];
@@ -89,10 +90,12 @@ __global__ __launch_bounds__(256) void k_gs_gather_run(const uint64_t* cmp_off, 
 }
 struct PackedResult { uint64_t key; uint64_t score_bits; };  // == ps_result {u64 key; f64 score}
 __global__ __launch_bounds__(256) void k_gs_pack(const uint32_t* kd, const uint64_t* sc, const uint32_t* perm,
-                                                 const uint64_t* cmp_off, const uint64_t* out_off, uint32_t n_runs,
-                                                 uint64_t n_out, const uint64_t* keys, PackedResult* out) {
-  for (uint64_t o = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; o < n_out; o += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t q = run_of(out_off, n_runs, o);
+                                                 const uint64_t* cmp_off, const uint64_t* out_off, uint32_t run0,
+                                                 uint32_t n_runs, uint64_t out_first, uint64_t n_out, const uint64_t* keys,
+                                                 PackedResult* out) {
+  for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_out; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t o = out_first + t;
+    const uint32_t q = run0 + run_of(out_off + run0, n_runs, o);
     const uint32_t i = perm[cmp_off[q] + (o - out_off[q])];
     out[o] = PackedResult{keys[kd[i]], sc[i]};
   }
@@ -107,24 +110,26 @@ inline unsigned grid_for(uint64_t n) { return (unsigned)std::min<uint64_t>((n + 
 
 hipError_t sort_runs_global(GlobalSort& g, void* temp, size_t& temp_bytes, hipStream_t st) {
   const unsigned doc_bits = bits_for(g.n_docs), run_bits = bits_for(g.n_runs);
-  uint32_t* kq_out = reinterpret_cast<uint32_t*>(g.ks_out);  // free again once the score sort is done
+  // the part's slices of the scratch arrays (the permutation VALUES stay indices of the whole batch)
+  uint32_t *kd = g.kd + g.first, *k32 = g.k32 + g.first, *ia = g.ia + g.first, *ib = g.ib + g.first;
+  uint64_t *ks = g.ks + g.first, *ks_out = g.ks_out + g.first;
+  uint32_t* kq_out = reinterpret_cast<uint32_t*>(ks_out);  // free again once the score sort is done
   size_t t1 = temp_bytes, t2 = temp_bytes, t3 = temp_bytes;
   hipError_t e;
   if (temp != nullptr) {
     hipLaunchKernelGGL(k_gs_compact, dim3(grid_for(g.n)), dim3(256), 0, st, g.doc, g.score_bits, g.run_off, g.cmp_off,
-                       g.n_runs, g.n, g.kd, g.sc, g.ia);
+                       g.run0, g.n_runs, g.first, g.n, g.kd, g.sc, g.ia);
   }
-  e = rocprim::radix_sort_pairs(temp, t1, g.kd, g.k32, g.ia, g.ib, g.n, 0, doc_bits, st);
+  e = rocprim::radix_sort_pairs(temp, t1, kd, k32, ia, ib, g.n, 0, doc_bits, st);
   if (e != hipSuccess) return e;
-  if (temp != nullptr)
-    hipLaunchKernelGGL(k_gs_gather_score, dim3(grid_for(g.n)), dim3(256), 0, st, g.sc, g.ib, g.n, g.ks);
-  e = rocprim::radix_sort_pairs_desc(temp, t2, g.ks, g.ks_out, g.ib, g.ia, g.n, 0, 64, st);
+  if (temp != nullptr) hipLaunchKernelGGL(k_gs_gather_score, dim3(grid_for(g.n)), dim3(256), 0, st, g.sc, ib, g.n, ks);
+  e = rocprim::radix_sort_pairs_desc(temp, t2, ks, ks_out, ib, ia, g.n, 0, 64, st);
   if (e != hipSuccess) return e;
   g.perm = g.ia;
   if (g.n_runs > 1) {
     if (temp != nullptr)
-      hipLaunchKernelGGL(k_gs_gather_run, dim3(grid_for(g.n)), dim3(256), 0, st, g.cmp_off, g.n_runs, g.ia, g.n, g.k32);
-    e = rocprim::radix_sort_pairs(temp, t3, g.k32, kq_out, g.ia, g.ib, g.n, 0, run_bits, st);
+      hipLaunchKernelGGL(k_gs_gather_run, dim3(grid_for(g.n)), dim3(256), 0, st, g.cmp_off + g.run0, g.n_runs, ia, g.n, k32);
+    e = rocprim::radix_sort_pairs(temp, t3, k32, kq_out, ia, ib, g.n, 0, run_bits, st);
     if (e != hipSuccess) return e;
     g.perm = g.ib;
   } else {
@@ -134,11 +139,11 @@ hipError_t sort_runs_global(GlobalSort& g, void* temp, size_t& temp_bytes, hipSt
   return temp != nullptr ? hipGetLastError() : hipSuccess;
 }
 
-hipError_t pack_sorted(const GlobalSort& g, const uint64_t* out_off, uint64_t n_out, const uint64_t* keys, void* out,
-                       hipStream_t st) {
+hipError_t pack_sorted(const GlobalSort& g, const uint64_t* out_off, uint64_t out_first, uint64_t n_out,
+                       const uint64_t* keys, void* out, hipStream_t st) {
   if (!n_out) return hipSuccess;
-  hipLaunchKernelGGL(k_gs_pack, dim3(grid_for(n_out)), dim3(256), 0, st, g.kd, g.sc, g.perm, g.cmp_off, out_off, g.n_runs,
-                     n_out, keys, static_cast<PackedResult*>(out));
+  hipLaunchKernelGGL(k_gs_pack, dim3(grid_for(n_out)), dim3(256), 0, st, g.kd, g.sc, g.perm, g.cmp_off, out_off, g.run0,
+                     g.n_runs, out_first, n_out, keys, static_cast<PackedResult*>(out));
   return hipGetLastError();
 }
 

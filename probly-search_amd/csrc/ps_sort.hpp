@@ -34,16 +34,21 @@ struct GlobalSort {
   // inputs (device)
   const uint32_t* doc;         // doc ids, run q at run_off[q]
   const uint64_t* score_bits;  // f64 scores as bits, same positions
-  const uint64_t* run_off;     // [n_runs]
-  const uint64_t* cmp_off;     // [n_runs + 1] offsets of the runs laid next to each other (sum of counts)
-  uint32_t n_runs;
-  uint32_t n;                  // cmp_off[n_runs]
+  const uint64_t* run_off;     // [n_runs_total]
+  const uint64_t* cmp_off;     // [n_runs_total + 1] offsets of the runs laid next to each other (sum of counts)
   uint32_t n_docs;
-  // scratch (device), [n] each
+  // the part of the batch this call sorts: runs [run0, run0 + n_runs), compact indices [first, first + n)
+  // (several parts of one batch share the scratch arrays: a part only touches its own index range, so the
+  // download of one part can overlap the sorts of the next)
+  uint32_t run0;
+  uint32_t n_runs;
+  uint32_t first;              // cmp_off[run0]
+  uint32_t n;                  // cmp_off[run0 + n_runs] - first
+  // scratch (device), one element per result of the whole batch
   uint32_t* kd;      // doc ids, compact (kept for pack_sorted)
   uint64_t* sc;      // scores, compact (kept for pack_sorted)
   uint32_t* k32;     // sort scratch
-  uint32_t* ia;      // permutation ping
+  uint32_t* ia;      // permutation ping (values: compact indices of the whole batch)
   uint32_t* ib;      // permutation pong
   uint64_t* ks;      // score keys in doc order
   uint64_t* ks_out;  // sort scratch
@@ -51,8 +56,9 @@ struct GlobalSort {
   const uint32_t* perm;
 };
 hipError_t sort_runs_global(GlobalSort& g, void* temp, size_t& temp_bytes, hipStream_t st);
-// out[o] for o in [out_off[q], out_off[q+1]) = {keys[doc], score} of run q's (o - out_off[q])-th result.
-hipError_t pack_sorted(const GlobalSort& g, const uint64_t* out_off, uint64_t n_out, const uint64_t* keys, void* out,
-                       hipStream_t st);
+// out[o] for o in [out_off[q], out_off[q+1]) = {keys[doc], score} of run q's (o - out_off[q])-th result, for the
+// runs of the part; out_first / n_out = out_off[run0] and the part's number of records (host-known).
+hipError_t pack_sorted(const GlobalSort& g, const uint64_t* out_off, uint64_t out_first, uint64_t n_out,
+                       const uint64_t* keys, void* out, hipStream_t st);
 
 }  // namespace ps

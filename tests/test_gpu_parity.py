@@ -611,12 +611,13 @@ def test_full_result_blocks_from_the_pinned_pool():
     queries = corpus.queries(12, 3) + ["", "zzzzzz"]
     boosts = [1.0, 1.5]
     L.ps_set_option(b"PS_RESULT_PINNED_MIN_KB", 0)
+    L.ps_set_option(b"PS_FULL_PARTS_MIN_KB", 0)  # ... and in up to 4 parts (downloads beside the next part's sorts)
     try:
         for name in ("bm25", "zero_to_one"):
             sc = product_scorer(name)
             exp = [o.query(q, oracle_scorer(name), boosts) for q in queries]
             assert sum(len(e) for e in exp[:12]) > 12 * 32768  # the runs are of the size that takes the device-wide sorts
-            for sel in (slice(0, 1), slice(3, 8), slice(0, 14)):
+            for sel in (slice(0, 1), slice(3, 8), slice(0, 14), slice(11, 14), slice(12, 14)):  # (the last two: parts that are empty runs)
                 for k in (0, 100):
                     got = snap.query_batch(queries[sel], sc, None, boosts, top_k=k)
                     for q, g, e in zip(queries[sel], got, exp[sel]):
@@ -637,3 +638,4 @@ def test_full_result_blocks_from_the_pinned_pool():
         assert seen[0] == seen[1] == seen[2], seen
     finally:
         L.ps_set_option(b"PS_RESULT_PINNED_MIN_KB", 4096)
+        L.ps_set_option(b"PS_FULL_PARTS_MIN_KB", 32768)
