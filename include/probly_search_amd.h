@@ -182,6 +182,35 @@ ps_status ps_index_remove_document(ps_index* idx, uint64_t key);
 /* Index::vacuum (src/index.rs:194-241) — unlinks removed postings, prunes empty trie subtrees. */
 ps_status ps_index_vacuum(ps_index* idx);
 
+/* ---- Key table: document keys that are not u64 -------------------------------------------------
+ * The reference's index is generic over its key, `Index<T: Eq + Hash + Copy + Debug>` (src/index.rs:19-33), and
+ * hands `T` back in `QueryResult<T>` (src/query.rs:10-17); this ABI carries uint64_t.  A binding for another `T`
+ * (uuid, (shard, row) pair, short string) gives the key's bytes to a key table and uses the dense id it gets back as
+ * the ABI key; after a query it turns the result ids back into key bytes.  Ids count up from 0 in first-seen order
+ * and are never reused: a removed and re-added key meets the index under its old id, as `remove_document(key)` /
+ * `add_document(.., key, ..)` require (src/index.rs:77-83,161-191).  Equal bytes == equal keys (the binding's
+ * serialisation must agree with `T: Eq`).  Ties in a result come out id-ascending == first-seen order.
+ * Threading: intern needs external exclusion (`&mut self` of add_document); find / key / resolve may run
+ * concurrently with each other.  Pointers returned by key / resolve point into the table and stay valid until the
+ * next intern.  Host code only. */
+typedef struct ps_keytable ps_keytable;
+ps_status ps_keytable_new(ps_keytable** out);
+void ps_keytable_free(ps_keytable* kt);
+size_t ps_keytable_len(const ps_keytable* kt);
+/* Id of `key` (len bytes; len 0 is a valid key), inserted if new.  *inserted (may be NULL) = 1 if it was new. */
+ps_status ps_keytable_intern(ps_keytable* kt, const void* key, size_t len, uint64_t* id, int* inserted);
+/* Bulk form beside ps_index_add_documents_flat: key i is bytes[offsets[i] .. offsets[i+1]); ids[i] receives its id
+ * (duplicates inside the batch get one id, as n_keys ps_keytable_intern calls in order would give). */
+ps_status ps_keytable_intern_flat(ps_keytable* kt, size_t n_keys, const void* bytes, const uint64_t* offsets,
+                                  uint64_t* ids);
+/* 1 and *id (may be NULL) if `key` has an id, 0 otherwise (remove_document of a key never added is a no-op in the
+ * reference, src/index.rs:161-164: the binding skips the call). */
+int ps_keytable_find(const ps_keytable* kt, const void* key, size_t len, uint64_t* id);
+/* Key bytes of one id / of results[i].key for i < n (keys[i] receives them).  PS_EINVAL for an id this table never
+ * handed out. */
+ps_status ps_keytable_key(const ps_keytable* kt, uint64_t id, ps_str* out);
+ps_status ps_keytable_resolve(const ps_keytable* kt, const ps_result* results, size_t n, ps_str* keys);
+
 /* Read-side introspection (the pub(crate) state the reference's unit tests look at). */
 size_t ps_index_fields_len(const ps_index* idx);
 size_t ps_index_docs_len(const ps_index* idx);                                   /* docs.len()          */

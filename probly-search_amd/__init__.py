@@ -8,8 +8,9 @@ extension and a GPU, and fail loudly otherwise.
 """
 from ._lib import LibraryNotBuilt, PsError, lib_path, load  # noqa: F401
 from .index import FieldDetails, Index, QueryResult, Snapshot, whitespace_tokenizer  # noqa: F401
+from .keys import KeyedIndex, KeyedSnapshot, KeyTable  # noqa: F401
 from . import score  # noqa: F401
 from .score import ScoreCalculator, bm25, zero_to_one  # noqa: F401
 
 __all__ = ["Index", "Snapshot", "QueryResult", "FieldDetails", "score", "bm25", "zero_to_one", "ScoreCalculator",
-           "whitespace_tokenizer", "PsError", "LibraryNotBuilt", "load", "lib_path"]
+           "whitespace_tokenizer", "KeyTable", "KeyedIndex", "KeyedSnapshot", "PsError", "LibraryNotBuilt", "load", "lib_path"]

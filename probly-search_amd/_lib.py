@@ -190,6 +190,14 @@ SYMBOLS = {
     "ps_snapshot_plan": (C.c_int, [_P, C.POINTER(ScorerDesc), C.c_char_p, C.c_size_t, _P, _P,
                                    C.POINTER(C.POINTER(PlanEntry)), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ps_snapshot_host_csr": (C.c_int, [_P, C.POINTER(HostCsr)]),
+    "ps_keytable_new": (C.c_int, [C.POINTER(_P)]),
+    "ps_keytable_free": (None, [_P]),
+    "ps_keytable_len": (C.c_size_t, [_P]),
+    "ps_keytable_intern": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "ps_keytable_intern_flat": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
+    "ps_keytable_find": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "ps_keytable_key": (C.c_int, [_P, C.c_uint64, _P]),
+    "ps_keytable_resolve": (C.c_int, [_P, _P, C.c_size_t, _P]),
 }
 
 _lib = None
