@@ -1815,8 +1815,11 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
             d[u] = p.doc[pi[u]];
           }
           if (p.alive != nullptr) {  // delta removals
+            uint32_t aw[UA];  // (every d[u] is a real doc id - out-of-range lanes re-read the last posting: all words requested together, no branch per posting)
 #pragma unroll
-            for (int u = 0; u < UA; ++u) alive[u] = alive[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
+            for (int u = 0; u < UA; ++u) aw[u] = p.alive[d[u] >> 5];
+#pragma unroll
+            for (int u = 0; u < UA; ++u) alive[u] = alive[u] & (bool)((aw[u] >> (d[u] & 31u)) & 1u);
           }
           plane_scores<F_, UA>(p, pi, alive, own_eb, s_own);
           bool any_alive = false;
@@ -1884,8 +1887,11 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
         d[u] = p.doc[pi[u]];
       }
       if (p.alive != nullptr) {  // delta removals
+        uint32_t aw[U];  // (every d[u] is a real doc id: all words requested together, no branch per posting)
 #pragma unroll
-        for (int u = 0; u < U; ++u) alive[u] = alive[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
+        for (int u = 0; u < U; ++u) aw[u] = p.alive[d[u] >> 5];
+#pragma unroll
+        for (int u = 0; u < U; ++u) alive[u] = alive[u] & (bool)((aw[u] >> (d[u] & 31u)) & 1u);
       }
       plane_scores<F_, U>(p, pi, alive, own_eb, s_own);
       bool any_alive = false;
@@ -2320,8 +2326,11 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
     // ---- own scores; first bound test: everything the other entries could add, at most - below theta the
     // document is out before anything is asked of another list ----
     if (p.alive != nullptr) {  // delta removals
+      uint32_t aw[U];  // (every d[u] is a real doc id: all words requested together, no branch per posting)
 #pragma unroll
-      for (int u = 0; u < U; ++u) inr[u] = inr[u] && ((p.alive[d[u] >> 5] >> (d[u] & 31u)) & 1u);
+      for (int u = 0; u < U; ++u) aw[u] = p.alive[d[u] >> 5];
+#pragma unroll
+      for (int u = 0; u < U; ++u) inr[u] = inr[u] & (bool)((aw[u] >> (d[u] & 31u)) & 1u);
     }
     double s_own[U];
     scores_from_plane<F_, U>(p, tw, inr, own_eb, s_own);
