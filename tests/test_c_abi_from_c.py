@@ -48,3 +48,13 @@ def test_c99_caller_gets_the_oracle_answer(tmp_path):
     r = subprocess.run([_build(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     _check_results(r.stdout)
+
+
+def test_c99_caller_of_the_key_table(tmp_path):
+    """tests/c_abi/keytable.c: `Index<T>` keys that are not u64 (src/index.rs:19-33) through ps_keytable_* - host only."""
+    exe = str(tmp_path / "keytable")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi", "keytable.c"), "-o", exe,
+                    "-L", CSRC, "-lprobly_search_amd", "-Wl,-rpath," + CSRC], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
