@@ -6,6 +6,6 @@ NAME=$1; shift
 cd "$(dirname "$0")/../probly-search_amd/csrc"
 mkdir -p alt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result "$@" -c ps_engine.hip -o alt/ps_engine_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o alt/lib$NAME.so ps_index.o ps_snapshot.o ps_capi.o alt/ps_engine_$NAME.o ps_sort.o ps_comm.o ps_build.o -pthread -ldl -lrt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o alt/lib$NAME.so ps_index.o ps_snapshot.o ps_capi.o ps_keytable.o alt/ps_engine_$NAME.o ps_sort.o ps_comm.o ps_build.o -pthread -ldl -lrt
 rm -f alt/ps_engine_$NAME.o
 echo built alt/lib$NAME.so
