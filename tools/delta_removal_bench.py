@@ -38,7 +38,7 @@ def run(tag):
         snap.query_batch_device_flat(text, offs, sc, [1.0] * F, K, base, base + 8 * B * K, base + 16 * B * K, stream=st.cuda_stream)
     st.synchronize()
     kt = snap.kernel_breakdown(reset=True)
-    return {"leg": tag, "kernel": kt["score_kernel"], "kernel_avg_ms": kt["score_ms"] / max(1, kt["launches"]), "launches": int(kt["launches"])}
+    return {"leg": tag, "kernel": kt["score_kernel"], "kernel_avg_ms": kt["score_ms"] / max(1, kt["launches"]), "rows_avg_ms": kt["rows_ms"] / max(1, kt["launches"]), "launches": int(kt["launches"])}
 
 
 out = [run("no removals (alive bitmap absent)")]
