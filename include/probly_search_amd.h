@@ -440,6 +440,9 @@ typedef struct ps_work_counters {
   uint64_t rows_used;           /* K1d: dense score rows read by the batches (resident ones included) */
   uint64_t bytes_touched;       /* the formula above applied to these counts, + 12 bytes per candidate
                                    slot written and 16 bytes per result                              */
+  uint64_t z_postings_scanned;  /* K1dz (zero_to_one): the part of postings_scanned read as doc id + packed words
+                                   (4 + 4F bytes instead of 4 + 8F)                                   */
+  uint64_t z_lookup_hits;       /* K1dz: the part of lookup_hits that fetched packed words (4F bytes) */
 } ps_work_counters;
 ps_status ps_snapshot_work_counters(ps_snapshot* snap, ps_work_counters* out, int reset);
 
@@ -456,8 +459,8 @@ typedef struct ps_plan_entry {
   double boost;        /* BM25TermCalculations::expansion_boost | zero_to_one: ScoreByTerm::score */
   uint32_t node;       /* zero_to_one: ordinal of the distinct trie node within the query | BM25: ordinal of the list (layer) in the snapshot */
   uint32_t qterm_index;/* TermData::query_term_index (position in the token list)                 */
-  uint32_t bm_off;     /* BM25: first word of the list's membership bitmap, 0xFFFFFFFF = none     */
-  uint32_t _pad;
+  uint32_t bm_off;     /* first word of the list's membership bitmap, 0xFFFFFFFF = none (K1d lookups) */
+  uint32_t layer;      /* ordinal of the list (version / delta layer of a term) in the snapshot   */
 } ps_plan_entry;
 ps_status ps_snapshot_plan(const ps_snapshot* snap, const ps_scorer_desc* scorer, const char* query,
                            size_t query_len, ps_tokenizer_fn tokenizer, void* user, ps_plan_entry** out,

@@ -84,7 +84,7 @@ class WorkCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "launches", "items", "items_run", "postings_scanned", "postings_reached_lookups", "lookups_row", "lookups_cell",
         "lookups_probe", "lookup_hits", "offers", "k1_items", "k1_postings", "k1_row_slices", "results", "rows_built", "rows_used",
-        "bytes_touched")]
+        "bytes_touched", "z_postings_scanned", "z_lookup_hits")]
 
 
 class SnapshotInfo(C.Structure):
@@ -106,7 +106,7 @@ class BatchStats(C.Structure):
 class PlanEntry(C.Structure):
     _fields_ = [("post_off", C.c_uint64), ("len", C.c_uint32), ("tbl_off", C.c_uint32), ("shift", C.c_uint32),
                 ("qterm", C.c_uint32), ("idf", C.c_double), ("boost", C.c_double), ("node", C.c_uint32),
-                ("qterm_index", C.c_uint32), ("bm_off", C.c_uint32), ("_pad", C.c_uint32)]
+                ("qterm_index", C.c_uint32), ("bm_off", C.c_uint32), ("layer", C.c_uint32)]
 
 
 class HostCsr(C.Structure):

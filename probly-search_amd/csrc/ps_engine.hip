@@ -48,6 +48,7 @@
 #include "ps_errors.hpp"
 #include "ps_kernels.hpp"
 #include "ps_prep_kernels.hpp"
+#include "ps_z21_daat.hpp"
 #include "ps_pool.hpp"
 #include "ps_sort.hpp"
 
@@ -144,6 +145,7 @@ struct Tuning {
   uint32_t z21_field_prune = 1;  // PS_Z21_FIELD_PRUNE: k_score<MODE_Z21S> drops fields whose pool bound fell below the query's threshold
   uint32_t daat_multi = 1;       // PS_DAAT_MULTI: also take batches with several expansions per query term (0: they stay on K1)
   uint32_t daat_small = 1;       // PS_DAAT_SMALL: plans of <= 4 lists, one per query term, take k_daat_small (all lookups of a trip in flight together)
+  uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
   uint32_t device_plan = 1;      // PS_DEVICE_PLAN: flat BM25 top-k batches (built-in tokenizer) are planned by k_plan on the device
   void load();
 };
@@ -194,7 +196,7 @@ struct EngineImpl {
     DevBuf<unsigned long long> M;
     struct JSet { std::vector<double> boosts; DevBuf<unsigned long long> J; DevBuf<double> plane; uint64_t last_use = 0; bool valid = false; hipEvent_t ready = nullptr; };
     hipEvent_t m_ready = nullptr;  // behind the kernel that last wrote M (batches on other streams wait for it)
-    JSet j[2];  // (each carries a score plane of 8F bytes per posting)
+    JSet j[3];  // (each carries a score plane of 8F bytes per posting)
     uint64_t epoch = 0;
     DevBuf<BoundUnit> units;
     uint32_t n_units = 0;
@@ -211,6 +213,8 @@ struct EngineImpl {
     uint64_t gen = 0;  // bumped whenever the choice changes (the contexts' resident rows follow)
   } cands;
   std::vector<uint32_t> z_minfl;  // zero_to_one field pruning: [layer][field] shortest field length holding the term (compute_z_bounds)
+  std::vector<uint32_t> z_maxtf;  // [layer] largest term frequency of the list in any field (K1dz: the numerators a list can produce)
+  std::map<std::pair<uint64_t, uint64_t>, double> z_ubnum_cache;  // (score bits, need | maxtf << 32) -> largest record numerator
   std::unordered_map<uint64_t, uint32_t> z_layer_of;  // post_off -> layer (zero_to_one plan entries do not carry it)
   hipStream_t copy_stream = nullptr;  // full-result mode: downloads of sorted parts beside the sorts of the next
   hipEvent_t part_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -276,7 +280,8 @@ struct EngineImpl {
     DevBuf<uint8_t> gord;
     DevBuf<DItem> ditems;
     DevBuf<double> cand_score, rows;
-    DevBuf<unsigned long long> gthr;
+    DevBuf<unsigned long long> gthr, gtie;
+    DevBuf<uint32_t> z_nabove;  // K1dz preparation scratch
     PrepCtl* ctl = nullptr;
     uint32_t* work = nullptr;
     RowState* row_state = nullptr;
@@ -585,8 +590,15 @@ void Engine::work_counters(ps_work_counters& out, bool reset) {
   out.rows_built = sum[WS_ROWS_BUILT];
   out.rows_used = sum[WS_ROWS_USED];
   const uint64_t F = m.snap->F, pw = 4 + 4 * F;  // K1: doc id + packed words; K1d: doc id + score plane (8 bytes per field)
-  out.bytes_touched = out.postings_scanned * (4 + 8 * F) + out.lookups_row * 8 + out.lookups_cell * 8 + out.lookups_probe * 4 +
-                      out.lookup_hits * 8 * F + out.k1_postings * pw + out.k1_row_slices * (uint64_t)m.snap->T * 8 +
+  // (K1dz reads the packed words where K1d reads the score plane: 4 bytes per field instead of 8)
+  const uint64_t z_scanned = sum[WS_Z_SCANNED], z_hits = sum[WS_Z_HIT];
+  out.postings_scanned += z_scanned;
+  out.lookup_hits += z_hits;
+  out.z_postings_scanned = z_scanned;
+  out.z_lookup_hits = z_hits;
+  out.bytes_touched = (out.postings_scanned - z_scanned) * (4 + 8 * F) + z_scanned * pw + out.lookups_row * 8 + out.lookups_cell * 8 +
+                      out.lookups_probe * 4 + (out.lookup_hits - z_hits) * 8 * F + z_hits * 4 * F + out.k1_postings * pw +
+                      out.k1_row_slices * (uint64_t)m.snap->T * 8 +
                       (m.wc_cand_slots + out.items_run * m.wc_k) * 12 + out.results * 16;
   if (reset) {
     PS_HIP(hipMemset(m.d_wstats, 0, w.size() * 8));
@@ -731,6 +743,7 @@ void Tuning::load() {
     device_plan = env_u32("PS_DEVICE_PLAN", device_plan);
     daat_small = env_u32("PS_DAAT_SMALL", daat_small);
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
+    daat_z = env_u32("PS_DAAT_Z", daat_z);
     z21_field_prune = env_u32("PS_Z21_FIELD_PRUNE", z21_field_prune);
     z21_exact_numerator = env_u32("PS_Z21_EXACT_NUMERATOR", z21_exact_numerator);
 }
@@ -879,8 +892,12 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
     PS_HIP(hipStreamWaitEvent(st, tgt->ready, 0));
     return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p), tgt->plane.p};
   }
-  // (M is rewritten in place and a J array may be recycled: their only readers are the preparation kernels,
-  // which run on this same stream, in order)
+  // M is rewritten in place and a J array may be recycled: their only readers are the preparation kernels, which
+  // run on this same stream, in order.  The score PLANE of a recycled slot is read by k_daat / k_daat_small on the
+  // scoring stream, by batches that may still be in flight (three contexts): nothing is overwritten before
+  // every batch enqueued so far has left its scoring kernel.
+  for (auto& c : m.dctx)
+    if (c.busy && c.scored) PS_HIP(hipStreamWaitEvent(st, c.scored, 0));
   const double t0 = now_ms();
   if (lb.n_layers != nl || lb.n_units == 0) {  // the work list: one wave per list, long lists in 16 Ki-posting segments
     std::vector<BoundUnit> units;
@@ -1122,16 +1139,21 @@ void compute_z_bounds(EngineImpl& m) {
   const size_t first = m.z_minfl.size() / std::max<size_t>(F, 1);
   if (first == nl) return;
   m.z_minfl.resize(nl * F, 0xFFFFFFFFu);
+  m.z_maxtf.resize(nl, 0u);
   auto body = [&](size_t l) {
     const LayerInfo& L = s.layers[l];
+    uint32_t mt = 0;
     for (size_t x = 0; x < F; ++x) {
       uint32_t mn = 0xFFFFFFFFu;
       const uint32_t* tf = s.tf.data() + x * s.P + L.post_off;
       const uint32_t* fl = s.fl.data() + x * s.P + L.post_off;
-      for (uint32_t i = 0; i < L.len; ++i)
+      for (uint32_t i = 0; i < L.len; ++i) {
         if (tf[i] && fl[i] < mn) mn = fl[i];
+        if (tf[i] > mt) mt = tf[i];
+      }
       m.z_minfl[l * F + x] = mn;
     }
+    m.z_maxtf[l] = mt;
   };
   const unsigned n_thr = s.n_postings > (1u << 20) ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
   if (n_thr <= 1 || nl - first < 1024) {
@@ -1837,9 +1859,20 @@ bool daat_eligible(const EngineImpl& m, const ps_scorer_desc& sc, const double* 
 // the rows the preparation listed.  Scoring stream: k_daat, then - once the caller's stream has reached the
 // point of the call, because the merge is the kernel that writes the caller's buffers - k_merge_items.
 // The caller's stream is made to wait for the batch, so work enqueued on it afterwards sees the results.
+// K1dz (zero_to_one, ps_z21_daat.hpp): what the batch's image carries beside the plan
+struct ZBatch {
+  const double* d_ubnum;  // [ne]
+  const double* d_zub;    // [ne][F]
+  uint32_t d0;            // doc id that separates the chunks that publish the tie threshold from those that use it (0 = off)
+};
+void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KParams& kp, ps_plan_entry* d_plan, const uint32_t* d_qbeg,
+                   size_t B, size_t ne, size_t items_bound);
+void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st);
+
 void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, ps_plan_entry* d_plan,
                   const uint32_t* d_qbeg, const uint32_t* d_qtl, size_t B, size_t ne, uint32_t max_qterms, uint32_t max_entries, bool multi,
-                  size_t n_items, uint32_t max_slots, size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller) {
+                  size_t n_items, uint32_t max_slots, size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller,
+                  const ZBatch* zb = nullptr) {
   const Snapshot& s = *m.snap;
   hipStream_t P = m.prep_stream, S = m.score_stream;
   KParams kp;
@@ -1849,16 +1882,22 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     kp.plan = d_plan; kp.qbeg = d_qbeg; kp.qterms_len = d_qtl;
     kp.work_counter = c.work;
     const size_t n_thr = B + 2;
-    const bool fresh = c.gthr.ensure(n_thr, true);
+    bool fresh = c.gthr.ensure(n_thr, true);
     kp.gthr = c.gthr.p;
+    if (zb) {  // (a second threshold word per query; zeroed behind the batch by k_merge_items like the first)
+      fresh = c.gtie.ensure(n_thr, true) || fresh;
+      kp.gtie = c.gtie.p;
+    }
     if (!(c.ctl_clean && !fresh)) {
-      PS_HIP(hipMemsetAsync(c.gthr.p, 0, n_thr * 8, P));
+      PS_HIP(hipMemsetAsync(c.gthr.p, 0, c.gthr.cap * 8, P));
+      if (c.gtie.p) PS_HIP(hipMemsetAsync(c.gtie.p, 0, c.gtie.cap * 8, P));
       PS_HIP(hipMemsetAsync(c.work, 0, 256, P));
       PS_HIP(hipMemsetAsync(c.ctl, 0, sizeof(PrepCtl), P));
     }
     c.ctl_clean = false;
     kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0;
-    launch_prep(m, c, sc, boosts, kp, d_plan, d_qbeg, B, ne, multi, n_items);
+    if (zb) launch_prep_z(m, c, *zb, kp, d_plan, d_qbeg, B, ne, n_items);
+    else launch_prep(m, c, sc, boosts, kp, d_plan, d_qbeg, B, ne, multi, n_items);
     kp.K = (uint32_t)top_k;
     const size_t n_cand = n_items * top_k;
     c.cand_score.ensure(n_cand + 1);
@@ -1873,7 +1912,7 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     // K0b on the preparation stream too: the rows to score were listed on the device (k_prep_finish); a fixed
     // grid takes (row, tile range) units.  (It evaluates the BM25 expression itself: no table involved.)
     PS_HIP(hipEventRecord(kt->a, P));
-    if (m.cands.n) {
+    if (m.cands.n && !zb) {
       const uint32_t per_row = std::min(2048u, std::max(256u, kp.n_tiles));
       const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_row * m.cands.n, 4096);
       hipLaunchKernelGGL(k_dense_rows_dyn, dim3(grid), dim3(256), 0, P, kp, c.rows.p, c.ctl, per_row);
@@ -1893,7 +1932,8 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     kp.item_trace = trace_buf.p;
 #endif
     PS_HIP(hipEventRecord(kt->m, S));
-    launch_daat(m, kp, multi, max_entries <= (uint32_t)DAAT_SMALL_MAX, m.n_cu, S);
+    if (zb) launch_daat_z(m, kp, S);
+    else launch_daat(m, kp, multi, max_entries <= (uint32_t)DAAT_SMALL_MAX, m.n_cu, S);
 #ifdef PS_ITEM_TRACE
     {  // profiling builds: the items' start / end times of this launch -> $PS_ITEM_TRACE_FILE (last batch wins)
       PS_HIP(hipStreamSynchronize(S));
@@ -1958,6 +1998,179 @@ void enqueue_daat_host(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
                d_keys, d_scores, d_counts, caller);
 }
 
+// ---- K1dz: zero_to_one top-k batches through the K1d pipeline (ps_z21_daat.hpp) ------------------------------------
+void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KParams& kp, ps_plan_entry* d_plan, const uint32_t* d_qbeg,
+                   size_t B, size_t ne, size_t items_bound) {
+  const Snapshot& s = *m.snap;
+  hipStream_t st = m.prep_stream;
+  ensure_bloom(m, st);
+  kp.bloom = m.d_bloom.p;
+  kp.layer_bloom = m.d_layer_bloom.p;
+  c.dentry.ensure(ne + 1); c.gen.ensure(ne + 1); c.z_nabove.ensure(ne + 1);
+  c.qslot.ensure(B + 1); c.qslot_n.ensure(B + 1);
+  c.ditems.ensure(items_bound + 1);
+  c.cand_cnt.ensure(items_bound + 1);
+  ZPrepParams pp;
+  memset(&pp, 0, sizeof(pp));
+  pp.plan = d_plan; pp.qbeg = d_qbeg; pp.zub = zb.d_zub; pp.table = m.d_table;
+  pp.B = (uint32_t)B; pp.ne = (uint32_t)ne; pp.F = s.F;
+  pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div;
+  pp.d0_tile = zb.d0 >> kp.t_log2;
+  pp.dentry = c.dentry.p; pp.gen = c.gen.p; pp.nabove_from = c.z_nabove.p;
+  pp.qslot = c.qslot.p; pp.qslot_n = c.qslot_n.p;
+  pp.items = c.ditems.p; pp.items_cap = (uint32_t)items_bound;
+  pp.ctl = c.ctl;
+  if (B) {
+    hipLaunchKernelGGL(k_zprep_query, dim3((uint32_t)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, pp);
+    if (ne) hipLaunchKernelGGL(k_zprep_items, dim3((uint32_t)((ne + 2 * WAVE - 1) / (2 * WAVE))), dim3(2 * WAVE), 0, st, pp);
+    PS_HIP(hipGetLastError());
+  }
+  kp.dentry = c.dentry.p; kp.ditems = c.ditems.p; kp.qslot = c.qslot.p; kp.qslot_n = c.qslot_n.p;
+  kp.n_ditems = (uint32_t)items_bound;
+  kp.n_ditems_dev = &c.ctl->n_items;
+  kp.prep_ctl = reinterpret_cast<uint32_t*>(c.ctl);
+  kp.prep_ctl_words = (uint32_t)(sizeof(PrepCtl) / 4);
+  kp.cand_cnt = c.cand_cnt.p;
+  kp.z_ubnum = zb.d_ubnum;
+  kp.z_d0 = zb.d0;
+}
+
+void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st) {
+  const uint32_t n_wg = (kp.n_ditems + DAAT_WGW - 1) / DAAT_WGW;
+  char nm[64];
+  snprintf(nm, sizeof(nm), "ps::k_daat_z<%d>", (int)kp.F);
+  m.score_kernel_name = nm;
+  switch (kp.F) {
+    case 1: hipLaunchKernelGGL((k_daat_z<1>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); break;
+    case 2: hipLaunchKernelGGL((k_daat_z<2>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); break;
+    case 3: hipLaunchKernelGGL((k_daat_z<3>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); break;
+    default: hipLaunchKernelGGL((k_daat_z<4>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); break;
+  }
+}
+
+// Largest numerator min(score / t, 1) * t (zero_to_one.rs:117-118) over the term frequencies need <= t <= maxtf, in
+// the scorer's own f64 arithmetic; 0 when no record of the list can be consumed.  A saturated maximum (the exact
+// value is not known here) is bounded two ulps above the real-number value.
+double z_numerator_bound(EngineImpl& m, double score, uint32_t need, uint32_t maxtf) {
+  uint64_t sb;
+  memcpy(&sb, &score, 8);
+  const auto key = std::make_pair(sb, (uint64_t)need | ((uint64_t)maxtf << 32));
+  auto it = m.z_ubnum_cache.find(key);
+  if (it != m.z_ubnum_cache.end()) return it->second;
+  double best = 0.0;
+  const uint32_t hi = std::min(maxtf, 4096u);
+  for (uint32_t t = std::max(need, 1u); t <= hi; ++t) {
+    const double df = (double)t;
+    best = std::max(best, std::fmin(score / df, 1.0) * df);
+  }
+  if (maxtf > hi && maxtf >= need) best = std::max(best, std::nextafter(std::nextafter(std::max(score, 0.0), INFINITY), INFINITY));
+  if (m.z_ubnum_cache.size() > (1u << 16)) m.z_ubnum_cache.clear();
+  m.z_ubnum_cache.emplace(key, best);
+  return best;
+}
+
+// A zero_to_one top-k batch for K1dz, or false when the batch does not qualify (it then takes k_score / k_z21).
+// Qualifies: every query "simple" in the sense of classify_zero_to_one - one version layer per entry, no two
+// records with the same (query term, node) - with at most DAAT_SMALL_MAX entries.  The image: entries per query in
+// the record-sort order (score desc, stable; zero_to_one.rs:98) | qbeg | query_terms_len | ubnum | zub.
+bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,
+                         void* d_scores, void* d_counts, hipStream_t caller) {
+  const Snapshot& s = *m.snap;
+  const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size(), F = s.F;
+  if (!(m.tune.daat && m.tune.daat_z && sc.kind == PS_SCORER_ZERO_TO_ONE && B >= m.tune.daat_min_batch && ne != 0 &&
+        plan.max_entries <= (uint32_t)DAAT_SMALL_MAX && F <= 4 && s.n_ids > 0))
+    return false;
+  for (size_t q = 0; q < B; ++q) {  // (the rule of classify_zero_to_one)
+    bool same_q = false, same_n = false;
+    for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
+      if (plan.entries[i].shift >> 8) return false;
+      for (uint32_t j = plan.qbeg[q]; j < i; ++j) {
+        same_q = same_q || plan.entries[j].qterm == plan.entries[i].qterm;
+        same_n = same_n || plan.entries[j].node == plan.entries[i].node;
+      }
+    }
+    // several expansions of a query term AND a node hit by two records: the pool rule's closed form (need) no longer holds
+    if (same_q && same_n) return false;
+  }
+  uint32_t max_slots = 0;
+  const size_t n_items = count_daat_items(m, plan, &max_slots);
+  if (!n_items || n_items >= 0x3FFFFFF0ull) return false;
+  compute_z_bounds(m);
+  EngineImpl::DaatCtx& c = acquire_ctx(m);
+  hipStream_t st = m.prep_stream;
+  const size_t off_q = ne * sizeof(ps_plan_entry), off_l = off_q + (B + 1) * 4, off_u = (off_l + B * 4 + 15) & ~(size_t)15,
+               off_z = off_u + ne * 8, total = (off_z + ne * F * 8 + 15) & ~(size_t)15;
+  Stage& sg = m.stage[m.next_stage];
+  m.next_stage = (m.next_stage + 1) % N_STAGE;
+  sg.ensure(total + 16);
+  ps_plan_entry* he = reinterpret_cast<ps_plan_entry*>(sg.p);
+  double* hu = reinterpret_cast<double*>(sg.p + off_u);
+  double* hz = reinterpret_cast<double*>(sg.p + off_z);
+  memcpy(sg.p + off_q, plan.qbeg.data(), (B + 1) * 4);
+  memcpy(sg.p + off_l, plan.qterms_len.data(), B * 4);
+  double last_w = -1.0;
+  uint64_t last_l = 0;
+  for (size_t q = 0; q < B; ++q) {
+    const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1], qtl = plan.qterms_len[q];
+    uint32_t zo[DAAT_SMALL_MAX];
+    for (uint32_t i = b; i < e; ++i) zo[i - b] = i;
+    std::stable_sort(zo, zo + (e - b), [&](uint32_t a, uint32_t d) { return plan.entries[d].boost < plan.entries[a].boost; });
+    for (uint32_t i = b; i < e; ++i) {
+      ps_plan_entry en = plan.entries[zo[i - b]];
+      uint32_t need = 1, qt = 0;  // occurrence rank of the node among the sorted records; dense ordinal of the query term
+      bool seen_qt = false;
+      for (uint32_t j = b; j < i; ++j) {
+        if (he[j].node == en.node) ++need;
+        if (plan.entries[zo[j - b]].qterm == en.qterm) { qt = (he[j].qterm_index >> 16) & 31u; seen_qt = true; }
+      }
+      if (!seen_qt) {  // a new query term: the next free ordinal (<= 3)
+        uint32_t used = 0;
+        for (uint32_t j = b; j < i; ++j) used |= 1u << ((he[j].qterm_index >> 16) & 31u);
+        while (used & (1u << qt)) ++qt;
+      }
+      en.qterm_index = need | (qt << 16);
+      if (!(en.boost == last_w)) {  // the one-division arm's limit, as stage_plan computes it
+        last_w = en.boost;
+        last_l = 0;
+        for (uint32_t t = 1; t <= 254; ++t) {
+          const double df = (double)t;
+          if (!(std::fmin(en.boost / df, 1.0) * df == en.boost)) break;
+          last_l = t;
+        }
+      }
+      memcpy(&en.idf, &last_l, 8);
+      he[i] = en;
+      const double un = z_numerator_bound(m, en.boost, need, m.z_maxtf[en.layer]);
+      hu[i] = un;
+      for (size_t x = 0; x < F; ++x) {
+        const uint32_t mn = m.z_minfl[(size_t)en.layer * F + x];
+        hz[i * F + x] = mn == 0xFFFFFFFFu ? 0.0 : un / (double)std::max(mn, qtl);
+      }
+    }
+  }
+  c.stage.ensure(total + 64);
+  const size_t n16 = (total + 15) / 16;
+  hipLaunchKernelGGL(k_upload, dim3((uint32_t)std::max<size_t>(1, std::min<size_t>(256, (n16 + 255) / 256))), dim3(256), 0, st,
+                     reinterpret_cast<const uint4*>(sg.dp), reinterpret_cast<uint4*>(c.stage.p), n16);
+  PS_HIP(hipGetLastError());
+  PS_HIP(hipEventRecord(sg.done, st));
+  sg.pending = true;
+  ZBatch zb;
+  zb.d_ubnum = reinterpret_cast<const double*>(c.stage.p + off_u);
+  zb.d_zub = reinterpret_cast<const double*>(c.stage.p + off_z);
+  // D0: a power of two (so it is a slot boundary of every list's table up to that coarseness) near a 16th of the id space
+  uint32_t d0 = 0;
+  if (s.n_ids >= 16ull * s.T) {
+    d0 = s.T;
+    while ((uint64_t)d0 * 2 <= s.n_ids / 16) d0 *= 2;
+  }
+  zb.d0 = d0;
+  enqueue_daat(m, c, sc, boosts, reinterpret_cast<ps_plan_entry*>(c.stage.p), reinterpret_cast<const uint32_t*>(c.stage.p + off_q),
+               reinterpret_cast<const uint32_t*>(c.stage.p + off_l), B, ne, plan.max_qterms, plan.max_entries, false, n_items, max_slots, top_k,
+               d_keys, d_scores, d_counts, caller, &zb);
+  return true;
+}
+
 // Enqueue plan upload + K1/K2 + K3 on `st`, writing the final top-k to the given buffers (device
 // memory, or device-mapped pinned host memory).  `sync_path`: the caller waits for `st` before it
 // returns — the latency path: no staging-slot fence, and HIP timing events only for batches of
@@ -1985,6 +2198,10 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
       TT("k1d batch");
       return;
     }
+  }
+  if (sc.kind == PS_SCORER_ZERO_TO_ONE && enqueue_daat_z_host(m, sc, boosts, plan, top_k, d_keys, d_scores, d_counts, st)) {
+    TT("k1dz batch");
+    return;
   }
   if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
   m.tail_pending = false;

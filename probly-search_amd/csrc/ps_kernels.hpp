@@ -165,6 +165,9 @@ struct KParams {
   uint32_t* work_counter;    // next (query, run) item for the persistent waves of k_score
   unsigned long long* wstats;  // [WS_SLOTS][WS_WORDS] work counters (always on; see WorkStats)
   unsigned long long* gthr;  // [B] bits of the best published local K-th score per query (0 = none)
+  unsigned long long* gtie;  // K1dz (ps_z21_daat.hpp): [B] the same among chunks that lie below doc id D0; zeroed by k_merge_items
+  const double* z_ubnum;     // K1dz: [n_plan_entries] largest record numerator of the list
+  uint32_t z_d0;             // K1dz: the doc id D0 (0 = tie thresholds off)
   double* cand_score;  // [B * n_super * K]
   uint32_t* cand_doc;
   // full-result mode
@@ -188,7 +191,7 @@ struct KParams {
 #endif
 constexpr uint32_t WS_SLOTS = 64, WS_WORDS = 16;  // one 128-byte line per slot
 enum { WS_ITEMS_RUN = 0, WS_SCANNED, WS_REACHED, WS_ROW, WS_CELL, WS_PROBE, WS_HIT, WS_OFFER, WS_K1_ITEMS, WS_K1_POSTINGS,
-       WS_K1_ROWSLICES, WS_ROWS_BUILT, WS_ROWS_USED, WS_ITEMS };
+       WS_K1_ROWSLICES, WS_ROWS_BUILT, WS_ROWS_USED, WS_ITEMS, WS_Z_SCANNED, WS_Z_HIT };  // (WS_Z_*: K1dz reads packed words, 4 bytes per field)
 struct WorkStats {  // K1d, per item
   uint32_t scanned = 0, reached = 0, row = 0, cell = 0, probe = 0, hit = 0, offer = 0;
 };
@@ -1332,6 +1335,7 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
   if (lane == 0) {
     p.out_counts[q] = tk.n;
     p.gthr[q] = 0ull;
+    if (p.gtie != nullptr) p.gtie[q] = 0ull;
     if (q == 0) *p.work_counter = 0u;
   }
 }
@@ -2178,7 +2182,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   const double own_eb = own.boost;
   const uint64_t own_off = own.post_off;
   const uint32_t own_rank = de.rank;
-  const double skip_thr = de.skip_thr, others = de.others;
+  const double skip_thr = de.skip_thr;
   // the other lists, in plan order (wave-uniform: scalar registers)
   uint64_t o_off[NO];
   uint32_t o_shift[NO], o_bm[NO], o_tbl[NO], o_row[NO], o_rank[NO];
@@ -2199,6 +2203,14 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       if (en.shift & DENSE_FLAG) ++n_row_lists; else if (en.bm_off != 0xFFFFFFFFu || o_bloom[k] != NO_BLOOM) ++n_cell_lists;
     }
   }
+  // A document is evaluated from its highest-ranked list only, so one that is evaluated HERE sits in no list ranked
+  // above the own one: only the lists ranked BELOW can add to it.  (A document that does sit in a higher-ranked list
+  // is cancelled further down if it gets that far; it is evaluated by that list's items, under that list's bounds.)
+  double others = 0.0;
+#pragma unroll
+  for (int k = 0; k < NO; ++k)
+    if ((uint32_t)k + 1u < ne && o_rank[k] > own_rank) others += o_ub[k];
+  others *= SLACK;
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
   double published = 0.0;
@@ -2400,7 +2412,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
             c = hit ? o_ub[k] : 0.0;
             if (hit) loc[k] = 0ull;
           }
-          bound += c;
+          if (o_rank[k] > own_rank) bound += c;  // (a higher-ranked list adds nothing to a document evaluated here)
           // (a document is evaluated from its highest-bound list only: known here for rows and bitmaps)
           if ((dense || bitmap) && hit && o_rank[k] < own_rank) alive = false;
         }
@@ -2501,6 +2513,7 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge_items(const KParam
   if (lane == 0) {
     p.out_counts[q] = tk.n;
     p.gthr[q] = 0ull;
+    if (p.gtie != nullptr) p.gtie[q] = 0ull;
     if (q == 0) *p.work_counter = 0u;
   }
   // the preparation's control words (bucket counts, row uses, ...) are consumed: clean for the next batch
@@ -2615,7 +2628,7 @@ __device__ __forceinline__ void plan_token(const DevTrie& t, const int64_t fn, c
         e.node = li;
         e.qterm_index = qi;
         e.bm_off = lb.y;
-        e._pad = 0;
+        e.layer = li;
         entries[w++] = e;
       } else {  // K1d work items of this list (the rule of k_prep_batch)
         uint32_t c = ((la.z + split_div - 1) / split_div + 255u) & ~255u;

@@ -140,9 +140,12 @@ __device__ __forceinline__ double prep_entry_ub(const PrepParams& pp, const ps_p
   return fmin(ub_m, ub_j);
 }
 
+__device__ __forceinline__ uint32_t prep_chunk_of(const uint32_t split_div, const uint32_t chunk_min, const uint32_t len) {
+  const uint32_t c = ((len + split_div - 1) / split_div + 255u) & ~255u;
+  return c > chunk_min ? c : chunk_min;
+}
 __device__ __forceinline__ uint32_t prep_chunk(const PrepParams& pp, const uint32_t len) {
-  const uint32_t c = ((len + pp.split_div - 1) / pp.split_div + 255u) & ~255u;
-  return c > pp.chunk_min ? c : pp.chunk_min;
+  return prep_chunk_of(pp.split_div, pp.chunk_min, len);
 }
 __device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint32_t len) {
   if (rank <= 1) {  // longest lists first: 64 classes, log2 with one fractional bit (the rank-1 lists that stay

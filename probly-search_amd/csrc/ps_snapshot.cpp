@@ -933,10 +933,9 @@ void Snapshot::plan_query(const ps_scorer_desc& sc, std::string_view q, ps_token
           e.len = L.len;
           e.tbl_off = L.tbl_off;
           e.shift = L.shift | (l << 8);  // bits 8.. = version layer (0 = newest)
-          if (sc.kind == PS_SCORER_BM25) {
-            e.node = li;                 // ordinal of the list (the engine's per-list bounds)
-            e.bm_off = L.bm_off;         // the list's membership bitmap (K1d lookups)
-          }
+          if (sc.kind == PS_SCORER_BM25) e.node = li;  // ordinal of the list (the engine's per-list bounds)
+          e.layer = li;
+          e.bm_off = L.bm_off;           // the list's membership bitmap (K1d lookups)
           plan.entries.push_back(e);
           plan.postings += L.len;
         }

@@ -1,0 +1,579 @@
+// ps_z21_daat.hpp — K1dz: exact top-K with dynamic pruning for zero_to_one (zero_to_one.rs:44-126), the
+// document-at-a-time skeleton of k_daat_small with the bounds of this scorer, plus its device-side preparation.
+//
+// Scope: top-k batches whose queries are all "simple" (ps_engine.hip, classification: one version layer, every
+// record of the query on its own (query term, trie node) pair; a node repeated under several query terms and
+// several expansions of one query term are both fine) with at most DAAT_SMALL_MAX lists.  Everything else stays
+// on k_score<MODE_Z21S> / k_z21.
+//
+// What a document scores (zero_to_one.rs:84-126 for such queries): per field x the pool
+//     pool_x = sum over the query's records in sorted order (score desc, stable: the entries arrive in that order)
+//              of  (min(score_e / tf, 1) * tf) / max(field_length_x, query_terms_len)
+//              for the records with tf_x >= need_e (the node's pool rule) whose query term is not consumed yet,
+// and the document's score is the maximum of its pools (starting from the merged dummy 0.0).
+//
+// Bounds (every one computed with the operations of the score itself, in the same order - NO slack factor,
+// because ties at the threshold are the common case of this scorer and have to prune, see below):
+//   * ubnum_e (host): the largest numerator min(score_e / t, 1) * t over the term frequencies t the list holds;
+//     u'_j = the non-increasing envelope of ubnum along the sorted order, so the first m of them dominate any m
+//     records term by term;
+//   * B(m, fl) = sum_{j < m} u'_j / max(fl, query_terms_len): no pool of a field of length fl fed by at most m
+//     records can exceed it (IEEE division and addition are monotone); tabulated per item for fl < 64 in LDS,
+//     and from it, per threshold, the longest field that can still beat the threshold with m records (FLMAX[m]):
+//     the scan tests postings with integer compares only;
+//   * zub[e][x] = ubnum_e / max(shortest field x holding the term, query_terms_len): what one list can add to
+//     pool x at most; DEntry::skip_thr = max_x of the in-order sum over the lists of rank >= rank(e).
+//
+// Thresholds.  The result order is (score desc, key asc) and doc ids ascend with keys, so a document that only
+// TIES the K-th best score still loses to K documents with lower ids.  Scores of this scorer are small
+// rationals: thousands of documents tie at the threshold, and "strictly below" pruning keeps all of them alive
+// (round 2's k_daat_z: 15-30 % of the postings).  Two words per query:
+//   gthr[q]  K-th best score of ANY wave of the query (as k_daat_small): prunes bound <  gthr;
+//   gtie[q]  K-th best score of a wave that has only scanned documents below doc id D0 so far (a power of two near
+//            N / 16; doc ids ascend along a chunk): K documents with ids < D0 score >= gtie, so a trip whose
+//            postings all lie at or above D0 also prunes bound == gtie, and so does the whole-chunk skip test of
+//            a chunk that starts at or above D0 (ZITEM_ABOVE, from the list's tile-offset table).
+#pragma once
+#include "ps_prep_kernels.hpp"
+
+namespace ps {
+
+#ifndef PS_DAAT_ZU
+#define PS_DAAT_ZU 4   // postings per lane in flight in the scan
+#endif
+constexpr uint32_t ZITEM_ABOVE = 0x80000000u;  // DItem::count bit 31: every document of the chunk has id >= D0 (its whole-chunk skip test may use the tie threshold)
+constexpr uint32_t ZITEM_COUNT = 0x3FFFFFFFu;
+constexpr int Z_FLN = 64;                      // field lengths the bound table holds (entry 63 stands for >= 63)
+constexpr int Z_ALL = 0x7FFFFFFF, Z_NONE = -1;
+
+struct ZPrepParams {
+  const ps_plan_entry* plan;   // [ne], per query in sorted record order
+  const uint32_t* qbeg;        // [B + 1]
+  const double* zub;           // [ne][F]
+  const uint32_t* table;
+  uint32_t B, ne, F, chunk_min, split_div;
+  uint32_t d0_tile;            // D0 >> t_log2; 0 = no D0 (tie thresholds off)
+  DEntry* dentry;
+  DItemGen* gen;
+  uint32_t* nabove_from;       // [ne] first chunk that lies entirely at or above D0 (= chunks: none / not known)
+  uint32_t* qslot;
+  uint32_t* qslot_n;
+  DItem* items;
+  uint32_t items_cap;
+  PrepCtl* ctl;
+};
+
+// Item order: rank-major like K1d (every query's shortest list first - thresholds exist before the long lists come
+// up -, longest lists first within a rank); the chunks of a list ascend in doc id, so its part below D0 comes first.
+
+// Thread per query: processing order (shortest list first: the long lists are the ones that become non-essential;
+// any order is exact), skip thresholds, chunking, candidate slots, bucket totals.
+__global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {
+  constexpr int NMAX = DAAT_SMALL_MAX;
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have = q < pp.B;
+  const uint32_t b = have ? pp.qbeg[q] : 0u, n = have ? min(pp.qbeg[q + 1] - b, (uint32_t)NMAX) : 0u;
+  uint32_t len[NMAX], rank[NMAX];
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) len[i] = (uint32_t)i < n ? pp.plan[b + i].len : 0u;
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+      if ((uint32_t)j < n && j != i && (len[j] < len[i] || (len[j] == len[i] && j < i))) ++r;
+    rank[i] = r;
+  }
+  uint32_t slots = 0;
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    if ((uint32_t)i < n) {
+      double skip = 0.0, ub = 0.0;
+      for (uint32_t x = 0; x < pp.F; ++x) {
+        double sum = 0.0;  // in the sorted record order, like the pools
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+          if ((uint32_t)j < n && rank[j] >= rank[i]) sum += pp.zub[(size_t)(b + j) * pp.F + x];
+        skip = fmax(skip, sum);
+        ub = fmax(ub, pp.zub[(size_t)(b + i) * pp.F + x]);
+      }
+      DEntry d;
+      d.skip_thr = skip;
+      d.others = 0.0;
+      d.ub = ub;
+      d.rank = rank[i];
+      d.q = q;
+      pp.dentry[b + i] = d;
+      const uint32_t c = prep_chunk_of(pp.split_div, pp.chunk_min, len[i]);
+      slots += (len[i] + c - 1) / c;
+    }
+  }
+  const uint32_t s0 = wave_add_by_key(&pp.ctl->total_slots, 0u, slots, have && n != 0);
+  if (have) { pp.qslot[q] = n ? s0 : 0u; pp.qslot_n[q] = slots; }
+  uint32_t sl = s0;
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {  // (wave-uniform trip count: the aggregated atomics need every lane)
+    const bool on = (uint32_t)i < n;
+    uint32_t nc = 0, bk = 0;
+    if (on) {
+      const ps_plan_entry& en = pp.plan[b + i];
+      const uint32_t c = prep_chunk_of(pp.split_div, pp.chunk_min, en.len);
+      nc = (en.len + c - 1) / c;
+      uint32_t na = nc;
+      const uint32_t sh = en.shift & 0xFFu;
+      if (pp.d0_tile && (pp.d0_tile & ((1u << sh) - 1u)) == 0u) {
+        // postings of the list with doc id < D0: the table slot that starts at D0 (slots span T << shift documents)
+        const uint32_t p0 = min(en.len, pp.table[en.tbl_off + (pp.d0_tile >> sh)]);
+        na = (p0 + c - 1) / c;            // chunks [na, nc) start at or after p0
+      }
+      pp.gen[b + i] = DItemGen{b + i, 0u, c, sl};
+      pp.nabove_from[b + i] = na;
+      sl += nc;
+      bk = prep_bucket(rank[i], en.len);
+    }
+    wave_add_by_key_noret(pp.ctl->bucket_total, bk, nc, on && nc != 0);
+  }
+  __threadfence();
+  uint32_t t = 0;
+  if (threadIdx.x == 0) t = atomicAdd(&pp.ctl->ticket, 1u);
+  t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  if (t + 1u == gridDim.x) {  // the wave that finishes last closes the counters
+    __threadfence();
+    if (threadIdx.x == 0) {
+      PrepCtl& c = *pp.ctl;
+      uint32_t at = 0;
+      for (uint32_t k = 0; k < PREP_BUCKETS; ++k) {
+        const uint32_t tot = __hip_atomic_load(&c.bucket_total[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.bucket_start[k] = at;
+        at += tot;
+      }
+      c.n_items = at;
+    }
+  }
+}
+
+// Thread per list: its items (bit 31 of the count: the chunk starts at or above D0).
+__global__ __launch_bounds__(2 * WAVE) void k_zprep_items(const ZPrepParams pp) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have = i < pp.ne;
+  uint32_t nc = 0, na = 0, bk = 0, len = 0, chunk = 1, first_slot = 0;
+  if (have) {
+    const ps_plan_entry& en = pp.plan[i];
+    const DItemGen g = pp.gen[i];
+    len = en.len; chunk = g.chunk; first_slot = g.first_slot;
+    nc = (len + chunk - 1) / chunk;
+    na = pp.nabove_from[i];
+    bk = prep_bucket(pp.dentry[i].rank, len);
+  }
+  const uint32_t off = wave_add_by_key(pp.ctl->bucket_fill, bk, nc, have && nc != 0);
+  if (have && nc) {
+    const uint32_t at0 = pp.ctl->bucket_start[bk] + off;
+    for (uint32_t j = 0; j < nc; ++j) {
+      const uint32_t pb = j * chunk;
+      if (at0 + j < pp.items_cap) pp.items[at0 + j] = DItem{i, pb, min(chunk, len - pb) | (j >= na ? ZITEM_ABOVE : 0u), first_slot + j};
+    }
+  }
+}
+
+// Does a score (or an upper bound of one) still matter?  ts: K documents score >= ts (0 = none known);
+// tt: K documents with LOWER doc ids than anything this chunk holds score >= tt (0 = none / not applicable).
+__device__ __forceinline__ bool z_beats(const double v, const double ts, const double tt) {
+  return v >= ts && (tt == 0.0 || v > tt);
+}
+
+template <int F_>
+__global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
+  static_assert(F_ >= 1 && F_ <= 4, "k_daat_z is instantiated per field count");
+  constexpr int U = PS_DAAT_ZU;
+  constexpr int NE = DAAT_SMALL_MAX;
+  constexpr int NO = NE - 1;  // other lists of a query, in sorted record order with the own one left out
+  constexpr uint32_t QCAP = 128;
+  constexpr uint32_t REL_NONE = 0xFFFFFFFFu, REL_MAYBE = 0xFFFFFFFEu;
+  __shared__ uint32_t q_d[DAAT_WGW][QCAP];        // survivor queue: doc id
+  __shared__ uint32_t q_i[DAAT_WGW][QCAP];        // ... its posting within the own list
+  __shared__ uint32_t q_w[F_][DAAT_WGW][QCAP];    // ... the own posting's packed {tf, field length} words
+  __shared__ uint32_t q_rel[NO][DAAT_WGW][QCAP];  // ... per other list: posting within that list (bitmap hit), REL_MAYBE (filter), REL_NONE
+  __shared__ double btab[DAAT_WGW][NE][Z_FLN];    // B(m, fl), m = 1..NE
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
+  const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
+  {
+    // most workgroups only hold chunks of lists that are already non-essential: they leave at once
+    int need = 0;
+    if (id < n_ditems) {
+      const DItem it0 = p.ditems[id];
+      const DEntry de = p.dentry[it0.entry];
+      const double ts = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      double tt = 0.0;
+      if (it0.count & ZITEM_ABOVE)
+        tt = __longlong_as_double((long long)__hip_atomic_load(&p.gtie[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      need = z_beats(de.skip_thr, ts, tt);
+    }
+    if (!__syncthreads_or(need)) {
+      if (id < n_ditems && lane == 0) p.cand_cnt[p.ditems[id].slot] = 0u;
+      return;
+    }
+  }
+  if (id >= n_ditems) return;
+  const DItem it = p.ditems[id];
+  const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
+  const DEntry de = p.dentry[e_own];
+  const uint32_t q = __builtin_amdgcn_readfirstlane(de.q);
+  const uint32_t e0 = p.qbeg[q], ne = min(p.qbeg[q + 1] - e0, (uint32_t)NE);
+  const uint32_t own_pos = e_own - e0;
+  const uint32_t own_rank = de.rank;
+  const uint32_t n_lower = ne - 1u - min(own_rank, ne - 1u);  // lists ranked below the own one
+  const double skip_thr = de.skip_thr;
+  const uint32_t qtl = p.qterms_len[q];
+  const uint64_t own_off = p.plan[e_own].post_off;
+  const uint32_t need_own = p.plan[e_own].qterm_index & 0xFFFFu;
+  // what the scan needs of the other lists (wave-uniform: scalar registers); the second level reads the rest of
+  // their entries when it runs
+  uint32_t o_bm[NO], o_rank[NO];
+  unsigned long long o_bloom[NO];
+#pragma unroll
+  for (int k = 0; k < NO; ++k) {
+    o_bm[k] = 0xFFFFFFFFu; o_rank[k] = 0xFFFFFFFFu; o_bloom[k] = NO_BLOOM;
+    if ((uint32_t)k + 1u < ne) {
+      const uint32_t j = e0 + (uint32_t)k + ((uint32_t)k >= own_pos ? 1u : 0u);
+      const ps_plan_entry& en = p.plan[j];
+      o_bm[k] = en.bm_off;
+      o_rank[k] = p.dentry[j].rank;
+      if (en.bm_off == 0xFFFFFFFFu && p.layer_bloom) o_bloom[k] = p.layer_bloom[en.layer];
+    }
+  }
+  // ---- bound table of this item: B(m, fl) for m = 1..ne records and fl = lane ----
+  {
+    double env[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) env[j] = (uint32_t)j < ne ? p.z_ubnum[e0 + j] : 0.0;
+#pragma unroll
+    for (int j = NE - 2; j >= 0; --j) env[j] = fmax(env[j], env[j + 1]);  // non-increasing envelope along the sorted order
+    const uint32_t den_u = (uint32_t)lane > qtl ? (uint32_t)lane : qtl;
+    const double den = (double)den_u;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      if ((uint32_t)j < ne) acc += env[j] / den;
+      btab[wave][j][lane] = acc;
+    }
+  }
+  int flmax[NE + 1];  // wave-uniform: the longest field that can still matter with m contributing records
+  auto set_flmax = [&](const double ts, const double tt) {
+    flmax[0] = z_beats(0.0, ts, tt) ? Z_ALL : Z_NONE;
+#pragma unroll
+    for (int m = 1; m <= NE; ++m) {
+      const unsigned long long ok = __ballot(z_beats(btab[wave][m - 1][lane], ts, tt));
+      const int n_ok = (int)__popcll(ok);  // B is non-increasing in fl: the lanes that pass are a prefix
+      flmax[m] = n_ok == WAVE ? Z_ALL : n_ok - 1;
+    }
+  };
+  TopK tk;
+  tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
+  double published = 0.0;
+  const uint32_t end = it.begin + (it.count & ZITEM_COUNT);
+  WorkStats ws;
+  uint32_t q_head = 0, q_n = 0;  // wave-uniform
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  double theta_s = 0.0, theta_t = 0.0;  // theta_t: the tie threshold the current trip may use (0 while the trip is not entirely at or above D0)
+  bool below = true;  // wave-uniform: every document scanned so far has id < D0 (doc ids ascend along the chunk)
+  const uint32_t d0 = p.z_d0;
+
+  // Second level + the pools in the sorted record order + the top-K offer for the first `count` (<= 64) queued
+  // documents, one per lane.
+  auto process = [&](const uint32_t count) {
+    const uint32_t at = (q_head + (uint32_t)lane) & (QCAP - 1u);
+    bool ok = (uint32_t)lane < count;
+    const uint32_t d = ok ? q_d[wave][at] : 0u;
+    const uint32_t own_i = ok ? q_i[wave][at] : 0u;
+    uint32_t w[NE][F_];   // packed words of the document's posting in list j (0: not in the list)
+    uint32_t rel[NE];     // ... its posting within list j
+    bool found[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      found[j] = false; rel[j] = 0u;
+#pragma unroll
+      for (int x = 0; x < F_; ++x) w[j][x] = 0u;
+      if ((uint32_t)j >= ne) continue;
+      if ((uint32_t)j == own_pos) {
+        found[j] = ok;
+        rel[j] = own_i;
+#pragma unroll
+        for (int x = 0; x < F_; ++x) w[j][x] = ok ? q_w[x][wave][at] : 0u;
+        continue;
+      }
+      const int k = j - ((uint32_t)j > own_pos ? 1 : 0);  // (own_pos is wave-uniform)
+      uint32_t loc = REL_NONE;
+#pragma unroll
+      for (int kk = 0; kk < NO; ++kk)
+        if (kk == k) loc = ok ? q_rel[kk][wave][at] : REL_NONE;
+      const ps_plan_entry& en = p.plan[e0 + j];
+      const uint64_t off = en.post_off;
+      if (en.bm_off != 0xFFFFFFFFu) {
+        found[j] = loc != REL_NONE;
+        rel[j] = found[j] ? loc : 0u;
+      } else {
+        // a sparse list whose filter said "maybe": its table slot holds a handful of postings - up to 4 doc ids per step
+        const uint32_t* docs = p.doc + off;
+        bool open = loc != REL_NONE;
+        uint32_t lo = 0, hi = 0;
+        if (open) {
+          const uint32_t slot = (d >> p.t_log2) >> (en.shift & 0xFFu);
+          lo = p.table[en.tbl_off + slot];
+          hi = p.table[en.tbl_off + slot + 1];
+        }
+        ws.probe += 2u * lanes_on(open);
+        open = open && lo < hi;
+        while (__any(open)) {
+          uint32_t v[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bool rd = open && lo + t < hi;
+            v[t] = rd ? docs[lo + t] : 0xFFFFFFFFu;
+            ws.probe += lanes_on(rd);
+          }
+          if (open) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (v[t] == d) { found[j] = true; rel[j] = lo + t; }
+            open = !found[j] && v[3] < d && lo + 4 < hi;
+            lo += 4;
+          }
+        }
+      }
+      ws.hit += lanes_on(found[j]);
+      if (__any(found[j])) {
+        uint32_t t[F_];
+#pragma unroll
+        for (int x = 0; x < F_; ++x) t[x] = 0u;
+        if (found[j]) tfl_load<F_>(p, off + rel[j], t);
+#pragma unroll
+        for (int x = 0; x < F_; ++x) w[j][x] = found[j] ? t[x] : 0u;
+      }
+      // a document is evaluated from its highest-ranked list only
+      if (found[j] && p.dentry[e0 + j].rank < own_rank) ok = false;
+    }
+    // pools (zero_to_one.rs:96-121), the document's score = the best pool (:122)
+    double score = 0.0;
+#pragma unroll
+    for (int x = 0; x < F_; ++x) {
+      // the field length is the document's: every posting of the document carries it
+      uint32_t flu = (ok ? q_w[x][wave][at] : 0u) & TFL_FL_ESC;
+      if (__any(ok && flu == TFL_FL_ESC)) {
+        if (ok && flu == TFL_FL_ESC) flu = p.fl[(uint64_t)x * p.P + own_off + own_i];
+      }
+      const double den = (double)(flu > qtl ? flu : qtl);
+      double pool = 0.0;
+      uint32_t consumed = 0u;
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        if ((uint32_t)j >= ne) continue;
+        const ps_plan_entry& en = p.plan[e0 + j];
+        const uint32_t l_need = en.qterm_index & 0xFFFFu;          // occurrence rank of the node among the sorted records (>= 1)
+        const uint32_t l_qbit = 1u << ((en.qterm_index >> 16) & 31u);  // consumed_index bit of the record's query term
+        const uint32_t l_tfx = (uint32_t)__double2loint(en.idf);   // largest tf with min(score / tf, 1) * tf == score (host, same arithmetic)
+        const double l_s = en.boost;                               // ScoreByTerm::score
+        uint32_t tfu = w[j][x] >> 24;
+        if (__any(found[j] && tfu == TFL_TF_ESC)) {
+          if (found[j] && tfu == TFL_TF_ESC) tfu = p.tf[(uint64_t)x * p.P + en.post_off + rel[j]];
+        }
+        const bool take = ok && found[j] && tfu >= l_need && tfu > 0u && !(consumed & l_qbit);
+        if (__any(take)) {
+          double num = l_s;
+          if (__any(take && tfu > l_tfx)) {
+            const double df = (double)(tfu ? tfu : 1u);
+            num = fmin(l_s / df, 1.0) * df;
+          }
+          const double c = num / den;
+          pool += take ? c : 0.0;
+          consumed |= take ? l_qbit : 0u;
+        }
+      }
+      score = fmax(pool, score);
+    }
+    // (the queue may hold documents of a trip below D0 next to documents of one above it: the tie rule is per document)
+    const bool offer = ok && z_beats(score, theta_s, d >= d0 ? theta_t : 0.0);
+    ws.offer += lanes_on(offer);
+    if (__any(offer)) topk_offer(tk, p.K, lane, offer, score, d, theta_s);
+    q_head = (q_head + count) & (QCAP - 1u);
+    q_n -= count;
+    if (tk.n == p.K && tk.thr_s > published && tk.thr_s > theta_s) {
+      published = tk.thr_s;
+      if (lane == 0) {
+        atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+        if (below && d0) atomicMax(&p.gtie[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+      }
+    }
+  };
+
+  bool first = true, essential = true;
+  for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
+    const unsigned long long sbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long tbits = d0 ? __hip_atomic_load(&p.gtie[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    uint32_t d[U], wv[U][F_], pi_l[U];
+    bool inr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + u * WAVE + lane;
+      inr[u] = i < end;
+      pi_l[u] = i < end ? i : end - 1;
+      d[u] = p.doc[own_off + pi_l[u]];
+      tfl_load<F_>(p, own_off + pi_l[u], wv[u]);
+    }
+    {
+      // the trip's place relative to D0: its first posting (lane 0 of slot 0) is its lowest doc id
+      const bool trip_above = d0 != 0u && (uint32_t)__builtin_amdgcn_readfirstlane((int)d[0]) >= d0;
+      bool over = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) over = over || (inr[u] && d[u] >= d0);
+      if (__any(over)) below = false;
+      const double ts = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(sbits >> 32)), __builtin_amdgcn_readfirstlane((int)(uint32_t)sbits));
+      const double tt = trip_above ? __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)), __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits)) : 0.0;
+      if (first || ts != theta_s || tt != theta_t) {
+        theta_s = ts; theta_t = tt;
+        set_flmax(ts, tt);
+        first = false;
+      }
+    }
+    essential = z_beats(skip_thr, theta_s, theta_t);  // false: the whole list has become non-essential
+    const uint32_t n_in = min(end - i0, (uint32_t)(WAVE * U));
+    if (!essential) {  // (its doc ids and words were requested with the thresholds: booked, then out)
+      ws.probe += n_in * (1u + (uint32_t)F_);
+      break;
+    }
+    if (p.alive != nullptr) {  // delta removals
+      uint32_t aw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) aw[u] = p.alive[d[u] >> 5];
+#pragma unroll
+      for (int u = 0; u < U; ++u) inr[u] = inr[u] & (bool)((aw[u] >> (d[u] & 31u)) & 1u);
+    }
+    // ---- first bound test, integers only: per field, could the own record (if it counts) + every other list
+    // still beat the thresholds? ----
+    // A document is evaluated from its highest-ranked list, so one that is evaluated HERE is in no list ranked above
+    // the own one: only the n_lower lists ranked below can add to it (a document that does sit in a higher-ranked
+    // list is cancelled below if it gets that far, and is evaluated there with the bound of that list's items).
+    int fmw = Z_NONE, fmo = Z_NONE;  // (flmax[] indexed by a wave-uniform value, without dynamic register indexing)
+#pragma unroll
+    for (int m = 0; m <= NE; ++m) {
+      if ((uint32_t)m == n_lower + 1u) fmw = flmax[m];
+      if ((uint32_t)m == n_lower) fmo = flmax[m];
+    }
+    bool rch[U];
+    uint32_t ownc[U];  // bit x: the own record can count for field x
+    ws.scanned += n_in;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool any = false;
+      ownc[u] = 0u;
+#pragma unroll
+      for (int x = 0; x < F_; ++x) {
+        const uint32_t tfu = wv[u][x] >> 24;
+        const int flu = (int)(wv[u][x] & TFL_FL_ESC);
+        const bool c = tfu >= need_own && tfu > 0u;
+        ownc[u] |= c ? (1u << x) : 0u;
+        any = any || flu <= (c ? fmw : fmo);
+      }
+      rch[u] = inr[u] && any;
+      const uint32_t nr = lanes_on(rch[u]);
+      ws.reached += nr;
+      ws.cell += nr * (ne - 1u);
+    }
+    // ---- first level of every other list for the documents that passed, all in flight together ----
+    uint2 fl[NO][U];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) fl[k][u] = make_uint2(0u, 0u);
+      if ((uint32_t)k + 1u >= ne) continue;
+      if (o_bm[k] != 0xFFFFFFFFu) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (rch[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(d[u] >> 5));
+      } else if (o_bloom[k] != NO_BLOOM) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          uint64_t wi;
+          unsigned long long mk;
+          bloom_probe(d[u], o_bloom[k], wi, mk);
+          const unsigned long long wd = rch[u] ? p.bloom[wi] : 0ull;
+          fl[k][u].x = (rch[u] && (wd & mk) == mk) ? 1u : 0u;  // maybe
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) fl[k][u].x = rch[u] ? 1u : 0u;  // no filter: ask the table
+      }
+    }
+    // ---- what the first level tells: how many lists can still count, exact membership of bitmap lists ----
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool alive = rch[u];
+      uint32_t hits = 0;
+      uint32_t loc[NO];
+#pragma unroll
+      for (int k = 0; k < NO; ++k) {
+        loc[k] = REL_NONE;
+        if ((uint32_t)k + 1u >= ne) continue;
+        if (o_bm[k] != 0xFFFFFFFFu) {
+          const uint32_t bit = d[u] & 31u;
+          const bool hit = (fl[k][u].x >> bit) & 1u;
+          if (hit) {
+            loc[k] = fl[k][u].y + (uint32_t)__popc(fl[k][u].x & ((1u << bit) - 1u));
+            if (o_rank[k] < own_rank) alive = false;  // evaluated from its highest-ranked list only
+            else ++hits;
+          }
+        } else if (fl[k][u].x != 0u) {
+          loc[k] = REL_MAYBE;  // (a "maybe" of a higher-ranked list adds nothing to the bound: found there, the document is cancelled)
+          if (o_rank[k] > own_rank) ++hits;
+        }
+      }
+      bool any = false;
+#pragma unroll
+      for (int x = 0; x < F_; ++x) {
+        const uint32_t m = hits + ((ownc[u] >> x) & 1u);
+        int fm = flmax[0];
+#pragma unroll
+        for (int k = 1; k <= NE; ++k) fm = m == (uint32_t)k ? flmax[k] : fm;
+        any = any || (int)(wv[u][x] & TFL_FL_ESC) <= fm;
+      }
+      alive = alive && any;
+      // ---- survivors wait in the queue until 64 are together ----
+      const unsigned long long mm = __ballot(alive);
+      if (mm) {
+        if (alive) {
+          const uint32_t at = (q_head + q_n + (uint32_t)__popcll(mm & lt)) & (QCAP - 1u);
+          q_d[wave][at] = d[u];
+          q_i[wave][at] = pi_l[u];
+#pragma unroll
+          for (int x = 0; x < F_; ++x) q_w[x][wave][at] = wv[u][x];
+#pragma unroll
+          for (int k = 0; k < NO; ++k)
+            if ((uint32_t)k + 1u < ne) q_rel[k][wave][at] = loc[k];
+        }
+        q_n += (uint32_t)__popcll(mm);
+        if (q_n >= (uint32_t)WAVE) process((uint32_t)WAVE);
+      }
+    }
+  }
+  while (q_n) process(min(q_n, (uint32_t)WAVE));
+  if ((uint32_t)lane < p.K) {
+    const uint64_t o = (uint64_t)it.slot * p.K + lane;
+    const bool ok = (uint32_t)lane < tk.n;
+    p.cand_score[o] = ok ? tk.s : 0.0;
+    p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
+    if (lane == 0) p.cand_cnt[it.slot] = tk.n;
+  }
+  if (PS_WORK_COUNTERS && lane == 0) {
+    unsigned long long* w = p.wstats + (size_t)(blockIdx.x & (WS_SLOTS - 1u)) * WS_WORDS;
+    atomicAdd(&w[WS_ITEMS_RUN], 1ull);
+    if (ws.scanned) atomicAdd(&w[WS_Z_SCANNED], (unsigned long long)ws.scanned);
+    if (ws.reached) atomicAdd(&w[WS_REACHED], (unsigned long long)ws.reached);
+    if (ws.cell) atomicAdd(&w[WS_CELL], (unsigned long long)ws.cell);
+    if (ws.probe) atomicAdd(&w[WS_PROBE], (unsigned long long)ws.probe);
+    if (ws.hit) atomicAdd(&w[WS_Z_HIT], (unsigned long long)ws.hit);
+    if (ws.offer) atomicAdd(&w[WS_OFFER], (unsigned long long)ws.offer);
+  }
+}
+
+}  // namespace ps

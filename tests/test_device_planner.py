@@ -28,7 +28,7 @@ def _same_plans(snap, queries):
             for k in a:
                 if k in ("idf", "boost"):
                     assert bits(a[k]) == bits(b[k]), (q, k, a[k], b[k])
-                elif k != "_pad":
+                else:
                     assert a[k] == b[k], (q, k, a[k], b[k])
 
 
@@ -129,6 +129,35 @@ def test_batches_in_flight_keep_their_results_apart():
             hip.hipStreamDestroy(st)
         finally:
             psa.load().ps_set_option(b"PS_DEVICE_PLAN", 1)
+
+
+def test_batches_in_flight_with_a_different_boost_vector_each():
+    """fields_boost is per call (src/query.rs:26).  The per-boost score planes are recycled (LRU); a batch still in its
+    scoring kernel must not see its plane rewritten for a later batch's boosts: nine batches, five distinct boost vectors
+    (and a changed k1 in between), back to back on one caller stream - every block equals the synchronous answer."""
+    hip = psd._DeviceBuffer.hip()
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    cfg = dict(synth.CONFIGS["C2"], n_docs=60_000, vocab=3_000)
+    corpus = synth.Corpus(**cfg)
+    snap = synth.fill(psa.Index(2), corpus).snapshot(device=0)
+    K, B = 10, 96
+    boosts = [[1.0, 1.0], [2.0, 0.5], [0.25, 3.0], [5.0, 5.0], [1.5, 0.75]]
+    scorers = [psa.bm25.new(), psa.bm25.BM25(0.9, 0.4)]
+    batches = [(corpus.queries(B, 3, salt=40 + s), boosts[s % 5], scorers[(s // 4) % 2]) for s in range(9)]
+    want = [[[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(b, sc, None, bo, top_k=K)] for b, bo, sc in batches]
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    bufs = [psd._DeviceBuffer(psd.block_bytes(B, K)) for _ in batches]
+    for (b, bo, sc), buf in zip(batches, bufs):
+        text, offsets = synth.pack_queries(b)
+        snap.query_batch_allgather_flat(None, text, offsets, sc, bo, K, buf.ptr.value, buf.ptr.value, stream=st.value)
+    assert hip.hipStreamSynchronize(st) == 0
+    for i, buf in enumerate(bufs):
+        got = psd.unpack_blocks(buf.to_host(), 1, B, K, [B])
+        assert [[(k, bits(s)) for k, s in rs] for rs in got] == want[i], i
+    hip.hipStreamDestroy(st)
 
 
 def test_work_counters_of_a_batch():

@@ -1,0 +1,138 @@
+"""K1dz (k_daat_z, ps_z21_daat.hpp): exact top-K with dynamic pruning for zero_to_one
+(src/score/default/zero_to_one.rs:44-126) - bit-identical to the oracle and to the streaming kernel
+(k_score<MODE_Z21S>, PS_DAAT_Z=0), ties at the threshold included: the scorer's scores are small rationals,
+thousands of documents tie, and the order among them is key ascending (src/lib.rs:54-58)."""
+import random
+
+import pytest
+
+import probly_search_amd as psa
+from emu import bits
+from oracle import oracle as orc
+from probly_search_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt(name, v):
+    psa.load().ps_set_option(name, v)
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    yield
+    _opt(b"PS_DAAT_Z", 1)
+    _opt(b"PS_DAAT_CHUNK", 4096)
+
+
+def _topk(snap, queries, K, boosts):
+    return [[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(queries, psa.zero_to_one.new(), None, boosts, top_k=K)]
+
+
+def _check(snap, o, queries, K, F, expect_kernel="ps::k_daat_z"):
+    boosts = [1.0] * F
+    _opt(b"PS_DAAT_Z", 1)
+    got = _topk(snap, queries, K, boosts)
+    name = snap.kernel_breakdown()["score_kernel"]
+    assert name.startswith(expect_kernel), name
+    _opt(b"PS_DAAT_Z", 0)
+    ref = _topk(snap, queries, K, boosts)
+    assert snap.kernel_breakdown()["score_kernel"].startswith(("ps::k_score", "ps::k_z21"))
+    _opt(b"PS_DAAT_Z", 1)
+    for q, g, r in zip(queries, got, ref):
+        assert g == r, (q, K, g[:4], r[:4])
+    for q, g in list(zip(queries, got))[:24]:
+        exp = [(k, bits(s)) for k, s in o.query(q, orc.zero_to_one(), boosts)[:K]]
+        assert g == exp, (q, K, g[:4], exp[:4])
+    return got
+
+
+def _tie_corpus(n_docs, fields, seed, vocab=40, short=(1, 4), long=(6, 14)):
+    """Few distinct terms, short fields: nearly every score is one of a handful of rationals."""
+    rng = random.Random(seed)
+    words = ["w%02d" % i for i in range(vocab)] + ["wa", "wab", "wabc"]
+    docs = []
+    for _ in range(n_docs):
+        vals = []
+        for f in range(fields):
+            lo, hi = short if f == 0 else long
+            vals.append(" ".join(rng.choice(words[: 6 + 3 * f] if rng.random() < 0.7 else words) for _ in range(rng.randint(lo, hi))))
+        docs.append(vals)
+    return words, docs
+
+
+def _build(docs, fields):
+    p, o = psa.Index(fields), orc.Index(fields)
+    for k, vals in enumerate(docs):
+        p.add_field_values(k * 3 + 1, vals)
+        o.add_document(k * 3 + 1, vals)
+    return p, o
+
+
+@pytest.mark.parametrize("fields", [1, 2, 3])
+@pytest.mark.parametrize("K", [1, 10, 64])
+def test_ties_everywhere(fields, K):
+    words, docs = _tie_corpus(30_000, fields, seed=fields * 10 + K)
+    p, o = _build(docs, fields)
+    snap = p.snapshot(device=0, tile_docs=256)
+    rng = random.Random(K)
+    queries = [" ".join(rng.choice(words[:8]) for _ in range(rng.randint(1, 4))) for _ in range(40)]
+    queries += ["w00 w00", "w01 w01 w01", "w00 w01 w00", "w02  w03", "zzz w00", "w00"] + ["w0%d w0%d w0%d" % (a, b, c) for a, b, c in [(0, 1, 2), (1, 2, 3), (3, 4, 5)]]
+    _opt(b"PS_DAAT_CHUNK", 256)  # several chunks per list, on both sides of D0
+    _check(snap, o, queries, K, fields)
+
+
+def test_prefix_expansions_within_four_lists():
+    """Several expansions of one query term (consumed_index, zero_to_one.rs:101-103) and the same node under
+    two query terms (the pool rule, :104-113) - as long as a query has at most 4 lists it stays on K1dz."""
+    words, docs = _tie_corpus(20_000, 2, seed=5)
+    p, o = _build(docs, 2)
+    snap = p.snapshot(device=0, tile_docs=256)
+    queries = ["wa", "wab w00", "wa w01", "wabc wabc", "wabc w00 wabc", "w00 wab", "wa w00"] * 2
+    plans = [snap.plan(q, psa.zero_to_one.new())[0] for q in queries]
+    assert max(len(e) for e in plans) <= 4 and any(len(e) > len(q.split()) for e, q in zip(plans, queries))
+    _opt(b"PS_DAAT_CHUNK", 256)
+    for K in (1, 10, 64):
+        _check(snap, o, queries, K, 2)
+    # several expansions of a term AND a node under two records ("wab wab": wab, wabc twice): the general kernel's case
+    got = _topk(snap, ["wab wab"] * 8, 10, [1.0, 1.0])
+    assert snap.kernel_breakdown()["score_kernel"].startswith(("ps::k_score", "ps::k_z21"))
+    assert got[0] == [(k, bits(s)) for k, s in o.query("wab wab", orc.zero_to_one(), [1.0, 1.0])[:10]]
+
+
+def test_batches_that_do_not_qualify_keep_the_streaming_kernels():
+    words, docs = _tie_corpus(5_000, 2, seed=6)
+    p, o = _build(docs, 2)
+    snap = p.snapshot(device=0, tile_docs=256)
+    queries = ["w"] * 4 + ["w00 w01"] * 8  # "w" expands to every word: far more than 4 lists
+    got = _topk(snap, queries, 10, [1.0, 1.0])
+    assert snap.kernel_breakdown()["score_kernel"].startswith(("ps::k_score", "ps::k_z21"))
+    for q, g in zip(queries[:5], got):
+        assert g == [(k, bits(s)) for k, s in o.query(q, orc.zero_to_one(), [1.0, 1.0])[:10]]
+
+
+def test_c3_shape_at_oracle_size_repeated_runs_are_bit_identical():
+    cfg = dict(synth.CONFIGS["C3"], n_docs=120_000, vocab=8_000)
+    corpus = synth.Corpus(**cfg)
+    p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
+    snap = p.snapshot(device=0)
+    queries = corpus.queries(256, 3)
+    first = _check(snap, o, queries, 10, 2)
+    for _ in range(3):
+        assert _topk(snap, queries, 10, [1.0, 1.0]) == first
+    w = snap.work_counters(reset=True)
+    assert w["z_postings_scanned"] > 0 and w["z_postings_scanned"] == w["postings_scanned"]
+
+
+def test_removed_documents_through_a_delta():
+    words, docs = _tie_corpus(20_000, 2, seed=9)
+    p, o = _build(docs, 2)
+    snap = p.snapshot(device=0, tile_docs=256, headroom_pct=10)
+    rng = random.Random(3)
+    for k in rng.sample(range(20_000), 700):
+        p.remove_document(k * 3 + 1)
+        o.remove_document(k * 3 + 1)
+    snap.update()
+    queries = [" ".join(rng.choice(words[:8]) for _ in range(3)) for _ in range(32)]
+    _opt(b"PS_DAAT_CHUNK", 256)
+    _check(snap, o, queries, 10, 2)
