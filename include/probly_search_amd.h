@@ -333,7 +333,9 @@ ps_status ps_snapshot_query_batch_device_flat(ps_snapshot* snap, const ps_scorer
  * top-k block, and only when the batch spans more than one rank.  One process per GPU.
  *   rank 0: ps_comm_get_unique_id(id) -> ship the 128 bytes to the other ranks (any channel)
  *   every rank: ps_comm_init_rank(id, world, rank, device, &comm)
- * librccl.so.1 is loaded on first use (a process that never creates a communicator never loads it).
+ * RCCL is resolved on first use (a process that never creates a communicator never loads it): the instance the
+ * process has already mapped (e.g. the one PyTorch ships, when the host application is a torch program), else
+ * librccl.so.1 by name - never a second instance beside the host application's.
  * PS_COMM_TRANSPORT=hostshm selects a debugging transport through POSIX shared memory for ranks
  * that share one GPU (RCCL refuses two ranks on one device); it is not a product path. */
 #define PS_COMM_ID_BYTES 128
@@ -341,6 +343,9 @@ ps_status ps_comm_get_unique_id(void* id_out /* PS_COMM_ID_BYTES */);
 ps_status ps_comm_init_rank(const void* id, int world_size, int rank, int device, ps_comm** out);
 void ps_comm_free(ps_comm* comm);
 int ps_comm_world_size(const ps_comm* comm);
+/* Path of the RCCL library the communicators use (resolves it if that has not happened yet); NULL + ps_last_error()
+ * if none could be loaded.  The string lives until the next call. */
+const char* ps_comm_rccl_path(void);
 int ps_comm_rank(const ps_comm* comm);
 /* A rank's top-k block: [n_queries*top_k u64 keys | n_queries*top_k f64 scores | n_queries u32
  * counts, padded to a multiple of 16 bytes]; unused slots key = ~0, score = 0. */

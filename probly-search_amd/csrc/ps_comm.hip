@@ -46,10 +46,25 @@ RcclApi& rccl() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
+    // One RCCL per process: a host application that already carries one (PyTorch's torch/lib/librccl.so under
+    // `bench.py --gpus N`, whose process group is the nccl backend) must not get a second instance with its own
+    // bootstrap state next to it.  So first the instance that is already mapped, whatever its path - found in
+    // /proc/self/maps, taken with RTLD_NOLOAD -, only then the system library by name.
+    {
+      FILE* maps = fopen("/proc/self/maps", "r");
+      char line[4352];
+      while (maps && !api.handle && fgets(line, sizeof(line), maps)) {
+        char* path = strchr(line, '/');
+        if (!path || !strstr(path, "librccl.so")) continue;
+        path[strcspn(path, "\n")] = 0;
+        api.handle = dlopen(path, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+      }
+      if (maps) fclose(maps);
+    }
     const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char* n : names) {
-      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (api.handle) break;
+      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!api.handle) return;
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
@@ -61,6 +76,14 @@ RcclApi& rccl() {
   if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather)
     throw ps::RcclError("librccl.so.1 could not be loaded (RCCL is required for a multi-GPU communicator)");
   return api;
+}
+
+// Path of the RCCL instance the communicators use (dladdr of one of its symbols).
+std::string rccl_path() {
+  RcclApi& api = rccl();
+  Dl_info info;
+  if (api.AllGather && dladdr(reinterpret_cast<void*>(api.AllGather), &info) && info.dli_fname) return info.dli_fname;
+  return "?";
 }
 
 void rccl_check(ncclResult_t r, const char* what) {
@@ -185,6 +208,19 @@ extern "C" {
 
 size_t ps_topk_block_bytes(size_t n_queries, size_t top_k) {
   return n_queries * top_k * 16 + ((n_queries * 4 + 15) & ~(size_t)15);
+}
+
+const char* ps_comm_rccl_path(void) {
+  static std::string path;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  try {
+    path = rccl_path();
+  } catch (const std::exception& e) {
+    ps::set_error(PS_ERCCL, e.what());
+    return nullptr;
+  }
+  return path.c_str();
 }
 
 ps_status ps_comm_get_unique_id(void* id_out) {

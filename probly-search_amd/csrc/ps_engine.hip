@@ -145,6 +145,8 @@ struct Tuning {
   uint32_t z21_field_prune = 1;  // PS_Z21_FIELD_PRUNE: k_score<MODE_Z21S> drops fields whose pool bound fell below the query's threshold
   uint32_t daat_multi = 1;       // PS_DAAT_MULTI: also take batches with several expansions per query term (0: they stay on K1)
   uint32_t daat_small = 1;       // PS_DAAT_SMALL: plans of <= 4 lists, one per query term, take k_daat_small (all lookups of a trip in flight together)
+  uint32_t work_counters = 1;    // PS_WORK_COUNTERS: the headline kernels (k_daat_small, k_daat_z) keep the work counters of ps_snapshot_work_counters (0: the serving instantiations, which carry none; the other kernels always count)
+  uint32_t daat_z_d0_div = 8;    // PS_DAAT_Z_D0_DIV: K1dz evaluates the documents below D0 ~ N / this first (threshold sample; tie threshold)
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
   uint32_t device_plan = 1;      // PS_DEVICE_PLAN: flat BM25 top-k batches (built-in tokenizer) are planned by k_plan on the device
   void load();
@@ -281,7 +283,7 @@ struct EngineImpl {
     DevBuf<DItem> ditems;
     DevBuf<double> cand_score, rows;
     DevBuf<unsigned long long> gthr, gtie;
-    DevBuf<uint32_t> z_nabove;  // K1dz preparation scratch
+    DevBuf<uint32_t> z_nbelow, z_nabove;  // K1dz preparation scratch
     PrepCtl* ctl = nullptr;
     uint32_t* work = nullptr;
     RowState* row_state = nullptr;
@@ -744,6 +746,8 @@ void Tuning::load() {
     daat_small = env_u32("PS_DAAT_SMALL", daat_small);
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
     daat_z = env_u32("PS_DAAT_Z", daat_z);
+    work_counters = env_u32("PS_WORK_COUNTERS", work_counters);
+    daat_z_d0_div = env_u32("PS_DAAT_Z_D0_DIV", daat_z_d0_div);
     z21_field_prune = env_u32("PS_Z21_FIELD_PRUNE", z21_field_prune);
     z21_exact_numerator = env_u32("PS_Z21_EXACT_NUMERATOR", z21_exact_numerator);
 }
@@ -1731,11 +1735,15 @@ void launch_daat(EngineImpl& m, KParams& kp, bool multi, bool small, int n_cu, h
     // plans of <= 4 lists, one per query term: the short-chain kernel
     const uint32_t n_wg = (kp.n_ditems + DAAT_WGW - 1) / DAAT_WGW;
     char nm[96];
-    snprintf(nm, sizeof(nm), "ps::k_daat_small<%d>", kp.F <= 2 ? (int)kp.F : 0);
+    snprintf(nm, sizeof(nm), "ps::k_daat_small<%d, %s>", kp.F <= 2 ? (int)kp.F : 0, m.tune.work_counters ? "true" : "false");
     m.score_kernel_name = nm;
-    if (kp.F == 1) hipLaunchKernelGGL((k_daat_small<1>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);
-    else if (kp.F == 2) hipLaunchKernelGGL((k_daat_small<2>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);
-    else hipLaunchKernelGGL((k_daat_small<0>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);
+#define PS_SMALL(FV)                                                                                                    \
+  do {                                                                                                                  \
+    if (m.tune.work_counters) hipLaunchKernelGGL((k_daat_small<FV, true>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp); \
+    else hipLaunchKernelGGL((k_daat_small<FV, false>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);                  \
+  } while (0)
+    if (kp.F == 1) PS_SMALL(1); else if (kp.F == 2) PS_SMALL(2); else PS_SMALL(0);
+#undef PS_SMALL
   } else if (multi) {
     if (kp.F == 1) PS_DAAT(1, true); else if (kp.F == 2) PS_DAAT(2, true); else PS_DAAT(0, true);
   } else {
@@ -2006,7 +2014,7 @@ void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KPar
   ensure_bloom(m, st);
   kp.bloom = m.d_bloom.p;
   kp.layer_bloom = m.d_layer_bloom.p;
-  c.dentry.ensure(ne + 1); c.gen.ensure(ne + 1); c.z_nabove.ensure(ne + 1);
+  c.dentry.ensure(ne + 1); c.gen.ensure(ne + 1); c.z_nbelow.ensure(ne + 1); c.z_nabove.ensure(ne + 1);
   c.qslot.ensure(B + 1); c.qslot_n.ensure(B + 1);
   c.ditems.ensure(items_bound + 1);
   c.cand_cnt.ensure(items_bound + 1);
@@ -2016,7 +2024,7 @@ void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KPar
   pp.B = (uint32_t)B; pp.ne = (uint32_t)ne; pp.F = s.F;
   pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div;
   pp.d0_tile = zb.d0 >> kp.t_log2;
-  pp.dentry = c.dentry.p; pp.gen = c.gen.p; pp.nabove_from = c.z_nabove.p;
+  pp.dentry = c.dentry.p; pp.gen = c.gen.p; pp.nbelow = c.z_nbelow.p; pp.nabove_from = c.z_nabove.p;
   pp.qslot = c.qslot.p; pp.qslot_n = c.qslot_n.p;
   pp.items = c.ditems.p; pp.items_cap = (uint32_t)items_bound;
   pp.ctl = c.ctl;
@@ -2038,14 +2046,20 @@ void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KPar
 void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st) {
   const uint32_t n_wg = (kp.n_ditems + DAAT_WGW - 1) / DAAT_WGW;
   char nm[64];
-  snprintf(nm, sizeof(nm), "ps::k_daat_z<%d>", (int)kp.F);
+  snprintf(nm, sizeof(nm), "ps::k_daat_z<%d, %s>", (int)std::min(kp.F, 4u), m.tune.work_counters ? "true" : "false");
   m.score_kernel_name = nm;
+#define PS_Z(FV)                                                                                                  \
+  do {                                                                                                            \
+    if (m.tune.work_counters) hipLaunchKernelGGL((k_daat_z<FV, true>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); \
+    else hipLaunchKernelGGL((k_daat_z<FV, false>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp);                  \
+  } while (0)
   switch (kp.F) {
-    case 1: hipLaunchKernelGGL((k_daat_z<1>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); break;
-    case 2: hipLaunchKernelGGL((k_daat_z<2>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); break;
-    case 3: hipLaunchKernelGGL((k_daat_z<3>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); break;
-    default: hipLaunchKernelGGL((k_daat_z<4>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); break;
+    case 1: PS_Z(1); break;
+    case 2: PS_Z(2); break;
+    case 3: PS_Z(3); break;
+    default: PS_Z(4); break;
   }
+#undef PS_Z
 }
 
 // Largest numerator min(score / t, 1) * t (zero_to_one.rs:117-118) over the term frequencies need <= t <= maxtf, in
@@ -2160,9 +2174,10 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   zb.d_zub = reinterpret_cast<const double*>(c.stage.p + off_z);
   // D0: a power of two (so it is a slot boundary of every list's table up to that coarseness) near a 16th of the id space
   uint32_t d0 = 0;
-  if (s.n_ids >= 16ull * s.T) {
+  const uint64_t div = std::max(2u, m.tune.daat_z_d0_div);
+  if (s.n_ids >= div * s.T) {
     d0 = s.T;
-    while ((uint64_t)d0 * 2 <= s.n_ids / 16) d0 *= 2;
+    while ((uint64_t)d0 * 2 <= s.n_ids / div) d0 *= 2;
   }
   zb.d0 = d0;
   enqueue_daat(m, c, sc, boosts, reinterpret_cast<ps_plan_entry*>(c.stage.p), reinterpret_cast<const uint32_t*>(c.stage.p + off_q),

@@ -2140,8 +2140,11 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
 #endif
 constexpr int DAAT_SMALL_MAX = 4;  // most lists per query
 
-template <int F_>
+// WC: keep the work counters (ps_work_counters).  The serving instantiation (PS_WORK_COUNTERS=0 at run time) carries none
+// of the ballots / popcounts / atomics they cost (4 % of the kernel on C2).
+template <int F_, bool WC>
 __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p) {
+  auto cnt = [](const bool b) -> uint32_t { return WC ? (uint32_t)__popcll(__ballot(b)) : 0u; };  // wave-uniform count of lanes where b holds
   constexpr int U = PS_DAAT_US;
   constexpr int NO = DAAT_SMALL_MAX - 1;  // other lists of a query
   constexpr int FA = F_ ? F_ : MAX_F;
@@ -2257,7 +2260,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
               lo = p.table[o_tbl[k] + slot];
               hi = p.table[o_tbl[k] + slot + 1];
             }
-            ws.probe += 2u * lanes_on(open);
+            ws.probe += 2u * cnt(open);
             open = open && lo < hi;
             while (__any(open)) {
               uint32_t v[4];
@@ -2265,7 +2268,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
               for (int t = 0; t < 4; ++t) {
                 const bool rd = open && lo + t < hi;
                 v[t] = rd ? docs[lo + t] : 0xFFFFFFFFu;
-                ws.probe += lanes_on(rd);
+                ws.probe += cnt(rd);
               }
               if (open) {
 #pragma unroll
@@ -2277,7 +2280,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
               }
             }
           }
-          ws.hit += lanes_on(found);
+          ws.hit += cnt(found);
           if (__any(found)) {
             double t[FA];
 #pragma unroll
@@ -2297,7 +2300,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       }
     }
     const bool offer = ok && P >= theta;
-    ws.offer += lanes_on(offer);
+    ws.offer += cnt(offer);
     if (!(PS_EXP & 1) && __any(offer)) topk_offer(tk, p.K, lane, ok, P, d, theta);
     q_head = (q_head + count) & (QCAP - 1u);
     q_n -= count;
@@ -2332,7 +2335,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
     essential = !(skip_thr < theta);  // false: the whole list has become non-essential
     const uint32_t n_in = min(end - i0, (uint32_t)(WAVE * U));
     if (!essential) {  // (its doc ids and plane values were requested with the threshold: booked, then out)
-      ws.probe += n_in * (1u + 2u * (F_ ? (uint32_t)F_ : p.F));
+      if (WC) ws.probe += n_in * (1u + 2u * (F_ ? (uint32_t)F_ : p.F));
       break;
     }
     // ---- own scores; first bound test: everything the other entries could add, at most - below theta the
@@ -2347,11 +2350,11 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
     double s_own[U];
     scores_from_plane<F_, U>(p, tw, inr, own_eb, s_own);
     bool rch[U];
-    ws.scanned += n_in;
+    if (WC) ws.scanned += n_in;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       rch[u] = inr[u] && (s_own[u] + others >= theta);
-      const uint32_t nr = lanes_on(rch[u]);  // every document that passed asks every other list's first level
+      const uint32_t nr = cnt(rch[u]);  // every document that passed asks every other list's first level
       ws.reached += nr; ws.row += nr * n_row_lists; ws.cell += nr * n_cell_lists;
     }
     // ---- first level of every other list for the documents that passed, all in flight together: dense-row
@@ -2449,7 +2452,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
     tr[3] = ws.scanned | ((unsigned long long)ws.reached << 32);
   }
 #endif
-  if (PS_WORK_COUNTERS && lane == 0) {
+  if (WC && lane == 0) {
     unsigned long long* w = p.wstats + (size_t)(blockIdx.x & (WS_SLOTS - 1u)) * WS_WORDS;
     atomicAdd(&w[WS_ITEMS_RUN], 1ull);
     if (ws.scanned) atomicAdd(&w[WS_SCANNED], (unsigned long long)ws.scanned);

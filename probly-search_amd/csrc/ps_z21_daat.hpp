@@ -55,6 +55,7 @@ struct ZPrepParams {
   uint32_t d0_tile;            // D0 >> t_log2; 0 = no D0 (tie thresholds off)
   DEntry* dentry;
   DItemGen* gen;
+  uint32_t* nbelow;            // [ne] chunks of the list that lie entirely below D0 (placed first in the launch)
   uint32_t* nabove_from;       // [ne] first chunk that lies entirely at or above D0 (= chunks: none / not known)
   uint32_t* qslot;
   uint32_t* qslot_n;
@@ -63,8 +64,16 @@ struct ZPrepParams {
   PrepCtl* ctl;
 };
 
-// Item order: rank-major like K1d (every query's shortest list first - thresholds exist before the long lists come
-// up -, longest lists first within a rank); the chunks of a list ascend in doc id, so its part below D0 comes first.
+// Item order: the chunks below D0 of every list first (rank-major among them) - a sample of the document space that
+// is evaluated almost unpruned and leaves thresholds close to the final ones, tie threshold included - then the rest
+// rank-major like K1d (every query's shortest list first, longest lists first within a rank).  Measured on C3: the
+// plain rank-major order scanned 202 M postings per batch (1.34 ms), this one 80 M (0.56 ms) with D0 = N / 8
+// (N / 16: 91 M, 0.61 ms; N / 32: 121 M, 0.79 ms; N / 4: 90 M, 0.67 ms; profiles/r04_c3_d0_sweep.jsonl).
+__device__ __forceinline__ uint32_t zprep_bucket(const bool below, const uint32_t rank, const uint32_t len) {
+  if (below) return rank < 3u ? rank : 3u;
+  return rank <= 1u ? 4u + prep_bucket(rank, len) : 4u + 2u * PREP_CLASSES + (rank - 2u < 3u ? rank - 2u : 3u);
+}
+static_assert(4u + 2u * PREP_CLASSES + 4u <= PREP_BUCKETS, "K1dz item buckets fit the preparation's control block");
 
 // Thread per query: processing order (shortest list first: the long lists are the ones that become non-essential;
 // any order is exact), skip thresholds, chunking, candidate slots, bucket totals.
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {
 #pragma unroll
   for (int i = 0; i < NMAX; ++i) {  // (wave-uniform trip count: the aggregated atomics need every lane)
     const bool on = (uint32_t)i < n;
-    uint32_t nc = 0, bk = 0;
+    uint32_t nc = 0, nb = 0, bk0 = 0, bk1 = 0;
     if (on) {
       const ps_plan_entry& en = pp.plan[b + i];
       const uint32_t c = prep_chunk_of(pp.split_div, pp.chunk_min, en.len);
@@ -124,14 +133,18 @@ __global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {
       if (pp.d0_tile && (pp.d0_tile & ((1u << sh) - 1u)) == 0u) {
         // postings of the list with doc id < D0: the table slot that starts at D0 (slots span T << shift documents)
         const uint32_t p0 = min(en.len, pp.table[en.tbl_off + (pp.d0_tile >> sh)]);
+        nb = p0 >= en.len ? nc : p0 / c;  // chunks [0, nb) end at or before p0
         na = (p0 + c - 1) / c;            // chunks [na, nc) start at or after p0
       }
       pp.gen[b + i] = DItemGen{b + i, 0u, c, sl};
+      pp.nbelow[b + i] = nb;
       pp.nabove_from[b + i] = na;
       sl += nc;
-      bk = prep_bucket(rank[i], en.len);
+      bk0 = zprep_bucket(true, rank[i], en.len);
+      bk1 = zprep_bucket(false, rank[i], en.len);
     }
-    wave_add_by_key_noret(pp.ctl->bucket_total, bk, nc, on && nc != 0);
+    wave_add_by_key_noret(pp.ctl->bucket_total, bk0, nb, on && nb != 0);
+    wave_add_by_key_noret(pp.ctl->bucket_total, bk1, nc - nb, on && nc != nb);
   }
   __threadfence();
   uint32_t t = 0;
@@ -156,21 +169,27 @@ __global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {
 __global__ __launch_bounds__(2 * WAVE) void k_zprep_items(const ZPrepParams pp) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = i < pp.ne;
-  uint32_t nc = 0, na = 0, bk = 0, len = 0, chunk = 1, first_slot = 0;
+  uint32_t nc = 0, nb = 0, na = 0, bk0 = 0, bk1 = 0, len = 0, chunk = 1, first_slot = 0;
   if (have) {
     const ps_plan_entry& en = pp.plan[i];
     const DItemGen g = pp.gen[i];
     len = en.len; chunk = g.chunk; first_slot = g.first_slot;
     nc = (len + chunk - 1) / chunk;
+    nb = pp.nbelow[i];
     na = pp.nabove_from[i];
-    bk = prep_bucket(pp.dentry[i].rank, len);
+    const uint32_t rank = pp.dentry[i].rank;
+    bk0 = zprep_bucket(true, rank, len);
+    bk1 = zprep_bucket(false, rank, len);
   }
-  const uint32_t off = wave_add_by_key(pp.ctl->bucket_fill, bk, nc, have && nc != 0);
-  if (have && nc) {
-    const uint32_t at0 = pp.ctl->bucket_start[bk] + off;
+  const uint32_t off0 = wave_add_by_key(pp.ctl->bucket_fill, bk0, nb, have && nb != 0);
+  const uint32_t off1 = wave_add_by_key(pp.ctl->bucket_fill, bk1, nc - nb, have && nc != nb);
+  if (have) {
+    const uint32_t at0 = nb ? pp.ctl->bucket_start[bk0] + off0 : 0u;
+    const uint32_t at1 = nc != nb ? pp.ctl->bucket_start[bk1] + off1 : 0u;
     for (uint32_t j = 0; j < nc; ++j) {
       const uint32_t pb = j * chunk;
-      if (at0 + j < pp.items_cap) pp.items[at0 + j] = DItem{i, pb, min(chunk, len - pb) | (j >= na ? ZITEM_ABOVE : 0u), first_slot + j};
+      const uint32_t at = j < nb ? at0 + j : at1 + (j - nb);
+      if (at < pp.items_cap) pp.items[at] = DItem{i, pb, min(chunk, len - pb) | (j >= na ? ZITEM_ABOVE : 0u), first_slot + j};
     }
   }
 }
@@ -181,9 +200,10 @@ __device__ __forceinline__ bool z_beats(const double v, const double ts, const d
   return v >= ts && (tt == 0.0 || v > tt);
 }
 
-template <int F_>
+template <int F_, bool WC>  // WC: keep the work counters (ps_work_counters); the serving instantiation carries none
 __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   static_assert(F_ >= 1 && F_ <= 4, "k_daat_z is instantiated per field count");
+  auto cnt = [](const bool b) -> uint32_t { return WC ? (uint32_t)__popcll(__ballot(b)) : 0u; };  // wave-uniform count of lanes where b holds
   constexpr int U = PS_DAAT_ZU;
   constexpr int NE = DAAT_SMALL_MAX;
   constexpr int NO = NE - 1;  // other lists of a query, in sorted record order with the own one left out
@@ -323,7 +343,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
           lo = p.table[en.tbl_off + slot];
           hi = p.table[en.tbl_off + slot + 1];
         }
-        ws.probe += 2u * lanes_on(open);
+        ws.probe += 2u * cnt(open);
         open = open && lo < hi;
         while (__any(open)) {
           uint32_t v[4];
@@ -331,7 +351,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
           for (int t = 0; t < 4; ++t) {
             const bool rd = open && lo + t < hi;
             v[t] = rd ? docs[lo + t] : 0xFFFFFFFFu;
-            ws.probe += lanes_on(rd);
+            ws.probe += cnt(rd);
           }
           if (open) {
 #pragma unroll
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
           }
         }
       }
-      ws.hit += lanes_on(found[j]);
+      ws.hit += cnt(found[j]);
       if (__any(found[j])) {
         uint32_t t[F_];
 #pragma unroll
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     }
     // (the queue may hold documents of a trip below D0 next to documents of one above it: the tie rule is per document)
     const bool offer = ok && z_beats(score, theta_s, d >= d0 ? theta_t : 0.0);
-    ws.offer += lanes_on(offer);
+    ws.offer += cnt(offer);
     if (__any(offer)) topk_offer(tk, p.K, lane, offer, score, d, theta_s);
     q_head = (q_head + count) & (QCAP - 1u);
     q_n -= count;
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     essential = z_beats(skip_thr, theta_s, theta_t);  // false: the whole list has become non-essential
     const uint32_t n_in = min(end - i0, (uint32_t)(WAVE * U));
     if (!essential) {  // (its doc ids and words were requested with the thresholds: booked, then out)
-      ws.probe += n_in * (1u + (uint32_t)F_);
+      if (WC) ws.probe += n_in * (1u + (uint32_t)F_);
       break;
     }
     if (p.alive != nullptr) {  // delta removals
@@ -462,7 +482,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     }
     bool rch[U];
     uint32_t ownc[U];  // bit x: the own record can count for field x
-    ws.scanned += n_in;
+    if (WC) ws.scanned += n_in;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       bool any = false;
@@ -476,7 +496,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
         any = any || flu <= (c ? fmw : fmo);
       }
       rch[u] = inr[u] && any;
-      const uint32_t nr = lanes_on(rch[u]);
+      const uint32_t nr = cnt(rch[u]);
       ws.reached += nr;
       ws.cell += nr * (ne - 1u);
     }
@@ -564,7 +584,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
     if (lane == 0) p.cand_cnt[it.slot] = tk.n;
   }
-  if (PS_WORK_COUNTERS && lane == 0) {
+  if (WC && lane == 0) {
     unsigned long long* w = p.wstats + (size_t)(blockIdx.x & (WS_SLOTS - 1u)) * WS_WORDS;
     atomicAdd(&w[WS_ITEMS_RUN], 1ull);
     if (ws.scanned) atomicAdd(&w[WS_Z_SCANNED], (unsigned long long)ws.scanned);

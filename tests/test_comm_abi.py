@@ -100,3 +100,30 @@ def test_world_of_one_goes_through_rccl(monkeypatch):
     assert got == exp
     comm.free()
     assert psd.query_batch_sharded(snap, queries, psa.bm25.new(), [1.0, 1.0], 10, None) == exp
+
+
+def _rccl_path_in_subprocess(preload_torch):
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n" % ROOT +
+            ("import torch\n" if preload_torch else "") +
+            "import probly_search_amd as psa\n"
+            "p = psa.load().ps_comm_rccl_path()\n"
+            "print('RCCL_PATH=' + (p.decode() if p else 'NONE'))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [l for l in out.stdout.splitlines() if l.startswith("RCCL_PATH=")][-1][len("RCCL_PATH="):]
+
+
+def test_one_rccl_per_process():
+    """bench.py --gpus N runs torch's nccl backend (torch/lib/librccl.so) and the library's own communicator in one
+    process: the library must pick up the instance that is already mapped instead of loading /opt/rocm's beside it;
+    a process without torch gets the system library.  No GPU needed: only the loader is exercised."""
+    import os
+    with_torch = _rccl_path_in_subprocess(True)
+    assert "librccl.so" in with_torch
+    mapped_by_torch = os.path.join("torch", "lib")
+    # (a torch build that links the system RCCL maps /opt/rocm's: either way it is the mapped one)
+    assert mapped_by_torch in with_torch or with_torch.startswith("/opt/rocm"), with_torch
+    alone = _rccl_path_in_subprocess(False)
+    assert "librccl.so" in alone and mapped_by_torch not in alone, alone

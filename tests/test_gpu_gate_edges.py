@@ -1,0 +1,115 @@
+"""Edges of the gates in front of the pruning kernels (ps_engine.hip: daat_eligible / bm25_params_sane): K1d takes BM25
+top-k batches with k1 >= 0, 0 <= b <= 1, positive finite boosts; everything else must fall through to K1 k_score and
+still equal the oracle bit for bit (src/score/default/bm25.rs:60-93, src/query.rs:150-164).  The admitted corners
+are the hard ones for exact pruning: k1 = 0 makes every saturated term frequency exactly 1, so whole lists tie and
+the result order is decided by the key-ascending tie-break alone (src/lib.rs:54-58)."""
+import math
+import random
+
+import pytest
+
+import probly_search_amd as psa
+from adapters import oracle_scorer, product_scorer
+from emu import bits
+from oracle import oracle as orc
+from probly_search_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N_DOCS = 50_000
+
+
+@pytest.fixture(scope="module")
+def corpus_pair():
+    cfg = dict(synth.CONFIGS["C2"], n_docs=N_DOCS, vocab=2_000)
+    corpus = synth.Corpus(**cfg)
+    p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
+    snap = p.snapshot(device=0, headroom_pct=10)
+    return corpus, p, o, snap
+
+
+def _run(snap, o, queries, kw, boosts, K, want_kernel):
+    sc = product_scorer("bm25", **kw)
+    got = snap.query_batch(queries, sc, None, boosts, top_k=K)
+    name = snap.kernel_breakdown()["score_kernel"]
+    assert name.startswith(want_kernel), (name, kw, boosts)
+    osc = oracle_scorer("bm25", **kw)
+    for q, g in list(zip(queries, got))[:10]:
+        exp = o.query(q, osc, boosts)[:K]
+        assert [(r.key, bits(r.score)) for r in g] == [(k, bits(s)) for k, s in exp], (q, kw, boosts, K, [tuple(r) for r in g][:3], exp[:3])
+    return got
+
+
+ADMITTED = [
+    ({"k1": 0.0}, [1.0, 1.0]),            # every tfn == 1: all documents of a list tie
+    ({"k1": 0.0, "b": 0.0}, [1.0, 1.0]),
+    ({"b": 0.0}, [1.0, 1.0]),             # no length normalisation
+    ({"b": 1.0}, [1.0, 1.0]),
+    ({"k1": 1e-300}, [1.0, 1.0]),         # k1 * (...) underflows towards 0 without being 0
+    ({"k1": 1e300}, [1.0, 1.0]),
+    ({}, [5e-324, 1.0]),                  # subnormal boost: products underflow to 0 -> score() returns None for that field
+    ({}, [1e300, 1e-300]),
+    ({}, [1e300, 1e300]),
+]
+REJECTED = [
+    ({"k1": -0.5}, [1.0, 1.0]),           # negative k1: tfn no longer monotone
+    ({"b": 1.5}, [1.0, 1.0]),
+    ({"b": -0.25}, [1.0, 1.0]),
+    ({}, [math.inf, 1.0]),                # +inf boost: inf scores, inf - inf free but no finite bound
+    ({}, [0.0, 1.0]),
+    ({}, [-1.0, 1.0]),
+    ({"k1": math.inf}, [1.0, 1.0]),
+]
+
+
+@pytest.mark.parametrize("K", [1, 10, 64])
+@pytest.mark.parametrize("case", range(len(ADMITTED)))
+def test_admitted_corners_run_on_k1d_and_match_the_oracle(corpus_pair, case, K):
+    corpus, p, o, snap = corpus_pair
+    kw, boosts = ADMITTED[case]
+    queries = corpus.queries(16, 3, salt=case) + ["", "zzzz"]
+    _run(snap, o, queries, kw, boosts, K, "ps::k_daat")
+
+
+@pytest.mark.parametrize("case", range(len(REJECTED)))
+def test_rejected_parameters_fall_through_to_k_score(corpus_pair, case):
+    corpus, p, o, snap = corpus_pair
+    kw, boosts = REJECTED[case]
+    queries = corpus.queries(16, 3, salt=100 + case)
+    _run(snap, o, queries, kw, boosts, 10, "ps::k_score")
+
+
+def test_all_ties_whole_batch_equals_the_streaming_kernel(corpus_pair):
+    """k1 = 0: the K-th best score is shared by thousands of documents; the pruned kernel and the streaming kernel must
+    return the same keys in the same order for every query of a larger batch."""
+    corpus, p, o, snap = corpus_pair
+    queries = corpus.queries(256, 3, salt=7)
+    sc = product_scorer("bm25", k1=0.0)
+    L = psa.load()
+    for K in (1, 10, 64):
+        a = snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=K)
+        assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_daat")
+        L.ps_set_option(b"PS_DAAT", 0)
+        try:
+            b = snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=K)
+            assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_score")
+        finally:
+            L.ps_set_option(b"PS_DAAT", 1)
+        assert [[(r.key, bits(r.score)) for r in rs] for rs in a] == [[(r.key, bits(r.score)) for r in rs] for rs in b], K
+
+
+def test_corners_under_a_delta_with_removals(corpus_pair):
+    """(last: it mutates the module's index)  Removed documents are tombstones until the next flatten; the tie order of
+    the survivors must not change."""
+    corpus, p, o, snap = corpus_pair
+    rng = random.Random(11)
+    for k in rng.sample(range(N_DOCS), 1500):
+        p.remove_document(k)
+        o.remove_document(k)
+    st = snap.update()
+    assert st["mode"] in (1, 2), st
+    queries = corpus.queries(24, 3, salt=9)
+    for kw, boosts in [({"k1": 0.0}, [1.0, 1.0]), ({"b": 0.0}, [2.0, 0.5]), ({}, [1.0, 1.0])]:
+        for K in (1, 10, 64):
+            _run(snap, o, queries, kw, boosts, K, "ps::k_daat")
+    _run(snap, o, queries, {"k1": -0.5}, [1.0, 1.0], 10, "ps::k_score")
