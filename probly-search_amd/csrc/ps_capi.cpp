@@ -404,10 +404,18 @@ ps_status ps_snapshot_update(ps_snapshot* snap, const ps_index* idx, ps_update_s
       if (snap->device >= 0) {
         try {
           eng.reset(new ps::Engine(*fresh, snap->device));
-        } catch (const std::exception&) {
+        } catch (const ps::DeviceOom&) {
+          // (only for lack of HBM: any other failure - wrong architecture, invalid device - propagates and leaves the
+          // old engine and snapshot in place)
           snap->engine.reset();
           snap->snap = fresh;
-          eng.reset(new ps::Engine(*fresh, snap->device));
+          try {
+            eng.reset(new ps::Engine(*fresh, snap->device));
+          } catch (const std::exception& e) {
+            throw std::runtime_error(std::string(e.what()) + " (ps_snapshot_update: the re-flattened snapshot does not fit the device even "
+                                     "with the old planes released; the handle now holds the fresh host copy WITHOUT an engine - queries "
+                                     "return PS_ENODEVICE until ps_snapshot_update succeeds)");
+          }
         }
       }
       snap->engine = std::move(eng);  // (the old engine still reads the old host arrays while it is torn down)

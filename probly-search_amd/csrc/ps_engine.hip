@@ -57,6 +57,10 @@ namespace ps {
 #define PS_HIP(call)                                                                            \
   do {                                                                                          \
     hipError_t _e = (call);                                                                     \
+    if (_e == hipErrorOutOfMemory) {                                                            \
+      (void)hipGetLastError();                                                                  \
+      throw ps::DeviceOom(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #call);   \
+    }                                                                                           \
     if (_e != hipSuccess)                                                                       \
       throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #call); \
   } while (0)
@@ -145,6 +149,7 @@ struct Tuning {
   uint32_t z21_field_prune = 1;  // PS_Z21_FIELD_PRUNE: k_score<MODE_Z21S> drops fields whose pool bound fell below the query's threshold
   uint32_t daat_multi = 1;       // PS_DAAT_MULTI: also take batches with several expansions per query term (0: they stay on K1)
   uint32_t daat_small = 1;       // PS_DAAT_SMALL: plans of <= 4 lists, one per query term, take k_daat_small (all lookups of a trip in flight together)
+  uint32_t kernel_timers = 1;    // PS_KERNEL_TIMERS: HIP timing events around the K1d scoring launches (ps_snapshot_kernel_breakdown); 0 in a serving setup
   uint32_t work_counters = 1;    // PS_WORK_COUNTERS: the headline kernels (k_daat_small, k_daat_z) keep the work counters of ps_snapshot_work_counters (0: the serving instantiations, which carry none; the other kernels always count)
   uint32_t daat_z_d0_div = 8;    // PS_DAAT_Z_D0_DIV: K1dz evaluates the documents below D0 ~ N / this first (threshold sample; tie threshold)
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
@@ -747,6 +752,7 @@ void Tuning::load() {
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
     daat_z = env_u32("PS_DAAT_Z", daat_z);
     work_counters = env_u32("PS_WORK_COUNTERS", work_counters);
+    kernel_timers = env_u32("PS_KERNEL_TIMERS", kernel_timers);
     daat_z_d0_div = env_u32("PS_DAAT_Z_D0_DIV", daat_z_d0_div);
     z21_field_prune = env_u32("PS_Z21_FIELD_PRUNE", z21_field_prune);
     z21_exact_numerator = env_u32("PS_Z21_EXACT_NUMERATOR", z21_exact_numerator);
@@ -1913,19 +1919,24 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     kp.cand_score = c.cand_score.p;
     kp.cand_doc = c.cand_doc.p;
     kp.out_keys = (uint64_t*)d_keys; kp.out_scores = (double*)d_scores; kp.out_counts = (uint32_t*)d_counts;
-    kt = &m.kt[m.next_kt];
-    m.next_kt = (m.next_kt + 1) % N_KTIMER;
-    m.harvest(*kt, true);
-    kt->split = true;
+    // (PS_KERNEL_TIMERS=0: no HIP timing events around the launches - four stream packets less per batch between two
+    // consecutive scoring kernels; ps_snapshot_kernel_breakdown then has nothing to report for these batches)
+    const bool timers = m.tune.kernel_timers != 0;
+    if (timers) {
+      kt = &m.kt[m.next_kt];
+      m.next_kt = (m.next_kt + 1) % N_KTIMER;
+      m.harvest(*kt, true);
+      kt->split = true;
+    }
     // K0b on the preparation stream too: the rows to score were listed on the device (k_prep_finish); a fixed
     // grid takes (row, tile range) units.  (It evaluates the BM25 expression itself: no table involved.)
-    PS_HIP(hipEventRecord(kt->a, P));
+    if (timers) PS_HIP(hipEventRecord(kt->a, P));
     if (m.cands.n && !zb) {
       const uint32_t per_row = std::min(2048u, std::max(256u, kp.n_tiles));
       const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)per_row * m.cands.n, 4096);
       hipLaunchKernelGGL(k_dense_rows_dyn, dim3(grid), dim3(256), 0, P, kp, c.rows.p, c.ctl, per_row);
     }
-    PS_HIP(hipEventRecord(kt->r, P));
+    if (timers) PS_HIP(hipEventRecord(kt->r, P));
     PS_HIP(hipEventRecord(c.prepared, P));
     // ---- scoring stream ----
     PS_HIP(hipStreamWaitEvent(S, c.prepared, 0));
@@ -1939,7 +1950,7 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     PS_HIP(hipMemsetAsync(trace_buf.p, 0, (size_t)kp.n_ditems * 32, S));
     kp.item_trace = trace_buf.p;
 #endif
-    PS_HIP(hipEventRecord(kt->m, S));
+    if (timers) PS_HIP(hipEventRecord(kt->m, S));
     if (zb) launch_daat_z(m, kp, S);
     else launch_daat(m, kp, multi, max_entries <= (uint32_t)DAAT_SMALL_MAX, m.n_cu, S);
 #ifdef PS_ITEM_TRACE
@@ -1952,8 +1963,10 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     }
 #endif
     PS_HIP(hipGetLastError());
-    PS_HIP(hipEventRecord(kt->b, S));
-    kt->pending = true;
+    if (timers) {
+      PS_HIP(hipEventRecord(kt->b, S));
+      kt->pending = true;
+    }
     m.last_kt = kt;
     PS_HIP(hipEventRecord(c.scored, S));
     S = m.merge_stream;
@@ -2398,6 +2411,9 @@ PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
   hipStream_t st = m.plan_stream;
   const size_t n_bytes = B ? (size_t)offsets[B] : 0;
   if (n_bytes >= 0xFFFFFFF0ull) throw std::length_error("device planner: more than 4 GiB of query text");
+  // k_plan follows the offsets without further checks: they must ascend and stay inside the text
+  for (size_t q = 0; q < B; ++q)
+    if (offsets[q] > offsets[q + 1] || offsets[q + 1] > offsets[B]) throw std::invalid_argument("query offsets must be non-decreasing and end at offsets[n_queries]");
   const size_t off_bytes = (B + 1) * 8, text_at = (off_bytes + 15) & ~(size_t)15;
   ps_.h.ensure(text_at + n_bytes + 16);  // (its previous copy finished before the previous totals were read)
   memcpy(ps_.h.p, offsets, off_bytes);

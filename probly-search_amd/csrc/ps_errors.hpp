@@ -14,5 +14,10 @@ struct NoDeviceError : std::runtime_error {
 struct RcclError : std::runtime_error {
   explicit RcclError(const std::string& m) : std::runtime_error(m) {}
 };
+// hipErrorOutOfMemory from an allocation (still PS_EHIP at the ABI): the one device error ps_snapshot_update answers
+// by releasing the old planes and trying again
+struct DeviceOom : std::runtime_error {
+  explicit DeviceOom(const std::string& m) : std::runtime_error(m) {}
+};
 
 }  // namespace ps

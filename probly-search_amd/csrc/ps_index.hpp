@@ -14,6 +14,7 @@
 #include <string_view>
 #include <unordered_map>
 #include <unordered_set>
+#include <mutex>
 #include <vector>
 
 #include "../../include/probly_search_amd.h"
@@ -160,7 +161,10 @@ class Index {
   int32_t root() const { return 0; }
   uint64_t epoch() const { return epoch_; }  // bumped by every mutation
   // Starts the change log at the current epoch (called by the flattener: a snapshot exists that can replay it).
+  // (const + mutable: snapshots take a const Index&, and two threads may take snapshots of one index at once - the
+  // header only asks for external exclusion around MUTATION - so the switch is guarded)
   void enable_change_log() const {
+    std::lock_guard<std::mutex> lock(log_mu_);
     if (log_enabled_) return;
     log_enabled_ = true;
     log_.clear();
@@ -200,6 +204,7 @@ class Index {
   mutable uint64_t log_base_ = 0;
   mutable size_t log_postings_ = 0;
   mutable bool log_enabled_ = false;
+  mutable std::mutex log_mu_;
   void log_push(IndexChange&& c);
   // add_document scratch
   std::vector<const char*> sp_;

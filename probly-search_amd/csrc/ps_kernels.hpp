@@ -1638,7 +1638,17 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
     const double own_eb = own.boost;
     const uint64_t own_off = own.post_off;
     const uint32_t own_rank = de.rank;
-    const double skip_thr = de.skip_thr, others = de.others;
+    const double skip_thr = de.skip_thr;
+    // What the OTHER lists can add to a document evaluated here.  A document is evaluated from its highest-ranked list
+    // only, so one that is evaluated here sits in no list ranked above the own one: for plans with one list per query
+    // term that is the sum of the bounds of the lists ranked BELOW it (the preparation's `others` counts every other list:
+    // still what the plan-order fallback arms use).
+    double others = de.others;
+    if (!MULTI && e1 - e0 <= 64u) {
+      others = 0.0;
+      for (uint32_t r = e0 + own_rank + 1u; r < e1; ++r) others += p.dentry[p.rorder[r]].ub;
+      others *= 1.0 + 1e-9;
+    }
     // multi-expansion queries: the query term of this list, and per query term the bound of its best
     // OTHER list (what pass 1 starts from)
     uint32_t own_grp = 0xFFFFFFFFu;
@@ -1646,9 +1656,10 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
     if (MULTI && p.dgroup != nullptr && e1 - e0 <= 64u) {
       own_grp = p.dgroup[e_own].grp;
       if (own_grp < 4u) {
-        for (uint32_t r = e1; r-- > e0;) {  // ascending bound: the last write per term is its best list
+        // (only the lists ranked BELOW the own one: a document evaluated here sits in no higher-ranked list - it would be
+        // evaluated there -, so those can add nothing; they are only asked, last, whether they cancel a survivor)
+        for (uint32_t r = e1; r-- > e0 + own_rank + 1u;) {  // ascending bound: the last write per term is its best list
           const uint32_t j = p.rorder[r];
-          if (j == e_own) continue;
           const DGroup gj = p.dgroup[j];
 #pragma unroll
           for (int g = 0; g < 4; ++g)
@@ -1681,9 +1692,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
         __shared__ double mq_s1[DAAT_WGW][QCAP];
         uint32_t q_head = 0, q_n = 0;  // wave-uniform
         const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-        uint32_t r1 = e1;
-        for (uint32_t r = e0; r < e1; ++r)
-          if (p.rorder[r] != e_own) { r1 = r; break; }
+        const uint32_t r1 = min(e1, e0 + own_rank + 1u);  // the highest-bound list ranked below the own one
         const bool has1 = r1 < e1;
         const uint32_t j1 = has1 ? p.rorder[r1] : e_own;
         const ps_plan_entry& en1 = p.plan[j1];
@@ -1748,6 +1757,14 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
               }
               any_alive = __any(alive1[0]);
             }
+          }
+          // the survivors: is the document in a list ranked above the own one?  Then it is evaluated there, not here.
+          for (uint32_t r = e0; r < e0 + own_rank && any_alive; ++r) {
+            const ps_plan_entry& en = p.plan[p.rorder[r]];
+            double s[1];
+            lookup_scores<F_, 1>(p, lut, en, d1, alive1, s, ws);
+            if (s[0] > 0.0) alive1[0] = false;
+            any_alive = __any(alive1[0]);
           }
 #ifdef PS_MQ_TIME
           mq_tb1 += __builtin_amdgcn_s_memrealtime() - t_b0;
@@ -1829,8 +1846,11 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
           bool any_alive = false;
 #pragma unroll
           for (int u = 0; u < UA; ++u) {
-            // everything the other entries could add, at most: below theta the document is out
-            alive[u] = alive[u] && (s_own[u] + others >= theta) && !(p.ablate & 32u);  // (debug: 32 = no lookups)
+            // everything the lower-ranked lists could add, at most (per query term the best of them): below theta the document is out
+            double b0 = 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b0 += fmax((uint32_t)g == own_grp ? s_own[u] : 0.0, rem0[g]);
+            alive[u] = alive[u] && (b0 >= theta) && !(p.ablate & 32u);  // (debug: 32 = no lookups)
             any_alive |= alive[u];
             ws.reached += lanes_on(alive[u]);
           }
@@ -1923,9 +1943,9 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
           unsigned long long hits[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) { bound[u] = s_own[u] + others; hits[u] = 0ull; }
-          for (uint32_t r = e0; r < e1 && any_alive; ++r) {
+          for (uint32_t r = e0 + own_rank + 1u; r < e1 && any_alive; ++r) {  // (the lists ranked below the own one: see others_low)
             const uint32_t j = p.rorder[r];
-            if (j != e_own) {
+            {
               const ps_plan_entry& en = p.plan[j];
               const DEntry dj = p.dentry[j];
               double s[U];
@@ -1943,6 +1963,16 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
               }
               any_alive = __any(any);
             }
+          }
+          // the survivors: a document that sits in a list ranked above the own one is evaluated there, not here
+          for (uint32_t r = e0; r < e0 + own_rank && any_alive; ++r) {
+            const ps_plan_entry& en = p.plan[p.rorder[r]];
+            double s[U];
+            lookup_scores<F_, U>(p, lut, en, d, alive, s, ws);
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { if (s[u] > 0.0) alive[u] = false; any |= alive[u]; }
+            any_alive = __any(any);
           }
           // Pass 2, the few survivors: the sum in PLAN order (query.rs:33-89; one list per query term:
           // always the `+` / assign arm, 0.0 + s == s), same operands, same order, same bits

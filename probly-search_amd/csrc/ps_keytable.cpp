@@ -111,7 +111,17 @@ struct ps_keytable {
       }
     }
     if (n >= 0xFFFFFFF0u) throw std::length_error("key table holds at most 2^32-16 keys (the engine's document limit)");
-    arena.insert(arena.end(), reinterpret_cast<const char*>(p), reinterpret_cast<const char*>(p) + len);
+    // Room for the new end offset first: if that allocation throws, the arena has not grown (a stray tail would be
+    // glued to the next key).  A key that points into the arena itself (a ps_str handed out by ps_keytable_key /
+    // ps_keytable_resolve) is copied before the arena may reallocate under it.
+    off.reserve(off.size() + 1);
+    const char* src = reinterpret_cast<const char*>(p);
+    std::string own;
+    if (!arena.empty() && src >= arena.data() && src < arena.data() + arena.size()) {
+      own.assign(src, len);
+      src = own.data();
+    }
+    arena.insert(arena.end(), src, src + len);
     off.push_back(arena.size());
     cells[s] = Cell{tag, uint32_t(n + 1)};
     if (inserted) *inserted = true;
