@@ -151,7 +151,9 @@ struct Tuning {
   uint32_t daat_small = 1;       // PS_DAAT_SMALL: plans of <= 4 lists, one per query term, take k_daat_small (all lookups of a trip in flight together)
   uint32_t kernel_timers = 1;    // PS_KERNEL_TIMERS: HIP timing events around the K1d scoring launches (ps_snapshot_kernel_breakdown); 0 in a serving setup
   uint32_t work_counters = 1;    // PS_WORK_COUNTERS: the headline kernels (k_daat_small, k_daat_z) keep the work counters of ps_snapshot_work_counters (0: the serving instantiations, which carry none; the other kernels always count)
-  uint32_t daat_z_d0_div = 8;    // PS_DAAT_Z_D0_DIV: K1dz evaluates the documents below D0 ~ N / this first (threshold sample; tie threshold)
+XX
+  uint32_t daat_z_level_shift = 2;  // PS_DAAT_Z_LEVEL_SHIFT: the levels below it are 2^shift apart
+  uint32_t daat_z_levels = 3;    // PS_DAAT_Z_LEVELS: how many of them (1..3)
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
   uint32_t device_plan = 1;      // PS_DEVICE_PLAN: flat BM25 top-k batches (built-in tokenizer) are planned by k_plan on the device
   void load();
@@ -754,6 +756,8 @@ void Tuning::load() {
     work_counters = env_u32("PS_WORK_COUNTERS", work_counters);
     kernel_timers = env_u32("PS_KERNEL_TIMERS", kernel_timers);
     daat_z_d0_div = env_u32("PS_DAAT_Z_D0_DIV", daat_z_d0_div);
+    daat_z_level_shift = env_u32("PS_DAAT_Z_LEVEL_SHIFT", daat_z_level_shift);
+    daat_z_levels = env_u32("PS_DAAT_Z_LEVELS", daat_z_levels);
     z21_field_prune = env_u32("PS_Z21_FIELD_PRUNE", z21_field_prune);
     z21_exact_numerator = env_u32("PS_Z21_EXACT_NUMERATOR", z21_exact_numerator);
 }
@@ -1877,7 +1881,7 @@ bool daat_eligible(const EngineImpl& m, const ps_scorer_desc& sc, const double* 
 struct ZBatch {
   const double* d_ubnum;  // [ne]
   const double* d_zub;    // [ne][F]
-  uint32_t d0;            // doc id that separates the chunks that publish the tie threshold from those that use it (0 = off)
+  uint32_t dl[Z_LEVELS];  // doc ids D_0 < D_1 < ... of the tie-threshold levels, Z_NO_LEVEL for a level that does not exist
 };
 void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KParams& kp, ps_plan_entry* d_plan, const uint32_t* d_qbeg,
                    size_t B, size_t ne, size_t items_bound);
@@ -1898,9 +1902,10 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     const size_t n_thr = B + 2;
     bool fresh = c.gthr.ensure(n_thr, true);
     kp.gthr = c.gthr.p;
-    if (zb) {  // (a second threshold word per query; zeroed behind the batch by k_merge_items like the first)
-      fresh = c.gtie.ensure(n_thr, true) || fresh;
+    if (zb) {  // (Z_LEVELS more threshold words per query; zeroed behind the batch by k_merge_items like the first)
+      fresh = c.gtie.ensure(n_thr * Z_LEVELS, true) || fresh;
       kp.gtie = c.gtie.p;
+      kp.z_tstride = (uint32_t)n_thr;
     }
     if (!(c.ctl_clean && !fresh)) {
       PS_HIP(hipMemsetAsync(c.gthr.p, 0, c.gthr.cap * 8, P));
@@ -2027,7 +2032,7 @@ void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KPar
   ensure_bloom(m, st);
   kp.bloom = m.d_bloom.p;
   kp.layer_bloom = m.d_layer_bloom.p;
-  c.dentry.ensure(ne + 1); c.gen.ensure(ne + 1); c.z_nbelow.ensure(ne + 1); c.z_nabove.ensure(ne + 1);
+  c.dentry.ensure(ne + 1); c.gen.ensure(ne + 1); c.z_nbelow.ensure(ne * Z_LEVELS + 1); c.z_nabove.ensure(ne * Z_LEVELS + 1);
   c.qslot.ensure(B + 1); c.qslot_n.ensure(B + 1);
   c.ditems.ensure(items_bound + 1);
   c.cand_cnt.ensure(items_bound + 1);
@@ -2036,7 +2041,7 @@ void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KPar
   pp.plan = d_plan; pp.qbeg = d_qbeg; pp.zub = zb.d_zub; pp.table = m.d_table;
   pp.B = (uint32_t)B; pp.ne = (uint32_t)ne; pp.F = s.F;
   pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div;
-  pp.d0_tile = zb.d0 >> kp.t_log2;
+  for (int l = 0; l < Z_LEVELS; ++l) pp.dl_tile[l] = zb.dl[l] == Z_NO_LEVEL ? 0u : zb.dl[l] >> kp.t_log2;
   pp.dentry = c.dentry.p; pp.gen = c.gen.p; pp.nbelow = c.z_nbelow.p; pp.nabove_from = c.z_nabove.p;
   pp.qslot = c.qslot.p; pp.qslot_n = c.qslot_n.p;
   pp.items = c.ditems.p; pp.items_cap = (uint32_t)items_bound;
@@ -2053,7 +2058,7 @@ void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KPar
   kp.prep_ctl_words = (uint32_t)(sizeof(PrepCtl) / 4);
   kp.cand_cnt = c.cand_cnt.p;
   kp.z_ubnum = zb.d_ubnum;
-  kp.z_d0 = zb.d0;
+  for (int l = 0; l < Z_LEVELS; ++l) kp.z_dl[l] = zb.dl[l];
 }
 
 void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st) {
@@ -2185,14 +2190,24 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   ZBatch zb;
   zb.d_ubnum = reinterpret_cast<const double*>(c.stage.p + off_u);
   zb.d_zub = reinterpret_cast<const double*>(c.stage.p + off_z);
-  // D0: a power of two (so it is a slot boundary of every list's table up to that coarseness) near a 16th of the id space
-  uint32_t d0 = 0;
-  const uint64_t div = std::max(2u, m.tune.daat_z_d0_div);
-  if (s.n_ids >= div * s.T) {
-    d0 = s.T;
-    while ((uint64_t)d0 * 2 <= s.n_ids / div) d0 *= 2;
+  // the levels: powers of two (slot boundaries of every list's table up to that coarseness), the top one near N / 8, the
+  // others 2^PS_DAAT_Z_LEVEL_SHIFT apart below it; a level of less than one tile does not exist
+  {
+    const uint64_t div = std::max(2u, m.tune.daat_z_d0_div);
+    uint64_t top = 0;
+    if (s.n_ids >= div * s.T) {
+      top = s.T;
+      while (top * 2 <= s.n_ids / div) top *= 2;
+    }
+    const uint32_t want = std::min<uint32_t>(std::max(1u, m.tune.daat_z_levels), Z_LEVELS), shift = std::min(m.tune.daat_z_level_shift, 8u);
+    int n = 0;
+    for (uint32_t k = 0; k < want && top; ++k) {
+      const uint64_t d = top >> (shift * k);
+      if (d >= s.T && (n == 0 || d < zb.dl[n - 1])) zb.dl[n++] = (uint32_t)d;
+    }
+    std::sort(zb.dl, zb.dl + n);
+    for (; n < Z_LEVELS; ++n) zb.dl[n] = Z_NO_LEVEL;
   }
-  zb.d0 = d0;
   enqueue_daat(m, c, sc, boosts, reinterpret_cast<ps_plan_entry*>(c.stage.p), reinterpret_cast<const uint32_t*>(c.stage.p + off_q),
                reinterpret_cast<const uint32_t*>(c.stage.p + off_l), B, ne, plan.max_qterms, plan.max_entries, false, n_items, max_slots, top_k,
                d_keys, d_scores, d_counts, caller, &zb);

@@ -167,7 +167,8 @@ struct KParams {
   unsigned long long* gthr;  // [B] bits of the best published local K-th score per query (0 = none)
   unsigned long long* gtie;  // K1dz (ps_z21_daat.hpp): [B] the same among chunks that lie below doc id D0; zeroed by k_merge_items
   const double* z_ubnum;     // K1dz: [n_plan_entries] largest record numerator of the list
-  uint32_t z_d0;             // K1dz: the doc id D0 (0 = tie thresholds off)
+  uint32_t z_dl[3];          // K1dz: the doc ids D_0 < D_1 < D_2 of the tie-threshold levels (0xFFFFFFFF: the level does not exist)
+  uint32_t z_tstride;        // K1dz: words between gtie[l] and gtie[l + 1]
   double* cand_score;  // [B * n_super * K]
   uint32_t* cand_doc;
   // full-result mode
@@ -1335,7 +1336,8 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
   if (lane == 0) {
     p.out_counts[q] = tk.n;
     p.gthr[q] = 0ull;
-    if (p.gtie != nullptr) p.gtie[q] = 0ull;
+    if (p.gtie != nullptr)
+      for (uint32_t l = 0; l < 3u; ++l) p.gtie[(size_t)l * p.z_tstride + q] = 0ull;
     if (q == 0) *p.work_counter = 0u;
   }
 }
@@ -2546,7 +2548,8 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge_items(const KParam
   if (lane == 0) {
     p.out_counts[q] = tk.n;
     p.gthr[q] = 0ull;
-    if (p.gtie != nullptr) p.gtie[q] = 0ull;
+    if (p.gtie != nullptr)
+      for (uint32_t l = 0; l < 3u; ++l) p.gtie[(size_t)l * p.z_tstride + q] = 0ull;
     if (q == 0) *p.work_counter = 0u;
   }
   // the preparation's control words (bucket counts, row uses, ...) are consumed: clean for the next batch

@@ -24,7 +24,7 @@ namespace ps {
 
 constexpr uint32_t PREP_CLASSES = 64;                 // length classes of the rank-0 and of the rank-1 lists (log2 with one fractional bit)
 constexpr uint32_t PREP_RANKS = 8;                    // ranks 2..7 get a bucket each, everything above shares the last
-constexpr uint32_t PREP_BUCKETS = 2 * PREP_CLASSES + PREP_RANKS;
+constexpr uint32_t PREP_BUCKETS = 2 * PREP_CLASSES + PREP_RANKS + 8;  // (K1d uses the first 2 * PREP_CLASSES + PREP_RANKS; K1dz 4 per phase + those)
 constexpr uint32_t PREP_MAX_ROWS = 64;                // dense-row candidates per snapshot
 constexpr uint32_t NO_CAND = 0xFFu;
 

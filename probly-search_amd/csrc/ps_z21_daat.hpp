@@ -29,10 +29,14 @@
 // rationals: thousands of documents tie at the threshold, and "strictly below" pruning keeps all of them alive
 // (round 2's k_daat_z: 15-30 % of the postings).  Two words per query:
 //   gthr[q]  K-th best score of ANY wave of the query (as k_daat_small): prunes bound <  gthr;
-//   gtie[q]  K-th best score of a wave that has only scanned documents below doc id D0 so far (a power of two near
-//            N / 16; doc ids ascend along a chunk): K documents with ids < D0 score >= gtie, so a trip whose
-//            postings all lie at or above D0 also prunes bound == gtie, and so does the whole-chunk skip test of
-//            a chunk that starts at or above D0 (ZITEM_ABOVE, from the list's tile-offset table).
+//   gtie[l][q]  (Z_LEVELS words per query) K-th best score of a wave that has only scanned documents below doc id D_l so
+//            far (D_0 < D_1 < D_2: powers of two, D_2 near N / 8, a factor 4 apart; doc ids ascend along a chunk): K
+//            documents with ids < D_l score >= gtie[l], so a trip whose postings all lie at or above D_l also prunes
+//            bound == gtie[l], and so does the whole-chunk skip test of a chunk that starts at or above D_l (its level
+//            rides in DItem::count, from the list's tile-offset table).
+// Launch order: the chunks that lie entirely below D_0 first, then those below D_1, below D_2, then the rest (rank-major
+// within a phase).  The first phase is a sample of the document space evaluated almost unpruned; each later phase is
+// several times larger and pruned with what the earlier ones left.
 #pragma once
 #include "ps_prep_kernels.hpp"
 
@@ -41,8 +45,10 @@ namespace ps {
 #ifndef PS_DAAT_ZU
 #define PS_DAAT_ZU 4   // postings per lane in flight in the scan
 #endif
-constexpr uint32_t ZITEM_ABOVE = 0x80000000u;  // DItem::count bit 31: every document of the chunk has id >= D0 (its whole-chunk skip test may use the tie threshold)
+constexpr int Z_LEVELS = 3;
+constexpr uint32_t ZITEM_LEVEL_SHIFT = 30;     // DItem::count bits 30-31: levels l (the lowest ones) with every document of the chunk at or above D_l
 constexpr uint32_t ZITEM_COUNT = 0x3FFFFFFFu;
+constexpr uint32_t Z_NO_LEVEL = 0xFFFFFFFFu;   // KParams::z_dl of a level that does not exist (tiny corpora)
 constexpr int Z_FLN = 64;                      // field lengths the bound table holds (entry 63 stands for >= 63)
 constexpr int Z_ALL = 0x7FFFFFFF, Z_NONE = -1;
 
@@ -52,11 +58,11 @@ struct ZPrepParams {
   const double* zub;           // [ne][F]
   const uint32_t* table;
   uint32_t B, ne, F, chunk_min, split_div;
-  uint32_t d0_tile;            // D0 >> t_log2; 0 = no D0 (tie thresholds off)
+  uint32_t dl_tile[Z_LEVELS];  // D_l >> t_log2; 0 = the level does not exist
   DEntry* dentry;
   DItemGen* gen;
-  uint32_t* nbelow;            // [ne] chunks of the list that lie entirely below D0 (placed first in the launch)
-  uint32_t* nabove_from;       // [ne] first chunk that lies entirely at or above D0 (= chunks: none / not known)
+  uint32_t* nbelow;            // [ne][Z_LEVELS] chunks of the list that lie entirely below D_l (non-decreasing in l)
+  uint32_t* nabove_from;       // [ne][Z_LEVELS] first chunk that lies entirely at or above D_l (= chunks: none / not known)
   uint32_t* qslot;
   uint32_t* qslot_n;
   DItem* items;
@@ -64,16 +70,16 @@ struct ZPrepParams {
   PrepCtl* ctl;
 };
 
-// Item order: the chunks below D0 of every list first (rank-major among them) - a sample of the document space that
-// is evaluated almost unpruned and leaves thresholds close to the final ones, tie threshold included - then the rest
-// rank-major like K1d (every query's shortest list first, longest lists first within a rank).  Measured on C3: the
-// plain rank-major order scanned 202 M postings per batch (1.34 ms), this one 80 M (0.56 ms) with D0 = N / 8
-// (N / 16: 91 M, 0.61 ms; N / 32: 121 M, 0.79 ms; N / 4: 90 M, 0.67 ms; profiles/r04_c3_d0_sweep.jsonl).
-__device__ __forceinline__ uint32_t zprep_bucket(const bool below, const uint32_t rank, const uint32_t len) {
-  if (below) return rank < 3u ? rank : 3u;
-  return rank <= 1u ? 4u + prep_bucket(rank, len) : 4u + 2u * PREP_CLASSES + (rank - 2u < 3u ? rank - 2u : 3u);
+// Item order: phase-major (phase = the levels a chunk is NOT entirely below: 0 = below D_0 ... Z_LEVELS = the rest), rank-major
+// within a phase; the last phase - most of the launch - as K1d orders it (every query's shortest list first, longest
+// lists first within a rank).  Measured on C3 with one level: plain rank-major order scanned 202 M postings per batch
+// (1.34 ms), the sample below D = N / 8 first 80 M (0.56 ms; N / 16: 91 M, N / 32: 121 M, N / 4: 90 M -
+// profiles/r04_c3_d0_sweep.jsonl).
+__device__ __forceinline__ uint32_t zprep_bucket(const uint32_t phase, const uint32_t rank, const uint32_t len) {
+  if (phase < (uint32_t)Z_LEVELS) return phase * 4u + (rank < 3u ? rank : 3u);
+  return 4u * Z_LEVELS + (rank <= 1u ? prep_bucket(rank, len) : 2u * PREP_CLASSES + (rank - 2u < 3u ? rank - 2u : 3u));
 }
-static_assert(4u + 2u * PREP_CLASSES + 4u <= PREP_BUCKETS, "K1dz item buckets fit the preparation's control block");
+static_assert(4u * Z_LEVELS + 2u * PREP_CLASSES + 4u <= PREP_BUCKETS, "K1dz item buckets fit the preparation's control block");
 
 // Thread per query: processing order (shortest list first: the long lists are the ones that become non-essential;
 // any order is exact), skip thresholds, chunking, candidate slots, bucket totals.
@@ -123,28 +129,42 @@ __global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {
 #pragma unroll
   for (int i = 0; i < NMAX; ++i) {  // (wave-uniform trip count: the aggregated atomics need every lane)
     const bool on = (uint32_t)i < n;
-    uint32_t nc = 0, nb = 0, bk0 = 0, bk1 = 0;
+    uint32_t nc = 0, nb[Z_LEVELS + 1], len_i = 0;
+#pragma unroll
+    for (int l = 0; l <= Z_LEVELS; ++l) nb[l] = 0;
     if (on) {
       const ps_plan_entry& en = pp.plan[b + i];
       const uint32_t c = prep_chunk_of(pp.split_div, pp.chunk_min, en.len);
       nc = (en.len + c - 1) / c;
-      uint32_t na = nc;
+      len_i = en.len;
       const uint32_t sh = en.shift & 0xFFu;
-      if (pp.d0_tile && (pp.d0_tile & ((1u << sh) - 1u)) == 0u) {
-        // postings of the list with doc id < D0: the table slot that starts at D0 (slots span T << shift documents)
-        const uint32_t p0 = min(en.len, pp.table[en.tbl_off + (pp.d0_tile >> sh)]);
-        nb = p0 >= en.len ? nc : p0 / c;  // chunks [0, nb) end at or before p0
-        na = (p0 + c - 1) / c;            // chunks [na, nc) start at or after p0
+      uint32_t prev = 0;
+#pragma unroll
+      for (int l = 0; l < Z_LEVELS; ++l) {
+        uint32_t na = nc, below = prev;  // (what lies below D_(l-1) lies below D_l)
+        const uint32_t dt = pp.dl_tile[l];
+        if (dt && (dt & ((1u << sh) - 1u)) == 0u) {
+          // postings of the list with doc id < D_l: the table slot that starts at D_l (slots span T << shift documents)
+          const uint32_t p0 = min(en.len, pp.table[en.tbl_off + (dt >> sh)]);
+          below = max(below, p0 >= en.len ? nc : p0 / c);  // chunks [0, below) end at or before p0
+          na = (p0 + c - 1) / c;                            // chunks [na, nc) start at or after p0
+        }
+        nb[l] = below;
+        prev = below;
+        pp.nbelow[(size_t)(b + i) * Z_LEVELS + l] = below;
+        pp.nabove_from[(size_t)(b + i) * Z_LEVELS + l] = na;
       }
+      nb[Z_LEVELS] = nc;
       pp.gen[b + i] = DItemGen{b + i, 0u, c, sl};
-      pp.nbelow[b + i] = nb;
-      pp.nabove_from[b + i] = na;
       sl += nc;
-      bk0 = zprep_bucket(true, rank[i], en.len);
-      bk1 = zprep_bucket(false, rank[i], en.len);
     }
-    wave_add_by_key_noret(pp.ctl->bucket_total, bk0, nb, on && nb != 0);
-    wave_add_by_key_noret(pp.ctl->bucket_total, bk1, nc - nb, on && nc != nb);
+    uint32_t lo = 0;
+#pragma unroll
+    for (int ph = 0; ph <= Z_LEVELS; ++ph) {  // chunks [lo, nb[ph]) are in phase ph
+      const uint32_t cnt = on && nb[ph] > lo ? nb[ph] - lo : 0u;
+      wave_add_by_key_noret(pp.ctl->bucket_total, zprep_bucket((uint32_t)ph, rank[i], len_i), cnt, cnt != 0);
+      lo = max(lo, nb[ph]);
+    }
   }
   __threadfence();
   uint32_t t = 0;
@@ -165,31 +185,49 @@ __global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {
   }
 }
 
-// Thread per list: its items (bit 31 of the count: the chunk starts at or above D0).
+// Thread per list: its items, each in the bucket of its phase; bits 30-31 of the count: the levels the chunk starts at or above.
 __global__ __launch_bounds__(2 * WAVE) void k_zprep_items(const ZPrepParams pp) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = i < pp.ne;
-  uint32_t nc = 0, nb = 0, na = 0, bk0 = 0, bk1 = 0, len = 0, chunk = 1, first_slot = 0;
+  uint32_t nc = 0, len = 0, chunk = 1, first_slot = 0, rank = 0;
+  uint32_t nb[Z_LEVELS + 1], na[Z_LEVELS];
+#pragma unroll
+  for (int l = 0; l <= Z_LEVELS; ++l) nb[l] = 0;
+#pragma unroll
+  for (int l = 0; l < Z_LEVELS; ++l) na[l] = 0;
   if (have) {
     const ps_plan_entry& en = pp.plan[i];
     const DItemGen g = pp.gen[i];
     len = en.len; chunk = g.chunk; first_slot = g.first_slot;
     nc = (len + chunk - 1) / chunk;
-    nb = pp.nbelow[i];
-    na = pp.nabove_from[i];
-    const uint32_t rank = pp.dentry[i].rank;
-    bk0 = zprep_bucket(true, rank, len);
-    bk1 = zprep_bucket(false, rank, len);
+#pragma unroll
+    for (int l = 0; l < Z_LEVELS; ++l) {
+      nb[l] = pp.nbelow[(size_t)i * Z_LEVELS + l];
+      na[l] = pp.nabove_from[(size_t)i * Z_LEVELS + l];
+    }
+    nb[Z_LEVELS] = nc;
+    rank = pp.dentry[i].rank;
   }
-  const uint32_t off0 = wave_add_by_key(pp.ctl->bucket_fill, bk0, nb, have && nb != 0);
-  const uint32_t off1 = wave_add_by_key(pp.ctl->bucket_fill, bk1, nc - nb, have && nc != nb);
+  uint32_t at[Z_LEVELS + 1], lo = 0;
+#pragma unroll
+  for (int ph = 0; ph <= Z_LEVELS; ++ph) {  // chunks [lo, nb[ph]) are in phase ph
+    const uint32_t cnt = have && nb[ph] > lo ? nb[ph] - lo : 0u;
+    const uint32_t bk = zprep_bucket((uint32_t)ph, rank, len);
+    const uint32_t off = wave_add_by_key(pp.ctl->bucket_fill, bk, cnt, cnt != 0);
+    at[ph] = cnt ? pp.ctl->bucket_start[bk] + off - lo : 0u;  // (so that chunk j of the phase lands at at[ph] + j)
+    lo = max(lo, nb[ph]);
+  }
   if (have) {
-    const uint32_t at0 = nb ? pp.ctl->bucket_start[bk0] + off0 : 0u;
-    const uint32_t at1 = nc != nb ? pp.ctl->bucket_start[bk1] + off1 : 0u;
     for (uint32_t j = 0; j < nc; ++j) {
       const uint32_t pb = j * chunk;
-      const uint32_t at = j < nb ? at0 + j : at1 + (j - nb);
-      if (at < pp.items_cap) pp.items[at] = DItem{i, pb, min(chunk, len - pb) | (j >= na ? ZITEM_ABOVE : 0u), first_slot + j};
+      uint32_t ph = 0, lv = 0;
+#pragma unroll
+      for (int l = 0; l < Z_LEVELS; ++l) { ph += j >= nb[l] ? 1u : 0u; lv += j >= na[l] ? 1u : 0u; }
+      uint32_t a = at[0];
+#pragma unroll
+      for (int l = 1; l <= Z_LEVELS; ++l) a = ph == (uint32_t)l ? at[l] : a;
+      a += j;
+      if (a < pp.items_cap) pp.items[a] = DItem{i, pb, min(chunk, len - pb) | (lv << ZITEM_LEVEL_SHIFT), first_slot + j};
     }
   }
 }
@@ -198,6 +236,24 @@ __global__ __launch_bounds__(2 * WAVE) void k_zprep_items(const ZPrepParams pp) 
 // tt: K documents with LOWER doc ids than anything this chunk holds score >= tt (0 = none / not applicable).
 __device__ __forceinline__ bool z_beats(const double v, const double ts, const double tt) {
   return v >= ts && (tt == 0.0 || v > tt);
+}
+
+// The tie threshold a chunk / trip may use whose documents all lie at or above the `lv` lowest levels: the best of
+// gtie[l][q], l < lv (each says: K documents with ids < D_l score at least this).
+__device__ __forceinline__ double z_tie_of(const KParams& p, const uint32_t q, const uint32_t lv) {
+  unsigned long long best = 0ull;  // (non-negative doubles order like their bit patterns)
+#pragma unroll
+  for (int l = 0; l < Z_LEVELS; ++l) {
+    const unsigned long long v = __hip_atomic_load(&p.gtie[(size_t)l * p.z_tstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)l < lv && v > best) best = v;
+  }
+  return __longlong_as_double((long long)best);
+}
+__device__ __forceinline__ uint32_t z_level_of(const KParams& p, const uint32_t d) {  // levels l with D_l <= d (the lowest ones)
+  uint32_t lv = 0;
+#pragma unroll
+  for (int l = 0; l < Z_LEVELS; ++l) lv += d >= p.z_dl[l] ? 1u : 0u;
+  return lv;
 }
 
 template <int F_, bool WC>  // WC: keep the work counters (ps_work_counters); the serving instantiation carries none
@@ -225,9 +281,8 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
       const DItem it0 = p.ditems[id];
       const DEntry de = p.dentry[it0.entry];
       const double ts = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      double tt = 0.0;
-      if (it0.count & ZITEM_ABOVE)
-        tt = __longlong_as_double((long long)__hip_atomic_load(&p.gtie[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const uint32_t lv = it0.count >> ZITEM_LEVEL_SHIFT;
+      const double tt = lv ? z_tie_of(p, de.q, lv) : 0.0;
       need = z_beats(de.skip_thr, ts, tt);
     }
     if (!__syncthreads_or(need)) {
@@ -296,9 +351,9 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   WorkStats ws;
   uint32_t q_head = 0, q_n = 0;  // wave-uniform
   const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-  double theta_s = 0.0, theta_t = 0.0;  // theta_t: the tie threshold the current trip may use (0 while the trip is not entirely at or above D0)
-  bool below = true;  // wave-uniform: every document scanned so far has id < D0 (doc ids ascend along the chunk)
-  const uint32_t d0 = p.z_d0;
+  double theta_s = 0.0, theta_t = 0.0;  // theta_t: the tie threshold of the current trip (0 while it is not entirely at or above D_0)
+  uint32_t tie_from = 0xFFFFFFFFu;      // ... which holds for the documents with ids >= tie_from (the boundary it was published below)
+  uint32_t pub_level = 0;               // wave-uniform: every document scanned so far has id < D_pub_level (doc ids ascend along the chunk)
 
   // Second level + the pools in the sorted record order + the top-K offer for the first `count` (<= 64) queued
   // documents, one per lane.
@@ -413,7 +468,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
       score = fmax(pool, score);
     }
     // (the queue may hold documents of a trip below D0 next to documents of one above it: the tie rule is per document)
-    const bool offer = ok && z_beats(score, theta_s, d >= d0 ? theta_t : 0.0);
+    const bool offer = ok && z_beats(score, theta_s, d >= tie_from ? theta_t : 0.0);
     ws.offer += cnt(offer);
     if (__any(offer)) topk_offer(tk, p.K, lane, offer, score, d, theta_s);
     q_head = (q_head + count) & (QCAP - 1u);
@@ -422,7 +477,8 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
       published = tk.thr_s;
       if (lane == 0) {
         atomicMax(&p.gthr[q], (unsigned long long)__double_as_longlong(tk.thr_s));
-        if (below && d0) atomicMax(&p.gtie[q], (unsigned long long)__double_as_longlong(tk.thr_s));
+        if (pub_level < (uint32_t)Z_LEVELS)
+          atomicMax(&p.gtie[(size_t)pub_level * p.z_tstride + q], (unsigned long long)__double_as_longlong(tk.thr_s));
       }
     }
   };
@@ -430,7 +486,9 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   bool first = true, essential = true;
   for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
     const unsigned long long sbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long tbits = d0 ? __hip_atomic_load(&p.gtie[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    unsigned long long tl[Z_LEVELS];
+#pragma unroll
+    for (int l = 0; l < Z_LEVELS; ++l) tl[l] = __hip_atomic_load(&p.gtie[(size_t)l * p.z_tstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t d[U], wv[U][F_], pi_l[U];
     bool inr[U];
 #pragma unroll
@@ -442,14 +500,28 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
       tfl_load<F_>(p, own_off + pi_l[u], wv[u]);
     }
     {
-      // the trip's place relative to D0: its first posting (lane 0 of slot 0) is its lowest doc id
-      const bool trip_above = d0 != 0u && (uint32_t)__builtin_amdgcn_readfirstlane((int)d[0]) >= d0;
-      bool over = false;
+      // the trip's place among the levels: its first posting (lane 0 of slot 0) is its lowest doc id, its last valid
+      // posting its highest
+      const uint32_t lv_first = z_level_of(p, (uint32_t)__builtin_amdgcn_readfirstlane((int)d[0]));
+      const uint32_t last = min(end - i0, (uint32_t)(WAVE * U)) - 1u;
+      uint32_t d_last = 0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) over = over || (inr[u] && d[u] >= d0);
-      if (__any(over)) below = false;
+      for (int u = 0; u < U; ++u)
+        if ((last >> 6) == (uint32_t)u) d_last = readlane_u32(d[u], (int)(last & 63u));
+      pub_level = max(pub_level, z_level_of(p, d_last));
+      unsigned long long tbits = 0ull;
+      uint32_t from = 0xFFFFFFFFu;
+#pragma unroll
+      for (int l = 0; l < Z_LEVELS; ++l) {
+        // (wave-uniform: one load instruction returned one value to the whole wave; the casts through uint32_t keep the
+        // int readfirstlane returns from sign-extending into the upper half)
+        const unsigned long long v = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tl[l]) |
+                                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tl[l] >> 32)) << 32);
+        if ((uint32_t)l < lv_first) { if (v > tbits) tbits = v; from = p.z_dl[l]; }
+      }
+      tie_from = from;
       const double ts = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(sbits >> 32)), __builtin_amdgcn_readfirstlane((int)(uint32_t)sbits));
-      const double tt = trip_above ? __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)), __builtin_amdgcn_readfirstlane((int)(uint32_t)tbits)) : 0.0;
+      const double tt = __longlong_as_double((long long)tbits);
       if (first || ts != theta_s || tt != theta_t) {
         theta_s = ts; theta_t = tt;
         set_flmax(ts, tt);

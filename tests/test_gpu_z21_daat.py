@@ -35,6 +35,8 @@ def _check(snap, o, queries, K, F, expect_kernel="ps::k_daat_z"):
     got = _topk(snap, queries, K, boosts)
     name = snap.kernel_breakdown()["score_kernel"]
     assert name.startswith(expect_kernel), name
+    for _ in range(3):  # (thresholds are published by racing waves: the answer must not depend on who wins)
+        assert _topk(snap, queries, K, boosts) == got
     _opt(b"PS_DAAT_Z", 0)
     ref = _topk(snap, queries, K, boosts)
     assert snap.kernel_breakdown()["score_kernel"].startswith(("ps::k_score", "ps::k_z21"))
