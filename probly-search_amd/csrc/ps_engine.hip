@@ -151,7 +151,7 @@ struct Tuning {
   uint32_t daat_small = 1;       // PS_DAAT_SMALL: plans of <= 4 lists, one per query term, take k_daat_small (all lookups of a trip in flight together)
   uint32_t kernel_timers = 1;    // PS_KERNEL_TIMERS: HIP timing events around the K1d scoring launches (ps_snapshot_kernel_breakdown); 0 in a serving setup
   uint32_t work_counters = 1;    // PS_WORK_COUNTERS: the headline kernels (k_daat_small, k_daat_z) keep the work counters of ps_snapshot_work_counters (0: the serving instantiations, which carry none; the other kernels always count)
-XX
+  uint32_t daat_z_d0_div = 4;    // PS_DAAT_Z_D0_DIV: K1dz's top tie-threshold level is the doc id ~ N / this (C3, three levels a factor 4 apart: 4 -> 0.495 ms, 8 -> 0.531; one level: 8 -> 0.587, 4 -> 0.667; profiles/r04_c3_levels_sweep.jsonl)
   uint32_t daat_z_level_shift = 2;  // PS_DAAT_Z_LEVEL_SHIFT: the levels below it are 2^shift apart
   uint32_t daat_z_levels = 3;    // PS_DAAT_Z_LEVELS: how many of them (1..3)
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
@@ -2190,7 +2190,7 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   ZBatch zb;
   zb.d_ubnum = reinterpret_cast<const double*>(c.stage.p + off_u);
   zb.d_zub = reinterpret_cast<const double*>(c.stage.p + off_z);
-  // the levels: powers of two (slot boundaries of every list's table up to that coarseness), the top one near N / 8, the
+  // the levels: powers of two (slot boundaries of every list's table up to that coarseness), the top one near N / PS_DAAT_Z_D0_DIV, the
   // others 2^PS_DAAT_Z_LEVEL_SHIFT apart below it; a level of less than one tile does not exist
   {
     const uint64_t div = std::max(2u, m.tune.daat_z_d0_div);

@@ -30,7 +30,7 @@
 // (round 2's k_daat_z: 15-30 % of the postings).  Two words per query:
 //   gthr[q]  K-th best score of ANY wave of the query (as k_daat_small): prunes bound <  gthr;
 //   gtie[l][q]  (Z_LEVELS words per query) K-th best score of a wave that has only scanned documents below doc id D_l so
-//            far (D_0 < D_1 < D_2: powers of two, D_2 near N / 8, a factor 4 apart; doc ids ascend along a chunk): K
+//            far (D_0 < D_1 < D_2: powers of two, D_2 near N / 4, a factor 4 apart; doc ids ascend along a chunk): K
 //            documents with ids < D_l score >= gtie[l], so a trip whose postings all lie at or above D_l also prunes
 //            bound == gtie[l], and so does the whole-chunk skip test of a chunk that starts at or above D_l (its level
 //            rides in DItem::count, from the list's tile-offset table).
