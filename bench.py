@@ -612,12 +612,19 @@ def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layo
     if os.path.exists(path):
         try:
             d = json.load(open(path))
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from derive_roofline import kernel_source_hash
+            fresh = d.get("kernel_sources_sha16") == kernel_source_hash(ROOT)
             same = (d.get("kernel") == kernel and d.get("config") == args.config and d.get("scorer") == cfg["scorer"]
                     and bool(d.get("resident_rows")) == bool(args.resident_rows) and not args.n_docs and not args.batch)
-            drv = d if same else None
+            drv = d if (same and fresh) else None
             if not same:
                 out["derivation_skipped"] = "profiles/roofline_%s.json was made for kernel %r / another setup" % (
                     args.config, d.get("kernel"))
+            elif not fresh:
+                out["derivation_skipped"] = ("profiles/roofline_%s.json was derived at head %s for other kernel sources (sha16 %s, now %s): "
+                                             "stale counters are not priced - rerun tools/profile_bench.sh" % (
+                                                 args.config, d.get("head"), d.get("kernel_sources_sha16"), kernel_source_hash(ROOT)))
         except Exception as e:  # noqa: BLE001
             out["derivation_skipped"] = "unreadable: %s" % e
     # Little's law for the latency bound: bytes in flight = rate x latency.  An 8-byte lookup that misses L2
@@ -642,8 +649,11 @@ def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layo
                     "bytes_touched_over_traffic": (touched / traffic) if traffic else None,
                     "pmc": {"resources": res, "wave_cycles_in_profiled_run": drv.get("wave_cycles"),
                             "work_counters_in_profiled_run": drv.get("work_counters"),
-                            "note": "per-launch counter amounts of the committed rocprofv3 PMC passes (same kernel symbol, "
-                                    "config, scorer, row mode) / this run's kernel time; traffic = 2 x FETCH_SIZE + WRITE_SIZE",
+                            "note": "per-launch counter amounts of the committed rocprofv3 PMC passes (same kernel symbol, config, scorer, row "
+                                    "mode, same kernel sources by hash) / this run's kernel time; traffic = 2 x FETCH_SIZE + WRITE_SIZE = bytes if "
+                                    "every fabric read request moved a 128-byte line (exact for streams, an upper bound for scattered 8-byte "
+                                    "lookups: calibration in profiles/r04_fetch_size_calibration.txt); fabric_requests prices the same counter as "
+                                    "what it counts - requests - against the 43 G/s the chip sustained for scattered L2-missing loads",
                             "derivation": "profiles/roofline_%s.json (tools/derive_roofline.py, head %s)" % (
                                 args.config, drv.get("head"))}})
     return out

@@ -1708,6 +1708,9 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
             if ((uint32_t)g == g1) rem1[g] = nxt;
         }
         double theta = 0.0;
+        double alt0 = 0.0, others0 = 0.0;  // the first bound test: the own term's best other list, the other terms' best lists (all ranked below)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { if ((uint32_t)g == own_grp) alt0 = rem0[g]; else others0 += rem0[g]; }
 #ifdef PS_MQ_TIME
         unsigned long long mq_tb1 = 0, mq_tb2 = 0, mq_cnt = 0;
 #endif
@@ -1849,10 +1852,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
 #pragma unroll
           for (int u = 0; u < UA; ++u) {
             // everything the lower-ranked lists could add, at most (per query term the best of them): below theta the document is out
-            double b0 = 0.0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b0 += fmax((uint32_t)g == own_grp ? s_own[u] : 0.0, rem0[g]);
-            alive[u] = alive[u] && (b0 >= theta) && !(p.ablate & 32u);  // (debug: 32 = no lookups)
+            alive[u] = alive[u] && (fmax(s_own[u], alt0) + others0 >= theta) && !(p.ablate & 32u);  // (debug: 32 = no lookups)
             any_alive |= alive[u];
             ws.reached += lanes_on(alive[u]);
           }
@@ -2167,6 +2167,9 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
 #ifndef PS_DAAT_US
 #define PS_DAAT_US 4   // postings per lane in flight
 #endif
+#ifndef PS_DAAT_STEP2
+#define PS_DAAT_STEP2 0  // 1: first level in two steps - the highest-bound lower-ranked list, then the rest for what it left alive (measured: row lookups 11.9 M -> 6.2 M per C2 launch, kernel 0.290 -> 0.327 ms: the extra dependency level costs more than the requests it saves)
+#endif
 #ifndef PS_EXP
 #define PS_EXP 0       // profiling builds only (wrong results): 1 = no top-K offers, 2 = no second level, 4 = no first-level loads
 #endif
@@ -2223,7 +2226,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   uint32_t o_shift[NO], o_bm[NO], o_tbl[NO], o_row[NO], o_rank[NO];
   unsigned long long o_bloom[NO];
   double o_eb[NO], o_ub[NO];
-  uint32_t n_row_lists = 0, n_cell_lists = 0;  // (work counters: lists asked with one 8-byte load per document)
 #pragma unroll
   for (int k = 0; k < NO; ++k) {
     o_off[k] = 0; o_shift[k] = 0; o_bm[k] = 0xFFFFFFFFu; o_tbl[k] = 0; o_row[k] = 0; o_rank[k] = 0xFFFFFFFFu;
@@ -2235,7 +2237,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       o_off[k] = en.post_off; o_shift[k] = en.shift; o_bm[k] = en.bm_off; o_tbl[k] = en.tbl_off; o_row[k] = en.node;
       o_eb[k] = en.boost; o_ub[k] = dj.ub; o_rank[k] = dj.rank;
       if (!(en.shift & DENSE_FLAG) && en.bm_off == 0xFFFFFFFFu && p.layer_bloom) o_bloom[k] = p.layer_bloom[en.node];
-      if (en.shift & DENSE_FLAG) ++n_row_lists; else if (en.bm_off != 0xFFFFFFFFu || o_bloom[k] != NO_BLOOM) ++n_cell_lists;
     }
   }
   // A document is evaluated from its highest-ranked list only, so one that is evaluated HERE sits in no list ranked
@@ -2246,6 +2247,17 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   for (int k = 0; k < NO; ++k)
     if ((uint32_t)k + 1u < ne && o_rank[k] > own_rank) others += o_ub[k];
   others *= SLACK;
+  int k_first = -1;          // the highest-bound list ranked below the own one
+  double others_rest = 0.0;  // ... and what the remaining lower-ranked lists can add
+  {
+    double best = -1.0;
+#pragma unroll
+    for (int k = 0; k < NO; ++k)
+      if ((uint32_t)k + 1u < ne && o_rank[k] > own_rank && o_ub[k] > best) { best = o_ub[k]; k_first = k; }
+#pragma unroll
+    for (int k = 0; k < NO; ++k)
+      if ((uint32_t)k + 1u < ne && o_rank[k] > own_rank && k != k_first) others_rest += o_ub[k];
+  }
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
   double published = 0.0;
@@ -2387,38 +2399,72 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
     for (int u = 0; u < U; ++u) {
       rch[u] = inr[u] && (s_own[u] + others >= theta);
       const uint32_t nr = cnt(rch[u]);  // every document that passed asks every other list's first level
-      ws.reached += nr; ws.row += nr * n_row_lists; ws.cell += nr * n_cell_lists;
+      ws.reached += nr;
     }
-    // ---- first level of every other list for the documents that passed, all in flight together: dense-row
-    // value, {bits, rank} bitmap cell, or the sparse list's Bloom-filter word ----
+    // ---- first level of the other lists for the documents that passed: dense-row value, {bits, rank} bitmap cell, or
+    // the sparse list's Bloom-filter word.  The launch is bound by the rate of scattered requests that miss L2
+    // (profiles/r04_fetch_size_calibration.txt: ~43 G/s, whatever their width), so the list that can add most - the
+    // highest-bound one ranked below the own list - is asked first, and only the documents it leaves alive ask the rest
+    // (PS_DAAT_STEP2; 0: every list at once, one dependency level less) ----
     uint2 fl[NO][U];
 #pragma unroll
-    for (int k = 0; k < NO; ++k) {
+    for (int k = 0; k < NO; ++k)
 #pragma unroll
       for (int u = 0; u < U; ++u) fl[k][u] = make_uint2(0u, 0u);
+    auto first_level = [&](const int k, const bool (&on)[U]) {
       if ((uint32_t)k + 1u < ne && !(PS_EXP & 4)) {
         if (o_shift[k] & DENSE_FLAG) {
 #pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (rch[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.rows + (uint64_t)o_row[k] * p.row_stride + d[u]);
+          for (int u = 0; u < U; ++u) {
+            if (on[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.rows + (uint64_t)o_row[k] * p.row_stride + d[u]);
+            ws.row += cnt(on[u]);
+          }
         } else if (o_bm[k] != 0xFFFFFFFFu) {
 #pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (rch[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(d[u] >> 5));
+          for (int u = 0; u < U; ++u) {
+            if (on[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(d[u] >> 5));
+            ws.cell += cnt(on[u]);
+          }
         } else if (o_bloom[k] != NO_BLOOM) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             uint64_t wi;
             unsigned long long mk;
             bloom_probe(d[u], o_bloom[k], wi, mk);
-            const unsigned long long w = rch[u] ? p.bloom[wi] : 0ull;
-            fl[k][u].x = (rch[u] && (w & mk) == mk) ? 1u : 0u;  // maybe
+            const unsigned long long w = on[u] ? p.bloom[wi] : 0ull;
+            fl[k][u].x = (on[u] && (w & mk) == mk) ? 1u : 0u;  // maybe
+            ws.cell += cnt(on[u]);
           }
         } else {
 #pragma unroll
-          for (int u = 0; u < U; ++u) fl[k][u].x = rch[u] ? 1u : 0u;  // no filter: ask the table
+          for (int u = 0; u < U; ++u) fl[k][u].x = on[u] ? 1u : 0u;  // no filter: ask the table
         }
       }
+    };
+    if (PS_DAAT_STEP2 && k_first >= 0) {
+#pragma unroll
+      for (int k = 0; k < NO; ++k)
+        if (k == k_first) first_level(k, rch);
+      bool rch2[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        double c1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) {
+          if (k == k_first) {
+            if (o_shift[k] & DENSE_FLAG) c1 = __hiloint2double((int)fl[k][u].y, (int)fl[k][u].x);
+            else if (o_bm[k] != 0xFFFFFFFFu) c1 = ((fl[k][u].x >> (d[u] & 31u)) & 1u) ? o_ub[k] : 0.0;
+            else c1 = fl[k][u].x != 0u ? o_ub[k] : 0.0;
+          }
+        }
+        rch2[u] = rch[u] && ((s_own[u] + c1 + others_rest) * SLACK >= theta);
+      }
+#pragma unroll
+      for (int k = 0; k < NO; ++k)
+        if (k != k_first) first_level(k, rch2);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NO; ++k) first_level(k, rch);
     }
     // ---- what the first level already tells: exact row values, bitmap membership, filter misses ----
 #pragma unroll

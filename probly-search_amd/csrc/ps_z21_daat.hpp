@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     }
   }
   int flmax[NE + 1];  // wave-uniform: the longest field that can still matter with m contributing records
-  auto set_flmax = [&](const double ts, const double tt) {
+  auto set_flmax = [&](const double ts, const double tt) __attribute__((always_inline)) {
     flmax[0] = z_beats(0.0, ts, tt) ? Z_ALL : Z_NONE;
 #pragma unroll
     for (int m = 1; m <= NE; ++m) {
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
 
   // Second level + the pools in the sorted record order + the top-K offer for the first `count` (<= 64) queued
   // documents, one per lane.
-  auto process = [&](const uint32_t count) {
+  auto process = [&](const uint32_t count) __attribute__((always_inline)) {
     const uint32_t at = (q_head + (uint32_t)lane) & (QCAP - 1u);
     bool ok = (uint32_t)lane < count;
     const uint32_t d = ok ? q_d[wave][at] : 0u;
@@ -489,15 +489,15 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     unsigned long long tl[Z_LEVELS];
 #pragma unroll
     for (int l = 0; l < Z_LEVELS; ++l) tl[l] = __hip_atomic_load(&p.gtie[(size_t)l * p.z_tstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t d[U], wv[U][F_], pi_l[U];
+    uint32_t d[U], wv[U][F_];
     bool inr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t i = i0 + u * WAVE + lane;
       inr[u] = i < end;
-      pi_l[u] = i < end ? i : end - 1;
-      d[u] = p.doc[own_off + pi_l[u]];
-      tfl_load<F_>(p, own_off + pi_l[u], wv[u]);
+      const uint32_t pi = i < end ? i : end - 1;
+      d[u] = p.doc[own_off + pi];
+      tfl_load<F_>(p, own_off + pi, wv[u]);
     }
     {
       // the trip's place among the levels: its first posting (lane 0 of slot 0) is its lowest doc id, its last valid
@@ -553,18 +553,15 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
       if ((uint32_t)m == n_lower) fmo = flmax[m];
     }
     bool rch[U];
-    uint32_t ownc[U];  // bit x: the own record can count for field x
     if (WC) ws.scanned += n_in;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       bool any = false;
-      ownc[u] = 0u;
 #pragma unroll
       for (int x = 0; x < F_; ++x) {
         const uint32_t tfu = wv[u][x] >> 24;
         const int flu = (int)(wv[u][x] & TFL_FL_ESC);
-        const bool c = tfu >= need_own && tfu > 0u;
-        ownc[u] |= c ? (1u << x) : 0u;
+        const bool c = tfu >= need_own && tfu > 0u;  // the own record can count for field x
         any = any || flu <= (c ? fmw : fmo);
       }
       rch[u] = inr[u] && any;
@@ -623,7 +620,8 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
       bool any = false;
 #pragma unroll
       for (int x = 0; x < F_; ++x) {
-        const uint32_t m = hits + ((ownc[u] >> x) & 1u);
+        const uint32_t tfu = wv[u][x] >> 24;
+        const uint32_t m = hits + ((tfu >= need_own && tfu > 0u) ? 1u : 0u);
         int fm = flmax[0];
 #pragma unroll
         for (int k = 1; k <= NE; ++k) fm = m == (uint32_t)k ? flmax[k] : fm;
@@ -636,7 +634,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
         if (alive) {
           const uint32_t at = (q_head + q_n + (uint32_t)__popcll(mm & lt)) & (QCAP - 1u);
           q_d[wave][at] = d[u];
-          q_i[wave][at] = pi_l[u];
+          q_i[wave][at] = i0 + (uint32_t)u * WAVE + (uint32_t)lane;  // (alive: within the chunk)
 #pragma unroll
           for (int x = 0; x < F_; ++x) q_w[x][wave][at] = wv[u][x];
 #pragma unroll

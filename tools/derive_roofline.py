@@ -9,11 +9,20 @@ in the kernel trace), averaged over the dispatches of the counter passes.
 
 Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed
 over waves; GRBM_GUI_ACTIVE counts shader clocks the chip was busy, summed over the 8 XCD instances;
-FETCH_SIZE / WRITE_SIZE are KiB of 64-byte fabric requests, and a wide coalesced read stream is
-tallied at half its bytes on gfx950 (read side doubled below, as the guide prescribes; for scattered
-narrow reads the doubling is an upper bound).  Peaks: HBM 8 TB/s (spec), L2 34.5 TB/s of 128-byte
+FETCH_SIZE / WRITE_SIZE are KiB of fabric requests tallied at 64 bytes each.  Calibrated on this chip
+(tools/fetch_size_calibration.sh, profiles/r04_fetch_size_calibration.txt): FETCH_SIZE x 1024 / 64 is the number
+of L2 -> fabric read requests (TCC_EA0_RDREQ); a wide coalesced stream issues one request per 128-byte line
+(counter = half the bytes: the guide's x 2), a scattered 4 / 8 / 16-byte load that misses L2 issues one request
+per load (counter = 64 bytes per load whatever its width; whether 64 or 128 bytes cross the fabric for it the
+counters do not say).  What the fabric sustains is a REQUEST rate: 41 G/s for the 128-byte requests of a stream
+(= 5.3 TB/s), 43 G/s for scattered loads over 8 GiB, 56 G/s when the target fits the Infinity Cache (hits there
+are counted, and cost nearly a full slot); only L2 hits (239 G/s) are free of it.  So beside
+hbm = 2 x FETCH_SIZE + WRITE_SIZE (bytes if every request moved a 128-byte line: exact for streams, an upper
+bound for scattered loads) the derivation reports `fabric_requests` against the measured 43 G/s ceiling - the
+roofline that binds a kernel of scattered lookups.  Other peaks: HBM 8 TB/s (spec), L2 34.5 TB/s of 128-byte
 lines, LDS 256 B/clk/CU, one VALU issue per SIMD per clock.
 """
+import hashlib
 import json
 import os
 import re
@@ -22,6 +31,16 @@ import sys
 
 N_CU, N_SIMD, N_XCD, CLOCK_HZ = 256, 1024, 8, 2.4e9
 HBM_PEAK, L2_PEAK, LDS_BPC = 8.0e12, 34.5e12, 256
+FABRIC_REQ_PEAK = 43.0e9  # scattered L2-missing loads per second this chip sustained (profiles/r04_fetch_size_calibration.txt)
+KERNEL_SOURCES = ("ps_kernels.hpp", "ps_prep_kernels.hpp", "ps_z21_daat.hpp")
+
+
+def kernel_source_hash(root):
+    """sha256 over the device-code headers: bench.py refuses a derivation made for other kernel sources."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(root, "probly-search_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def demangle(name):
@@ -58,6 +77,16 @@ def main():
     if not score:
         sys.exit("no scoring kernel in the kernel trace")
     dom = max(score, key=lambda k: score[k]["total_us"])
+    # bench.py times the headline with the serving instantiation (no work counters) and prices the roofline with the
+    # counting one: take the symbol the traced run's bench line names, if the trace holds it
+    try:
+        line = [l for l in open(os.path.join(d, "kt.bench.json")) if l.startswith("{")][-1]
+        want = json.loads(line)["roofline"]["kernel"]
+        named = [k for k in score if demangle(k) == want]
+        if named:
+            dom = named[0]
+    except Exception:  # noqa: BLE001
+        pass
     key = dom[:48]  # rocpd_summary truncates names in the PMC section
     ctr = {}
     for f in sorted(os.listdir(d)):
@@ -74,7 +103,11 @@ def main():
     if g("FETCH_SIZE") is not None:
         rd, wr = 2 * g("FETCH_SIZE") * 1024, (g("WRITE_SIZE") or 0) * 1024
         res["hbm"] = {"per_launch": rd + wr, "unit": "B", "scale": 1e9, "peak": HBM_PEAK / 1e9, "rate_unit": "GB/s"}
-        notes.append("hbm = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B)")
+        notes.append("hbm = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B): bytes if every read request moved a 128-byte line")
+        res["fabric_requests"] = {"per_launch": g("FETCH_SIZE") * 1024 / 64, "unit": "read requests", "scale": 1e9, "peak": FABRIC_REQ_PEAK / 1e9,
+                                  "rate_unit": "G requests/s"}
+        notes.append("fabric_requests = FETCH_SIZE x 1024 / 64 (= TCC_EA0_RDREQ) against the 43 G/s this chip sustained for scattered "
+                     "L2-missing loads (calibration); a pure 128-byte stream tops out at 41 G/s = 5.3 TB/s")
     if g("TCC_REQ_sum") is not None:
         res["l2"] = {"per_launch": g("TCC_REQ_sum") * 128, "unit": "B (128-B line requests)", "scale": 1e9, "peak": L2_PEAK / 1e9,
                      "rate_unit": "GB/s"}
@@ -114,7 +147,8 @@ def main():
                 "kernel_avg_ms_live": rl.get("kernel_avg_ms")}
     except Exception:  # noqa: BLE001
         pass
-    out = {"config": cfg, "scorer": scorer, "head": head, "kernel": demangle(dom), "kernel_symbol": dom, "work_counters": work,
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {"config": cfg, "scorer": scorer, "head": head, "kernel_sources_sha16": kernel_source_hash(root), "kernel": demangle(dom), "kernel_symbol": dom, "work_counters": work,
            "resident_rows": "--resident-rows" in args, "bench_args": args,
            "kernel_avg_us_in_trace": score[dom]["avg_us"], "registers": {k: score[dom][k] for k in ("vgpr", "sgpr", "lds")},
            "measured_clock_GHz": clock / 1e9, "counters_per_launch": ctr,

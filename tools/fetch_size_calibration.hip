@@ -63,6 +63,14 @@ __global__ void cal_sorted8(const uint64_t* __restrict__ a, size_t n_elems, size
   if (acc == 0x1234567u) *sink = acc;
 }
 
+// (reads a region once so that it is cache resident; not one of the calibrated patterns: its name lacks the cal_ prefix)
+__global__ void warm_region(const uint4* __restrict__ a, size_t n, uint64_t* sink) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  uint64_t acc = 0;
+  for (; i < n; i += stride) acc += a[i].x;
+  if (acc == 0x1234567u) *sink = acc;
+}
+
 template <typename T>
 __global__ void cal_stream_write(T* __restrict__ a, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -114,6 +122,21 @@ int main(int argc, char** argv) {
     double span = (double)n * gap * 8;
     double l64 = gap >= 8 ? (double)n : span / 64, l128 = gap >= 16 ? (double)n : span / 128;
     timed(name, n * 8.0, l64, l128, [&] { cal_sorted8<<<grid, block>>>((uint64_t*)a, bytes / 8, n, gap, sink); });
+  }
+  // the same scattered 8-byte loads confined to regions that fit the Infinity Cache (256 MiB) / one XCD's L2 (4 MiB):
+  // does a request that hits there cost a fabric request slot like one that goes to HBM?  (each region is read once
+  // first, so it is resident; the flush between patterns is skipped for these)
+  for (size_t mib : {128, 32, 2}) {
+    const size_t sub = mib << 20;
+    char name[64]; snprintf(name, sizeof name, "cal_random<uint2> in %zu MiB", mib);
+    warm_region<<<grid, block>>>(a, sub / 16, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(ev.a, 0));
+    cal_random<uint2><<<grid, block>>>((uint2*)a, sub / 8, n_loads, 0x61ull + mib, sink);
+    CK(hipEventRecord(ev.b, 0)); CK(hipEventSynchronize(ev.b));
+    float ms; CK(hipEventElapsedTime(&ms, ev.a, ev.b));
+    printf("{\"kernel\": \"%s\", \"useful_bytes\": %.0f, \"bytes_as_64B_lines\": %.0f, \"bytes_as_128B_lines\": %.0f, \"ms\": %.4f, \"useful_GBps\": %.1f}\n",
+           name, n_loads * 8.0, expect_distinct(sub / 64.0, n_loads) * 64, expect_distinct(sub / 128.0, n_loads) * 128, ms, n_loads * 8.0 / ms / 1e6);
   }
   timed("cal_stream_write<uint4>", bytes / 4.0, L64 / 4, L128 / 4, [&] { cal_stream_write<uint4><<<grid, block>>>(a, bytes / 64); });
   timed("cal_random_write8", n_loads * 8.0, expect_distinct(L64, n_loads), expect_distinct(L128, n_loads),
