@@ -140,7 +140,7 @@ struct Tuning {
   uint32_t daat = 1;             // PS_DAAT: BM25 top-k batches take K1d k_daat (exact dynamic pruning)
   uint32_t daat_min_batch = 8;   // PS_DAAT_MIN_BATCH: smaller batches keep the k_score latency path
   uint32_t daat_chunk = 4096;    // PS_DAAT_CHUNK: smallest chunk of a list one item covers
-  uint32_t daat_dense_min_density_pct = 40;  // PS_DAAT_DENSE_MIN_DENSITY_PCT
+  uint32_t daat_dense_min_density_pct = 60;  // PS_DAAT_DENSE_MIN_DENSITY_PCT (step level, profiles/r04_daat_row_density_step_level.txt: 40 / 55 / 60 / 65 -> C2 0.346 / 0.328 / 0.329 / 0.380 ms, C4 1.29 / 1.20 / 1.19 / 1.54, C5 unchanged)
   uint32_t daat_merge_waves = 4;   // PS_DAAT_MERGE_WAVES: most waves per query in K3d (16 / 4 / 2 measured 30 / 24 / 31 us on C2)
   uint32_t daat_split_div = 64;  // PS_DAAT_SPLIT_DIV: a list is cut into at most this many chunks
   uint32_t daat_rows = 1;        // PS_DAAT_ROWS: hot dense lists are looked up through dense score rows
