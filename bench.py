@@ -60,6 +60,9 @@ def parse_args(argv=None):
                     help="skip the leg that alternates two fields_boost vectors between steps (reported as alternating_boosts)")
     ap.add_argument("--no-streaming-leg", action="store_true",
                     help="skip the untimed-for-headline K1 k_score leg (PS_DAAT=0) reported under roofline.streaming_kernel_leg")
+    ap.add_argument("--no-plan-ahead", action="store_true",
+                    help="do not announce the next batch to the library (ps_snapshot_plan_ahead_flat): every step then waits for its own "
+                         "planner totals (~0.25 ms of host time per step, hidden only while three batches are in flight)")
     ap.add_argument("--no-config4-leg", action="store_true",
                     help="N > 1 only: skip the untimed-for-headline leg on BASELINE config 4 (5M docs, ONE 8192-query batch split "
                          "over the ranks, all-gather of the top-k blocks), reported as config4")
@@ -248,7 +251,15 @@ def main():
             if hip.hipHostGetDevicePointer(ctypes.byref(dp), ctypes.c_void_p(hb.data_ptr()), 0) == 0 and dp.value:
                 host_dev_ptr[i] = dp.value
 
-    def step(batch, i, boosts=boosts):
+    def step(batch, i, boosts=boosts, nxt=None):
+        """One step.  nxt: the batch of the NEXT step - announced to the library right after this one is enqueued
+        (ps_snapshot_plan_ahead_flat: a serving loop's double-buffered submission), so that its planner count pass runs
+        beside this step's scoring and the next call does not wait for the plan's totals."""
+        _step(batch, i, boosts)
+        if nxt is not None and not args.no_plan_ahead:
+            snap.plan_ahead_flat(nxt[0], nxt[1], scorer, boosts)
+
+    def _step(batch, i, boosts):
         text, offsets = batch
         slot = i % n_blk
         if args.device_plan and world == 1:
@@ -279,7 +290,7 @@ def main():
     L.ps_set_option(b"PS_WORK_COUNTERS", 0)
     L.ps_set_option(b"PS_KERNEL_TIMERS", 0)  # (no HIP timing events between the launches of the timed region either)
     for s in range(args.warmup):
-        step(packed[s], s)
+        step(packed[s], s, nxt=packed[s + 1] if s + 1 < n_total else None)
     fence()
     snap.kernel_breakdown(reset=True)
     snap.work_counters(reset=True)
@@ -294,7 +305,7 @@ def main():
     t_start = time.perf_counter()
     for s in range(args.warmup, n_total):
         ts = time.perf_counter()
-        step(packed[s], s)
+        step(packed[s], s, nxt=packed[s + 1] if s + 1 < n_total else None)
         st = snap.last_stats()
         postings += st["postings_visited"]
         layout_bytes += st["layout_bytes"]
@@ -314,7 +325,7 @@ def main():
     fence()
     t_dev0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + n_dev):
-        step(packed[s], s)
+        step(packed[s], s, nxt=packed[s + 1] if s + 1 < args.warmup + n_dev else None)
     fence()
     elapsed_dev = (time.perf_counter() - t_dev0) / n_dev
     if world > 1:
@@ -397,7 +408,9 @@ def main():
             "p50_single_query_ms": float(np.median(single) * 1e3) if single else None,
             "p50_batch_submit_ms": float(np.median(lat) * 1e3),
             "host_plan_ms_per_step": plan_ms / steps,
-            "host_plan_note": ("device-planned: the host's wait for the planner's totals (one sync of the planning stream per batch)"
+            "host_plan_note": (("device-planned, every batch announced one step ahead (ps_snapshot_plan_ahead_flat): what is left of the host's "
+                                "wait for the planner's totals" if not args.no_plan_ahead else
+                                "device-planned: the host's wait for the planner's totals (one sync per batch)")
                                if dev_planned else "host planner: tokenise + expand + before_each on the host"),
             "bounds_recomputed_in_timed_steps": bounds_rc,
             "postings_per_step": postings / max(1, n_roof),

@@ -178,6 +178,7 @@ SYMBOLS = {
     "ps_index_snapshot_ex": (C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "ps_snapshot_update": (C.c_int, [_P, _P, C.POINTER(UpdateStats)]),
     "ps_index_snapshot_multi": (C.c_int, [_P, C.POINTER(C.c_int), C.c_size_t, C.c_uint32, C.POINTER(_P)]),
+    "ps_snapshot_plan_ahead_flat": (C.c_int, [_P, C.POINTER(ScorerDesc), _P, _P, C.c_size_t, C.POINTER(C.c_int)]),
     "ps_comm_get_unique_id": (C.c_int, [_P]),
     "ps_comm_init_rank": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "ps_comm_free": (None, [_P]),

@@ -604,6 +604,17 @@ ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc
   });
 }
 
+ps_status ps_snapshot_plan_ahead_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text, const uint64_t* offsets,
+                                      size_t n_queries, int* accepted) {
+  return guard([&]() -> ps_status {
+    if (!snap || !scorer || (n_queries && (!text || !offsets))) return fail(PS_EINVAL, "null argument");
+    if (!snap->engine) return fail(PS_ENODEVICE, "host-only snapshot");
+    const bool ok = snap->engine->plan_ahead(*scorer, text, offsets, n_queries);
+    if (accepted) *accepted = ok ? 1 : 0;
+    return PS_OK;
+  });
+}
+
 ps_status ps_snapshot_query_batch_device_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text,
                                               const uint64_t* offsets, size_t n_queries, const double* fields_boost,
                                               size_t n_boost, ps_tokenizer_fn tokenizer, void* user, size_t top_k,

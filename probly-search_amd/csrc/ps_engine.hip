@@ -159,8 +159,9 @@ struct Tuning {
   void load();
 };
 
-constexpr int N_STAGE = 4;
+constexpr int N_STAGE = 6;  // (>= N_DCTX: host-planned batches take a pinned staging slot each)
 constexpr int N_KTIMER = 32;
+constexpr int N_DCTX = 5;  // K1d batch contexts (batches of one snapshot in flight)
 
 struct EngineImpl {
   const Snapshot* snap;
@@ -299,12 +300,19 @@ struct EngineImpl {
     uint64_t cands_gen = 0;        // RowCands::gen its rows belong to
     bool ctl_clean = false;        // k_merge_items left the control words zeroed
   };
-  DaatCtx dctx[3];  // (three: the count pass of batch s + 1 must not wait for batch s - 1, whose k_daat may still be running)
+  // Five: batch s + 1 reuses the context of batch s + 1 - N_DCTX, whose merge must be through first.  With three, the chain
+  // behind k_daat(s - 2) - its merge (100-200 us beside a running k_daat), then text upload, count pass, scan, the host's
+  // read of the totals, fill pass, k_prep_query, k_prep_items, K0b of batch s + 1 - was longer than one k_daat, so the
+  // scoring stream idled 25-30 us per batch (kernel timeline, profiles/r04_c2_timeline_3ctx.txt).
+  DaatCtx dctx[N_DCTX];
   int next_dctx = 0;
   hipStream_t prep_stream = nullptr, score_stream = nullptr, plan_stream = nullptr, merge_stream = nullptr;
   hipEvent_t lut_ready = nullptr;  // behind the most recent k_bm25_lut
-  PlanTotals* h_totals = nullptr;  // pinned, device-mapped: k_plan_scan writes the totals where the host reads them
+  PlanTotals* h_totals = nullptr;  // [N_DCTX] pinned, device-mapped, one per batch context: k_plan_scan writes the totals where the host reads them
   PlanTotals* d_totals_mapped = nullptr;
+  // A batch announced ahead of its query call (Engine::plan_ahead): its text is in the context's pinned slot, its
+  // count pass is in flight or done.  The next device-planned call with the same text picks it up.
+  struct Ahead { bool valid = false; int ctx = -1; size_t B = 0, n_bytes = 0; } ahead;
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0, last_rows_built = 0;
@@ -503,6 +511,7 @@ void Engine::apply_delta(const DeltaRanges& r, std::vector<uint64_t>& removed_df
   std::lock_guard<std::mutex> lock(m.mu);
   PS_HIP(hipSetDevice(m.device));
   PS_HIP(hipDeviceSynchronize());  // no batch of this snapshot is in flight while its planes change
+  m.ahead.valid = false;           // (a batch announced ahead was counted against the old trie: its query call plans again)
   uint64_t up = 0;
   auto put = [&](void* dst, const void* src, size_t bytes) {
     if (!bytes) return;
@@ -1076,8 +1085,19 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   kp.row_planes = 1; kp.row_mode = 0; kp.row_stride = (uint64_t)s.tiles_cap * s.T;
 }
 
+// Drops a batch that was announced ahead (Engine::plan_ahead) and never asked for: its context goes back into the
+// rotation behind its count pass.
+void drop_ahead(EngineImpl& m) {
+  if (!m.ahead.valid) return;
+  m.ahead.valid = false;
+  EngineImpl::DaatCtx& c = m.dctx[m.ahead.ctx];
+  PS_HIP(hipEventRecord(c.done, m.plan_stream));  // (whoever gets the context next waits for the abandoned count pass)
+  c.busy = true;
+}
+
 // The next K1d batch context (they alternate); the two streams, its events and control blocks exist from first use.
 EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
+  if (m.ahead.valid && m.next_dctx == m.ahead.ctx) drop_ahead(m);  // (the rotation came round to an announced batch nobody asked for)
   if (!m.prep_stream) {
     // the preparation stream at the highest priority: a queue of its own (queues are pooled per priority),
     // and its small kernels do not wait behind the tens of thousands of workgroups of a running k_daat
@@ -1093,7 +1113,7 @@ EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
     PS_HIP(hipStreamCreateWithPriority(&m.merge_stream, hipStreamNonBlocking, hi));
   }
   EngineImpl::DaatCtx& c = m.dctx[m.next_dctx];
-  m.next_dctx = (m.next_dctx + 1) % 3;
+  m.next_dctx = (m.next_dctx + 1) % N_DCTX;
   if (!c.done) {
     PS_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.entry, hipEventDisableTiming));
@@ -2411,16 +2431,17 @@ void ensure_dev_trie(EngineImpl& m) {
     up(m.d_fbits, fb);
   }
   if (!m.h_totals) {
-    PS_HIP(hipHostMalloc((void**)&m.h_totals, sizeof(PlanTotals), hipHostMallocMapped | hipHostMallocCoherent));
+    PS_HIP(hipHostMalloc((void**)&m.h_totals, N_DCTX * sizeof(PlanTotals), hipHostMallocMapped | hipHostMallocCoherent));
     PS_HIP(hipHostGetDevicePointer((void**)&m.d_totals_mapped, m.h_totals, 0));
   }
   m.dev_trie_valid = true;
 }
 
-// Plans a flat BM25 batch on the device into context `c`: text -> k_plan count pass -> k_plan_scan -> (the
-// host reads the totals: one short synchronisation of the PREPARATION stream - the scoring stream keeps
-// running the previous batch) -> k_plan fill pass.
-PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, const uint64_t* offsets, size_t B) {
+// Plans a flat BM25 batch on the device into context `c`, in two halves.  device_plan_begin: text -> k_plan count
+// pass -> k_plan_scan (planning stream; nothing waits).  device_plan_finish: the host reads the totals - one short
+// wait for the context's `counted` event unless the batch was announced ahead (Engine::plan_ahead), in which case the
+// count pass finished long ago - and enqueues the fill pass on the preparation stream.
+void device_plan_begin(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, const uint64_t* offsets, size_t B) {
   ensure_dev_trie(m);
   EngineImpl::PlanSet& ps_ = c.plan;
   hipStream_t st = m.plan_stream;
@@ -2451,20 +2472,58 @@ PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
                      nullptr, ps_.cnt.p, ps_.qtl.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, nullptr, ps_.items.p, m.tune.daat_chunk,
                      m.tune.daat_split_div, ps_.tok_node.p);
   // (the totals are written straight into pinned, device-mapped host memory: no copy-engine transfer to wait for)
+  const int ci = (int)(&c - m.dctx);
   hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(WAVE), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
-                     ps_.qbeg.p, m.d_totals_mapped);
+                     ps_.qbeg.p, m.d_totals_mapped + ci);
   PS_HIP(hipGetLastError());
   PS_HIP(hipEventRecord(c.counted, st));
-  sync_stream(st);
-  const PlanTotals tot = *m.h_totals;
+}
+
+PlanTotals device_plan_finish(EngineImpl& m, EngineImpl::DaatCtx& c, size_t B) {
+  EngineImpl::PlanSet& ps_ = c.plan;
+  {  // latency-oriented wait for the count pass (poll briefly, then block)
+    const double t0 = now_ms();
+    hipError_t e = hipErrorNotReady;
+    while (now_ms() - t0 < 0.5 && (e = hipEventQuery(c.counted)) == hipErrorNotReady) {}
+    if (e != hipSuccess) PS_HIP(hipEventSynchronize(c.counted));
+  }
+  const PlanTotals tot = m.h_totals[&c - m.dctx];
   ps_.entries.ensure((size_t)tot.n_entries + 1);
-  st = m.prep_stream;  // the fill pass and everything behind it: preparation stream
+  hipStream_t st = m.prep_stream;  // the fill pass and everything behind it: preparation stream
   PS_HIP(hipStreamWaitEvent(st, c.counted, 0));
+  const size_t off_bytes = (B + 1) * 8, text_at = (off_bytes + 15) & ~(size_t)15;
+  const uint64_t* d_qoff = reinterpret_cast<const uint64_t*>(ps_.qtext.p);
+  const char* d_qtext = ps_.qtext.p + text_at;
+  DevTrie t{m.d_fnodes.p, m.d_fchar.p, m.d_fchild.p, m.d_term_df.p, m.d_term_meta.p, m.d_term_delta.p, m.d_term_idf.p,
+            m.d_layer_a.p, m.d_layer_b.p, m.d_eb_table.p, m.eb_n, m.d_fbits.p};
+  const uint32_t blocks = (uint32_t)((B + PLAN_WAVES - 1) / PLAN_WAVES);
   hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, ps_.qbeg.p,
                      ps_.entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, ps_.qorder.p, nullptr, m.tune.daat_chunk,
                      m.tune.daat_split_div, ps_.tok_node.p);
   PS_HIP(hipGetLastError());
   return tot;
+}
+
+PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, const uint64_t* offsets, size_t B) {
+  device_plan_begin(m, c, text, offsets, B);
+  return device_plan_finish(m, c, B);
+}
+
+// The context of a batch announced ahead, if this is that batch (same query count, same offsets, same text);
+// otherwise the announced batch is dropped (its context goes back into the rotation behind its count pass).
+EngineImpl::DaatCtx* take_ahead(EngineImpl& m, const char* text, const uint64_t* offsets, size_t B) {
+  if (!m.ahead.valid) return nullptr;
+  EngineImpl::DaatCtx& c = m.dctx[m.ahead.ctx];
+  if (offsets != nullptr && m.ahead.B == B) {
+    const size_t n_bytes = B ? (size_t)offsets[B] : 0, off_bytes = (B + 1) * 8, text_at = (off_bytes + 15) & ~(size_t)15;
+    if (m.ahead.n_bytes == n_bytes && memcmp(c.plan.h.p, offsets, off_bytes) == 0 &&
+        (n_bytes == 0 || memcmp(c.plan.h.p + text_at, text, n_bytes) == 0)) {
+      m.ahead.valid = false;
+      return &c;
+    }
+  }
+  drop_ahead(m);
+  return nullptr;
 }
 
 // The parts of KParams every top-k launch over this snapshot shares.
@@ -2499,6 +2558,7 @@ void Engine::plan_device(const char* text, const uint64_t* offsets, size_t B, Pl
   std::lock_guard<std::mutex> lock(m.mu);
   PS_HIP(hipSetDevice(m.device));
   refresh_tuning(m);
+  (void)take_ahead(m, nullptr, nullptr, (size_t)-1);  // (an announced batch is dropped: this call plans its own)
   EngineImpl::DaatCtx& c = acquire_ctx(m);
   const PlanTotals tot = device_plan(m, c, text, offsets, B);
   out = Plan{};
@@ -2515,6 +2575,26 @@ void Engine::plan_device(const char* text, const uint64_t* offsets, size_t B, Pl
   out.max_entries = tot.max_entries;
   out.max_qterms = tot.max_qterms;
   out.multi_expansion = tot.multi != 0;
+}
+
+// Announces the next flat BM25 batch: text copy + planner count pass start now, on the planning stream, while the
+// batches before it are still being scored; the query call that follows with the same text finds the totals ready
+// instead of waiting for them.  Returns false when the batch would not be planned on the device anyway.
+bool Engine::plan_ahead(const ps_scorer_desc& sc, const char* text, const uint64_t* offsets, size_t B) {
+  EngineImpl& m = *impl_;
+  if (sc.kind != PS_SCORER_BM25 || m.snap->F > (uint32_t)MAX_F) return false;
+  std::lock_guard<std::mutex> lock(m.mu);
+  PS_HIP(hipSetDevice(m.device));
+  refresh_tuning(m);
+  if (!(m.tune.device_plan && m.tune.daat && B >= m.tune.daat_min_batch)) return false;
+  (void)take_ahead(m, nullptr, nullptr, (size_t)-1);  // (at most one batch is announced at a time)
+  EngineImpl::DaatCtx& c = acquire_ctx(m);
+  device_plan_begin(m, c, text, offsets, B);
+  m.ahead.valid = true;
+  m.ahead.ctx = (int)(&c - m.dctx);
+  m.ahead.B = B;
+  m.ahead.n_bytes = B ? (size_t)offsets[B] : 0;
+  return true;
 }
 
 bool Engine::wants_device_plan(size_t n_queries) {
@@ -2542,8 +2622,10 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   const double t0 = now_ms();
   m.last_bounds_recomputed = false;
   hipStream_t st = stream ? (hipStream_t)stream : m.stream;
-  EngineImpl::DaatCtx& c = acquire_ctx(m);
-  const PlanTotals tot = device_plan(m, c, text, offsets, B);
+  EngineImpl::DaatCtx* announced = take_ahead(m, text, offsets, B);
+  EngineImpl::DaatCtx& c = announced ? *announced : acquire_ctx(m);
+  if (!announced) device_plan_begin(m, c, text, offsets, B);
+  const PlanTotals tot = device_plan_finish(m, c, B);
   if (tot.max_qterms >= 0x7FFF) throw std::length_error("more than 32766 non-empty terms in one query");
   const double t1 = now_ms();
   EngineImpl::PlanSet& ps_ = c.plan;

@@ -110,6 +110,8 @@ class Engine {
   // Whether a flat BM25 top-k batch of this size (built-in tokenizer) should be planned on the device
   // (PS_DEVICE_PLAN, default on; small batches keep the host planner's latency path).
   bool wants_device_plan(size_t n_queries);
+  // Announce the NEXT flat BM25 batch (ps_snapshot_plan_ahead_flat): its planner count pass starts now.
+  bool plan_ahead(const ps_scorer_desc& sc, const char* text, const uint64_t* offsets, size_t n_queries);
   void run_device_planned(const ps_scorer_desc& sc, const double* boosts, const char* text, const uint64_t* offsets,
                           size_t n_queries, size_t top_k, void* d_keys, void* d_scores, void* d_counts, void* stream,
                           ps_batch_stats& stats);

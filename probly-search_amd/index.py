@@ -334,6 +334,15 @@ class Snapshot:
         except PsError as e:
             _raise(e)
 
+    def plan_ahead_flat(self, text, offsets, score_calculator, fields_boost=None):
+        """ps_snapshot_plan_ahead_flat: announce the next flat batch (its planner count pass starts now); the flat query
+        call that follows with the same (text, offsets) finds the totals ready.  -> accepted (bool)."""
+        desc = self._cached_args(score_calculator, fields_boost)[0] if fields_boost is not None else _scorer_desc(score_calculator)
+        ok = C.c_int(0)
+        _lib.check(self._L.ps_snapshot_plan_ahead_flat(self._h, C.byref(desc), text.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                                       C.byref(ok)))
+        return bool(ok.value)
+
     def query_batch_device_planned_flat(self, text, offsets, score_calculator, fields_boost, top_k, d_keys, d_scores,
                                         d_counts, stream=None):
         """ps_snapshot_query_batch_device_planned_flat: like query_batch_device_flat, but the query planner

@@ -160,6 +160,59 @@ def test_batches_in_flight_with_a_different_boost_vector_each():
     hip.hipStreamDestroy(st)
 
 
+def test_batches_announced_ahead():
+    """ps_snapshot_plan_ahead_flat: the planner's count pass of the NEXT batch starts while the current ones are scored.
+    Announced and asked for, announced and NOT asked for (another batch, another scorer, a host-planned batch, nothing
+    at all), announced twice - every query call returns its own batch's answer, back to back on one caller stream."""
+    hip = psd._DeviceBuffer.hip()
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    cfg = dict(synth.CONFIGS["C2"], n_docs=60_000, vocab=3_000)
+    corpus = synth.Corpus(**cfg)
+    snap = synth.fill(psa.Index(2), corpus).snapshot(device=0)
+    sc, z, K, B = psa.bm25.new(), psa.zero_to_one.new(), 10, 96
+    batches = [corpus.queries(B, 3, salt=70 + s) for s in range(8)]
+    packed = [synth.pack_queries(b) for b in batches]
+    want = [[[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(b, sc, None, [1.0, 1.0], top_k=K)] for b in batches]
+    want_z = [[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(batches[0], z, None, [1.0, 1.0], top_k=K)]
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    bufs = [psd._DeviceBuffer(psd.block_bytes(B, K)) for _ in range(12)]
+    got_order = []
+
+    def run(i, buf, scorer=sc):
+        text, offsets = packed[i]
+        snap.query_batch_allgather_flat(None, text, offsets, scorer, [1.0, 1.0], K, buf.ptr.value, buf.ptr.value, stream=st.value)
+        got_order.append((i, scorer is z))
+
+    assert snap.plan_ahead_flat(*packed[0], sc) is True
+    run(0, bufs[0])                                   # announced and asked for
+    assert snap.last_stats()["device_planned"] == 1 and snap.last_stats()["plan_ms"] < 5.0
+    for i in range(1, 4):                             # the serving loop: announce s + 1, then ask for it
+        snap.plan_ahead_flat(*packed[i], sc)
+        run(i, bufs[i])
+    snap.plan_ahead_flat(*packed[4], sc)
+    run(5, bufs[4])                                   # announced 4, asked for 5
+    run(4, bufs[5])                                   # ... then 4 after all (planned afresh)
+    snap.plan_ahead_flat(*packed[6], sc)
+    snap.plan_ahead_flat(*packed[7], sc)              # announced twice: the first is dropped
+    run(7, bufs[6])
+    snap.plan_ahead_flat(*packed[6], sc)
+    run(0, bufs[7], scorer=z)                         # another scorer in between (host-planned zero_to_one batch)
+    run(6, bufs[8])
+    assert snap.plan_ahead_flat(*packed[0], z) is False   # zero_to_one is planned on the host: nothing to announce
+    snap.plan_ahead_flat(*packed[1], sc)              # announced and never asked for before the snapshot is queried synchronously
+    sync = [[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(batches[2], sc, None, [1.0, 1.0], top_k=K)]
+    assert sync == want[2]
+    assert hip.hipStreamSynchronize(st) == 0
+    for (i, is_z), buf in zip(got_order, bufs):
+        got = psd.unpack_blocks(buf.to_host(), 1, B, K, [B])
+        exp = want_z if is_z else want[i]
+        assert [[(k, bits(s)) for k, s in rs] for rs in got] == exp, (i, is_z)
+    hip.hipStreamDestroy(st)
+
+
 def test_work_counters_of_a_batch():
     """ps_snapshot_work_counters: what the kernels counted is consistent with the plan (K1d scans a part of the
     postings the reference walks; k_score streams all of them), bytes follow the documented formula, reset works."""
