@@ -71,6 +71,20 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def shared_snapshot_dir(need_bytes):
+    """Where local rank 0 leaves the snapshot file the other ranks mmap: /dev/shm when it has the room (a container's
+    /dev/shm may be 64 MiB), else the temp directory; None if neither has."""
+    import shutil
+    import tempfile
+    for d in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if shutil.disk_usage(d).free > need_bytes * 1.25 + (64 << 20):
+                return d
+        except OSError:
+            pass
+    return None
+
+
 def launch_ranks(args):
     """--gpus N without a launcher: become the launcher (one rank per GPU, RCCL over xGMI)."""
     import socket
@@ -164,7 +178,11 @@ def main():
     # ---- the index: built once per node, shared through the snapshot file --------------------------
     t_index = t_generate = t_snap = 0.0
     bulk = None
-    snap_path = "/dev/shm/ps_bench_%s_%s.snap" % (os.environ.get("MASTER_PORT", str(os.getpid())), args.config)
+    # (the flattened snapshot is about 1.1 KB per document of these corpora)
+    snap_dir = shared_snapshot_dir(cfg["n_docs"] * 1200) if world > 1 else None
+    if world > 1 and snap_dir is None:
+        sys.exit("bench.py: no room for the shared snapshot file in /dev/shm or the temp directory")
+    snap_path = os.path.join(snap_dir or "/dev/shm", "ps_bench_%s_%s.snap" % (os.environ.get("MASTER_PORT", str(os.getpid())), args.config))
     if local_rank == 0:
         t0 = time.time()
         index = psa.Index(F)
@@ -233,6 +251,7 @@ def main():
     # real (non-null) streams: the library then only enqueues and returns, so the host plans batch
     # s+1 while the GPU scores batch s
     streams = [torch.cuda.Stream() for _ in range(n_blk)]
+    torch.cuda.synchronize()  # (the zero fills above ran on torch's default stream; the steps run on non-blocking ones)
     # Index::query returns an owned Vec (src/query.rs:97-105): a step is not done before its results are in the CALLER's
     # memory.  Every step ends with the asynchronous device -> host copy of its top-k block(s) into pinned host memory, on
     # the step's stream, inside the timed region (`deliver`; the device-only figure is reported beside the headline).
@@ -488,17 +507,37 @@ def config4_leg(args, world, rank, local_rank, dev, comm, dist, debug_1gpu):
     F, K, G = cfg["fields"], cfg["top_k"], cfg["batch"]
     Bq = (G + world - 1) // world
     corpus = synth.Corpus(**cfg)
-    path = "/dev/shm/ps_bench_%s_C4leg.snap" % os.environ.get("MASTER_PORT", str(os.getpid()))
     t0 = time.time()
+    # local rank 0 builds and shares; whether that worked is agreed on by all ranks before anybody waits for a file
+    flag = [None]
+    snap = None
     if local_rank == 0:
-        snap = synth.fill(psa.Index(F), corpus).snapshot(device=dev)
-        snap.save(path)
-    dist.barrier()
+        try:
+            d = shared_snapshot_dir(cfg["n_docs"] * 1200)
+            if d is None:
+                raise OSError("no room for a %d MB snapshot file in /dev/shm or the temp directory" % (cfg["n_docs"] * 1200 >> 20))
+            path = os.path.join(d, "ps_bench_%s_C4leg.snap" % os.environ.get("MASTER_PORT", str(os.getpid())))
+            snap = synth.fill(psa.Index(F), corpus).snapshot(device=dev)
+            snap.save(path)
+            flag[0] = path
+        except Exception as e:  # noqa: BLE001
+            flag[0] = "ERR: %s" % e
+    dist.broadcast_object_list(flag, src=0)
+    if flag[0].startswith("ERR"):
+        return {"skipped": flag[0][5:]}
+    path = flag[0]
+    ok = 1
     if local_rank != 0:
-        snap = psa.Snapshot.load(path, device=dev)
-    dist.barrier()
+        try:
+            snap = psa.Snapshot.load(path, device=dev)
+        except Exception:  # noqa: BLE001
+            ok = 0
+    oks = torch.tensor([ok], dtype=torch.int32, device="cpu" if debug_1gpu else "cuda")
+    dist.all_reduce(oks, op=dist.ReduceOp.MIN)
     if local_rank == 0:
         os.unlink(path)
+    if int(oks.item()) == 0:
+        return {"skipped": "a rank could not load the shared C4 snapshot (device memory?)"}
     t_build = time.time() - t0
     steps, warm = 10, 2
     scorer, boosts = psa.bm25.new(), [1.0] * F
@@ -658,6 +697,15 @@ def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layo
             res[name] = {"per_launch": r["per_launch"], "unit": r["unit"], "achieved": rr / r["scale"],
                          "peak": r["peak"], "rate_unit": r["rate_unit"], "frac": rr / r["scale"] / r["peak"]}
         traffic = drv.get("hbm_bytes_per_launch")
+        if "fabric_requests" in res:
+            fr = res["fabric_requests"]
+            out["request_roofline"] = {
+                "bound": "fabric read requests (L2 misses)", "achieved": fr["achieved"], "peak": fr["peak"], "unit": "G requests/s",
+                "frac": fr["frac"], "requests_per_launch": fr["per_launch"],
+                "why": "calibrated on this chip (profiles/r04_fetch_size_calibration.txt): FETCH_SIZE counts L2 -> fabric read requests; a "
+                       "scattered 8-byte lookup that misses L2 costs one request like a whole 128-byte line of a stream, and the fabric "
+                       "sustains 41-43 G requests/s either way (= 5.3 TB/s only when every request is a full line).  A kernel of lookups is "
+                       "bound by this rate, not by bytes: `frac` above (bytes touched / 8 TB/s) cannot approach 1 for it"}
         out.update({"traffic": traffic,
                     "bytes_touched_over_traffic": (touched / traffic) if traffic else None,
                     "pmc": {"resources": res, "wave_cycles_in_profiled_run": drv.get("wave_cycles"),

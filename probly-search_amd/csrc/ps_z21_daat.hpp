@@ -483,8 +483,15 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     }
   };
 
+#ifdef PS_ITEM_TRACE
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  uint32_t n_trips = 0;
+#endif
   bool first = true, essential = true;
   for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
+#ifdef PS_ITEM_TRACE
+    ++n_trips;
+#endif
     const unsigned long long sbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long tl[Z_LEVELS];
 #pragma unroll
@@ -654,6 +661,13 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     p.cand_doc[o] = ok ? tk.d : 0xFFFFFFFFu;
     if (lane == 0) p.cand_cnt[it.slot] = tk.n;
   }
+#ifdef PS_ITEM_TRACE
+  if (p.item_trace != nullptr && lane == 0) {  // (profiling builds: tools/item_trace.py; "rank" = the chunk's level here)
+    unsigned long long* tr = p.item_trace + (size_t)id * 4;
+    tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = (unsigned long long)n_trips | ((unsigned long long)(it.count >> ZITEM_LEVEL_SHIFT) << 32);
+    tr[3] = ws.scanned | ((unsigned long long)ws.reached << 32);
+  }
+#endif
   if (WC && lane == 0) {
     unsigned long long* w = p.wstats + (size_t)(blockIdx.x & (WS_SLOTS - 1u)) * WS_WORDS;
     atomicAdd(&w[WS_ITEMS_RUN], 1ull);

@@ -44,7 +44,7 @@ def test_two_ranks_debug_one_gpu_end_to_end():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0
     assert "DEBUG" in d["data"]
     # N > 1 also reports BASELINE config 4 (one 8192-query batch split over the ranks) and which RCCL was resolved
-    assert d["config4"]["queries_per_s"] > 0 and "8192-query" in d["config4"]["workload"] and "rccl_path" in d
+    assert d["config4"].get("queries_per_s", 0) > 0 and "8192-query" in d["config4"]["workload"] and "rccl_path" in d, d["config4"]
 
 
 @pytest.mark.gpu

@@ -170,6 +170,7 @@ def test_deterministic_and_device_topk_buffers():
     dk = torch.zeros(64 * K, dtype=torch.int64, device="cuda:0")
     ds = torch.zeros(64 * K, dtype=torch.float64, device="cuda:0")
     dc = torch.zeros(64, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()  # (the zero fills run on torch's stream; the library's own streams are non-blocking: no implicit order)
     st = torch.cuda.current_stream()
     snap.query_batch_device(queries, psa.bm25.new(), None, [1.0, 1.0], K, dk.data_ptr(), ds.data_ptr(),
                             dc.data_ptr(), stream=st.cuda_stream)

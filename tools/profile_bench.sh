@@ -13,10 +13,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 BENCH="python bench.py --no-cpu-baseline --no-single-latency --no-bulk-index --no-streaming-leg --no-alternating-boosts-leg $*"
-echo "rocprofv3 <pass> -- $BENCH --steps 3 --warmup 1" > $OUT/command.txt
+echo "rocprofv3 <pass> -- $BENCH --steps 6 --warmup 2" > $OUT/command.txt
 run() {  # name, rocprof args...
   local name=$1; shift
-  timeout 300 rocprofv3 "$@" -d $OUT/$name -o $name -- $BENCH --steps 3 --warmup 1 > $OUT/$name.bench.json 2> $OUT/$name.err
+  timeout 300 rocprofv3 "$@" -d $OUT/$name -o $name -- $BENCH --steps 6 --warmup 2 > $OUT/$name.bench.json 2> $OUT/$name.err
   echo "$name rc=$?"
   python tools/rocpd_summary.py $OUT/$name/${name}_results.db 100000 > $OUT/$name.txt 2>&1
   rm -rf $OUT/$name
