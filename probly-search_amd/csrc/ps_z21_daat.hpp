@@ -45,6 +45,9 @@ namespace ps {
 #ifndef PS_DAAT_ZU
 #define PS_DAAT_ZU 4   // postings per lane in flight in the scan
 #endif
+#ifndef PS_DAAT_ZPF
+#define PS_DAAT_ZPF 0  // 1: the next trip's own postings are requested before this trip's lookups (measured: no gain, 12-18 more VGPRs)
+#endif
 constexpr int Z_LEVELS = 3;
 constexpr uint32_t ZITEM_LEVEL_SHIFT = 30;     // DItem::count bits 30-31: levels l (the lowest ones) with every document of the chunk at or above D_l
 constexpr uint32_t ZITEM_COUNT = 0x3FFFFFFFu;
@@ -270,6 +273,13 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   __shared__ uint32_t q_w[F_][DAAT_WGW][QCAP];    // ... the own posting's packed {tf, field length} words
   __shared__ uint32_t q_rel[NO][DAAT_WGW][QCAP];  // ... per other list: posting within that list (bitmap hit), REL_MAYBE (filter), REL_NONE
   __shared__ double btab[DAAT_WGW][NE][Z_FLN];    // B(m, fl), m = 1..NE
+  // Reach queue (wave-private LDS ring): the postings that passed the scan's integer test - a few percent of the lanes
+  // of a trip - wait here until 64 are together; the first level of the other lists (address arithmetic, filter
+  // hashes, the loads, the tightening) then runs with every lane busy instead of four times per trip for a handful
+  // of lanes (the scan is VALU-issue bound: profiles/r04_C3_rocprof_summary.txt)
+  __shared__ uint32_t r_d[DAAT_WGW][QCAP];
+  __shared__ uint32_t r_i[DAAT_WGW][QCAP];
+  __shared__ uint32_t r_w[F_][DAAT_WGW][QCAP];
   const int lane = threadIdx.x & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
@@ -334,14 +344,19 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
       btab[wave][j][lane] = acc;
     }
   }
-  int flmax[NE + 1];  // wave-uniform: the longest field that can still matter with m contributing records
+  // wave-uniform: the longest field that can still matter with m contributing records - under both thresholds
+  // (flmax: documents at or above tie_from) and under the strict one alone (flmax_s: queued documents below it)
+  int flmax[NE + 1], flmax_s[NE + 1];
   auto set_flmax = [&](const double ts, const double tt) __attribute__((always_inline)) {
     flmax[0] = z_beats(0.0, ts, tt) ? Z_ALL : Z_NONE;
+    flmax_s[0] = z_beats(0.0, ts, 0.0) ? Z_ALL : Z_NONE;
 #pragma unroll
     for (int m = 1; m <= NE; ++m) {
-      const unsigned long long ok = __ballot(z_beats(btab[wave][m - 1][lane], ts, tt));
-      const int n_ok = (int)__popcll(ok);  // B is non-increasing in fl: the lanes that pass are a prefix
+      const double bv = btab[wave][m - 1][lane];
+      const int n_ok = (int)__popcll(__ballot(z_beats(bv, ts, tt)));  // B is non-increasing in fl: the lanes that pass are a prefix
       flmax[m] = n_ok == WAVE ? Z_ALL : n_ok - 1;
+      const int n_s = (int)__popcll(__ballot(z_beats(bv, ts, 0.0)));
+      flmax_s[m] = n_s == WAVE ? Z_ALL : n_s - 1;
     }
   };
   TopK tk;
@@ -350,6 +365,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   const uint32_t end = it.begin + (it.count & ZITEM_COUNT);
   WorkStats ws;
   uint32_t q_head = 0, q_n = 0;  // wave-uniform
+  uint32_t r_head = 0, r_n = 0;  // (the reach queue)
   const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
   double theta_s = 0.0, theta_t = 0.0;  // theta_t: the tie threshold of the current trip (0 while it is not entirely at or above D_0)
   uint32_t tie_from = 0xFFFFFFFFu;      // ... which holds for the documents with ids >= tie_from (the boundary it was published below)
@@ -483,11 +499,108 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     }
   };
 
+  // First level of every other list for the first `count` (<= 64) documents of the reach queue, one per lane, all
+  // loads in flight together; then what it tells - how many lists can still count, exact membership of bitmap lists -
+  // against the current thresholds; the survivors move on to the survivor queue.
+  auto level1 = [&](const uint32_t count) __attribute__((always_inline)) {
+    const uint32_t rat = (r_head + (uint32_t)lane) & (QCAP - 1u);
+    const bool on = (uint32_t)lane < count;
+    const uint32_t dq = on ? r_d[wave][rat] : 0u, iq = on ? r_i[wave][rat] : 0u;
+    uint32_t wq[F_];
+#pragma unroll
+    for (int x = 0; x < F_; ++x) wq[x] = on ? r_w[x][wave][rat] : 0u;
+    r_head = (r_head + count) & (QCAP - 1u);
+    r_n -= count;
+    ws.reached += cnt(on);
+    uint2 fl[NO];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+      fl[k] = make_uint2(0u, 0u);
+      if ((uint32_t)k + 1u >= ne) continue;
+      ws.cell += cnt(on);
+      if (o_bm[k] != 0xFFFFFFFFu) {
+        if (on) fl[k] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(dq >> 5));
+      } else if (o_bloom[k] != NO_BLOOM) {
+        uint64_t wi;
+        unsigned long long mk;
+        bloom_probe(dq, o_bloom[k], wi, mk);
+        const unsigned long long wd = on ? p.bloom[wi] : 0ull;
+        fl[k].x = (on && (wd & mk) == mk) ? 1u : 0u;  // maybe
+      } else {
+        fl[k].x = on ? 1u : 0u;  // no filter: ask the table
+      }
+    }
+    bool alive = on;
+    uint32_t hits = 0;
+    uint32_t loc[NO];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+      loc[k] = REL_NONE;
+      if ((uint32_t)k + 1u >= ne) continue;
+      if (o_bm[k] != 0xFFFFFFFFu) {
+        const uint32_t bit = dq & 31u;
+        const bool hit = (fl[k].x >> bit) & 1u;
+        if (hit) {
+          loc[k] = fl[k].y + (uint32_t)__popc(fl[k].x & ((1u << bit) - 1u));
+          if (o_rank[k] < own_rank) alive = false;  // evaluated from its highest-ranked list only
+          else ++hits;
+        }
+      } else if (fl[k].x != 0u) {
+        loc[k] = REL_MAYBE;  // (a "maybe" of a higher-ranked list adds nothing to the bound: found there, the document is cancelled)
+        if (o_rank[k] > own_rank) ++hits;
+      }
+    }
+    // (the queue may hold documents of a trip below tie_from next to documents above it: the tie rule is per document)
+    const bool tie = dq >= tie_from;
+    bool any = false;
+#pragma unroll
+    for (int x = 0; x < F_; ++x) {
+      const uint32_t tfu = wq[x] >> 24;
+      const uint32_t m = hits + ((tfu >= need_own && tfu > 0u) ? 1u : 0u);
+      int fm = tie ? flmax[0] : flmax_s[0];
+#pragma unroll
+      for (int k = 1; k <= NE; ++k) fm = m == (uint32_t)k ? (tie ? flmax[k] : flmax_s[k]) : fm;
+      any = any || (int)(wq[x] & TFL_FL_ESC) <= fm;
+    }
+    alive = alive && any;
+    // ---- survivors wait in the survivor queue until 64 are together ----
+    const unsigned long long mm = __ballot(alive);
+    if (mm) {
+      if (alive) {
+        const uint32_t at = (q_head + q_n + (uint32_t)__popcll(mm & lt)) & (QCAP - 1u);
+        q_d[wave][at] = dq;
+        q_i[wave][at] = iq;
+#pragma unroll
+        for (int x = 0; x < F_; ++x) q_w[x][wave][at] = wq[x];
+#pragma unroll
+        for (int k = 0; k < NO; ++k)
+          if ((uint32_t)k + 1u < ne) q_rel[k][wave][at] = loc[k];
+      }
+      q_n += (uint32_t)__popcll(mm);
+      if (q_n >= (uint32_t)WAVE) process((uint32_t)WAVE);
+    }
+  };
+
 #ifdef PS_ITEM_TRACE
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
   uint32_t n_trips = 0;
 #endif
   bool first = true, essential = true;
+  // The own postings of a trip (doc id + packed words; out-of-range lanes re-read the chunk's last posting).  With
+  // PS_DAAT_ZPF the postings of trip t + 1 are requested before trip t's lookups go out: a trip is otherwise two or
+  // three memory round trips one after the other (own postings -> first level -> survivors' second level), and this
+  // kernel - a scan with few lookups - is bound by that chain, not by a throughput roof.
+  auto load_trip = [&](const uint32_t i0, uint32_t (&dd)[U], uint32_t (&ww)[U][F_]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + u * WAVE + lane;
+      const uint32_t pi = i < end ? i : end - 1;
+      dd[u] = p.doc[own_off + pi];
+      tfl_load<F_>(p, own_off + pi, ww[u]);
+    }
+  };
+  uint32_t d[U], wv[U][F_];
+  if (PS_DAAT_ZPF) load_trip(it.begin, d, wv);
   for (uint32_t i0 = it.begin; i0 < end && essential; i0 += WAVE * U) {
 #ifdef PS_ITEM_TRACE
     ++n_trips;
@@ -496,16 +609,15 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     unsigned long long tl[Z_LEVELS];
 #pragma unroll
     for (int l = 0; l < Z_LEVELS; ++l) tl[l] = __hip_atomic_load(&p.gtie[(size_t)l * p.z_tstride + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t d[U], wv[U][F_];
+    uint32_t dn[U], wn[U][F_];  // (PS_DAAT_ZPF) the next trip's postings, in flight while this trip is worked on
+    if (PS_DAAT_ZPF) {
+      if (i0 + WAVE * U < end) load_trip(i0 + WAVE * U, dn, wn);
+    } else {
+      load_trip(i0, d, wv);
+    }
     bool inr[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t i = i0 + u * WAVE + lane;
-      inr[u] = i < end;
-      const uint32_t pi = i < end ? i : end - 1;
-      d[u] = p.doc[own_off + pi];
-      tfl_load<F_>(p, own_off + pi, wv[u]);
-    }
+    for (int u = 0; u < U; ++u) inr[u] = i0 + u * WAVE + lane < end;
     {
       // the trip's place among the levels: its first posting (lane 0 of slot 0) is its lowest doc id, its last valid
       // posting its highest
@@ -559,7 +671,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
       if ((uint32_t)m == n_lower + 1u) fmw = flmax[m];
       if ((uint32_t)m == n_lower) fmo = flmax[m];
     }
-    bool rch[U];
     if (WC) ws.scanned += n_in;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -571,88 +682,31 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
         const bool c = tfu >= need_own && tfu > 0u;  // the own record can count for field x
         any = any || flu <= (c ? fmw : fmo);
       }
-      rch[u] = inr[u] && any;
-      const uint32_t nr = cnt(rch[u]);
-      ws.reached += nr;
-      ws.cell += nr * (ne - 1u);
-    }
-    // ---- first level of every other list for the documents that passed, all in flight together ----
-    uint2 fl[NO][U];
-#pragma unroll
-    for (int k = 0; k < NO; ++k) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) fl[k][u] = make_uint2(0u, 0u);
-      if ((uint32_t)k + 1u >= ne) continue;
-      if (o_bm[k] != 0xFFFFFFFFu) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (rch[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(d[u] >> 5));
-      } else if (o_bloom[k] != NO_BLOOM) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          uint64_t wi;
-          unsigned long long mk;
-          bloom_probe(d[u], o_bloom[k], wi, mk);
-          const unsigned long long wd = rch[u] ? p.bloom[wi] : 0ull;
-          fl[k][u].x = (rch[u] && (wd & mk) == mk) ? 1u : 0u;  // maybe
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u) fl[k][u].x = rch[u] ? 1u : 0u;  // no filter: ask the table
-      }
-    }
-    // ---- what the first level tells: how many lists can still count, exact membership of bitmap lists ----
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      bool alive = rch[u];
-      uint32_t hits = 0;
-      uint32_t loc[NO];
-#pragma unroll
-      for (int k = 0; k < NO; ++k) {
-        loc[k] = REL_NONE;
-        if ((uint32_t)k + 1u >= ne) continue;
-        if (o_bm[k] != 0xFFFFFFFFu) {
-          const uint32_t bit = d[u] & 31u;
-          const bool hit = (fl[k][u].x >> bit) & 1u;
-          if (hit) {
-            loc[k] = fl[k][u].y + (uint32_t)__popc(fl[k][u].x & ((1u << bit) - 1u));
-            if (o_rank[k] < own_rank) alive = false;  // evaluated from its highest-ranked list only
-            else ++hits;
-          }
-        } else if (fl[k][u].x != 0u) {
-          loc[k] = REL_MAYBE;  // (a "maybe" of a higher-ranked list adds nothing to the bound: found there, the document is cancelled)
-          if (o_rank[k] > own_rank) ++hits;
-        }
-      }
-      bool any = false;
-#pragma unroll
-      for (int x = 0; x < F_; ++x) {
-        const uint32_t tfu = wv[u][x] >> 24;
-        const uint32_t m = hits + ((tfu >= need_own && tfu > 0u) ? 1u : 0u);
-        int fm = flmax[0];
-#pragma unroll
-        for (int k = 1; k <= NE; ++k) fm = m == (uint32_t)k ? flmax[k] : fm;
-        any = any || (int)(wv[u][x] & TFL_FL_ESC) <= fm;
-      }
-      alive = alive && any;
-      // ---- survivors wait in the queue until 64 are together ----
-      const unsigned long long mm = __ballot(alive);
+      const bool rch = inr[u] && any;
+      // ---- the postings that passed wait in the reach queue until 64 are together ----
+      const unsigned long long mm = __ballot(rch);
       if (mm) {
-        if (alive) {
-          const uint32_t at = (q_head + q_n + (uint32_t)__popcll(mm & lt)) & (QCAP - 1u);
-          q_d[wave][at] = d[u];
-          q_i[wave][at] = i0 + (uint32_t)u * WAVE + (uint32_t)lane;  // (alive: within the chunk)
+        if (rch) {
+          const uint32_t at = (r_head + r_n + (uint32_t)__popcll(mm & lt)) & (QCAP - 1u);
+          r_d[wave][at] = d[u];
+          r_i[wave][at] = i0 + (uint32_t)u * WAVE + (uint32_t)lane;  // (reached: within the chunk)
 #pragma unroll
-          for (int x = 0; x < F_; ++x) q_w[x][wave][at] = wv[u][x];
-#pragma unroll
-          for (int k = 0; k < NO; ++k)
-            if ((uint32_t)k + 1u < ne) q_rel[k][wave][at] = loc[k];
+          for (int x = 0; x < F_; ++x) r_w[x][wave][at] = wv[u][x];
         }
-        q_n += (uint32_t)__popcll(mm);
-        if (q_n >= (uint32_t)WAVE) process((uint32_t)WAVE);
+        r_n += (uint32_t)__popcll(mm);
+        if (r_n >= (uint32_t)WAVE) level1((uint32_t)WAVE);
+      }
+    }
+    if (PS_DAAT_ZPF && i0 + WAVE * U < end) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        d[u] = dn[u];
+#pragma unroll
+        for (int x = 0; x < F_; ++x) wv[u][x] = wn[u][x];
       }
     }
   }
+  while (r_n) level1(min(r_n, (uint32_t)WAVE));
   while (q_n) process(min(q_n, (uint32_t)WAVE));
   if ((uint32_t)lane < p.K) {
     const uint64_t o = (uint64_t)it.slot * p.K + lane;
