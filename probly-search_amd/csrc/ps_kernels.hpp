@@ -42,6 +42,9 @@ constexpr int WAVE = 64;
 #ifndef PS_DAAT_UMQ
 #define PS_DAAT_UMQ 4            // ... postings per lane in flight in its scan stage
 #endif
+#ifndef PS_DAAT_MRQ
+#define PS_DAAT_MRQ 1            // ... the postings that pass the first bound test wait in a reach queue until 64 are together (the first lookup with every lane busy)
+#endif
 #ifndef PS_HARVEST_UNROLL
 #define PS_HARVEST_UNROLL 8  // 16-byte LDS reads in flight per lane while a tile is harvested
 #endif
@@ -1692,6 +1695,17 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
         __shared__ uint32_t mq_d[DAAT_WGW][QCAP];
         __shared__ double mq_so[DAAT_WGW][QCAP];
         __shared__ double mq_s1[DAAT_WGW][QCAP];
+#if PS_DAAT_MRQ
+        // Reach queue: the postings that pass the first bound test (about one in seven on C5) wait here until 64 are
+        // together; the first lookup then runs with every lane busy instead of once per trip over four sparse slots
+        // (512 entries: a trip adds up to UA x 64 to < 64.  level1 and process each have ONE call site, at the top of the
+        // loop: inlined at several sites the two bodies - every lookup_scores in them - no longer fit the instruction
+        // cache, 6.7 ms instead of 1.7)
+        constexpr uint32_t RCAP = 512;
+        __shared__ uint32_t rq_d[DAAT_WGW][RCAP];
+        __shared__ double rq_so[DAAT_WGW][RCAP];
+        uint32_t rq_head = 0, rq_n = 0;  // wave-uniform
+#endif
         uint32_t q_head = 0, q_n = 0;  // wave-uniform
         const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
         const uint32_t r1 = min(e1, e0 + own_rank + 1u);  // the highest-bound list ranked below the own one
@@ -1817,13 +1831,56 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
           mq_tb2 += __builtin_amdgcn_s_memrealtime() - t_b2;
 #endif
         };
+#if PS_DAAT_MRQ
+        // the first lookup (the highest-bound list ranked below the own one) for the first `count` (<= 64) documents of the
+        // reach queue, one per lane; what is still alive moves on to the survivor queue
+        auto level1 = [&](const uint32_t count) {
+          const uint32_t rat = (rq_head + (uint32_t)lane) & (RCAP - 1u);
+          bool on[1] = {(uint32_t)lane < count};
+          const uint32_t dq[1] = {on[0] ? rq_d[wave][rat] : 0u};
+          const double so = on[0] ? rq_so[wave][rat] : 0.0;
+          rq_head = (rq_head + count) & (RCAP - 1u);
+          rq_n -= count;
+          double s1[1] = {0.0};
+          if (has1) lookup_scores<F_, 1>(p, lut, en1, dq, on, s1, ws);
+          if (on[0]) {
+            double bound = 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              double a = (uint32_t)g == own_grp ? so : 0.0;
+              if ((uint32_t)g == g1 && s1[0] > 0.0) a = fmax(a, s1[0]);
+              bound += fmax(a, rem1[g]);
+            }
+            if (bound < theta || (s1[0] > 0.0 && j1_rank < own_rank)) on[0] = false;
+          }
+          const unsigned long long m = __ballot(on[0]);
+          if (m) {
+            if (on[0]) {
+              const uint32_t at = (q_head + q_n + (uint32_t)__popcll(m & lt)) & (QCAP - 1u);
+              mq_d[wave][at] = dq[0];
+              mq_so[wave][at] = so;
+              mq_s1[wave][at] = s1[0];
+            }
+            q_n += (uint32_t)__popcll(m);  // (a push adds <= 64 to < 64: the survivor queue is drained first at the top of the loop)
+          }
+        };
+#endif
         uint32_t i0 = it.begin;
 #ifdef PS_MQ_TIME
         const unsigned long long t_a0 = __builtin_amdgcn_s_memrealtime();
 #endif
         for (;;) {
           const bool scanning = i0 < end && essential;
-          if (q_n >= (uint32_t)WAVE || (!scanning && q_n)) { process(min(q_n, (uint32_t)WAVE)); continue; }
+#if PS_DAAT_MRQ
+          const uint32_t rq_left = rq_n;
+#else
+          const uint32_t rq_left = 0u;
+#endif
+          // (the survivor queue first, so that it holds < 64 whenever the reach queue hands it up to 64 more; its rest last)
+          if (q_n >= (uint32_t)WAVE || (!scanning && !rq_left && q_n)) { process(min(q_n, (uint32_t)WAVE)); continue; }
+#if PS_DAAT_MRQ
+          if (rq_n >= (uint32_t)WAVE || (!scanning && rq_n)) { level1(min(rq_n, (uint32_t)WAVE)); continue; }
+#endif
           if (!scanning) break;
           const unsigned long long tbits = __hip_atomic_load(&p.gthr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           theta = __hiloint2double(__builtin_amdgcn_readfirstlane((int)(tbits >> 32)),
@@ -1859,6 +1916,21 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
           if (essential) ws.scanned += min(end - i0, (uint32_t)(WAVE * UA)); else ws.probe += min(end - i0, (uint32_t)(WAVE * UA));
           i0 += WAVE * UA;
           if (!__any(any_alive)) continue;
+#if PS_DAAT_MRQ
+#pragma unroll
+          for (int u = 0; u < UA; ++u) {
+            const unsigned long long m = __ballot(alive[u]);
+            if (m) {
+              if (alive[u]) {
+                const uint32_t at = (rq_head + rq_n + (uint32_t)__popcll(m & lt)) & (RCAP - 1u);
+                rq_d[wave][at] = d[u];
+                rq_so[wave][at] = s_own[u];
+              }
+              rq_n += (uint32_t)__popcll(m);
+            }
+          }
+        }
+#else
           double s1[UA];
 #pragma unroll
           for (int u = 0; u < UA; ++u) s1[u] = 0.0;
@@ -1888,6 +1960,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
             }
           }
         }
+#endif
 #ifdef PS_MQ_TIME
         ws.probe = (uint32_t)mq_tb1; ws.offer = (uint32_t)mq_tb2; ws.row = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_a0); ws.hit = (uint32_t)mq_cnt;
 #endif

@@ -446,7 +446,7 @@ def test_resident_rows_reuse_eviction_and_invalidation(monkeypatch):
     monkeypatch.setenv("PS_DAAT_DENSE_MIN_DENSITY_PCT", "0")
     monkeypatch.setenv("PS_DENSE_MAX_ROWS", "6")
     monkeypatch.setenv("PS_ROW_CACHE_MB", "1")
-    monkeypatch.setenv("PS_DAAT_Z", "0")  # (the zero_to_one steps are here for the row slab: K1dz reads no rows)
+    psa.load().ps_set_option(b"PS_DAAT_Z", 0)  # (the zero_to_one steps are here for the row slab: K1dz reads no rows; reset by conftest)
     cfg = dict(synth.CONFIGS["C2"], n_docs=30_000, vocab=400)   # 240 KB per row: 6 slots (the per-batch minimum)
     corpus = synth.Corpus(**cfg)
     p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
