@@ -95,6 +95,11 @@ struct DItem {         // a chunk of one list
   uint32_t begin;      // first posting of the chunk within the list
   uint32_t count;
   uint32_t slot;       // candidate slot (query-major)
+  // copies of DEntry::skip_thr / q of the list: nine workgroups in ten only exist to find their list non-essential and
+  // leave, and with these here that costs two dependent loads (item -> threshold) instead of three
+  double skip_thr;
+  uint32_t q;
+  uint32_t _pad;
 };
 
 struct DItemGen {      // per plan entry: k_prep_items expands it into its DItems on the device
@@ -1613,9 +1618,9 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
     const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
     int need = 0;
     if (id < n_ditems) {
-      const DEntry de = p.dentry[p.ditems[p.item_base + id].entry];
-      const double theta = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      need = !(de.skip_thr < theta);
+      const DItem it0 = p.ditems[p.item_base + id];
+      const double theta = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[it0.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      need = !(it0.skip_thr < theta);
     }
     if (!__syncthreads_or(need)) {
       if (id < n_ditems && lane == 0) p.cand_cnt[p.ditems[p.item_base + id].slot] = 0u;
@@ -2273,9 +2278,9 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
     // most workgroups of a launch only hold chunks of lists that are already non-essential: they leave at once
     int need = 0;
     if (id < n_ditems) {
-      const DEntry de = p.dentry[p.ditems[id].entry];
-      const double theta = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      need = !(de.skip_thr < theta);
+      const DItem it0 = p.ditems[id];
+      const double theta = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[it0.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      need = !(it0.skip_thr < theta);
     }
     if (!__syncthreads_or(need)) {
       if (id < n_ditems && lane == 0) p.cand_cnt[p.ditems[id].slot] = 0u;

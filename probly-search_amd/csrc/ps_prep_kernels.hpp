@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint3
 
 // ---- descriptors of one query ---------------------------------------------------------------------
 // Result of the per-query part: candidate slots the query needs (its items), and per entry the chunking.
-// Two implementations with the same outputs: plans of <= 8 entries are handled in registers (every global
+// Two implementations with the same outputs: plans of <= 4 entries are handled in registers (every global
 // load of the query is issued up front, all the O(n^2) logic is ALU work), wider ones (<= 64) walk their
 // arrays in HBM.
 constexpr double PREP_SLACK = 1.0 + 1e-9;  // the bounds are summed in another order than the scores
@@ -444,7 +444,9 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
   const bool have = q < pp.B;
   const uint32_t b = have ? pp.qbeg[q] : 0u, n = have ? pp.qbeg[q + 1] - b : 0u;
   uint32_t slots = 0;
-  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n) : n <= 8 ? prep_query_small<8>(pp, q, b, n) : prep_query_general(pp, q, b, n);
+  // (plans of <= 4 entries - one list per query term: C2, C4 - entirely in registers; wider ones walk their arrays in HBM.
+  // An 8-entry register variant cost this kernel 145 VGPRs and 58 SGPR spills for every batch: 76 / 0 without it.)
+  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n) : prep_query_general(pp, q, b, n);
   // candidate slots: query-major within the query; the wave's queries take one block of the batch's slots
   const uint32_t s0 = wave_add_by_key(&pp.ctl->total_slots, 0u, slots, have && n != 0);
   if (have) { pp.qslot[q] = n ? s0 : 0u; pp.qslot_n[q] = slots; }
@@ -485,14 +487,17 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
 __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = i < pp.ne;
-  uint32_t nc = 0, bk = 0, len_i = 0, chunk = 1, first_slot = 0;
+  uint32_t nc = 0, bk = 0, len_i = 0, chunk = 1, first_slot = 0, q_i = 0;
+  double skip_i = 0.0;
   if (have) {
     ps_plan_entry& en = pp.plan[i];
     const DItemGen g = pp.gen[i];
     const uint32_t len = en.len, c = g.chunk;
     len_i = len; chunk = c; first_slot = g.first_slot;
     nc = (len + c - 1) / c;
-    bk = prep_bucket(pp.dentry[i].rank, len);
+    const DEntry de_i = pp.dentry[i];
+    skip_i = de_i.skip_thr; q_i = de_i.q;
+    bk = prep_bucket(de_i.rank, len);
     if (pp.n_cand) {
       const uint32_t cd = pp.cand_of_layer[en.node];
       if (cd != NO_CAND) {
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
     pp.gen[i].item_at = at;
     for (uint32_t j = 0; j < nc; ++j) {
       const uint32_t pb = j * chunk;
-      if (at + j < pp.items_cap) pp.items[at + j] = DItem{i, pb, min(chunk, len_i - pb), first_slot + j};
+      if (at + j < pp.items_cap) pp.items[at + j] = DItem{i, pb, min(chunk, len_i - pb), first_slot + j, skip_i, q_i, 0u};
     }
   }
 }

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {
 __global__ __launch_bounds__(2 * WAVE) void k_zprep_items(const ZPrepParams pp) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = i < pp.ne;
-  uint32_t nc = 0, len = 0, chunk = 1, first_slot = 0, rank = 0;
+  uint32_t nc = 0, len = 0, chunk = 1, first_slot = 0, rank = 0, q_i = 0;
+  double skip_i = 0.0;
   uint32_t nb[Z_LEVELS + 1], na[Z_LEVELS];
 #pragma unroll
   for (int l = 0; l <= Z_LEVELS; ++l) nb[l] = 0;
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(2 * WAVE) void k_zprep_items(const ZPrepParams pp) 
       na[l] = pp.nabove_from[(size_t)i * Z_LEVELS + l];
     }
     nb[Z_LEVELS] = nc;
-    rank = pp.dentry[i].rank;
+    const DEntry de_i = pp.dentry[i];
+    rank = de_i.rank; skip_i = de_i.skip_thr; q_i = de_i.q;
   }
   uint32_t at[Z_LEVELS + 1], lo = 0;
 #pragma unroll
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_zprep_items(const ZPrepParams pp) 
 #pragma unroll
       for (int l = 1; l <= Z_LEVELS; ++l) a = ph == (uint32_t)l ? at[l] : a;
       a += j;
-      if (a < pp.items_cap) pp.items[a] = DItem{i, pb, min(chunk, len - pb) | (lv << ZITEM_LEVEL_SHIFT), first_slot + j};
+      if (a < pp.items_cap) pp.items[a] = DItem{i, pb, min(chunk, len - pb) | (lv << ZITEM_LEVEL_SHIFT), first_slot + j, skip_i, q_i, 0u};
     }
   }
 }
@@ -289,11 +291,10 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     int need = 0;
     if (id < n_ditems) {
       const DItem it0 = p.ditems[id];
-      const DEntry de = p.dentry[it0.entry];
-      const double ts = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[de.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const double ts = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[it0.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       const uint32_t lv = it0.count >> ZITEM_LEVEL_SHIFT;
-      const double tt = lv ? z_tie_of(p, de.q, lv) : 0.0;
-      need = z_beats(de.skip_thr, ts, tt);
+      const double tt = lv ? z_tie_of(p, it0.q, lv) : 0.0;
+      need = z_beats(it0.skip_thr, ts, tt);
     }
     if (!__syncthreads_or(need)) {
       if (id < n_ditems && lane == 0) p.cand_cnt[p.ditems[id].slot] = 0u;
