@@ -319,12 +319,12 @@ ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc
                                          ps_tokenizer_fn tokenizer, void* user, size_t top_k, void* d_keys,
                                          void* d_scores, void* d_counts, void* hip_stream);
 
-/* Pipelined submission (optional): announce the NEXT flat BM25 top-k batch this snapshot will be asked to score.  The
+/* Pipelined submission (optional): announce the NEXT flat top-k batch (BM25, or zero_to_one) this snapshot will be asked to score.  The
  * library copies the text and starts the device planner's count pass at once, beside the batches still being scored;
  * the flat query call that follows with byte-identical (text, offsets) finds the plan's totals ready instead of waiting
  * ~0.25 ms for them.  One batch can be announced at a time; any other call in between simply drops it (nothing is
  * ever scored from an announced batch that was not asked for).  *accepted = 0 when the batch would not be planned on
- * the device anyway (other scorer, custom tokenizer paths, small batches).  src/query.rs:21-27 is still what the
+ * the device anyway (custom scorers, small batches).  src/query.rs:21-27 is still what the
  * query call mirrors; this is the async half of a server's double-buffered submission loop. */
 ps_status ps_snapshot_plan_ahead_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text, const uint64_t* offsets,
                                       size_t n_queries, int* accepted);

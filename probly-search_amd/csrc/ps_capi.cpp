@@ -168,18 +168,20 @@ ps_status run_device_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const
     if (n_queries && (!text || !offsets)) return fail(PS_EINVAL, "null argument");
     // BM25 top-k batches with the built-in tokenizer are planned on the device too (k_plan): the host
     // hands the text over and sizes the launches from the plan's totals
-    if (!tokenizer && snap && scorer && scorer->kind == PS_SCORER_BM25 && snap->engine && top_k >= 1 && top_k <= PS_MAX_DEVICE_TOPK &&
-        offsets && snap->engine->wants_device_plan(n_queries)) {
+    // (zero_to_one: the batches K1dz takes; run_device_planned hands the others back before anything is enqueued)
+    if (!tokenizer && snap && scorer && (scorer->kind == PS_SCORER_BM25 || scorer->kind == PS_SCORER_ZERO_TO_ONE) && snap->engine &&
+        top_k >= 1 && top_k <= PS_MAX_DEVICE_TOPK && offsets && snap->engine->wants_device_plan(n_queries)) {
       ps_status st = check_query_args(snap, scorer, fields_boost, n_boost);
       if (st != PS_OK) return st;
       if (!d_keys || !d_scores || !d_counts) return fail(PS_EINVAL, "null argument");
       const double t0 = wall_ms();
       ps_batch_stats stats;
-      snap->engine->run_device_planned(*scorer, fields_boost, text, offsets, n_queries, top_k, d_keys, d_scores, d_counts, hip_stream,
-                                       stats);
-      stats.total_ms = wall_ms() - t0;
-      set_stats(snap, stats);
-      return PS_OK;
+      if (snap->engine->run_device_planned(*scorer, fields_boost, text, offsets, n_queries, top_k, d_keys, d_scores, d_counts, hip_stream,
+                                           stats)) {
+        stats.total_ms = wall_ms() - t0;
+        set_stats(snap, stats);
+        return PS_OK;
+      }
     }
     std::vector<std::string_view> qs(n_queries);
     for (size_t i = 0; i < n_queries; ++i) qs[i] = std::string_view(text + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
@@ -633,8 +635,10 @@ ps_status ps_snapshot_query_batch_device_planned_flat(ps_snapshot* snap, const p
     if (!d_keys || !d_scores || !d_counts || !offsets || (n_queries && !text)) return fail(PS_EINVAL, "null argument");
     const double t0 = wall_ms();
     ps_batch_stats stats;
-    snap->engine->run_device_planned(*scorer, fields_boost, text, offsets, n_queries, top_k, d_keys, d_scores, d_counts,
-                                     hip_stream, stats);
+    if (!snap->engine->run_device_planned(*scorer, fields_boost, text, offsets, n_queries, top_k, d_keys, d_scores, d_counts,
+                                          hip_stream, stats))
+      return ps::run_device_flat(snap, scorer, text, offsets, n_queries, fields_boost, n_boost, nullptr, nullptr, top_k, d_keys, d_scores,
+                                 d_counts, hip_stream);  // (a zero_to_one batch K1dz does not take: the host planner)
     stats.total_ms = wall_ms() - t0;
     set_stats(snap, stats);
     return PS_OK;

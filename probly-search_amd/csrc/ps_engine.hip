@@ -224,6 +224,8 @@ struct EngineImpl {
   } cands;
   std::vector<uint32_t> z_minfl;  // zero_to_one field pruning: [layer][field] shortest field length holding the term (compute_z_bounds)
   std::vector<uint32_t> z_maxtf;  // [layer] largest term frequency of the list in any field (K1dz: the numerators a list can produce)
+  DevBuf<uint32_t> d_z_minfl, d_z_maxtf;  // the two on the device (k_zplan_arrange: device-planned zero_to_one batches)
+  size_t z_dev_layers = 0;
   std::map<std::pair<uint64_t, uint64_t>, double> z_ubnum_cache;  // (score bits, need | maxtf << 32) -> largest record numerator
   std::unordered_map<uint64_t, uint32_t> z_layer_of;  // post_off -> layer (zero_to_one plan entries do not carry it)
   hipStream_t copy_stream = nullptr;  // full-result mode: downloads of sorted parts beside the sorts of the next
@@ -260,10 +262,11 @@ struct EngineImpl {
     DevBuf<unsigned long long> post;
     DevBuf<ps_plan_entry> entries;
     DevBuf<int32_t> tok_node;  // [B][64] trie node of every token (count pass -> fill pass)
+    DevBuf<double> z_ubnum, z_zub;  // zero_to_one: K1dz's per-record bounds (k_zplan_arrange)
     Stage h;  // pinned copy of the batch's offsets | text (the caller's buffer may be pageable)
     void release() {
       qtext.release(); cnt.release(); qtl.release(); nterms.release(); multi.release(); qbeg.release();
-      qorder.release(); items.release(); post.release(); entries.release(); tok_node.release();
+      qorder.release(); items.release(); post.release(); entries.release(); tok_node.release(); z_ubnum.release(); z_zub.release();
       if (h.p) (void)hipHostFree(h.p);
       if (h.done) (void)hipEventDestroy(h.done);
     }
@@ -2100,6 +2103,40 @@ void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st) {
 #undef PS_Z
 }
 
+// K1dz's tie-threshold levels: powers of two (slot boundaries of every list's table up to that coarseness), the top one near
+// N / PS_DAAT_Z_D0_DIV, the others 2^PS_DAAT_Z_LEVEL_SHIFT apart below it; a level of less than one tile does not exist
+void z_levels(const EngineImpl& m, ZBatch& zb) {
+  const Snapshot& s = *m.snap;
+  const uint64_t div = std::max(2u, m.tune.daat_z_d0_div);
+  uint64_t top = 0;
+  if (s.n_ids >= div * s.T) {
+    top = s.T;
+    while (top * 2 <= s.n_ids / div) top *= 2;
+  }
+  const uint32_t want = std::min<uint32_t>(std::max(1u, m.tune.daat_z_levels), Z_LEVELS), shift = std::min(m.tune.daat_z_level_shift, 8u);
+  int n = 0;
+  for (uint32_t k = 0; k < want && top; ++k) {
+    const uint64_t d = top >> (shift * k);
+    if (d >= s.T && (n == 0 || d < zb.dl[n - 1])) zb.dl[n++] = (uint32_t)d;
+  }
+  std::sort(zb.dl, zb.dl + n);
+  for (; n < Z_LEVELS; ++n) zb.dl[n] = Z_NO_LEVEL;
+}
+
+// zero_to_one's per-list bounds where k_zplan_arrange reads them (grown with the layers; rare: a blocking copy)
+void ensure_dev_z_bounds(EngineImpl& m) {
+  compute_z_bounds(m);
+  const size_t nl = m.z_maxtf.size(), F = m.snap->F;
+  if (m.z_dev_layers == nl) return;
+  m.d_z_maxtf.ensure(nl + 1);
+  m.d_z_minfl.ensure(nl * F + 1);
+  if (nl) {
+    PS_HIP(hipMemcpy(m.d_z_maxtf.p, m.z_maxtf.data(), nl * 4, hipMemcpyHostToDevice));
+    PS_HIP(hipMemcpy(m.d_z_minfl.p, m.z_minfl.data(), nl * F * 4, hipMemcpyHostToDevice));
+  }
+  m.z_dev_layers = nl;
+}
+
 // Largest numerator min(score / t, 1) * t (zero_to_one.rs:117-118) over the term frequencies need <= t <= maxtf, in
 // the scorer's own f64 arithmetic; 0 when no record of the list can be consumed.  A saturated maximum (the exact
 // value is not known here) is bounded two ulps above the real-number value.
@@ -2210,24 +2247,7 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   ZBatch zb;
   zb.d_ubnum = reinterpret_cast<const double*>(c.stage.p + off_u);
   zb.d_zub = reinterpret_cast<const double*>(c.stage.p + off_z);
-  // the levels: powers of two (slot boundaries of every list's table up to that coarseness), the top one near N / PS_DAAT_Z_D0_DIV, the
-  // others 2^PS_DAAT_Z_LEVEL_SHIFT apart below it; a level of less than one tile does not exist
-  {
-    const uint64_t div = std::max(2u, m.tune.daat_z_d0_div);
-    uint64_t top = 0;
-    if (s.n_ids >= div * s.T) {
-      top = s.T;
-      while (top * 2 <= s.n_ids / div) top *= 2;
-    }
-    const uint32_t want = std::min<uint32_t>(std::max(1u, m.tune.daat_z_levels), Z_LEVELS), shift = std::min(m.tune.daat_z_level_shift, 8u);
-    int n = 0;
-    for (uint32_t k = 0; k < want && top; ++k) {
-      const uint64_t d = top >> (shift * k);
-      if (d >= s.T && (n == 0 || d < zb.dl[n - 1])) zb.dl[n++] = (uint32_t)d;
-    }
-    std::sort(zb.dl, zb.dl + n);
-    for (; n < Z_LEVELS; ++n) zb.dl[n] = Z_NO_LEVEL;
-  }
+  z_levels(m, zb);
   enqueue_daat(m, c, sc, boosts, reinterpret_cast<ps_plan_entry*>(c.stage.p), reinterpret_cast<const uint32_t*>(c.stage.p + off_q),
                reinterpret_cast<const uint32_t*>(c.stage.p + off_l), B, ne, plan.max_qterms, plan.max_entries, false, n_items, max_slots, top_k,
                d_keys, d_scores, d_counts, caller, &zb);
@@ -2470,7 +2490,7 @@ void device_plan_begin(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
   ps_.tok_node.ensure(B * (size_t)WAVE + 1);
   hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, nullptr,
                      nullptr, ps_.cnt.p, ps_.qtl.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, nullptr, ps_.items.p, m.tune.daat_chunk,
-                     m.tune.daat_split_div, ps_.tok_node.p);
+                     m.tune.daat_split_div, ps_.tok_node.p, 0u);
   // (the totals are written straight into pinned, device-mapped host memory: no copy-engine transfer to wait for)
   const int ci = (int)(&c - m.dctx);
   hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(WAVE), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
@@ -2479,15 +2499,19 @@ void device_plan_begin(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
   PS_HIP(hipEventRecord(c.counted, st));
 }
 
-PlanTotals device_plan_finish(EngineImpl& m, EngineImpl::DaatCtx& c, size_t B) {
-  EngineImpl::PlanSet& ps_ = c.plan;
+PlanTotals device_plan_totals(EngineImpl& m, EngineImpl::DaatCtx& c) {
   {  // latency-oriented wait for the count pass (poll briefly, then block)
     const double t0 = now_ms();
     hipError_t e = hipErrorNotReady;
     while (now_ms() - t0 < 0.5 && (e = hipEventQuery(c.counted)) == hipErrorNotReady) {}
     if (e != hipSuccess) PS_HIP(hipEventSynchronize(c.counted));
   }
-  const PlanTotals tot = m.h_totals[&c - m.dctx];
+  return m.h_totals[&c - m.dctx];
+}
+
+// The fill pass; zmode: zero_to_one's record score and the expanded term's node in every entry (K1dz; plan_token)
+void device_plan_fill(EngineImpl& m, EngineImpl::DaatCtx& c, size_t B, const PlanTotals& tot, uint32_t zmode) {
+  EngineImpl::PlanSet& ps_ = c.plan;
   ps_.entries.ensure((size_t)tot.n_entries + 1);
   hipStream_t st = m.prep_stream;  // the fill pass and everything behind it: preparation stream
   PS_HIP(hipStreamWaitEvent(st, c.counted, 0));
@@ -2499,8 +2523,13 @@ PlanTotals device_plan_finish(EngineImpl& m, EngineImpl::DaatCtx& c, size_t B) {
   const uint32_t blocks = (uint32_t)((B + PLAN_WAVES - 1) / PLAN_WAVES);
   hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, ps_.qbeg.p,
                      ps_.entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, ps_.qorder.p, nullptr, m.tune.daat_chunk,
-                     m.tune.daat_split_div, ps_.tok_node.p);
+                     m.tune.daat_split_div, ps_.tok_node.p, zmode);
   PS_HIP(hipGetLastError());
+}
+
+PlanTotals device_plan_finish(EngineImpl& m, EngineImpl::DaatCtx& c, size_t B) {
+  const PlanTotals tot = device_plan_totals(m, c);
+  device_plan_fill(m, c, B, tot, 0u);
   return tot;
 }
 
@@ -2574,7 +2603,7 @@ void Engine::plan_device(const char* text, const uint64_t* offsets, size_t B, Pl
   out.postings = tot.postings;
   out.max_entries = tot.max_entries;
   out.max_qterms = tot.max_qterms;
-  out.multi_expansion = tot.multi != 0;
+  out.multi_expansion = (tot.multi & PLAN_MULTI) != 0;
 }
 
 // Announces the next flat BM25 batch: text copy + planner count pass start now, on the planning stream, while the
@@ -2582,11 +2611,13 @@ void Engine::plan_device(const char* text, const uint64_t* offsets, size_t B, Pl
 // instead of waiting for them.  Returns false when the batch would not be planned on the device anyway.
 bool Engine::plan_ahead(const ps_scorer_desc& sc, const char* text, const uint64_t* offsets, size_t B) {
   EngineImpl& m = *impl_;
-  if (sc.kind != PS_SCORER_BM25 || m.snap->F > (uint32_t)MAX_F) return false;
+  const bool z = sc.kind == PS_SCORER_ZERO_TO_ONE;
+  if ((sc.kind != PS_SCORER_BM25 && !z) || m.snap->F > (uint32_t)MAX_F) return false;
   std::lock_guard<std::mutex> lock(m.mu);
   PS_HIP(hipSetDevice(m.device));
   refresh_tuning(m);
   if (!(m.tune.device_plan && m.tune.daat && B >= m.tune.daat_min_batch)) return false;
+  if (z && !(m.tune.daat_z && m.snap->F <= 4 && m.snap->n_ids > 0)) return false;  // (the count pass is the same for both scorers)
   (void)take_ahead(m, nullptr, nullptr, (size_t)-1);  // (at most one batch is announced at a time)
   EngineImpl::DaatCtx& c = acquire_ctx(m);
   device_plan_begin(m, c, text, offsets, B);
@@ -2608,12 +2639,13 @@ bool Engine::wants_device_plan(size_t n_queries) {
 // device-side preparation -> K1d k_daat -> K3d k_merge_items (K1 k_score / K3 k_merge for the batches K1d
 // does not take).  The host only learns the plan's totals (entries, largest plan, most query terms,
 // whether any term has several expansions, work items) to size the launches.
-void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, const char* text, const uint64_t* offsets,
+bool Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, const char* text, const uint64_t* offsets,
                                 size_t B, size_t top_k, void* d_keys, void* d_scores, void* d_counts, void* stream,
                                 ps_batch_stats& stats) {
   EngineImpl& m = *impl_;
   const Snapshot& s = *m.snap;
-  if (sc.kind != PS_SCORER_BM25) throw std::invalid_argument("the device planner handles BM25 (zero_to_one classifies its queries on the host)");
+  const bool z = sc.kind == PS_SCORER_ZERO_TO_ONE;
+  if (sc.kind != PS_SCORER_BM25 && !z) throw std::invalid_argument("the device planner handles the built-in scorers");
   if (s.F > (uint32_t)MAX_F) throw std::length_error("the GPU path supports at most 8 fields");
   if (top_k < 1 || top_k > PS_MAX_DEVICE_TOPK) throw std::invalid_argument("top_k must be in [1, 64] for the device top-k path");
   std::lock_guard<std::mutex> lock(m.mu);
@@ -2622,15 +2654,42 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   const double t0 = now_ms();
   m.last_bounds_recomputed = false;
   hipStream_t st = stream ? (hipStream_t)stream : m.stream;
+  // zero_to_one: the batches K1dz takes (ps_z21_daat.hpp) are planned here; the others go back to the caller for the
+  // host planner (false), before or after the count pass has classified the queries
+  if (z && !(m.tune.daat && m.tune.daat_z && m.tune.device_plan && B >= m.tune.daat_min_batch && s.F <= 4 && s.n_ids > 0)) return false;
+  if (z) ensure_dev_z_bounds(m);
   EngineImpl::DaatCtx* announced = take_ahead(m, text, offsets, B);
   EngineImpl::DaatCtx& c = announced ? *announced : acquire_ctx(m);
   if (!announced) device_plan_begin(m, c, text, offsets, B);
-  const PlanTotals tot = device_plan_finish(m, c, B);
+  const PlanTotals tot = device_plan_totals(m, c);
+  if (z && !(tot.n_entries && tot.max_entries <= (uint32_t)DAAT_SMALL_MAX && !(tot.multi & PLAN_Z_NOT_SIMPLE) && tot.n_items &&
+             tot.n_items < 0x3FFFFFF0ull)) {
+    PS_HIP(hipEventRecord(c.done, m.plan_stream));  // (the context goes back into the rotation behind its count pass)
+    c.busy = true;
+    return false;
+  }
+  device_plan_fill(m, c, B, tot, z ? 1u : 0u);
   if (tot.max_qterms >= 0x7FFF) throw std::length_error("more than 32766 non-empty terms in one query");
   const double t1 = now_ms();
   EngineImpl::PlanSet& ps_ = c.plan;
-  if (daat_eligible(m, sc, boosts, B, tot.n_entries, tot.max_entries, tot.multi != 0) && tot.n_items && tot.n_items < 0xFFFFFFF0ull) {
-    enqueue_daat(m, c, sc, boosts, ps_.entries.p, ps_.qbeg.p, ps_.qtl.p, B, tot.n_entries, tot.max_qterms, tot.max_entries, tot.multi != 0,
+  if (z) {
+    // records into the record-sort order + their bounds (k_zplan_arrange), then K1dz as for a host-planned batch
+    const size_t ne = tot.n_entries;
+    ps_.z_ubnum.ensure(ne + 1);
+    ps_.z_zub.ensure(ne * s.F + 1);
+    hipLaunchKernelGGL(k_zplan_arrange, dim3((uint32_t)((B + 63) / 64)), dim3(64), 0, m.prep_stream, ps_.entries.p, ps_.qbeg.p, ps_.qtl.p,
+                       (uint32_t)B, s.F, m.d_z_maxtf.p, m.d_z_minfl.p, ps_.z_ubnum.p, ps_.z_zub.p);
+    PS_HIP(hipGetLastError());
+    ZBatch zb;
+    zb.d_ubnum = ps_.z_ubnum.p;
+    zb.d_zub = ps_.z_zub.p;
+    z_levels(m, zb);
+    enqueue_daat(m, c, sc, boosts, ps_.entries.p, ps_.qbeg.p, ps_.qtl.p, B, ne, tot.max_qterms, tot.max_entries, false, (size_t)tot.n_items, 0u,
+                 top_k, d_keys, d_scores, d_counts, st, &zb);
+  } else {
+  const bool multi = (tot.multi & PLAN_MULTI) != 0;
+  if (daat_eligible(m, sc, boosts, B, tot.n_entries, tot.max_entries, multi) && tot.n_items && tot.n_items < 0xFFFFFFF0ull) {
+    enqueue_daat(m, c, sc, boosts, ps_.entries.p, ps_.qbeg.p, ps_.qtl.p, B, tot.n_entries, tot.max_qterms, tot.max_entries, multi,
                  (size_t)tot.n_items, 0u, top_k, d_keys, d_scores, d_counts, st);
   } else {
     // the batches K1d does not take: K1 k_score / K3 k_merge from the device-built plan, in the engine's
@@ -2643,7 +2702,7 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
     Plan shape;  // the scalars the launch geometry needs; the entries stay on the device
     shape.max_entries = tot.max_entries;
     shape.max_qterms = tot.max_qterms;
-    shape.multi_expansion = tot.multi != 0;
+    shape.multi_expansion = multi;
     shape.postings = tot.postings;
     KParams kp;
     try {
@@ -2696,6 +2755,7 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
     m.tail_stream = st;
     m.tail_pending = true;
   }
+  }
   memset(&stats, 0, sizeof(stats));
   stats.n_queries = B;
   stats.n_plan_entries = tot.n_entries;
@@ -2709,6 +2769,7 @@ void Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
     read_kernel_times(m, stats);
   }
   stats.total_ms = now_ms() - t0;
+  return true;
 }
 
 void Engine::run_device(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,

@@ -103,7 +103,7 @@ class Engine {
   void run_device(const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,
                   void* d_scores, void* d_counts, void* stream, ps_batch_stats& stats);
 
-  // SURVEY 8f N2 - device-side planner (BM25, built-in tokenizer): tokenise, term lookup in the frozen
+  // SURVEY 8f N2 - device-side planner (BM25 and zero_to_one, built-in tokenizer): tokenise, term lookup in the frozen
   // trie, prefix expansion and before_each run on the GPU.  plan_device copies the plan back (tests);
   // run_device_planned scores the batch without the plan ever existing on the host.
   void plan_device(const char* text, const uint64_t* offsets, size_t n_queries, Plan& out);
@@ -112,7 +112,9 @@ class Engine {
   bool wants_device_plan(size_t n_queries);
   // Announce the NEXT flat BM25 batch (ps_snapshot_plan_ahead_flat): its planner count pass starts now.
   bool plan_ahead(const ps_scorer_desc& sc, const char* text, const uint64_t* offsets, size_t n_queries);
-  void run_device_planned(const ps_scorer_desc& sc, const double* boosts, const char* text, const uint64_t* offsets,
+  // false (zero_to_one only): the batch is not one K1dz takes (a query that is not simple, more than 4 lists, fewer
+  // than PS_DAAT_MIN_BATCH queries ...) - nothing was enqueued, the caller plans it on the host.
+  bool run_device_planned(const ps_scorer_desc& sc, const double* boosts, const char* text, const uint64_t* offsets,
                           size_t n_queries, size_t top_k, void* d_keys, void* d_scores, void* d_counts, void* stream,
                           ps_batch_stats& stats);
 

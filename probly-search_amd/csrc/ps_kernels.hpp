@@ -2714,6 +2714,11 @@ struct PlanTotals {  // written by k_plan_scan
   unsigned long long n_items;  // K1d work items of the batch under the chunking rule (chunk_min, split_div)
 };
 
+// q_multi / PlanTotals::multi bits.  PLAN_Z_NOT_SIMPLE: the query is not "simple" in classify_zero_to_one's sense (a term with
+// several version layers, or several expansions of a query term AND a term reached by two query terms) - decided
+// conservatively (two query terms whose expansion ranges intersect count as sharing a term even if the shared terms are dead).
+constexpr uint32_t PLAN_MULTI = 1u, PLAN_Z_NOT_SIMPLE = 2u;
+
 __device__ __forceinline__ uint32_t utf8_next(const char* s, uint32_t& i, const uint32_t end) {
   const unsigned char c = (unsigned char)s[i++];
   if (c < 0x80) return c;
@@ -2762,8 +2767,10 @@ __device__ __forceinline__ int64_t dev_find_node(const DevTrie& t, const char* s
 template <bool FILL>
 __device__ __forceinline__ void plan_token(const DevTrie& t, const int64_t fn, const uint32_t tok_bytes, const uint32_t qord, const uint32_t qi,
                                            const uint32_t chunk_min, const uint32_t split_div, ps_plan_entry* entries, uint32_t w,
-                                           uint32_t& here, unsigned long long& postings, uint32_t& items) {
+                                           uint32_t& here, unsigned long long& postings, uint32_t& items, const uint32_t zmode = 0u,
+                                           uint32_t* layered = nullptr) {
   here = 0; postings = 0; items = 0;
+  if (layered) *layered = 0u;
   if (fn < 0) return;
   const uint4 node = t.fnodes[fn];
   for (uint32_t o = node.z; o < node.w; ++o) {  // == expand_term order (query.rs:130-147)
@@ -2786,6 +2793,14 @@ __device__ __forceinline__ void plan_token(const DevTrie& t, const int64_t fn, c
         const uint32_t delta = byte_len - tok_bytes;
         e.boost = (t.term_meta[4 * o + 3] == (uint32_t)fn) ? 1.0 : t.eb_table[delta < t.eb_n ? delta : 0];
         e.node = li;
+        if (zmode) {
+          // ScoreByTerm::score (zero_to_one.rs:57-73): 1 - |len_expanded - len_query| / len_expanded, the host planner's
+          // expression; records pool per expanded term: `node` names the term (its trie node), as K1dz's arrangement needs
+          const double el = (double)byte_len, tl = (double)tok_bytes;
+          e.boost = 1.0 - fabs(el - tl) / el;
+          e.idf = 0.0;
+          e.node = t.term_meta[4 * o + 3];
+        }
         e.qterm_index = qi;
         e.bm_off = lb.y;
         e.layer = li;
@@ -2797,6 +2812,7 @@ __device__ __forceinline__ void plan_token(const DevTrie& t, const int64_t fn, c
       }
       postings += la.z;
       ++here;
+      if (l && layered) *layered = 1u;  // a second version / delta layer of one term
       ++l;
       // base layers are contiguous, then the delta chain
       if (l < n_layers) li = first_layer + l;
@@ -2811,8 +2827,8 @@ template <bool FILL>
 __device__ __noinline__ void plan_query_seq(const DevTrie& t, const char* s, const uint32_t qb, const uint32_t qe, const uint32_t q,
                                             const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt, uint32_t* q_terms_len,
                                             uint32_t* q_nterms, uint32_t* q_multi, unsigned long long* q_postings, uint32_t* q_items,
-                                            const uint32_t chunk_min, const uint32_t split_div) {
-  uint32_t n_tokens = 0, qord = 0, n_ent = 0, multi = 0, items = 0;
+                                            const uint32_t chunk_min, const uint32_t split_div, const uint32_t zmode) {
+  uint32_t n_tokens = 0, qord = 0, n_ent = 0, multi = PLAN_Z_NOT_SIMPLE, items = 0;  // (K1dz does not take these queries: not classified here)
   unsigned long long postings = 0;
   uint32_t w = FILL ? qbeg[q] : 0u;
   // s.split(' ') (lib.rs:42-44): k separators -> k + 1 tokens; empty ones are skipped but counted (query.rs:32-35)
@@ -2824,9 +2840,9 @@ __device__ __noinline__ void plan_query_seq(const DevTrie& t, const char* s, con
     if (te > tb) {
       uint32_t here, it;
       unsigned long long po;
-      plan_token<FILL>(t, dev_find_node(t, s, tb, te), te - tb, qord, qi, chunk_min, split_div, entries, w, here, po, it);
+      plan_token<FILL>(t, dev_find_node(t, s, tb, te), te - tb, qord, qi, chunk_min, split_div, entries, w, here, po, it, zmode);
       w += here; postings += po; items += it;
-      if (here > 1) multi = 1;
+      if (here > 1) multi |= PLAN_MULTI;
       n_ent += here;
       ++qord;
     }
@@ -2852,7 +2868,7 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
                                           const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt,
                                           uint32_t* q_terms_len, uint32_t* q_nterms, uint32_t* q_multi,
                                           unsigned long long* q_postings, uint32_t* qorder, uint32_t* q_items,
-                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node) {
+                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node, const uint32_t zmode) {
   __shared__ uint32_t sh_tb[PLAN_WAVES][WAVE], sh_te[PLAN_WAVES][WAVE];
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const uint32_t q = blockIdx.x * PLAN_WAVES + wv;
@@ -2886,7 +2902,7 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
   ++n_tokens;  // the last token (k separators -> k + 1 tokens)
   if (overflow) {  // more than 64 tokens: one lane walks the query
     if (lane == 0) {
-      plan_query_seq<FILL>(t, s, qb, qe, q, qbeg, entries, q_cnt, q_terms_len, q_nterms, q_multi, q_postings, q_items, chunk_min, split_div);
+      plan_query_seq<FILL>(t, s, qb, qe, q, qbeg, entries, q_cnt, q_terms_len, q_nterms, q_multi, q_postings, q_items, chunk_min, split_div, zmode);
       if (FILL) qorder[q] = q;
     }
     return;
@@ -2905,9 +2921,22 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
   uint32_t here = 0, items = 0;
   unsigned long long postings = 0;
   if (!FILL) {
-    if (nonempty) plan_token<false>(t, fn, te - tb, qord, lane, chunk_min, split_div, nullptr, 0u, here, postings, items);
+    uint32_t layered = 0;
+    if (nonempty) plan_token<false>(t, fn, te - tb, qord, lane, chunk_min, split_div, nullptr, 0u, here, postings, items, 0u, &layered);
+    // zero_to_one's K1dz takes "simple" queries only (PLAN_Z_NOT_SIMPLE): no term with several layers; and, if any query
+    // term has several expansions, no term reached by two query terms - the expansions of a node are a contiguous range
+    // of term ordinals, so two query terms can share a term only where their ranges intersect
+    bool not_simple = layered != 0u;
+    if (__any(here > 1)) {
+      uint32_t rz = 0, rw = 0;
+      if (here) { const uint4 nd = t.fnodes[fn]; rz = nd.z; rw = nd.w; }
+      for (uint32_t j = 0; j < n_tokens; ++j) {
+        const uint32_t oz = (uint32_t)__shfl((int)rz, (int)j), ow = (uint32_t)__shfl((int)rw, (int)j);
+        if (j != lane && rz < rw && oz < ow && rz < ow && oz < rw) not_simple = true;
+      }
+    }
     // per-query totals
-    uint32_t n_ent = here, multi = here > 1 ? 1u : 0u, it = items;
+    uint32_t n_ent = here, multi = (here > 1 ? PLAN_MULTI : 0u) | (not_simple ? PLAN_Z_NOT_SIMPLE : 0u), it = items;
     unsigned long long po = postings;
     for (int o = 32; o > 0; o >>= 1) {
       n_ent += __shfl_xor(n_ent, o); multi |= __shfl_xor(multi, o); it += __shfl_xor(it, o); po += __shfl_xor(po, o);
@@ -2929,7 +2958,7 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
     uint32_t inc = cnt;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
     const uint32_t w = qbeg[q] + inc - cnt;
-    if (nonempty && cnt) plan_token<true>(t, fn, te - tb, qord, lane, chunk_min, split_div, entries, w, here, postings, items);
+    if (nonempty && cnt) plan_token<true>(t, fn, te - tb, qord, lane, chunk_min, split_div, entries, w, here, postings, items, zmode);
     if (lane == 0) qorder[q] = q;
   }
 }
@@ -2968,9 +2997,10 @@ __global__ __launch_bounds__(WAVE * PLAN_WAVES) void k_plan(const DevTrie t, con
                                                           const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt,
                                                           uint32_t* q_terms_len, uint32_t* q_nterms, uint32_t* q_multi,
                                                           unsigned long long* q_postings, uint32_t* qorder, uint32_t* q_items,
-                                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node) {
+                                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node,
+                                                          const uint32_t zmode) {
   plan_wave<FILL>(t, text, offsets, B, qbeg, entries, q_cnt, q_terms_len, q_nterms, q_multi, q_postings, qorder, q_items, chunk_min,
-                  split_div, tok_node);
+                  split_div, tok_node, zmode);
 }
 
 // Plan upload without the copy engine: the staged batch is read from the pinned, device-mapped

@@ -84,6 +84,82 @@ __device__ __forceinline__ uint32_t zprep_bucket(const uint32_t phase, const uin
 }
 static_assert(4u * Z_LEVELS + 2u * PREP_CLASSES + 4u <= PREP_BUCKETS, "K1dz item buckets fit the preparation's control block");
 
+// K1dz's batch image from a device-built plan (k_plan, zmode): a thread per query puts the query's records (<= DAAT_SMALL_MAX,
+// one list each: the count pass established that every query is simple) into the record-sort order (score desc,
+// stable: zero_to_one.rs:98) and derives what enqueue_daat_z_host derives on the host, in the same arithmetic:
+// qterm_index = occurrence rank of the record's term among the sorted records | dense ordinal of its query term << 16;
+// idf = the largest tf with min(score / tf, 1) * tf == score (the one-division arm's limit); ubnum = the largest
+// numerator over the term frequencies the list holds (z_numerator_bound); zub[e][x] = ubnum / max(shortest field x
+// holding the term, query_terms_len).
+__global__ __launch_bounds__(64) void k_zplan_arrange(ps_plan_entry* __restrict__ entries, const uint32_t* __restrict__ qbeg,
+                                                      const uint32_t* __restrict__ qtl, const uint32_t B, const uint32_t F,
+                                                      const uint32_t* __restrict__ maxtf, const uint32_t* __restrict__ minfl,
+                                                      double* __restrict__ ubnum, double* __restrict__ zub) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= B) return;
+  const uint32_t b = qbeg[q], n = min(qbeg[q + 1] - b, (uint32_t)DAAT_SMALL_MAX);
+  const uint32_t ql = qtl[q];
+  ps_plan_entry en[DAAT_SMALL_MAX];
+#pragma unroll
+  for (int i = 0; i < DAAT_SMALL_MAX; ++i)
+    if ((uint32_t)i < n) en[i] = entries[b + i];
+  // stable insertion sort, score descending (a later record moves ahead of an earlier one only if its score is higher)
+  int ord[DAAT_SMALL_MAX];
+#pragma unroll
+  for (int i = 0; i < DAAT_SMALL_MAX; ++i) ord[i] = i;
+#pragma unroll
+  for (int i = 1; i < DAAT_SMALL_MAX; ++i)
+#pragma unroll
+    for (int j = i; j > 0; --j)
+      if ((uint32_t)j < n && en[ord[j]].boost > en[ord[j - 1]].boost) { const int t = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t; }
+  uint32_t s_node[DAAT_SMALL_MAX], s_qterm[DAAT_SMALL_MAX], s_qt[DAAT_SMALL_MAX];
+#pragma unroll
+  for (int i = 0; i < DAAT_SMALL_MAX; ++i) {
+    if ((uint32_t)i >= n) break;
+    ps_plan_entry e = en[0];
+#pragma unroll
+    for (int k = 1; k < DAAT_SMALL_MAX; ++k)
+      if (ord[i] == k) e = en[k];
+    uint32_t need = 1, qt = 0, used = 0;
+    bool seen = false;
+#pragma unroll
+    for (int j = 0; j < DAAT_SMALL_MAX; ++j) {
+      if (j >= i) break;
+      if (s_node[j] == e.node) ++need;
+      if (s_qterm[j] == e.qterm) { qt = s_qt[j]; seen = true; }
+      used |= 1u << s_qt[j];
+    }
+    if (!seen) {
+      qt = 0;
+      while (used & (1u << qt)) ++qt;
+    }
+    s_node[i] = e.node; s_qterm[i] = e.qterm; s_qt[i] = qt;
+    const double w = e.boost;
+    uint64_t lim = 0;
+    for (uint32_t t = 1; t <= 254u; ++t) {
+      const double df = (double)t;
+      if (!(fmin(w / df, 1.0) * df == w)) break;
+      lim = t;
+    }
+    e.qterm_index = need | (qt << 16);
+    e.idf = __longlong_as_double((long long)lim);
+    entries[b + i] = e;
+    // z_numerator_bound
+    const uint32_t mt = maxtf[e.layer], hi = min(mt, 4096u);
+    double best = 0.0;
+    for (uint32_t t = max(need, 1u); t <= hi; ++t) {
+      const double df = (double)t;
+      best = fmax(best, fmin(w / df, 1.0) * df);
+    }
+    if (mt > hi && mt >= need) best = fmax(best, __longlong_as_double(__double_as_longlong(fmax(w, 0.0)) + 2));  // two ulps above
+    ubnum[b + i] = best;
+    for (uint32_t x = 0; x < F; ++x) {
+      const uint32_t mn = minfl[(size_t)e.layer * F + x];
+      zub[(size_t)(b + i) * F + x] = mn == 0xFFFFFFFFu ? 0.0 : best / (double)max(mn, ql);
+    }
+  }
+}
+
 // Thread per query: processing order (shortest list first: the long lists are the ones that become non-essential;
 // any order is exact), skip thresholds, chunking, candidate slots, bucket totals.
 __global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {

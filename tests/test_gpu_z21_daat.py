@@ -138,3 +138,119 @@ def test_removed_documents_through_a_delta():
     queries = [" ".join(rng.choice(words[:8]) for _ in range(3)) for _ in range(32)]
     _opt(b"PS_DAAT_CHUNK", 256)
     _check(snap, o, queries, 10, 2)
+
+
+# ---- the same batches planned on the device (k_plan zmode -> k_zplan_arrange -> K1dz; SURVEY 8f N2 for zero_to_one) ----
+
+def _planned(snap, queries, K, boosts):
+    from adapters import run_device_planned
+    got = run_device_planned(snap, queries, boosts, K, scorer=psa.zero_to_one.new())
+    return [[(k, bits(s)) for k, s in rs] for rs in got]
+
+
+def _check_planned(snap, o, queries, K, F, device_planned=1):
+    """Device-planned == host-planned (both through K1dz when the batch qualifies) == oracle."""
+    boosts = [1.0] * F
+    got = _planned(snap, queries, K, boosts)
+    st = snap.last_stats()
+    assert st["device_planned"] == device_planned, st
+    name = snap.kernel_breakdown()["score_kernel"]
+    assert name.startswith("ps::k_daat_z" if device_planned else ("ps::k_score", "ps::k_z21", "ps::k_daat_z")), name
+    for _ in range(2):
+        assert _planned(snap, queries, K, boosts) == got
+    _opt(b"PS_DEVICE_PLAN", 0)
+    try:
+        ref = _planned(snap, queries, K, boosts)
+        assert snap.last_stats()["device_planned"] == 0
+    finally:
+        _opt(b"PS_DEVICE_PLAN", 1)
+    for q, g, r in zip(queries, got, ref):
+        assert g == r, (q, K, g[:4], r[:4])
+    for q, g in list(zip(queries, got))[:24]:
+        exp = [(k, bits(s)) for k, s in o.query(q, orc.zero_to_one(), boosts)[:K]]
+        assert g == exp, (q, K, g[:4], exp[:4])
+
+
+@pytest.mark.parametrize("fields", [1, 2, 3])
+@pytest.mark.parametrize("K", [1, 10, 64])
+def test_device_planned_ties_everywhere(fields, K):
+    words, docs = _tie_corpus(30_000, fields, seed=fields * 10 + K)
+    p, o = _build(docs, fields)
+    snap = p.snapshot(device=0, tile_docs=256)
+    rng = random.Random(K)
+    queries = [" ".join(rng.choice(words[:8]) for _ in range(rng.randint(1, 4))) for _ in range(40)]
+    queries += ["w00 w00", "w01 w01 w01", "w00 w01 w00", "w02  w03", "zzz w00", "w00", "", " ", "w00 w06 w06 w00"]
+    _opt(b"PS_DAAT_CHUNK", 256)
+    _check_planned(snap, o, queries, K, fields)
+
+
+def test_device_planned_prefix_expansions_and_hand_back():
+    """Expansions within 4 lists stay on the device planner; a query that is not simple ("wab wab": two expansions of a
+    term AND a term under two records), or one with more than 4 lists, sends the batch back to the host planner - same
+    answers either way."""
+    words, docs = _tie_corpus(20_000, 2, seed=5)
+    p, o = _build(docs, 2)
+    snap = p.snapshot(device=0, tile_docs=256)
+    queries = ["wa", "wab w00", "wa w01", "wabc wabc", "wabc w00 wabc", "w00 wab", "wa w00"] * 2
+    _opt(b"PS_DAAT_CHUNK", 256)
+    for K in (1, 10):
+        _check_planned(snap, o, queries, K, 2)
+    _check_planned(snap, o, ["wab wab"] * 8 + ["w00"], 10, 2, device_planned=0)
+    _check_planned(snap, o, ["w"] * 4 + ["w00 w01"] * 8, 10, 2, device_planned=0)
+    _check_planned(snap, o, ["w00 w01"] * 4, 10, 2, device_planned=0)  # (fewer than PS_DAAT_MIN_BATCH queries)
+    # and the device planner is taken again afterwards (the abandoned contexts went back into the rotation)
+    _check_planned(snap, o, queries, 10, 2)
+
+
+def test_device_planned_after_a_delta():
+    """New documents, new terms and removals through ps_snapshot_update: a term with a delta layer has two lists - the batch
+    goes to the host planner; terms without one keep the device planner."""
+    words, docs = _tie_corpus(20_000, 2, seed=9)
+    p, o = _build(docs, 2)
+    snap = p.snapshot(device=0, tile_docs=256, headroom_pct=10)
+    rng = random.Random(3)
+    for k in rng.sample(range(20_000), 300):
+        p.remove_document(k * 3 + 1)
+        o.remove_document(k * 3 + 1)
+    for i in range(40):
+        vals = ["fresh%d w39" % (i % 3), "w38 fresh%d" % (i % 2)]
+        p.add_field_values(100_000 + i, vals)
+        o.add_document(100_000 + i, vals)
+    snap.update()
+    _opt(b"PS_DAAT_CHUNK", 256)
+    untouched = [" ".join(rng.choice(words[:8]) for _ in range(3)) for _ in range(32)]
+    _check_planned(snap, o, untouched, 10, 2)
+    _check_planned(snap, o, untouched[:12] + ["w39 w00", "fresh1", "w38"], 10, 2, device_planned=0)
+
+
+def test_device_planned_c3_shape_and_batches_in_flight():
+    """C3's shape at a size the oracle finishes; then six different batches back to back on one caller stream, announced
+    ahead (ps_snapshot_plan_ahead_flat), every block compared with the synchronous answer."""
+    import ctypes as C
+    from probly_search_amd import dist as psd
+    cfg = dict(synth.CONFIGS["C3"], n_docs=120_000, vocab=8_000)
+    corpus = synth.Corpus(**cfg)
+    p, o = synth.fill(psa.Index(2), corpus), synth.fill(orc.Index(2), corpus)
+    snap = p.snapshot(device=0)
+    _check_planned(snap, o, corpus.queries(256, 3), 10, 2)
+    sc, K, B = psa.zero_to_one.new(), 10, 128
+    batches = [corpus.queries(B, 3, salt=s) for s in range(6)]
+    want = [_topk(snap, b, K, [1.0, 1.0]) for b in batches]
+    hip = psd._DeviceBuffer.hip()
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    bufs = [psd._DeviceBuffer(psd.block_bytes(B, K)) for _ in batches]
+    packed = [synth.pack_queries(b) for b in batches]
+    for i, ((text, offsets), buf) in enumerate(zip(packed, bufs)):
+        snap.query_batch_allgather_flat(None, text, offsets, sc, [1.0, 1.0], K, buf.ptr.value, buf.ptr.value, stream=st.value)
+        assert snap.last_stats()["device_planned"] == 1
+        if i + 1 < len(packed):
+            assert snap.plan_ahead_flat(packed[i + 1][0], packed[i + 1][1], sc, [1.0, 1.0])
+    assert hip.hipStreamSynchronize(st) == 0
+    for i, buf in enumerate(bufs):
+        got = psd.unpack_blocks(buf.to_host(), 1, B, K, [B])
+        assert [[(k, bits(s)) for k, s in rs] for rs in got] == want[i], i
+    hip.hipStreamDestroy(st)
