@@ -40,7 +40,7 @@ constexpr int WAVE = 64;
 #define PS_DAAT_MQ 1             // K1d, multi-expansion arm: survivors of the first lookup level wait in a wave-private LDS queue (0: the round-2 arm)
 #endif
 #ifndef PS_DAAT_UMQ
-#define PS_DAAT_UMQ 4            // ... postings per lane in flight in its scan stage
+#define PS_DAAT_UMQ 3            // ... postings per lane in flight in its scan stage (4: 12 KB of reach ring, 4.5 waves per SIMD by LDS: C5 1.715 ms against 1.60 at 3 and 1.61 at 2)
 #endif
 #ifndef PS_DAAT_MRQ
 #define PS_DAAT_MRQ 1            // ... the postings that pass the first bound test wait in a reach queue until 64 are together (the first lookup with every lane busy)
@@ -1599,8 +1599,11 @@ __device__ __forceinline__ void lookup_scores(const KParams& p, const double* lu
   if (__any(any_found)) plane_scores<F_, U>(p, pi, found, en.boost, s);
 }
 
+#ifndef PS_DAAT_MULTI_WAVES
+#define PS_DAAT_MULTI_WAVES 5  // waves per SIMD the multi-expansion arm is compiled for (its register budget)
+#endif
 template <int F_, bool MULTI>
-__global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
+__global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu(MULTI ? PS_DAAT_MULTI_WAVES : 4))) void k_daat(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int U = (F_ && !MULTI) ? PS_DAAT_U : (F_ ? PS_DAAT_UM : 2);  // postings per lane in flight (the multi-expansion arm keeps per-term maxima per posting)
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1706,7 +1709,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat(const KParams p) {
         // (512 entries: a trip adds up to UA x 64 to < 64.  level1 and process each have ONE call site, at the top of the
         // loop: inlined at several sites the two bodies - every lookup_scores in them - no longer fit the instruction
         // cache, 6.7 ms instead of 1.7)
-        constexpr uint32_t RCAP = 512;
+        constexpr uint32_t RCAP = (UA + 1) * 64 <= 256 ? 256 : 512;  // (a trip adds up to UA x 64 to < 64)
         __shared__ uint32_t rq_d[DAAT_WGW][RCAP];
         __shared__ double rq_so[DAAT_WGW][RCAP];
         uint32_t rq_head = 0, rq_n = 0;  // wave-uniform
