@@ -1616,17 +1616,14 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
   const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
   const bool by_index = p.n_ditems <= gridDim.x * (uint32_t)DAAT_WGW;
   if (by_index) {
-    // most workgroups of a launch only hold chunks of lists that are already non-essential: they
-    // leave before they stage the LUT
+    // most waves of a launch only hold a chunk of a list that is already non-essential: they leave at once (every wave
+    // for itself - the waves of a workgroup share nothing -, so none waits for its neighbour's two loads)
     const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
-    int need = 0;
-    if (id < n_ditems) {
-      const DItem it0 = p.ditems[p.item_base + id];
-      const double theta = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[it0.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      need = !(it0.skip_thr < theta);
-    }
-    if (!__syncthreads_or(need)) {
-      if (id < n_ditems && lane == 0) p.cand_cnt[p.ditems[p.item_base + id].slot] = 0u;
+    if (id >= n_ditems) return;
+    const DItem it0 = p.ditems[p.item_base + id];
+    const double theta0 = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[it0.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (__builtin_amdgcn_readfirstlane((int)(it0.skip_thr < theta0))) {
+      if (lane == 0) p.cand_cnt[it0.slot] = 0u;
       return;
     }
   }
@@ -2258,6 +2255,12 @@ constexpr int DAAT_SMALL_MAX = 4;  // most lists per query
 
 // WC: keep the work counters (ps_work_counters).  The serving instantiation (PS_WORK_COUNTERS=0 at run time) carries none
 // of the ballots / popcounts / atomics they cost (4 % of the kernel on C2).
+#ifndef PS_DAAT_SMALL_BARRIER
+// 1: the waves of a workgroup decide together whether to leave at once (one __syncthreads_or); 0: every wave for itself,
+// as k_daat and k_daat_z do.  Nothing is shared either way - but without the barrier this kernel compiles to 78 VGPRs and
+// 145-165 SGPR spills instead of 123 / 114, and that code is slower: C2 0.273 -> 0.276 ms, C4 1.095 -> 1.212 (same box).
+#define PS_DAAT_SMALL_BARRIER 1
+#endif
 template <int F_, bool WC>
 __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p) {
   auto cnt = [](const bool b) -> uint32_t { return WC ? (uint32_t)__popcll(__ballot(b)) : 0u; };  // wave-uniform count of lanes where b holds
@@ -2277,6 +2280,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
   const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
+#if PS_DAAT_SMALL_BARRIER
   {
     // most workgroups of a launch only hold chunks of lists that are already non-essential: they leave at once
     int need = 0;
@@ -2292,6 +2296,19 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   }
   if (id >= n_ditems) return;
   const DItem it = p.ditems[id];
+#else
+  if (id >= n_ditems) return;
+  const DItem it = p.ditems[id];
+  {
+    // most waves of a launch only hold a chunk of a list that is already non-essential: they leave at once (every wave
+    // for itself - the waves of a workgroup share nothing -, so none waits for its neighbour's two loads)
+    const double theta0 = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[it.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (__builtin_amdgcn_readfirstlane((int)(it.skip_thr < theta0))) {
+      if (lane == 0) p.cand_cnt[it.slot] = 0u;
+      return;
+    }
+  }
+#endif
   const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
   const ps_plan_entry& own = p.plan[e_own];
   const DEntry de = p.dentry[e_own];

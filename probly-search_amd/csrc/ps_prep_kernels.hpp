@@ -147,12 +147,18 @@ __device__ __forceinline__ uint32_t prep_chunk_of(const uint32_t split_div, cons
 __device__ __forceinline__ uint32_t prep_chunk(const PrepParams& pp, const uint32_t len) {
   return prep_chunk_of(pp.split_div, pp.chunk_min, len);
 }
-__device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint32_t len) {
-  if (rank <= 1) {  // longest lists first: 64 classes, log2 with one fractional bit (the rank-1 lists that stay
-                    // essential are what a launch ends on: the long ones must not start last)
+__device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint32_t len, const bool short_first = false) {
+  if (rank <= 1) {  // 64 length classes, log2 with one fractional bit
+    // First-ranked lists (every chunk runs): longest first.  Second-ranked lists: longest first as well for plans with one
+    // list per query term (the ones that stay essential are what a launch ends on: the long ones must not start last),
+    // SHORTEST first for multi-expansion batches (`short_first`) - there the short lists are the ones that stay essential
+    // while the chunks of the long ones mostly leave at once, and a chunk that runs cannot start before the dispatch front
+    // has passed everything in front of it.  Same box, serving kernels, shortest first against longest first:
+    // C5 1.600 -> 1.550 ms; C2 0.273 -> 0.273, C4 1.095 -> 1.113 (hence not there).
     const uint32_t l = len ? len : 1u;
     const uint32_t lg = 31u - (uint32_t)__clz((int)l);
-    return rank * PREP_CLASSES + 63u - (2u * lg + (lg ? ((l >> (lg - 1)) & 1u) : 0u));
+    const uint32_t cls = 2u * lg + (lg ? ((l >> (lg - 1)) & 1u) : 0u);
+    return rank == 1u && short_first ? PREP_CLASSES + cls : rank * PREP_CLASSES + 63u - cls;
   }
   return 2 * PREP_CLASSES + (rank < PREP_RANKS ? rank : PREP_RANKS) - 1u;
 }
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
       nc = (en.len + c - 1) / c;
       pp.gen[b + i] = DItemGen{b + i, 0u, c, sl};
       sl += nc;
-      bk = prep_bucket(pp.dentry[b + i].rank, en.len);
+      bk = prep_bucket(pp.dentry[b + i].rank, en.len, pp.multi != 0u);
       if (pp.n_cand) cd = pp.cand_of_layer[en.node];
     }
     wave_add_by_key_noret(pp.ctl->bucket_total, bk, nc, on && nc != 0);
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
     nc = (len + c - 1) / c;
     const DEntry de_i = pp.dentry[i];
     skip_i = de_i.skip_thr; q_i = de_i.q;
-    bk = prep_bucket(de_i.rank, len);
+    bk = prep_bucket(de_i.rank, len, pp.multi != 0u);
     if (pp.n_cand) {
       const uint32_t cd = pp.cand_of_layer[en.node];
       if (cd != NO_CAND) {

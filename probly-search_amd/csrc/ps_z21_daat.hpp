@@ -362,23 +362,19 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
   const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
+  if (id >= n_ditems) return;
+  const DItem it = p.ditems[id];
   {
-    // most workgroups only hold chunks of lists that are already non-essential: they leave at once
-    int need = 0;
-    if (id < n_ditems) {
-      const DItem it0 = p.ditems[id];
-      const double ts = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[it0.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const uint32_t lv = it0.count >> ZITEM_LEVEL_SHIFT;
-      const double tt = lv ? z_tie_of(p, it0.q, lv) : 0.0;
-      need = z_beats(it0.skip_thr, ts, tt);
-    }
-    if (!__syncthreads_or(need)) {
-      if (id < n_ditems && lane == 0) p.cand_cnt[p.ditems[id].slot] = 0u;
+    // most waves only hold a chunk of a list that is already non-essential: they leave at once (every wave for itself -
+    // the waves of a workgroup share nothing -, so none waits for its neighbour's loads)
+    const double ts = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[it.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const uint32_t lv = it.count >> ZITEM_LEVEL_SHIFT;
+    const double tt = lv ? z_tie_of(p, it.q, lv) : 0.0;
+    if (!__builtin_amdgcn_readfirstlane((int)z_beats(it.skip_thr, ts, tt))) {
+      if (lane == 0) p.cand_cnt[it.slot] = 0u;
       return;
     }
   }
-  if (id >= n_ditems) return;
-  const DItem it = p.ditems[id];
   const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
   const DEntry de = p.dentry[e_own];
   const uint32_t q = __builtin_amdgcn_readfirstlane(de.q);

@@ -24,8 +24,8 @@ BUDGET = {
     # (36 bytes of frame are reserved for k_daat_z but its ISA holds no scratch instruction)
     # (its scan holds ~95 VGPRs since the first level moved behind the reach queue: 5 waves per SIMD for the serving
     # instantiation; the wave-uniform state - two sets of field-length limits, three tie levels - spills more SGPRs)
-    "ps::k_daat_z<2, true>": (104, 4, 36, 235),
-    "ps::k_daat_z<2, false>": (104, 5, 36, 195),
+    "ps::k_daat_z<2, true>": (104, 4, 36, 300),   # (the counting instantiation; 85 VGPRs)
+    "ps::k_daat_z<2, false>": (104, 5, 36, 200),
     "ps::k_daat_z<1, false>": (96, 5, 36, 195),
     "ps::k_score<0, 2, false, false, 8>": (128, 4, 0, 115),
     "ps::k_score<1, 2, false, false, 8>": (128, 4, 0, 125),
