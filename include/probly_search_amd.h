@@ -374,11 +374,15 @@ ps_status ps_snapshot_query_batch_allgather_flat(ps_snapshot* snap, ps_comm* com
  * term lookup in the frozen trie, prefix expansion in the reference's newest-first DFS order
  * (src/query.rs:109-147, src/index.rs:300-337) and BM25's before_each (src/score/default/bm25.rs:35-58)
  * run in a kernel over the trie kept in HBM; the plan never exists on the host (the host learns the
- * plan's totals to size the launches).  BM25 with the built-in tokenizer.  The K1d work descriptors
- * (per-list bounds, ranks, skip thresholds, items, dense-row choice) are built on the device as well,
- * so such a batch runs the same kernels as a host-planned one.  The flat batch entry points above take
- * this path by themselves for BM25 top-k batches with the built-in tokenizer (knob PS_DEVICE_PLAN,
- * default 1); this entry forces it.  Same results as ps_snapshot_query_batch_device_flat. */
+ * plan's totals to size the launches).  BM25 with the built-in tokenizer, and the zero_to_one batches the
+ * pruning kernel takes (>= 8 queries, every query "simple" - zero_to_one.rs:98-113's pool rule in closed
+ * form - with at most 4 lists: the planner's count pass classifies them, the record-sort order and the
+ * per-record bounds are derived on the device; any other zero_to_one batch is planned on the host, with the
+ * same results).  The K1d work descriptors (per-list bounds, ranks, skip thresholds, items, dense-row
+ * choice) are built on the device as well, so such a batch runs the same kernels as a host-planned one.
+ * The flat batch entry points above take this path by themselves for top-k batches with the built-in
+ * tokenizer (knob PS_DEVICE_PLAN, default 1); this entry asks for it explicitly.  Same results as
+ * ps_snapshot_query_batch_device_flat. */
 ps_status ps_snapshot_query_batch_device_planned_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text,
                                                       const uint64_t* offsets, size_t n_queries, const double* fields_boost,
                                                       size_t n_boost, size_t top_k, void* d_keys, void* d_scores,
