@@ -154,6 +154,7 @@ struct Tuning {
   uint32_t daat_z_d0_div = 4;    // PS_DAAT_Z_D0_DIV: K1dz's top tie-threshold level is the doc id ~ N / this (C3, three levels a factor 4 apart: 4 -> 0.495 ms, 8 -> 0.531; one level: 8 -> 0.587, 4 -> 0.667; profiles/r04_c3_levels_sweep.jsonl)
   uint32_t daat_z_level_shift = 2;  // PS_DAAT_Z_LEVEL_SHIFT: the levels below it are 2^shift apart
   uint32_t daat_z_levels = 3;    // PS_DAAT_Z_LEVELS: how many of them (1..3)
+  uint32_t daat_z_split = 1;     // PS_DAAT_Z_SPLIT: a zero_to_one batch with queries K1dz does not take is split (those to the streaming kernels) instead of taking the streaming kernels whole
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
   uint32_t device_plan = 1;      // PS_DEVICE_PLAN: flat BM25 top-k batches (built-in tokenizer) are planned by k_plan on the device
   void load();
@@ -765,6 +766,7 @@ void Tuning::load() {
     daat_small = env_u32("PS_DAAT_SMALL", daat_small);
     daat_multi = env_u32("PS_DAAT_MULTI", daat_multi);
     daat_z = env_u32("PS_DAAT_Z", daat_z);
+    daat_z_split = env_u32("PS_DAAT_Z_SPLIT", daat_z_split);
     work_counters = env_u32("PS_WORK_COUNTERS", work_counters);
     kernel_timers = env_u32("PS_KERNEL_TIMERS", kernel_timers);
     daat_z_d0_div = env_u32("PS_DAAT_Z_D0_DIV", daat_z_d0_div);
@@ -1913,7 +1915,7 @@ void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st);
 void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, ps_plan_entry* d_plan,
                   const uint32_t* d_qbeg, const uint32_t* d_qtl, size_t B, size_t ne, uint32_t max_qterms, uint32_t max_entries, bool multi,
                   size_t n_items, uint32_t max_slots, size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller,
-                  const ZBatch* zb = nullptr) {
+                  const ZBatch* zb = nullptr, const uint32_t* d_out_row = nullptr) {
   const Snapshot& s = *m.snap;
   hipStream_t P = m.prep_stream, S = m.score_stream;
   KParams kp;
@@ -1947,6 +1949,7 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     kp.cand_score = c.cand_score.p;
     kp.cand_doc = c.cand_doc.p;
     kp.out_keys = (uint64_t*)d_keys; kp.out_scores = (double*)d_scores; kp.out_counts = (uint32_t*)d_counts;
+    kp.out_row = d_out_row;
     // (PS_KERNEL_TIMERS=0: no HIP timing events around the launches - four stream packets less per batch between two
     // consecutive scoring kernels; ps_snapshot_kernel_breakdown then has nothing to report for these batches)
     const bool timers = m.tune.kernel_timers != 0;
@@ -2162,25 +2165,32 @@ double z_numerator_bound(EngineImpl& m, double score, uint32_t need, uint32_t ma
 // Qualifies: every query "simple" in the sense of classify_zero_to_one - one version layer per entry, no two
 // records with the same (query term, node) - with at most DAAT_SMALL_MAX entries.  The image: entries per query in
 // the record-sort order (score desc, stable; zero_to_one.rs:98) | qbeg | query_terms_len | ubnum | zub.
+// Whether K1dz can take query q: at most DAAT_SMALL_MAX records, one version layer each, and "simple" (the rule of
+// classify_zero_to_one).
+bool z_query_fits_k1dz(const Plan& plan, size_t q) {
+  if (plan.qbeg[q + 1] - plan.qbeg[q] > (uint32_t)DAAT_SMALL_MAX) return false;
+  bool same_q = false, same_n = false;
+  for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
+    if (plan.entries[i].shift >> 8) return false;
+    for (uint32_t j = plan.qbeg[q]; j < i; ++j) {
+      same_q = same_q || plan.entries[j].qterm == plan.entries[i].qterm;
+      same_n = same_n || plan.entries[j].node == plan.entries[i].node;
+    }
+  }
+  // several expansions of a query term AND a node hit by two records: the pool rule's closed form (need) no longer holds
+  return !(same_q && same_n);
+}
+
+// `rows` (a batch split between K1dz and the streaming kernels): the output row of each of the plan's queries.
 bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k, void* d_keys,
-                         void* d_scores, void* d_counts, hipStream_t caller) {
+                         void* d_scores, void* d_counts, hipStream_t caller, const std::vector<uint32_t>* rows = nullptr) {
   const Snapshot& s = *m.snap;
   const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size(), F = s.F;
   if (!(m.tune.daat && m.tune.daat_z && sc.kind == PS_SCORER_ZERO_TO_ONE && B >= m.tune.daat_min_batch && ne != 0 &&
         plan.max_entries <= (uint32_t)DAAT_SMALL_MAX && F <= 4 && s.n_ids > 0))
     return false;
-  for (size_t q = 0; q < B; ++q) {  // (the rule of classify_zero_to_one)
-    bool same_q = false, same_n = false;
-    for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
-      if (plan.entries[i].shift >> 8) return false;
-      for (uint32_t j = plan.qbeg[q]; j < i; ++j) {
-        same_q = same_q || plan.entries[j].qterm == plan.entries[i].qterm;
-        same_n = same_n || plan.entries[j].node == plan.entries[i].node;
-      }
-    }
-    // several expansions of a query term AND a node hit by two records: the pool rule's closed form (need) no longer holds
-    if (same_q && same_n) return false;
-  }
+  for (size_t q = 0; q < B; ++q)
+    if (!z_query_fits_k1dz(plan, q)) return false;
   uint32_t max_slots = 0;
   const size_t n_items = count_daat_items(m, plan, &max_slots);
   if (!n_items || n_items >= 0x3FFFFFF0ull) return false;
@@ -2188,7 +2198,7 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   EngineImpl::DaatCtx& c = acquire_ctx(m);
   hipStream_t st = m.prep_stream;
   const size_t off_q = ne * sizeof(ps_plan_entry), off_l = off_q + (B + 1) * 4, off_u = (off_l + B * 4 + 15) & ~(size_t)15,
-               off_z = off_u + ne * 8, total = (off_z + ne * F * 8 + 15) & ~(size_t)15;
+               off_z = off_u + ne * 8, off_m = (off_z + ne * F * 8 + 15) & ~(size_t)15, total = (off_m + (rows ? B * 4 : 0) + 15) & ~(size_t)15;
   Stage& sg = m.stage[m.next_stage];
   m.next_stage = (m.next_stage + 1) % N_STAGE;
   sg.ensure(total + 16);
@@ -2197,6 +2207,7 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   double* hz = reinterpret_cast<double*>(sg.p + off_z);
   memcpy(sg.p + off_q, plan.qbeg.data(), (B + 1) * 4);
   memcpy(sg.p + off_l, plan.qterms_len.data(), B * 4);
+  if (rows) memcpy(sg.p + off_m, rows->data(), B * 4);
   double last_w = -1.0;
   uint64_t last_l = 0;
   for (size_t q = 0; q < B; ++q) {
@@ -2250,7 +2261,7 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   z_levels(m, zb);
   enqueue_daat(m, c, sc, boosts, reinterpret_cast<ps_plan_entry*>(c.stage.p), reinterpret_cast<const uint32_t*>(c.stage.p + off_q),
                reinterpret_cast<const uint32_t*>(c.stage.p + off_l), B, ne, plan.max_qterms, plan.max_entries, false, n_items, max_slots, top_k,
-               d_keys, d_scores, d_counts, caller, &zb);
+               d_keys, d_scores, d_counts, caller, &zb, rows ? reinterpret_cast<const uint32_t*>(c.stage.p + off_m) : nullptr);
   return true;
 }
 
@@ -2258,8 +2269,31 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
 // memory, or device-mapped pinned host memory).  `sync_path`: the caller waits for `st` before it
 // returns — the latency path: no staging-slot fence, and HIP timing events only for batches of
 // >= 8 queries (two extra stream packets are a visible share of a single query's round trip).
+// The queries `qs` of a plan as a plan of their own.
+Plan sub_plan_of(const Plan& plan, const std::vector<uint32_t>& qs) {
+  Plan p2;
+  p2.qbeg.push_back(0);
+  for (uint32_t q : qs) {
+    uint32_t qt_max = 0;
+    for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
+      p2.entries.push_back(plan.entries[i]);
+      p2.postings += plan.entries[i].len;
+      qt_max = std::max(qt_max, plan.entries[i].qterm + 1);
+      if (i > plan.qbeg[q] && plan.entries[i].qterm == plan.entries[i - 1].qterm) p2.multi_expansion = true;
+    }
+    p2.qbeg.push_back((uint32_t)p2.entries.size());
+    p2.qterms_len.push_back(plan.qterms_len[q]);
+    p2.n_nodes.push_back(plan.n_nodes[q]);
+    p2.max_entries = std::max(p2.max_entries, plan.qbeg[q + 1] - plan.qbeg[q]);
+    p2.max_nodes = std::max(p2.max_nodes, plan.n_nodes[q]);
+    p2.max_qterms = std::max(p2.max_qterms, qt_max);
+  }
+  return p2;
+}
+
+// `rows`: the plan is one part of a split batch - query q's results go to row rows[q] of the output block.
 void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t top_k,
-                  void* d_keys, void* d_scores, void* d_counts, hipStream_t st, bool sync_path) {
+                  void* d_keys, void* d_scores, void* d_counts, hipStream_t st, bool sync_path, const std::vector<uint32_t>* rows = nullptr) {
   const size_t B = plan.qbeg.size() - 1;
   KParams kp;
   static const bool trace = env_u32("PS_TRACE", 0) != 0;
@@ -2273,7 +2307,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   };
   refresh_tuning(m);
   m.last_bounds_recomputed = false;
-  if (daat_eligible(m, sc, boosts, B, plan.entries.size(), plan.max_entries, plan.multi_expansion)) {
+  if (rows == nullptr && daat_eligible(m, sc, boosts, B, plan.entries.size(), plan.max_entries, plan.multi_expansion)) {
     uint32_t max_slots = 0;
     const size_t n_items = count_daat_items(m, plan, &max_slots);
     if (n_items && n_items < 0xFFFFFFF0ull) {
@@ -2282,17 +2316,46 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
       return;
     }
   }
-  if (sc.kind == PS_SCORER_ZERO_TO_ONE && enqueue_daat_z_host(m, sc, boosts, plan, top_k, d_keys, d_scores, d_counts, st)) {
-    TT("k1dz batch");
-    return;
+  if (sc.kind == PS_SCORER_ZERO_TO_ONE && rows == nullptr) {
+    if (enqueue_daat_z_host(m, sc, boosts, plan, top_k, d_keys, d_scores, d_counts, st)) {
+      TT("k1dz batch");
+      return;
+    }
+    // A mixed batch: the queries K1dz takes (simple, <= 4 lists) go there, the others through the streaming kernels -
+    // two sub-batches, each kernel's merge writing its queries' rows of the caller's block (KParams::out_row).  (Whole, the
+    // batch would take the streaming kernels: 2.1 ms against 0.36 ms on C3's shape.)
+    if (m.tune.daat && m.tune.daat_z && m.tune.daat_z_split && B >= m.tune.daat_min_batch && m.snap->F <= 4 && m.snap->n_ids > 0) {
+      std::vector<uint32_t> rows_a, rows_b;
+      for (size_t q = 0; q < B; ++q) (z_query_fits_k1dz(plan, q) ? rows_a : rows_b).push_back((uint32_t)q);
+      if (rows_a.size() >= m.tune.daat_min_batch && !rows_b.empty()) {
+        const Plan plan_a = sub_plan_of(plan, rows_a), plan_b = sub_plan_of(plan, rows_b);
+        if (enqueue_daat_z_host(m, sc, boosts, plan_a, top_k, d_keys, d_scores, d_counts, st, &rows_a)) {
+          enqueue_topk(m, sc, boosts, plan_b, top_k, d_keys, d_scores, d_counts, st, sync_path, &rows_b);
+          TT("split batch");
+          return;
+        }
+      }
+    }
   }
   if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
   m.tail_pending = false;
   const bool timed = !sync_path || B >= 8 || time_all;
   EngineImpl::KTimer* kt = nullptr;
+  Stage* row_slot = nullptr;
   try {
   stage_plan(m, sc, boosts, plan, st, kp, true, sync_path);
   TT("stage_plan");
+  if (rows) {  // the merge kernel reads the rows from a pinned, device-mapped slot (fenced behind it below)
+    row_slot = &m.stage[m.next_stage];
+    m.next_stage = (m.next_stage + 1) % N_STAGE;
+    if (row_slot == m.cur_stage) {  // (the slot stage_plan has just filled: the next one)
+      row_slot = &m.stage[m.next_stage];
+      m.next_stage = (m.next_stage + 1) % N_STAGE;
+    }
+    row_slot->ensure(B * 4 + 16);
+    memcpy(row_slot->p, rows->data(), B * 4);
+    kp.out_row = reinterpret_cast<const uint32_t*>(row_slot->dp);
+  }
   kp.K = (uint32_t)top_k;
   const size_t n_cand = (size_t)B * kp.n_super * top_k;
   m.d_cand_score.ensure(n_cand + 1);
@@ -2329,6 +2392,10 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     hipLaunchKernelGGL(k_merge, dim3((uint32_t)B), dim3(WAVE * mw), 0, st, kp);
     PS_HIP(hipGetLastError());
     m.ctl_clean = true;  // k_merge zeroes the control words behind itself
+  }
+  if (row_slot) {
+    PS_HIP(hipEventRecord(row_slot->done, st));
+    row_slot->pending = true;
   }
   if (m.cur_zero_copy && !sync_path) {  // the kernels read the slot in place: fence it behind them
     PS_HIP(hipEventRecord(m.cur_stage->done, st));

@@ -188,6 +188,7 @@ struct KParams {
   uint64_t* out_keys;
   double* out_scores;
   uint32_t* out_counts;
+  const uint32_t* out_row;   // [B] the output row of query q; nullptr: q itself (set when a batch is split between two scoring kernels)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1335,14 +1336,15 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
     const bool has = (uint32_t)lane < sh_n[w];
     topk_offer(tk, K, lane, has, sh_s[w][lane], sh_d[w][lane]);
   }
+  const uint32_t row = p.out_row != nullptr ? p.out_row[q] : q;
   if ((uint32_t)lane < K) {
     const bool ok = (uint32_t)lane < tk.n;
-    const uint64_t o = (uint64_t)q * K + lane;
+    const uint64_t o = (uint64_t)row * K + lane;
     p.out_keys[o] = ok ? p.keys[tk.d] : ~0ull;
     p.out_scores[o] = ok ? tk.s : 0.0;
   }
   if (lane == 0) {
-    p.out_counts[q] = tk.n;
+    p.out_counts[row] = tk.n;
     p.gthr[q] = 0ull;
     if (p.gtie != nullptr)
       for (uint32_t l = 0; l < 3u; ++l) p.gtie[(size_t)l * p.z_tstride + q] = 0ull;
@@ -2683,14 +2685,15 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge_items(const KParam
     const bool has = (uint32_t)lane < sh_n[w];
     topk_offer(tk, K, lane, has, sh_s[w][lane], sh_d[w][lane]);
   }
+  const uint32_t row = p.out_row != nullptr ? p.out_row[q] : q;
   if ((uint32_t)lane < K) {
     const bool ok = (uint32_t)lane < tk.n;
-    const uint64_t o = (uint64_t)q * K + lane;
+    const uint64_t o = (uint64_t)row * K + lane;
     p.out_keys[o] = ok ? p.keys[tk.d] : ~0ull;
     p.out_scores[o] = ok ? tk.s : 0.0;
   }
   if (lane == 0) {
-    p.out_counts[q] = tk.n;
+    p.out_counts[row] = tk.n;
     p.gthr[q] = 0ull;
     if (p.gtie != nullptr)
       for (uint32_t l = 0; l < 3u; ++l) p.gtie[(size_t)l * p.z_tstride + q] = 0ull;

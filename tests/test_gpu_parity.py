@@ -356,6 +356,8 @@ def test_dense_rows_path_forced(seed, monkeypatch):
     monkeypatch.setenv("PS_DENSE_MIN_USES", "1")
     monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "0")
     monkeypatch.setenv("PS_DAAT_DENSE_MIN_DENSITY_PCT", "0")
+    # (the zero_to_one batch whole on the streaming kernels - the rows are theirs; split, its complex queries alone take k_z21)
+    psa.load().ps_set_option(b"PS_DAAT_Z_SPLIT", 0)
     F, steps, vocab = build_script(300 + seed, n_docs=400, fields=1 + seed % 2, vocab_size=25, shuffle_keys=seed % 2 == 1)
     o, p = orc.Index(F), ProductIndex(F)
     replay(steps, F, o, p)

@@ -254,3 +254,90 @@ def test_device_planned_c3_shape_and_batches_in_flight():
         got = psd.unpack_blocks(buf.to_host(), 1, B, K, [B])
         assert [[(k, bits(s)) for k, s in rs] for rs in got] == want[i], i
     hip.hipStreamDestroy(st)
+
+
+# ---- mixed batches: the queries K1dz takes go there, the others through the streaming kernels (KParams::out_row) ----
+
+@pytest.mark.parametrize("planner", [1, 0])
+def test_mixed_batches_are_split(planner):
+    """A zero_to_one batch in which some queries are not for K1dz (not simple: "wab wab"; more than 4 lists: "w", five
+    terms) is split - every query's row must hold its own answer, whichever kernel wrote it; device planner (hands the
+    batch back) and host planner alike; with PS_DAAT_Z_SPLIT=0 the whole batch takes the streaming kernels: same answers."""
+    words, docs = _tie_corpus(20_000, 2, seed=11)
+    p, o = _build(docs, 2)
+    snap = p.snapshot(device=0, tile_docs=256)
+    rng = random.Random(7)
+    simple = [" ".join(rng.choice(words[:8]) for _ in range(rng.randint(1, 4))) for _ in range(40)]
+    other = ["wab wab", "w", "w00 w01 w02 w03 w04", "wa wab", "w0 w1", "wab wab w00"]
+    queries = []
+    for i, q in enumerate(simple):
+        queries.append(q)
+        if i % 5 == 2:
+            queries.append(other[(i // 5) % len(other)])
+    queries += ["", "w00"]
+    _opt(b"PS_DAAT_CHUNK", 256)
+    _opt(b"PS_DEVICE_PLAN", planner)
+    try:
+        for K in (1, 10, 64):
+            boosts = [1.0, 1.0]
+            snap.work_counters(reset=True)
+            got = _planned(snap, queries, K, boosts)
+            assert snap.last_stats()["device_planned"] == 0  # (handed back to the host planner, which splits it)
+            assert snap.work_counters(reset=True)["z_postings_scanned"] > 0  # (K1dz took its part)
+            for _ in range(2):
+                assert _planned(snap, queries, K, boosts) == got
+            _opt(b"PS_DAAT_Z_SPLIT", 0)
+            snap.work_counters(reset=True)
+            whole = _planned(snap, queries, K, boosts)
+            assert snap.kernel_breakdown()["score_kernel"].startswith(("ps::k_score", "ps::k_z21"))
+            assert snap.work_counters(reset=True)["z_postings_scanned"] == 0
+            _opt(b"PS_DAAT_Z_SPLIT", 1)
+            for q, g, w in zip(queries, got, whole):
+                assert g == w, (q, K, g[:3], w[:3])
+            for q, g in zip(queries, got):
+                exp = [(k, bits(s)) for k, s in o.query(q, orc.zero_to_one(), boosts)[:K]]
+                assert g == exp, (q, K, g[:3], exp[:3])
+        # the host-result entry point (ps_snapshot_query_batch) takes the same path
+        assert _topk(snap, queries, 10, [1.0, 1.0]) == _planned(snap, queries, 10, [1.0, 1.0])
+        # fewer than PS_DAAT_MIN_BATCH queries for K1dz: not split
+        few = ["wab wab"] * 6 + ["w00 w01"] * 3
+        assert _planned(snap, few, 10, [1.0, 1.0]) == [[(k, bits(s)) for k, s in o.query(q, orc.zero_to_one(), [1.0, 1.0])[:10]] for q in few]
+    finally:
+        _opt(b"PS_DEVICE_PLAN", 1)
+        _opt(b"PS_DAAT_Z_SPLIT", 1)
+
+
+def test_mixed_batches_in_flight():
+    """Split batches back to back on one caller stream, pure batches between them."""
+    import ctypes as C
+    from probly_search_amd import dist as psd
+    words, docs = _tie_corpus(30_000, 2, seed=12)
+    p, o = _build(docs, 2)
+    snap = p.snapshot(device=0, tile_docs=256)
+    sc, K, B = psa.zero_to_one.new(), 10, 64
+    rng = random.Random(5)
+    batches = []
+    for s in range(6):
+        qs = [" ".join(rng.choice(words[:10]) for _ in range(rng.randint(1, 4))) for _ in range(B)]
+        if s % 2 == 0:
+            for i in range(3, B, 7):
+                qs[i] = ["wab wab", "w", "w00 w01 w02 w03 w04"][i % 3]
+        batches.append(qs)
+    _opt(b"PS_DAAT_Z_SPLIT", 0)
+    want = [_topk(snap, b, K, [1.0, 1.0]) for b in batches]
+    _opt(b"PS_DAAT_Z_SPLIT", 1)
+    hip = psd._DeviceBuffer.hip()
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    bufs = [psd._DeviceBuffer(psd.block_bytes(B, K)) for _ in batches]
+    for b, buf in zip(batches, bufs):
+        text, offsets = synth.pack_queries(b)
+        snap.query_batch_allgather_flat(None, text, offsets, sc, [1.0, 1.0], K, buf.ptr.value, buf.ptr.value, stream=st.value)
+    assert hip.hipStreamSynchronize(st) == 0
+    for i, buf in enumerate(bufs):
+        got = psd.unpack_blocks(buf.to_host(), 1, B, K, [B])
+        assert [[(k, bits(s)) for k, s in rs] for rs in got] == want[i], i
+    hip.hipStreamDestroy(st)
