@@ -424,6 +424,10 @@ typedef struct ps_kernel_times {
   double rows_ms;
   uint64_t launches;
   char score_kernel[96];
+  double score_busy_ms; /* wall-clock during which at least one of those scoring launches was executing (the union of their
+                         * [start, end] intervals): equals score_ms while launches run one after the other, less when consecutive
+                         * batches' kernels overlap on two hardware queues (PS_SCORE_ALT) - then THIS is the time the chip spent
+                         * scoring, and score_ms / launches overstates a batch's share of it */
 } ps_kernel_times;
 ps_status ps_snapshot_kernel_breakdown(ps_snapshot* snap, ps_kernel_times* out, int reset);
 /* Work the scoring kernels really did, counted BY THE KERNELS (always on): every wave adds its counts

@@ -77,7 +77,7 @@ class UpdateStats(C.Structure):
 
 class KernelTimes(C.Structure):
     _fields_ = [("score_ms", C.c_double), ("rows_ms", C.c_double), ("launches", C.c_uint64),
-                ("score_kernel", C.c_char * 96)]
+                ("score_kernel", C.c_char * 96), ("score_busy_ms", C.c_double)]
 
 
 class WorkCounters(C.Structure):

@@ -156,13 +156,18 @@ struct Tuning {
   uint32_t daat_z_levels = 3;    // PS_DAAT_Z_LEVELS: how many of them (1..3)
   uint32_t daat_z_split = 1;     // PS_DAAT_Z_SPLIT: a zero_to_one batch with queries K1dz does not take is split (those to the streaming kernels) instead of taking the streaming kernels whole
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
+  uint32_t daat_split_first = 0; // PS_DAAT_SPLIT_FIRST: a query's SHORTEST list (its first-ranked one: every chunk runs, and the longest of them are a launch's critical path) is cut into at most this many chunks (0: like the others, PS_DAAT_SPLIT_DIV)
+  uint32_t daat_sample_div = 24; // PS_DAAT_SAMPLE_DIV: multi-expansion K1d launches (k_daat<F, true>: C5) start with the chunks below doc id ~ N / this, of every rank (0: plain rank-major order)
+  uint32_t daat_sample_all = 0;  // PS_DAAT_SAMPLE_ALL: ... every K1d BM25 launch does (C2 / C4: slower)
+  uint32_t dctx = 5;             // PS_DCTX: K1d batch contexts in the rotation (<= N_DCTX)
+  uint32_t score_alt = 1;        // PS_SCORE_ALT: consecutive K1d batches alternate between the scoring stream and a second one at the LOWEST stream priority (1) - a hardware queue of its own, whose kernel fills what the other's tail leaves free (two streams of one priority share a queue and serialise: 3); 0: one scoring stream; 2: everything on the low-priority stream; 4: three-way rotation normal / low / high.  Round 5, same box: C2 0.3025 -> 0.289 ms per step, C3 0.363 -> 0.312, C4 1.118 -> 0.940, C5 1.585 -> 1.213
   uint32_t device_plan = 1;      // PS_DEVICE_PLAN: flat BM25 top-k batches (built-in tokenizer) are planned by k_plan on the device
   void load();
 };
 
-constexpr int N_STAGE = 6;  // (>= N_DCTX: host-planned batches take a pinned staging slot each)
+constexpr int N_STAGE = 9;  // (>= N_DCTX: host-planned batches take a pinned staging slot each)
 constexpr int N_KTIMER = 32;
-constexpr int N_DCTX = 5;  // K1d batch contexts (batches of one snapshot in flight)
+constexpr int N_DCTX = 8;  // K1d batch contexts (most batches of one snapshot in flight; PS_DCTX of them are in the rotation)
 
 struct EngineImpl {
   const Snapshot* snap;
@@ -311,12 +316,14 @@ struct EngineImpl {
   DaatCtx dctx[N_DCTX];
   int next_dctx = 0;
   hipStream_t prep_stream = nullptr, score_stream = nullptr, plan_stream = nullptr, merge_stream = nullptr;
+  hipStream_t score_stream_lo = nullptr, score_stream_b = nullptr, score_stream_hi = nullptr;  // PS_SCORE_ALT
+  uint32_t score_flip = 0;
   hipEvent_t lut_ready = nullptr;  // behind the most recent k_bm25_lut
   PlanTotals* h_totals = nullptr;  // [N_DCTX] pinned, device-mapped, one per batch context: k_plan_scan writes the totals where the host reads them
   PlanTotals* d_totals_mapped = nullptr;
   // A batch announced ahead of its query call (Engine::plan_ahead): its text is in the context's pinned slot, its
   // count pass is in flight or done.  The next device-planned call with the same text picks it up.
-  struct Ahead { bool valid = false; int ctx = -1; size_t B = 0, n_bytes = 0; } ahead;
+  struct Ahead { bool valid = false; int ctx = -1; size_t B = 0, n_bytes = 0; uint64_t tune_gen = 0; } ahead;  // tune_gen: the knobs its count pass chunked the lists with
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0, last_rows_built = 0;
@@ -355,6 +362,11 @@ struct EngineImpl {
   double kt_total_ms = 0.0;  // scoring kernel alone (m -> b)
   double kt_rows_ms = 0.0;   // K0 + K0b in front of it (a -> m)
   uint64_t kt_launches = 0;
+  // With PS_SCORE_ALT consecutive scoring kernels overlap (two hardware queues): their individual durations no longer add up
+  // to the time the chip spent scoring.  kt_busy_ms = length of the union of the launches' [start, end] intervals, measured
+  // against a reference event (re-recorded at every reset: hipEventElapsedTime is a float).
+  hipEvent_t kt_ref = nullptr;
+  double kt_busy_ms = 0.0, kt_cur_end = -1.0;
   std::string score_kernel_name;  // demangled symbol of the scoring kernel of the most recent batch
   void harvest(KTimer& t, bool wait) {
     if (!t.pending) return;
@@ -362,6 +374,14 @@ struct EngineImpl {
     if (wait) (void)hipEventSynchronize(t.b);
     float ms = 0, ms0 = 0;
     if (hipEventElapsedTime(&ms, t.m, t.b) == hipSuccess) { kt_total_ms += ms; kt_launches++; }
+    float s0 = 0, e0 = 0;
+    if (kt_ref && hipEventElapsedTime(&s0, kt_ref, t.m) == hipSuccess && hipEventElapsedTime(&e0, kt_ref, t.b) == hipSuccess) {
+      const double from = std::max((double)s0, kt_cur_end);
+      if ((double)e0 > from) kt_busy_ms += (double)e0 - from;
+      kt_cur_end = std::max(kt_cur_end, (double)e0);
+    } else {
+      kt_busy_ms += ms;
+    }
     // (K1d batches score their rows on the preparation stream: a -> r there, m -> b on the scoring stream)
     if (hipEventElapsedTime(&ms0, t.a, t.split ? t.r : t.m) == hipSuccess) kt_rows_ms += ms0;
     t.pending = false;
@@ -466,6 +486,10 @@ Engine::~Engine() {
   if (m.plan_stream) (void)hipStreamDestroy(m.plan_stream);
   if (m.merge_stream) (void)hipStreamDestroy(m.merge_stream);
   if (m.score_stream) (void)hipStreamDestroy(m.score_stream);
+  if (m.score_stream_lo) (void)hipStreamDestroy(m.score_stream_lo);
+  if (m.score_stream_b) (void)hipStreamDestroy(m.score_stream_b);
+  if (m.score_stream_hi) (void)hipStreamDestroy(m.score_stream_hi);
+  if (m.kt_ref) (void)hipEventDestroy(m.kt_ref);
   if (m.copy_stream) (void)hipStreamDestroy(m.copy_stream);
   for (auto& e : m.part_done) if (e) (void)hipEventDestroy(e);
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fbits.release(); m.d_fchar.release(); m.d_fchild.release();
@@ -573,13 +597,19 @@ void Engine::kernel_times(ps_kernel_times& out, bool reset) {
   EngineImpl& m = *impl_;
   std::lock_guard<std::mutex> lock(m.mu);
   (void)hipSetDevice(m.device);
-  for (auto& t : m.kt) m.harvest(t, true);
+  for (int i = 0; i < N_KTIMER; ++i) m.harvest(m.kt[(m.next_kt + i) % N_KTIMER], true);  // (oldest first: the busy-interval bookkeeping wants launch order)
   memset(&out, 0, sizeof(out));
   out.score_ms = m.kt_total_ms;
   out.rows_ms = m.kt_rows_ms;
   out.launches = m.kt_launches;
+  out.score_busy_ms = m.kt_busy_ms;
   snprintf(out.score_kernel, sizeof(out.score_kernel), "%s", m.score_kernel_name.c_str());
-  if (reset) { m.kt_total_ms = 0.0; m.kt_rows_ms = 0.0; m.kt_launches = 0; }
+  if (reset) {
+    m.kt_total_ms = 0.0; m.kt_rows_ms = 0.0; m.kt_launches = 0; m.kt_busy_ms = 0.0; m.kt_cur_end = -1.0;
+    // a fresh reference for the busy-interval bookkeeping (every timer was harvested above: nothing refers to the old one)
+    if (!m.kt_ref) (void)hipEventCreate(&m.kt_ref);
+    if (m.kt_ref && hipEventRecord(m.kt_ref, m.stream) == hipSuccess) (void)hipEventSynchronize(m.kt_ref);
+  }
 }
 int Engine::device() const { return impl_->device; }
 
@@ -732,6 +762,8 @@ bool result_block_release(void* p) {
   return true;
 }
 
+inline uint32_t split_first_of(const Tuning& t) { return t.daat_split_first ? std::max(t.daat_split_first, t.daat_split_div) : t.daat_split_div; }
+
 void Tuning::load() {
     dense_max_rows = env_u32("PS_DENSE_MAX_ROWS", dense_max_rows);
     row_cache_mb = env_u32("PS_ROW_CACHE_MB", row_cache_mb);
@@ -769,6 +801,11 @@ void Tuning::load() {
     daat_z_split = env_u32("PS_DAAT_Z_SPLIT", daat_z_split);
     work_counters = env_u32("PS_WORK_COUNTERS", work_counters);
     kernel_timers = env_u32("PS_KERNEL_TIMERS", kernel_timers);
+    score_alt = env_u32("PS_SCORE_ALT", score_alt);
+    daat_sample_div = env_u32("PS_DAAT_SAMPLE_DIV", daat_sample_div);
+    daat_sample_all = env_u32("PS_DAAT_SAMPLE_ALL", daat_sample_all);
+    dctx = std::max(2u, std::min((uint32_t)N_DCTX, env_u32("PS_DCTX", dctx)));
+    daat_split_first = env_u32("PS_DAAT_SPLIT_FIRST", daat_split_first);
     daat_z_d0_div = env_u32("PS_DAAT_Z_D0_DIV", daat_z_d0_div);
     daat_z_level_shift = env_u32("PS_DAAT_Z_LEVEL_SHIFT", daat_z_level_shift);
     daat_z_levels = env_u32("PS_DAAT_Z_LEVELS", daat_z_levels);
@@ -1063,7 +1100,15 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   memset(&pp, 0, sizeof(pp));
   pp.plan = d_plan; pp.qbeg = d_qbeg;
   pp.B = (uint32_t)B; pp.ne = (uint32_t)ne; pp.F = s.F; pp.multi = multi ? 1u : 0u;
-  pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div;
+  pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div; pp.split_first = split_first_of(m.tune);
+  pp.table = m.d_table;
+  if (m.tune.daat_sample_div > 1 && (multi || m.tune.daat_sample_all) && s.n_ids >= 4096) {  // the sample boundary D0 ~ N / div, on a tile boundary that every table of this snapshot resolves as finely as it can
+    const uint32_t tiles = std::max<uint32_t>(1u, (uint32_t)((s.n_ids / m.tune.daat_sample_div) / s.T));
+    // lists of >= one chunk have one table slot per tile (shift 0); a multiple of 8 tiles also serves the tables up to 8 x coarser
+    uint32_t al = 1;
+    while (al * 2 <= tiles) al *= 2;
+    pp.sample_tile = tiles >= 16 ? (tiles & ~7u) : al;
+  }
   for (uint32_t x = 0; x < s.F; ++x) pp.boost[x] = boosts[x];
   pp.bound_m = br.M; pp.bound_j = br.J;
   kp.splane = br.plane;
@@ -1113,12 +1158,15 @@ EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
     // for its totals, and that wait should not sit behind the previous batch's preparation kernels
     PS_HIP(hipStreamCreateWithPriority(&m.plan_stream, hipStreamNonBlocking, hi));
     PS_HIP(hipStreamCreateWithFlags(&m.score_stream, hipStreamNonBlocking));
+    PS_HIP(hipStreamCreateWithPriority(&m.score_stream_lo, hipStreamNonBlocking, lo));
+    PS_HIP(hipStreamCreateWithFlags(&m.score_stream_b, hipStreamNonBlocking));
+    PS_HIP(hipStreamCreateWithPriority(&m.score_stream_hi, hipStreamNonBlocking, hi));
     // the merge of batch s (the kernel that waits for the caller's stream) off the scoring stream: k_daat of
     // batch s + 1 starts the moment k_daat of batch s ends
     PS_HIP(hipStreamCreateWithPriority(&m.merge_stream, hipStreamNonBlocking, hi));
   }
   EngineImpl::DaatCtx& c = m.dctx[m.next_dctx];
-  m.next_dctx = (m.next_dctx + 1) % N_DCTX;
+  m.next_dctx = (m.next_dctx + 1) % (int)m.tune.dctx;
   if (!c.done) {
     PS_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.entry, hipEventDisableTiming));
@@ -1154,13 +1202,19 @@ size_t count_daat_items(const EngineImpl& m, const Plan& plan, uint32_t* max_slo
   size_t n = 0;
   uint32_t mx = 0;
   const size_t B = plan.qbeg.size() - 1;
+  const uint32_t sf = split_first_of(m.tune);
+  auto chunks = [&](uint32_t len, uint32_t div) {
+    const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + div - 1) / div + 255) & ~255u);
+    return (len + c - 1) / c;
+  };
   for (size_t q = 0; q < B; ++q) {
-    uint32_t sl = 0;
+    uint32_t sl = 0, mn = 0xFFFFFFFFu;
     for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
       const uint32_t len = plan.entries[i].len;
-      const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + m.tune.daat_split_div - 1) / m.tune.daat_split_div + 255) & ~255u);
-      sl += (len + c - 1) / c;
+      sl += chunks(len, m.tune.daat_split_div);
+      mn = std::min(mn, len);
     }
+    if (mn != 0xFFFFFFFFu && mn && sf != m.tune.daat_split_div) sl += chunks(mn, sf) - chunks(mn, m.tune.daat_split_div);  // (the query's shortest list: prep_fine_entry)
     n += sl;
     mx = std::max(mx, sl);
   }
@@ -1918,6 +1972,13 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
                   const ZBatch* zb = nullptr, const uint32_t* d_out_row = nullptr) {
   const Snapshot& s = *m.snap;
   hipStream_t P = m.prep_stream, S = m.score_stream;
+  if (m.tune.score_alt == 4) {  // three-way rotation: normal, low, high
+    const uint32_t r = m.score_flip++ % 3u;
+    S = r == 0 ? m.score_stream : r == 1 ? m.score_stream_lo : m.score_stream_hi;
+  } else if (m.tune.score_alt) {
+    const bool odd = (m.score_flip++ & 1u) != 0;
+    S = m.tune.score_alt == 2 ? m.score_stream_lo : !odd ? m.score_stream : m.tune.score_alt == 3 ? m.score_stream_b : m.score_stream_lo;
+  }
   KParams kp;
   EngineImpl::KTimer* kt = nullptr;
   try {
@@ -2306,6 +2367,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
     tt = now_ms();
   };
   refresh_tuning(m);
+  if (rows == nullptr) drop_ahead(m);  // (a host-planned call between an announcement and its query call: the announced batch is dropped, as the header says)
   m.last_bounds_recomputed = false;
   if (rows == nullptr && daat_eligible(m, sc, boosts, B, plan.entries.size(), plan.max_entries, plan.multi_expansion)) {
     uint32_t max_slots = 0;
@@ -2557,7 +2619,7 @@ void device_plan_begin(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
   ps_.tok_node.ensure(B * (size_t)WAVE + 1);
   hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, nullptr,
                      nullptr, ps_.cnt.p, ps_.qtl.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, nullptr, ps_.items.p, m.tune.daat_chunk,
-                     m.tune.daat_split_div, ps_.tok_node.p, 0u);
+                     m.tune.daat_split_div, ps_.tok_node.p, 0u, split_first_of(m.tune));
   // (the totals are written straight into pinned, device-mapped host memory: no copy-engine transfer to wait for)
   const int ci = (int)(&c - m.dctx);
   hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(WAVE), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
@@ -2590,7 +2652,7 @@ void device_plan_fill(EngineImpl& m, EngineImpl::DaatCtx& c, size_t B, const Pla
   const uint32_t blocks = (uint32_t)((B + PLAN_WAVES - 1) / PLAN_WAVES);
   hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, ps_.qbeg.p,
                      ps_.entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, ps_.qorder.p, nullptr, m.tune.daat_chunk,
-                     m.tune.daat_split_div, ps_.tok_node.p, zmode);
+                     m.tune.daat_split_div, ps_.tok_node.p, zmode, m.tune.daat_split_div);
   PS_HIP(hipGetLastError());
 }
 
@@ -2612,9 +2674,17 @@ EngineImpl::DaatCtx* take_ahead(EngineImpl& m, const char* text, const uint64_t*
   EngineImpl::DaatCtx& c = m.dctx[m.ahead.ctx];
   if (offsets != nullptr && m.ahead.B == B) {
     const size_t n_bytes = B ? (size_t)offsets[B] : 0, off_bytes = (B + 1) * 8, text_at = (off_bytes + 15) & ~(size_t)15;
-    if (m.ahead.n_bytes == n_bytes && memcmp(c.plan.h.p, offsets, off_bytes) == 0 &&
+    // (a knob changed since the announcement - ps_set_option; refresh_tuning ran just before this - means the count
+    // pass's item total was computed under another chunking rule than the preparation kernels will apply: plan again)
+    if (m.ahead.tune_gen == m.tune_gen && m.ahead.n_bytes == n_bytes && memcmp(c.plan.h.p, offsets, off_bytes) == 0 &&
         (n_bytes == 0 || memcmp(c.plan.h.p + text_at, text, n_bytes) == 0)) {
       m.ahead.valid = false;
+      // what acquire_ctx orders for a fresh context, for whatever was enqueued since the announcement: a k_score /
+      // full-result batch still in flight shares the engine's per-batch buffers and tables
+      if (m.tail_pending) {
+        PS_HIP(hipStreamWaitEvent(m.prep_stream, m.ev[0], 0));
+        PS_HIP(hipStreamWaitEvent(m.plan_stream, m.ev[0], 0));
+      }
       return &c;
     }
   }
@@ -2692,6 +2762,7 @@ bool Engine::plan_ahead(const ps_scorer_desc& sc, const char* text, const uint64
   m.ahead.ctx = (int)(&c - m.dctx);
   m.ahead.B = B;
   m.ahead.n_bytes = B ? (size_t)offsets[B] : 0;
+  m.ahead.tune_gen = m.tune_gen;
   return true;
 }
 
@@ -2949,6 +3020,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   KParams kp;
   if (m.tail_pending && m.tail_stream != st) PS_HIP(hipStreamWaitEvent(st, m.ev[0], 0));
   m.tail_pending = false;
+  drop_ahead(m);
   try {
   stage_plan(m, sc, boosts, plan, st, kp, false, false);
   kp.K = 1;

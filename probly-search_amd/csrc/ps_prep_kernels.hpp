@@ -24,7 +24,8 @@ namespace ps {
 
 constexpr uint32_t PREP_CLASSES = 64;                 // length classes of the rank-0 and of the rank-1 lists (log2 with one fractional bit)
 constexpr uint32_t PREP_RANKS = 8;                    // ranks 2..7 get a bucket each, everything above shares the last
-constexpr uint32_t PREP_BUCKETS = 2 * PREP_CLASSES + PREP_RANKS + 8;  // (K1d uses the first 2 * PREP_CLASSES + PREP_RANKS; K1dz 4 per phase + those)
+constexpr uint32_t PREP_SAMPLE_BUCKETS = 4;           // K1d's sample phase: ranks 0, 1, 2, 3+ (in front of everything else)
+constexpr uint32_t PREP_BUCKETS = 2 * PREP_CLASSES + PREP_RANKS + 8 + PREP_SAMPLE_BUCKETS;  // (K1d: sample + 2 * PREP_CLASSES + PREP_RANKS; K1dz 4 per phase + the same)
 constexpr uint32_t PREP_MAX_ROWS = 64;                // dense-row candidates per snapshot
 constexpr uint32_t NO_CAND = 0xFFu;
 
@@ -54,6 +55,11 @@ struct PrepParams {
   uint32_t B, ne, F;
   uint32_t multi;            // some query term has several entries (expansions / version layers)
   uint32_t chunk_min, split_div;
+  uint32_t sample_tile;      // PS_DAAT_SAMPLE_DIV: tile index of the doc id D0 ~ N / div (0: off) - the chunks that lie entirely below D0 are
+                             // the launch's first items, whatever their list's rank (a sample of the document space that publishes
+                             // thresholds before the long lists start; K1dz's phase order, ps_z21_daat.hpp)
+  const uint32_t* table;     // tile-offset tables (the sample phase finds a list's first posting at or above D0 there)
+  uint32_t split_first;      // most chunks of a query's shortest list (the first entry of that length in plan order)
   double boost[MAX_F];
   // per-list bounds (k_list_bounds)
   const double* bound_m;     // [n_layers][F]
@@ -144,8 +150,20 @@ __device__ __forceinline__ uint32_t prep_chunk_of(const uint32_t split_div, cons
   const uint32_t c = ((len + split_div - 1) / split_div + 255u) & ~255u;
   return c > chunk_min ? c : chunk_min;
 }
-__device__ __forceinline__ uint32_t prep_chunk(const PrepParams& pp, const uint32_t len) {
-  return prep_chunk_of(pp.split_div, pp.chunk_min, len);
+__device__ __forceinline__ uint32_t prep_chunk(const PrepParams& pp, const uint32_t len, const bool fine = false) {
+  return prep_chunk_of(fine ? pp.split_first : pp.split_div, pp.chunk_min, len);
+}
+// The entry of a query that gets the finer chunking: its shortest list (first in plan order among equals) - in practice the
+// first-ranked one, every chunk of which runs; a rule of the lengths alone, so the planner's count pass (plan_extra_items)
+// and the host (count_daat_items) size the launch exactly without knowing the bounds.
+__device__ __forceinline__ uint32_t prep_fine_entry(const PrepParams& pp, const uint32_t b, const uint32_t n) {
+  uint32_t fine = 0xFFFFFFFFu, mn = 0xFFFFFFFFu;
+  if (pp.split_first != pp.split_div)
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t len = pp.plan[b + i].len;
+      if (len < mn) { mn = len; fine = i; }
+    }
+  return fine;
 }
 __device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint32_t len, const bool short_first = false) {
   if (rank <= 1) {  // 64 length classes, log2 with one fractional bit
@@ -158,9 +176,18 @@ __device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint3
     const uint32_t l = len ? len : 1u;
     const uint32_t lg = 31u - (uint32_t)__clz((int)l);
     const uint32_t cls = 2u * lg + (lg ? ((l >> (lg - 1)) & 1u) : 0u);
-    return rank == 1u && short_first ? PREP_CLASSES + cls : rank * PREP_CLASSES + 63u - cls;
+    return PREP_SAMPLE_BUCKETS + (rank == 1u && short_first ? PREP_CLASSES + cls : rank * PREP_CLASSES + 63u - cls);
   }
-  return 2 * PREP_CLASSES + (rank < PREP_RANKS ? rank : PREP_RANKS) - 1u;
+  return PREP_SAMPLE_BUCKETS + 2 * PREP_CLASSES + (rank < PREP_RANKS ? rank : PREP_RANKS) - 1u;
+}
+// Chunks [0, result) of a list cut into chunks of `c` postings lie entirely below the sample boundary (0: no sample phase, or
+// the list's table is too coarse to tell).  Scheduling only: any value in [0, chunks] is correct.
+__device__ __forceinline__ uint32_t prep_sample_chunks(const PrepParams& pp, const ps_plan_entry& en, const uint32_t c, const uint32_t nc) {
+  if (!pp.sample_tile) return 0u;
+  const uint32_t sh = en.shift & 0xFFu;
+  if (pp.sample_tile & ((1u << sh) - 1u)) return 0u;
+  const uint32_t p0 = min(en.len, pp.table[en.tbl_off + (pp.sample_tile >> sh)]);  // postings with doc id < D0
+  return p0 >= en.len ? nc : p0 / c;
 }
 
 // ---- descriptors of one query ---------------------------------------------------------------------
@@ -178,7 +205,7 @@ __device__ __forceinline__ bool prep_before(const double ua, const uint32_t la, 
 }
 
 template <int NMAX>
-__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n) {
+__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, const uint32_t fine) {
   double ub[NMAX];
   uint32_t len[NMAX], grp[NMAX], rank[NMAX], qt[NMAX];
 #pragma unroll
@@ -261,14 +288,14 @@ __device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const
         dg._pad[0] = dg._pad[1] = dg._pad[2] = 0;
         pp.dgroup[b + i] = dg;
       }
-      const uint32_t c = prep_chunk(pp, len[i]);
+      const uint32_t c = prep_chunk(pp, len[i], (uint32_t)i == fine);
       slots += (len[i] + c - 1) / c;
     }
   }
   return slots;
 }
 
-__device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n) {
+__device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, const uint32_t fine) {
   // bounds; dense ordinal of every entry's query term (the entries of a term are adjacent in plan order)
   uint32_t n_groups = 0, cur = 0xFFFFFFFFu;
   for (uint32_t i = 0; i < n; ++i) {
@@ -345,7 +372,7 @@ __device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const 
   uint32_t slots = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t len = pp.plan[b + i].len;
-    const uint32_t c = prep_chunk(pp, len);
+    const uint32_t c = prep_chunk(pp, len, i == fine);
     slots += (len + c - 1) / c;
   }
   return slots;
@@ -452,7 +479,8 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
   uint32_t slots = 0;
   // (plans of <= 4 entries - one list per query term: C2, C4 - entirely in registers; wider ones walk their arrays in HBM.
   // An 8-entry register variant cost this kernel 145 VGPRs and 58 SGPR spills for every batch: 76 / 0 without it.)
-  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n) : prep_query_general(pp, q, b, n);
+  const uint32_t fine = prep_fine_entry(pp, b, n);
+  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n, fine) : prep_query_general(pp, q, b, n, fine);
   // candidate slots: query-major within the query; the wave's queries take one block of the batch's slots
   const uint32_t s0 = wave_add_by_key(&pp.ctl->total_slots, 0u, slots, have && n != 0);
   if (have) { pp.qslot[q] = n ? s0 : 0u; pp.qslot_n[q] = slots; }
@@ -461,17 +489,21 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
   uint32_t sl = s0;
   for (uint32_t i = 0; i < n_max; ++i) {  // (wave-uniform trip count: the aggregated atomics need every lane)
     const bool on = i < n;
-    uint32_t bk = 0, nc = 0, cd = NO_CAND;
+    uint32_t bk = 0, bs = 0, nc = 0, ns = 0, cd = NO_CAND;
     if (on) {
       const ps_plan_entry& en = pp.plan[b + i];
-      const uint32_t c = prep_chunk(pp, en.len);
+      const uint32_t c = prep_chunk(pp, en.len, i == fine);
       nc = (en.len + c - 1) / c;
-      pp.gen[b + i] = DItemGen{b + i, 0u, c, sl};
+      ns = prep_sample_chunks(pp, en, c, nc);
+      pp.gen[b + i] = DItemGen{b + i, ns, c, sl};
       sl += nc;
-      bk = prep_bucket(pp.dentry[b + i].rank, en.len, pp.multi != 0u);
+      const uint32_t rk = pp.dentry[b + i].rank;
+      bk = prep_bucket(rk, en.len, pp.multi != 0u);
+      bs = rk < PREP_SAMPLE_BUCKETS ? rk : PREP_SAMPLE_BUCKETS - 1u;
       if (pp.n_cand) cd = pp.cand_of_layer[en.node];
     }
-    wave_add_by_key_noret(pp.ctl->bucket_total, bk, nc, on && nc != 0);
+    wave_add_by_key_noret(pp.ctl->bucket_total, bk, nc - ns, on && nc != ns);
+    if (pp.sample_tile) wave_add_by_key_noret(pp.ctl->bucket_total, bs, ns, on && ns != 0);
     if (pp.n_cand) {
       wave_add_by_key_noret(pp.ctl->row_use, cd == NO_CAND ? 0u : cd, 1u, on && cd != NO_CAND);
       if (on && cd != NO_CAND) atomicMax(&pp.ctl->row_first[cd], ~(unsigned long long)(b + i));
@@ -493,7 +525,7 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
 __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = i < pp.ne;
-  uint32_t nc = 0, bk = 0, len_i = 0, chunk = 1, first_slot = 0, q_i = 0;
+  uint32_t nc = 0, ns = 0, bk = 0, bs = 0, len_i = 0, chunk = 1, first_slot = 0, q_i = 0;
   double skip_i = 0.0;
   if (have) {
     ps_plan_entry& en = pp.plan[i];
@@ -501,9 +533,11 @@ __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
     const uint32_t len = en.len, c = g.chunk;
     len_i = len; chunk = c; first_slot = g.first_slot;
     nc = (len + c - 1) / c;
+    ns = g.item_at;  // (k_prep_query: the list's chunks in the sample phase)
     const DEntry de_i = pp.dentry[i];
     skip_i = de_i.skip_thr; q_i = de_i.q;
     bk = prep_bucket(de_i.rank, len, pp.multi != 0u);
+    bs = de_i.rank < PREP_SAMPLE_BUCKETS ? de_i.rank : PREP_SAMPLE_BUCKETS - 1u;
     if (pp.n_cand) {
       const uint32_t cd = pp.cand_of_layer[en.node];
       if (cd != NO_CAND) {
@@ -516,14 +550,19 @@ __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
       }
     }
   }
-  const uint32_t off = wave_add_by_key(pp.ctl->bucket_fill, bk, nc, have && nc != 0);
-  const uint32_t at = have && nc ? pp.ctl->bucket_start[bk] + off : 0u;
+  const uint32_t off = wave_add_by_key(pp.ctl->bucket_fill, bk, nc - ns, have && nc != ns);
+  const uint32_t at = have && nc != ns ? pp.ctl->bucket_start[bk] + off : 0u;
+  uint32_t at_s = 0;
+  if (pp.sample_tile) {
+    const uint32_t off_s = wave_add_by_key(pp.ctl->bucket_fill, bs, ns, have && ns != 0);
+    at_s = have && ns ? pp.ctl->bucket_start[bs] + off_s : 0u;
+  }
   if (have) {
-    // the list's items (<= 64, ~20 on average): stores nobody waits for
-    pp.gen[i].item_at = at;
+    // the list's items (~20 on average): stores nobody waits for; chunks [0, ns) are in the sample phase
     for (uint32_t j = 0; j < nc; ++j) {
       const uint32_t pb = j * chunk;
-      if (at + j < pp.items_cap) pp.items[at + j] = DItem{i, pb, min(chunk, len_i - pb), first_slot + j, skip_i, q_i, 0u};
+      const uint32_t a = j < ns ? at_s + j : at + (j - ns);
+      if (a < pp.items_cap) pp.items[a] = DItem{i, pb, min(chunk, len_i - pb), first_slot + j, skip_i, q_i, 0u};
     }
   }
 }

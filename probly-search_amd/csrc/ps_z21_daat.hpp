@@ -80,7 +80,7 @@ struct ZPrepParams {
 // profiles/r04_c3_d0_sweep.jsonl).
 __device__ __forceinline__ uint32_t zprep_bucket(const uint32_t phase, const uint32_t rank, const uint32_t len) {
   if (phase < (uint32_t)Z_LEVELS) return phase * 4u + (rank < 3u ? rank : 3u);
-  return 4u * Z_LEVELS + (rank <= 1u ? prep_bucket(rank, len) : 2u * PREP_CLASSES + (rank - 2u < 3u ? rank - 2u : 3u));
+  return 4u * Z_LEVELS + (rank <= 1u ? prep_bucket(rank, len) - PREP_SAMPLE_BUCKETS : 2u * PREP_CLASSES + (rank - 2u < 3u ? rank - 2u : 3u));
 }
 static_assert(4u * Z_LEVELS + 2u * PREP_CLASSES + 4u <= PREP_BUCKETS, "K1dz item buckets fit the preparation's control block");
 

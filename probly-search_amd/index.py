@@ -386,12 +386,13 @@ class Snapshot:
         return t.value, n.value
 
     def kernel_breakdown(self, reset=False):
-        """dict(score_ms, rows_ms, launches, score_kernel): the scoring kernel alone, K0/K0b in front
-        of it, and the scoring kernel's demangled symbol (ps_snapshot_kernel_breakdown)."""
+        """dict(score_ms, rows_ms, launches, score_kernel, score_busy_ms): the scoring kernel alone, K0/K0b in front
+        of it, the scoring kernel's demangled symbol, and the wall-clock during which at least one scoring launch was
+        executing (== score_ms unless consecutive batches' kernels overlap; ps_snapshot_kernel_breakdown)."""
         kt = _lib.KernelTimes()
         _lib.check(self._L.ps_snapshot_kernel_breakdown(self._h, C.byref(kt), 1 if reset else 0))
         return {"score_ms": kt.score_ms, "rows_ms": kt.rows_ms, "launches": kt.launches,
-                "score_kernel": kt.score_kernel.decode("utf-8", "replace")}
+                "score_kernel": kt.score_kernel.decode("utf-8", "replace"), "score_busy_ms": kt.score_busy_ms}
 
     def work_counters(self, reset=False):
         """What the scoring kernels counted themselves since the last reset (ps_snapshot_work_counters):

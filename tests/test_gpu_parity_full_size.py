@@ -33,6 +33,7 @@ def _default_kernels():
     yield
     _set("PS_DAAT", 1)
     _set("PS_DAAT_MULTI", 1)
+    _set("PS_DAAT_Z", 1)
 
 
 def _tuples(results):
@@ -86,6 +87,22 @@ def _full_size(config, n_full_lists, batch, n_oracle_topk=64):
                 for qi in range(8):
                     assert_same([tuple(r) for r in a[qi]], exp[qi], (config, qi, "boosts", bs))
         _set("PS_DAAT", 1)
+    else:
+        # zero_to_one at full size: the pruning kernel K1dz by name, the whole batch against the streaming kernels
+        # (PS_DAAT_Z=0: k_score<MODE_Z21S> / k_z21, which prune nothing), device- and host-planned, and repeated runs
+        assert kernel.startswith("ps::k_daat_z"), kernel
+        dev = run_device_planned(snap, queries, boosts, K, scorer=ps_sc)
+        assert snap.last_stats()["device_planned"] == 1
+        assert [[(k, bits(sc_)) for k, sc_ in rs] for rs in dev] == _tuples(top), (config, "device-planned batch != host-planned batch")
+        for rep in range(2):
+            assert _tuples(snap.query_batch(queries, ps_sc, None, boosts, top_k=K)) == _tuples(top), ("repeat", rep)
+        _set("PS_DAAT_Z", 0)
+        try:
+            top_stream = snap.query_batch(queries, ps_sc, None, boosts, top_k=K)
+            assert snap.kernel_breakdown(reset=True)["score_kernel"].startswith(("ps::k_score", "ps::k_z21"))
+        finally:
+            _set("PS_DAAT_Z", 1)
+        assert _tuples(top_stream) == _tuples(top), (config, "K1dz batch != streaming batch")
     # oracle top-k for many queries (one per host thread), whole lists for a few
     import os
     nq = min(n_oracle_topk, batch)

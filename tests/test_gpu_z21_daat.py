@@ -84,6 +84,27 @@ def test_ties_everywhere(fields, K):
     _check(snap, o, queries, K, fields)
 
 
+@pytest.mark.parametrize("fields,kernel", [(4, "ps::k_daat_z"), (5, ("ps::k_score", "ps::k_z21"))])
+def test_field_count_gate_edge(fields, kernel):
+    """K1dz keeps its per-field state in registers for F <= 4 (ps_engine.hip: the `s.F <= 4` gates): F = 4 is taken, F = 5 goes to
+    the streaming kernels - both against the oracle, ties included."""
+    words, docs = _tie_corpus(12_000, fields, seed=40 + fields)
+    p, o = _build(docs, fields)
+    snap = p.snapshot(device=0, tile_docs=256)
+    rng = random.Random(fields)
+    queries = [" ".join(rng.choice(words[:8]) for _ in range(rng.randint(1, 4))) for _ in range(32)] + ["w00 w01 w00", "zzz w00", "w00"]
+    _opt(b"PS_DAAT_CHUNK", 256)
+    boosts = [1.0] * fields
+    got = _topk(snap, queries, 10, boosts)
+    assert snap.kernel_breakdown()["score_kernel"].startswith(kernel), snap.kernel_breakdown()["score_kernel"]
+    for q, g in zip(queries, got):
+        exp = [(k, bits(s)) for k, s in o.query(q, orc.zero_to_one(), boosts)[:10]]
+        assert g == exp, (fields, q, g[:4], exp[:4])
+    if fields == 4:
+        _opt(b"PS_DAAT_Z", 0)
+        assert _topk(snap, queries, 10, boosts) == got
+
+
 def test_prefix_expansions_within_four_lists():
     """Several expansions of one query term (consumed_index, zero_to_one.rs:101-103) and the same node under
     two query terms (the pool rule, :104-113) - as long as a query has at most 4 lists it stays on K1dz."""

@@ -54,7 +54,7 @@ def run(tag):
     n = max(1, int(kt["launches"]))
     keep = ("items", "items_run", "postings_scanned", "postings_reached_lookups", "lookups_row", "lookups_cell", "lookups_probe", "lookup_hits",
             "offers", "bytes_touched")
-    return {"leg": tag, "kernel": kt["score_kernel"], "kernel_avg_ms": round(kt["score_ms"] / n, 4), "step_ms": round(step_ms, 4),
+    return {"leg": tag, "kernel": kt["score_kernel"], "kernel_avg_ms": round(kt["score_ms"] / n, 4), "kernel_busy_ms": round(kt["score_busy_ms"] / n, 4), "step_ms": round(step_ms, 4),
             "rows_avg_ms": round(kt["rows_ms"] / n, 4), "per_launch": {k: round(w[k] / n) for k in keep}}
 
 
