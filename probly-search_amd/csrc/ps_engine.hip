@@ -158,6 +158,7 @@ struct Tuning {
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
   uint32_t daat_split_first = 0; // PS_DAAT_SPLIT_FIRST: a query's SHORTEST list (its first-ranked one: every chunk runs, and the longest of them are a launch's critical path) is cut into at most this many chunks (0: like the others, PS_DAAT_SPLIT_DIV)
   uint32_t daat_sample_div = 24; // PS_DAAT_SAMPLE_DIV: multi-expansion K1d launches (k_daat<F, true>: C5) start with the chunks below doc id ~ N / this, of every rank (0: plain rank-major order)
+  uint32_t daat_split = 1;       // PS_DAAT_SPLIT: a BM25 K1d batch that holds queries k_daat_small takes AND others (more than 4 lists, several expansions of a term) is scored by both kernels, each over its part of the item array (0: one such query sends the whole batch to k_daat)
   uint32_t daat_sample_all = 0;  // PS_DAAT_SAMPLE_ALL: ... every K1d BM25 launch does (C2 / C4: slower)
   uint32_t dctx = 5;             // PS_DCTX: K1d batch contexts in the rotation (<= N_DCTX)
   uint32_t score_alt = 1;        // PS_SCORE_ALT: consecutive K1d batches alternate between the scoring stream and a second one at the LOWEST stream priority (1) - a hardware queue of its own, whose kernel fills what the other's tail leaves free (two streams of one priority share a queue and serialise: 3); 0: one scoring stream; 2: everything on the low-priority stream; 4: three-way rotation normal / low / high.  Round 5, same box: C2 0.3025 -> 0.289 ms per step, C3 0.363 -> 0.312, C4 1.118 -> 0.940, C5 1.585 -> 1.213
@@ -210,9 +211,14 @@ struct EngineImpl {
     std::vector<double> avg;
     size_t n_layers = 0;
     DevBuf<unsigned long long> M;
-    struct JSet { std::vector<double> boosts; DevBuf<unsigned long long> J; DevBuf<double> plane; uint64_t last_use = 0; bool valid = false; hipEvent_t ready = nullptr; };
-    hipEvent_t m_ready = nullptr;  // behind the kernel that last wrote M (batches on other streams wait for it)
-    JSet j[3];  // (each carries a score plane of 8F bytes per posting)
+    // (three fields and more: the joint maximum of a boost vector is a pass over the packed words - no plane is written -, and the
+    // arrays of the most recent vectors stay resident; one or two fields need none: M itself / the direction supports H)
+    struct JSet { std::vector<double> boosts; DevBuf<unsigned long long> J; uint64_t last_use = 0; bool valid = false; hipEvent_t ready = nullptr; };
+    hipEvent_t m_ready = nullptr;  // behind the kernel that last wrote M / H / the plane (batches on other streams wait for it)
+    JSet j[3];
+    DevBuf<double> plane;          // tfn * idf per (posting, field): boost-free, one per (k1, b, averages)
+    DevBuf<unsigned long long> H;  // [n_layers][PREP_NDIR] (F == 2)
+    DevBuf<double2> dirs;          // the PREP_NDIR directions
     uint64_t epoch = 0;
     DevBuf<BoundUnit> units;
     uint32_t n_units = 0;
@@ -470,7 +476,8 @@ Engine::~Engine() {
   m.d_gthr.release(); m.d_rows.release(); m.d_removed_df.release();
   m.bounds.M.release(); m.bounds.units.release();
   if (m.bounds.m_ready) (void)hipEventDestroy(m.bounds.m_ready);
-  for (auto& js : m.bounds.j) { js.J.release(); js.plane.release(); if (js.ready) (void)hipEventDestroy(js.ready); }
+  for (auto& js : m.bounds.j) { js.J.release(); if (js.ready) (void)hipEventDestroy(js.ready); }
+  m.bounds.plane.release(); m.bounds.H.release(); m.bounds.dirs.release();
   if (m.lut_ready) (void)hipEventDestroy(m.lut_ready);
   m.cands.of_layer.release();
   for (auto& c : m.dctx) {
@@ -804,6 +811,7 @@ void Tuning::load() {
     score_alt = env_u32("PS_SCORE_ALT", score_alt);
     daat_sample_div = env_u32("PS_DAAT_SAMPLE_DIV", daat_sample_div);
     daat_sample_all = env_u32("PS_DAAT_SAMPLE_ALL", daat_sample_all);
+    daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
     dctx = std::max(2u, std::min((uint32_t)N_DCTX, env_u32("PS_DCTX", dctx)));
     daat_split_first = env_u32("PS_DAAT_SPLIT_FIRST", daat_split_first);
     daat_z_d0_div = env_u32("PS_DAAT_Z_D0_DIV", daat_z_d0_div);
@@ -936,7 +944,45 @@ void ensure_dev_trie(EngineImpl& m);  // (defined with the device planner below)
 // Per-list score bounds on the device (k_list_bounds) for the current (k1, b, avg) and boosts; see
 // EngineImpl::ListBounds.  Enqueued on `st` in front of the batch that needs them; nothing is recomputed
 // while the parameters stay what they were, and a boost vector seen recently finds its J array resident.
-struct BoundsRef { const double* M; const double* J; const double* plane; };
+struct BoundsRef { const double* M; const double* J; const double* plane; const double* H; uint32_t h_lo; double h_a, h_b; };
+
+// The PREP_NDIR directions of the two-field joint bound (ps_prep_kernels.hpp): angles 0 .. 90 degrees in equal steps.
+inline void bound_dir(int d, double& c, double& sn) {
+  if (d == 0) { c = 1.0; sn = 0.0; return; }
+  if (d == PREP_NDIR - 1) { c = 0.0; sn = 1.0; return; }
+  const double th = (3.14159265358979323846 / 2.0) * (double)d / (double)(PREP_NDIR - 1);
+  c = std::cos(th); sn = std::sin(th);
+}
+// boosts (two positive finite numbers) as a conic combination of the two directions around them: lo, a, b with
+// a * w_lo + b * w_(lo+1) >= boosts componentwise (verified below; inflated by what the solve may have rounded away), so that
+// a * H[lo] + b * H[lo+1] bounds boosts . v for every point v >= 0 of a list.
+inline void boost_cone(const double* boosts, uint32_t& lo, double& a, double& b) {
+  const double b0 = boosts[0], b1 = boosts[1];
+  const double th = std::atan2(b1, b0), step = (3.14159265358979323846 / 2.0) / (double)(PREP_NDIR - 1);
+  int d = (int)std::floor(th / step);
+  d = std::max(0, std::min(PREP_NDIR - 2, d));
+  for (int tries = 0; tries < 3; ++tries) {
+    double c0, s0, c1, s1;
+    bound_dir(d, c0, s0); bound_dir(d + 1, c1, s1);
+    const double det = c0 * s1 - s0 * c1;
+    double al = (b0 * s1 - b1 * c1) / det, be = (c0 * b1 - s0 * b0) / det;
+    if (al < 0.0 && d > 0 && tries < 2) { --d; continue; }                  // (rounding put the angle one sector off)
+    if (be < 0.0 && d < PREP_NDIR - 2 && tries < 2) { ++d; continue; }
+    al = std::max(al, 0.0); be = std::max(be, 0.0);
+    const double r0 = al * c0 + be * c1, r1 = al * s0 + be * s1;
+    double scale = 1.0;
+    if (!(r0 >= b0)) scale = std::max(scale, b0 / r0);
+    if (!(r1 >= b1)) scale = std::max(scale, b1 / r1);
+    if (!(scale >= 1.0) || !std::isfinite(scale)) break;
+    scale *= 1.0 + 1e-12;
+    lo = (uint32_t)d; a = al * scale; b = be * scale;
+    if (std::isfinite(a) && std::isfinite(b)) return;
+    break;
+  }
+  // (cannot happen for the boosts K1d admits - positive and finite; the per-field sum of maxima is always valid)
+  lo = 0; a = b0; b = b1 * 1e308;  // b * H[1] = +inf for any list with field-1 postings: min(ub_m, ub_j) keeps ub_m
+}
+
 BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const KParams& kp, hipStream_t st) {
   const Snapshot& s = *m.snap;
   EngineImpl::ListBounds& lb = m.bounds;
@@ -947,22 +993,34 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
   if (!m_ok)
     for (auto& js : lb.j) js.valid = false;
   ++lb.epoch;
+  const bool need_j = F >= 3;  // (one field: M is the joint maximum; two: the direction supports H give it for any boosts)
   EngineImpl::ListBounds::JSet* tgt = nullptr;
-  for (auto& js : lb.j)
-    if (js.valid && js.boosts == bv) tgt = &js;
-  if (m_ok && tgt) {
-    tgt->last_use = lb.epoch;
-    // (they may have been computed on another context's stream a moment ago)
+  if (need_j)
+    for (auto& js : lb.j)
+      if (js.valid && js.boosts == bv) tgt = &js;
+  BoundsRef ref{nullptr, nullptr, nullptr, nullptr, 0u, 0.0, 0.0};
+  if (F == 2) boost_cone(boosts, ref.h_lo, ref.h_a, ref.h_b);
+  auto fill = [&]() {
+    ref.M = reinterpret_cast<const double*>(lb.M.p);
+    ref.J = need_j ? reinterpret_cast<const double*>(tgt->J.p) : nullptr;
+    ref.plane = lb.plane.p;
+    ref.H = F == 2 ? reinterpret_cast<const double*>(lb.H.p) : nullptr;
+    return ref;
+  };
+  if (m_ok && (!need_j || tgt)) {
+    if (tgt) tgt->last_use = lb.epoch;
+    // (they may have been computed on another stream a moment ago)
     PS_HIP(hipStreamWaitEvent(st, lb.m_ready, 0));
-    PS_HIP(hipStreamWaitEvent(st, tgt->ready, 0));
-    return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p), tgt->plane.p};
+    if (tgt) PS_HIP(hipStreamWaitEvent(st, tgt->ready, 0));
+    return fill();
   }
-  // M is rewritten in place and a J array may be recycled: their only readers are the preparation kernels, which
-  // run on this same stream, in order.  The score PLANE of a recycled slot is read by k_daat / k_daat_small on the
-  // scoring stream, by batches that may still be in flight (three contexts): nothing is overwritten before
-  // every batch enqueued so far has left its scoring kernel.
-  for (auto& c : m.dctx)
-    if (c.busy && c.scored) PS_HIP(hipStreamWaitEvent(st, c.scored, 0));
+  // M, H and a recycled J array are only read by the preparation kernels, which run on this same stream, in order.  The
+  // score PLANE is read by k_daat / k_daat_small on the scoring streams, by batches that may still be in flight: when the
+  // scorer parameters, the averages or the lists changed (never for a new fields_boost) nothing is overwritten before every
+  // batch enqueued so far has left its scoring kernel.
+  if (!m_ok)
+    for (auto& c : m.dctx)
+      if (c.busy && c.scored) PS_HIP(hipStreamWaitEvent(st, c.scored, 0));
   const double t0 = now_ms();
   if (lb.n_layers != nl || lb.n_units == 0) {  // the work list: one wave per list, long lists in 16 Ki-posting segments
     std::vector<BoundUnit> units;
@@ -976,27 +1034,41 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
     if (!units.empty()) PS_HIP(hipMemcpy(lb.units.p, units.data(), units.size() * sizeof(BoundUnit), hipMemcpyHostToDevice));
     lb.n_units = (uint32_t)units.size();
   }
-  if (!tgt) {  // an invalid slot, else the least recently used one
+  if (need_j && !tgt) {  // an invalid slot, else the least recently used one
     for (auto& js : lb.j)
       if (!tgt || (!js.valid && tgt->valid) || (js.valid == tgt->valid && js.last_use < tgt->last_use)) tgt = &js;
+    if (!tgt->ready) PS_HIP(hipEventCreateWithFlags(&tgt->ready, hipEventDisableTiming));
+  }
+  if (!lb.dirs.p) {
+    std::vector<double2> dv(PREP_NDIR);
+    for (int d = 0; d < PREP_NDIR; ++d) bound_dir(d, dv[d].x, dv[d].y);
+    lb.dirs.ensure(PREP_NDIR);
+    PS_HIP(hipMemcpy(lb.dirs.p, dv.data(), sizeof(double2) * PREP_NDIR, hipMemcpyHostToDevice));
   }
   lb.M.ensure(nl * F + 1);
-  tgt->J.ensure(nl + 1);
-  tgt->plane.ensure((size_t)s.P * F + 2);
-  if (!m_ok) PS_HIP(hipMemsetAsync(lb.M.p, 0, (nl * F + 1) * 8, st));
-  PS_HIP(hipMemsetAsync(tgt->J.p, 0, (nl + 1) * 8, st));
+  if (F == 2) lb.H.ensure(nl * PREP_NDIR + 1);
+  if (tgt) tgt->J.ensure(nl + 1);
+  lb.plane.ensure((size_t)s.P * F + 2);
+  if (!m_ok) {
+    PS_HIP(hipMemsetAsync(lb.M.p, 0, (nl * F + 1) * 8, st));
+    if (F == 2) PS_HIP(hipMemsetAsync(lb.H.p, 0, (nl * PREP_NDIR + 1) * 8, st));
+  }
+  if (tgt) PS_HIP(hipMemsetAsync(tgt->J.p, 0, (nl + 1) * 8, st));
   if (lb.n_units) {
     hipLaunchKernelGGL(k_list_bounds, dim3((lb.n_units + 3) / 4), dim3(256), 0, st, kp, lb.units.p, lb.n_units, m.d_layer_a.p, lb.M.p,
-                       tgt->J.p, m_ok ? 0 : 1, tgt->plane.p, m.d_layer_idf.p);
+                       tgt ? tgt->J.p : nullptr, (!m_ok && F == 2) ? lb.H.p : nullptr, lb.dirs.p, m_ok ? 0 : 1,
+                       m_ok ? nullptr : lb.plane.p, m.d_layer_idf.p);
     PS_HIP(hipGetLastError());
   }
   if (!m_ok) PS_HIP(hipEventRecord(lb.m_ready, st)); else PS_HIP(hipStreamWaitEvent(st, lb.m_ready, 0));
-  PS_HIP(hipEventRecord(tgt->ready, st));
+  if (tgt) {
+    PS_HIP(hipEventRecord(tgt->ready, st));
+    tgt->valid = true; tgt->boosts = bv; tgt->last_use = lb.epoch;
+  }
   lb.m_valid = true; lb.k1 = sc.bm25_k1; lb.b = sc.bm25_b; lb.avg = avg; lb.n_layers = nl;
-  tgt->valid = true; tgt->boosts = bv; tgt->last_use = lb.epoch;
   lb.last_ms = now_ms() - t0;
   ++lb.recomputed;
-  return BoundsRef{reinterpret_cast<const double*>(lb.M.p), reinterpret_cast<const double*>(tgt->J.p), tgt->plane.p};
+  return fill();
 }
 
 // Bloom filters of the lists that have no membership bitmap (fewer than N / 128 postings): 16 bits per posting,
@@ -1070,7 +1142,7 @@ void ensure_row_candidates(EngineImpl& m, hipStream_t st) {
 // candidate slots -> items and dense-row flags.  `items_bound` >= the batch's item count (exact when the
 // host knows the list lengths).  Fills the K1d members of `kp`.
 void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, KParams& kp, ps_plan_entry* d_plan,
-                 const uint32_t* d_qbeg, size_t B, size_t ne, bool multi, size_t items_bound) {
+                 const uint32_t* d_qbeg, size_t B, size_t ne, bool multi, size_t items_bound, bool split_kinds) {
   const Snapshot& s = *m.snap;
   hipStream_t st = m.prep_stream;
   const uint64_t rc0 = m.bounds.recomputed;
@@ -1102,6 +1174,8 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   pp.B = (uint32_t)B; pp.ne = (uint32_t)ne; pp.F = s.F; pp.multi = multi ? 1u : 0u;
   pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div; pp.split_first = split_first_of(m.tune);
   pp.table = m.d_table;
+  pp.split_kinds = split_kinds ? 1u : 0u;
+  pp.sample_small = m.tune.daat_sample_all;
   if (m.tune.daat_sample_div > 1 && (multi || m.tune.daat_sample_all) && s.n_ids >= 4096) {  // the sample boundary D0 ~ N / div, on a tile boundary that every table of this snapshot resolves as finely as it can
     const uint32_t tiles = std::max<uint32_t>(1u, (uint32_t)((s.n_ids / m.tune.daat_sample_div) / s.T));
     // lists of >= one chunk have one table slot per tile (shift 0); a multiple of 8 tiles also serves the tables up to 8 x coarser
@@ -1110,7 +1184,7 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
     pp.sample_tile = tiles >= 16 ? (tiles & ~7u) : al;
   }
   for (uint32_t x = 0; x < s.F; ++x) pp.boost[x] = boosts[x];
-  pp.bound_m = br.M; pp.bound_j = br.J;
+  pp.bound_m = br.M; pp.bound_j = br.J; pp.bound_h = br.H; pp.h_lo = br.h_lo; pp.h_a = br.h_a; pp.h_b = br.h_b;
   kp.splane = br.plane;
   pp.dentry = c.dentry.p; pp.rorder = c.rorder.p; pp.dgroup = multi ? c.dgroup.p : nullptr; pp.gord = c.gord.p;
   pp.gen = c.gen.p; pp.qslot = c.qslot.p; pp.qslot_n = c.qslot_n.p;
@@ -1198,8 +1272,8 @@ void wait_daat_contexts(EngineImpl& m, hipStream_t st) {
 }
 
 // Items a batch has under the chunking rule of k_prep_query (host-planned batches: exact).
-size_t count_daat_items(const EngineImpl& m, const Plan& plan, uint32_t* max_slots) {
-  size_t n = 0;
+size_t count_daat_items(const EngineImpl& m, const Plan& plan, uint32_t* max_slots, size_t* n_big = nullptr) {
+  size_t n = 0, nb = 0;
   uint32_t mx = 0;
   const size_t B = plan.qbeg.size() - 1;
   const uint32_t sf = split_first_of(m.tune);
@@ -1209,16 +1283,20 @@ size_t count_daat_items(const EngineImpl& m, const Plan& plan, uint32_t* max_slo
   };
   for (size_t q = 0; q < B; ++q) {
     uint32_t sl = 0, mn = 0xFFFFFFFFu;
+    bool big = plan.qbeg[q + 1] - plan.qbeg[q] > (uint32_t)DAAT_SMALL_MAX;  // PLAN_BIG's rule (k_plan, k_prep_query)
     for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
       const uint32_t len = plan.entries[i].len;
       sl += chunks(len, m.tune.daat_split_div);
       mn = std::min(mn, len);
+      if (i > plan.qbeg[q] && plan.entries[i].qterm == plan.entries[i - 1].qterm) big = true;
     }
     if (mn != 0xFFFFFFFFu && mn && sf != m.tune.daat_split_div) sl += chunks(mn, sf) - chunks(mn, m.tune.daat_split_div);  // (the query's shortest list: prep_fine_entry)
     n += sl;
+    if (big) nb += sl;
     mx = std::max(mx, sl);
   }
   if (max_slots) *max_slots = mx;
+  if (n_big) *n_big = nb;
   return n;
 }
 
@@ -1961,15 +2039,17 @@ struct ZBatch {
   const double* d_ubnum;  // [ne]
   const double* d_zub;    // [ne][F]
   uint32_t dl[Z_LEVELS];  // doc ids D_0 < D_1 < ... of the tie-threshold levels, Z_NO_LEVEL for a level that does not exist
+  int zn = DAAT_SMALL_MAX;  // most records of a query of the batch, rounded up to an instantiation (DAAT_SMALL_MAX or Z_MAX_LISTS)
 };
+inline int z_width(uint32_t max_entries) { return max_entries <= (uint32_t)DAAT_SMALL_MAX ? DAAT_SMALL_MAX : Z_MAX_LISTS; }
 void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KParams& kp, ps_plan_entry* d_plan, const uint32_t* d_qbeg,
                    size_t B, size_t ne, size_t items_bound);
-void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st);
+void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st, int zn);
 
 void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, ps_plan_entry* d_plan,
                   const uint32_t* d_qbeg, const uint32_t* d_qtl, size_t B, size_t ne, uint32_t max_qterms, uint32_t max_entries, bool multi,
                   size_t n_items, uint32_t max_slots, size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller,
-                  const ZBatch* zb = nullptr, const uint32_t* d_out_row = nullptr) {
+                  const ZBatch* zb = nullptr, const uint32_t* d_out_row = nullptr, size_t n_items_big = 0) {
   const Snapshot& s = *m.snap;
   hipStream_t P = m.prep_stream, S = m.score_stream;
   if (m.tune.score_alt == 4) {  // three-way rotation: normal, low, high
@@ -2001,8 +2081,11 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     }
     c.ctl_clean = false;
     kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0;
+    // a BM25 batch with both kinds of queries - those k_daat_small takes (<= 4 lists, one per query term) and others - is scored
+    // by both kernels, each over its part of one item array (the preparation puts the second kind's items behind the first's)
+    const bool split_kinds = !zb && m.tune.daat_split && m.tune.daat_small && !m.tune.daat_persistent && n_items_big > 0 && n_items_big < n_items;
     if (zb) launch_prep_z(m, c, *zb, kp, d_plan, d_qbeg, B, ne, n_items);
-    else launch_prep(m, c, sc, boosts, kp, d_plan, d_qbeg, B, ne, multi, n_items);
+    else launch_prep(m, c, sc, boosts, kp, d_plan, d_qbeg, B, ne, multi, n_items, split_kinds);
     kp.K = (uint32_t)top_k;
     const size_t n_cand = n_items * top_k;
     c.cand_score.ensure(n_cand + 1);
@@ -2043,8 +2126,20 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     kp.item_trace = trace_buf.p;
 #endif
     if (timers) PS_HIP(hipEventRecord(kt->m, S));
-    if (zb) launch_daat_z(m, kp, S);
-    else launch_daat(m, kp, multi, max_entries <= (uint32_t)DAAT_SMALL_MAX, m.n_cu, S);
+    if (zb) launch_daat_z(m, kp, S, zb->zn);
+    else if (split_kinds) {
+      uint32_t* split_at = &c.ctl->bucket_start[PREP_SET_BUCKETS];  // first item of the second kind, as k_prep_query's last wave counted it
+      KParams ks = kp;
+      ks.n_ditems = (uint32_t)(n_items - n_items_big);
+      ks.n_ditems_dev = split_at;
+      launch_daat(m, ks, false, true, m.n_cu, S);
+      const std::string small_name = m.score_kernel_name;
+      KParams kb = kp;
+      kb.n_ditems = (uint32_t)n_items_big;
+      kb.item_split_dev = split_at;
+      launch_daat(m, kb, multi, false, m.n_cu, S);
+      m.score_kernel_name = small_name + " + " + m.score_kernel_name;
+    } else launch_daat(m, kp, multi, max_entries <= (uint32_t)DAAT_SMALL_MAX, m.n_cu, S);
 #ifdef PS_ITEM_TRACE
     {  // profiling builds: the items' start / end times of this launch -> $PS_ITEM_TRACE_FILE (last batch wins)
       PS_HIP(hipStreamSynchronize(S));
@@ -2088,7 +2183,7 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
 // A host-planned K1d batch: the plan image (entries | qbeg | qterms_len) goes through a pinned slot into
 // the context's device buffer (k_upload on the context's stream), everything else as above.
 void enqueue_daat_host(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const Plan& plan, size_t n_items, uint32_t max_slots,
-                       size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller) {
+                       size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller, size_t n_items_big) {
   EngineImpl::DaatCtx& c = acquire_ctx(m);
   hipStream_t st = m.prep_stream;
   const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size();
@@ -2108,7 +2203,7 @@ void enqueue_daat_host(EngineImpl& m, const ps_scorer_desc& sc, const double* bo
   sg.pending = true;
   enqueue_daat(m, c, sc, boosts, reinterpret_cast<ps_plan_entry*>(c.stage.p), reinterpret_cast<const uint32_t*>(c.stage.p + off_q),
                reinterpret_cast<const uint32_t*>(c.stage.p + off_l), B, ne, plan.max_qterms, plan.max_entries, plan.multi_expansion, n_items, max_slots, top_k,
-               d_keys, d_scores, d_counts, caller);
+               d_keys, d_scores, d_counts, caller, nullptr, nullptr, n_items_big);
 }
 
 // ---- K1dz: zero_to_one top-k batches through the K1d pipeline (ps_z21_daat.hpp) ------------------------------------
@@ -2134,7 +2229,8 @@ void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KPar
   pp.items = c.ditems.p; pp.items_cap = (uint32_t)items_bound;
   pp.ctl = c.ctl;
   if (B) {
-    hipLaunchKernelGGL(k_zprep_query, dim3((uint32_t)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, pp);
+    if (zb.zn <= DAAT_SMALL_MAX) hipLaunchKernelGGL(k_zprep_query<DAAT_SMALL_MAX>, dim3((uint32_t)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, pp);
+    else hipLaunchKernelGGL(k_zprep_query<Z_MAX_LISTS>, dim3((uint32_t)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, pp);
     if (ne) hipLaunchKernelGGL(k_zprep_items, dim3((uint32_t)((ne + 2 * WAVE - 1) / (2 * WAVE))), dim3(2 * WAVE), 0, st, pp);
     PS_HIP(hipGetLastError());
   }
@@ -2148,14 +2244,18 @@ void launch_prep_z(EngineImpl& m, EngineImpl::DaatCtx& c, const ZBatch& zb, KPar
   for (int l = 0; l < Z_LEVELS; ++l) kp.z_dl[l] = zb.dl[l];
 }
 
-void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st) {
+void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st, int zn) {
   const uint32_t n_wg = (kp.n_ditems + DAAT_WGW - 1) / DAAT_WGW;
   char nm[64];
-  snprintf(nm, sizeof(nm), "ps::k_daat_z<%d, %s>", (int)std::min(kp.F, 4u), m.tune.work_counters ? "true" : "false");
+  const bool wide = zn > DAAT_SMALL_MAX;
+  snprintf(nm, sizeof(nm), wide ? "ps::k_daat_z<%d, %s, 8>" : "ps::k_daat_z<%d, %s>", (int)std::min(kp.F, 4u), m.tune.work_counters ? "true" : "false");
   m.score_kernel_name = nm;
 #define PS_Z(FV)                                                                                                  \
   do {                                                                                                            \
-    if (m.tune.work_counters) hipLaunchKernelGGL((k_daat_z<FV, true>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); \
+    if (wide) {                                                                                                   \
+      if (m.tune.work_counters) hipLaunchKernelGGL((k_daat_z<FV, true, Z_MAX_LISTS>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); \
+      else hipLaunchKernelGGL((k_daat_z<FV, false, Z_MAX_LISTS>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp);  \
+    } else if (m.tune.work_counters) hipLaunchKernelGGL((k_daat_z<FV, true>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp); \
     else hipLaunchKernelGGL((k_daat_z<FV, false>), dim3(n_wg), dim3(WAVE * DAAT_WGW), 0, st, kp);                  \
   } while (0)
   switch (kp.F) {
@@ -2224,12 +2324,12 @@ double z_numerator_bound(EngineImpl& m, double score, uint32_t need, uint32_t ma
 
 // A zero_to_one top-k batch for K1dz, or false when the batch does not qualify (it then takes k_score / k_z21).
 // Qualifies: every query "simple" in the sense of classify_zero_to_one - one version layer per entry, no two
-// records with the same (query term, node) - with at most DAAT_SMALL_MAX entries.  The image: entries per query in
+// records with the same (query term, node) - with at most Z_MAX_LISTS entries.  The image: entries per query in
 // the record-sort order (score desc, stable; zero_to_one.rs:98) | qbeg | query_terms_len | ubnum | zub.
-// Whether K1dz can take query q: at most DAAT_SMALL_MAX records, one version layer each, and "simple" (the rule of
+// Whether K1dz can take query q: at most Z_MAX_LISTS records, one version layer each, and "simple" (the rule of
 // classify_zero_to_one).
 bool z_query_fits_k1dz(const Plan& plan, size_t q) {
-  if (plan.qbeg[q + 1] - plan.qbeg[q] > (uint32_t)DAAT_SMALL_MAX) return false;
+  if (plan.qbeg[q + 1] - plan.qbeg[q] > (uint32_t)Z_MAX_LISTS) return false;
   bool same_q = false, same_n = false;
   for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
     if (plan.entries[i].shift >> 8) return false;
@@ -2248,7 +2348,7 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   const Snapshot& s = *m.snap;
   const size_t B = plan.qbeg.size() - 1, ne = plan.entries.size(), F = s.F;
   if (!(m.tune.daat && m.tune.daat_z && sc.kind == PS_SCORER_ZERO_TO_ONE && B >= m.tune.daat_min_batch && ne != 0 &&
-        plan.max_entries <= (uint32_t)DAAT_SMALL_MAX && F <= 4 && s.n_ids > 0))
+        plan.max_entries <= (uint32_t)Z_MAX_LISTS && F <= 4 && s.n_ids > 0))
     return false;
   for (size_t q = 0; q < B; ++q)
     if (!z_query_fits_k1dz(plan, q)) return false;
@@ -2273,7 +2373,7 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   uint64_t last_l = 0;
   for (size_t q = 0; q < B; ++q) {
     const uint32_t b = plan.qbeg[q], e = plan.qbeg[q + 1], qtl = plan.qterms_len[q];
-    uint32_t zo[DAAT_SMALL_MAX];
+    uint32_t zo[Z_MAX_LISTS];
     for (uint32_t i = b; i < e; ++i) zo[i - b] = i;
     std::stable_sort(zo, zo + (e - b), [&](uint32_t a, uint32_t d) { return plan.entries[d].boost < plan.entries[a].boost; });
     for (uint32_t i = b; i < e; ++i) {
@@ -2317,6 +2417,7 @@ bool enqueue_daat_z_host(EngineImpl& m, const ps_scorer_desc& sc, const double* 
   PS_HIP(hipEventRecord(sg.done, st));
   sg.pending = true;
   ZBatch zb;
+  zb.zn = z_width(plan.max_entries);
   zb.d_ubnum = reinterpret_cast<const double*>(c.stage.p + off_u);
   zb.d_zub = reinterpret_cast<const double*>(c.stage.p + off_z);
   z_levels(m, zb);
@@ -2371,9 +2472,10 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   m.last_bounds_recomputed = false;
   if (rows == nullptr && daat_eligible(m, sc, boosts, B, plan.entries.size(), plan.max_entries, plan.multi_expansion)) {
     uint32_t max_slots = 0;
-    const size_t n_items = count_daat_items(m, plan, &max_slots);
+    size_t n_big = 0;
+    const size_t n_items = count_daat_items(m, plan, &max_slots, &n_big);
     if (n_items && n_items < 0xFFFFFFF0ull) {
-      enqueue_daat_host(m, sc, boosts, plan, n_items, max_slots, top_k, d_keys, d_scores, d_counts, st);
+      enqueue_daat_host(m, sc, boosts, plan, n_items, max_slots, top_k, d_keys, d_scores, d_counts, st, n_big);
       TT("k1d batch");
       return;
     }
@@ -2800,7 +2902,7 @@ bool Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   EngineImpl::DaatCtx& c = announced ? *announced : acquire_ctx(m);
   if (!announced) device_plan_begin(m, c, text, offsets, B);
   const PlanTotals tot = device_plan_totals(m, c);
-  if (z && !(tot.n_entries && tot.max_entries <= (uint32_t)DAAT_SMALL_MAX && !(tot.multi & PLAN_Z_NOT_SIMPLE) && tot.n_items &&
+  if (z && !(tot.n_entries && tot.max_entries <= (uint32_t)Z_MAX_LISTS && !(tot.multi & PLAN_Z_NOT_SIMPLE) && tot.n_items &&
              tot.n_items < 0x3FFFFFF0ull)) {
     PS_HIP(hipEventRecord(c.done, m.plan_stream));  // (the context goes back into the rotation behind its count pass)
     c.busy = true;
@@ -2815,10 +2917,15 @@ bool Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
     const size_t ne = tot.n_entries;
     ps_.z_ubnum.ensure(ne + 1);
     ps_.z_zub.ensure(ne * s.F + 1);
-    hipLaunchKernelGGL(k_zplan_arrange, dim3((uint32_t)((B + 63) / 64)), dim3(64), 0, m.prep_stream, ps_.entries.p, ps_.qbeg.p, ps_.qtl.p,
-                       (uint32_t)B, s.F, m.d_z_maxtf.p, m.d_z_minfl.p, ps_.z_ubnum.p, ps_.z_zub.p);
+    if (z_width(tot.max_entries) <= DAAT_SMALL_MAX)
+      hipLaunchKernelGGL(k_zplan_arrange<DAAT_SMALL_MAX>, dim3((uint32_t)((B + 63) / 64)), dim3(64), 0, m.prep_stream, ps_.entries.p, ps_.qbeg.p,
+                         ps_.qtl.p, (uint32_t)B, s.F, m.d_z_maxtf.p, m.d_z_minfl.p, ps_.z_ubnum.p, ps_.z_zub.p);
+    else
+      hipLaunchKernelGGL(k_zplan_arrange<Z_MAX_LISTS>, dim3((uint32_t)((B + 63) / 64)), dim3(64), 0, m.prep_stream, ps_.entries.p, ps_.qbeg.p,
+                         ps_.qtl.p, (uint32_t)B, s.F, m.d_z_maxtf.p, m.d_z_minfl.p, ps_.z_ubnum.p, ps_.z_zub.p);
     PS_HIP(hipGetLastError());
     ZBatch zb;
+    zb.zn = z_width(tot.max_entries);
     zb.d_ubnum = ps_.z_ubnum.p;
     zb.d_zub = ps_.z_zub.p;
     z_levels(m, zb);
@@ -2828,7 +2935,7 @@ bool Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   const bool multi = (tot.multi & PLAN_MULTI) != 0;
   if (daat_eligible(m, sc, boosts, B, tot.n_entries, tot.max_entries, multi) && tot.n_items && tot.n_items < 0xFFFFFFF0ull) {
     enqueue_daat(m, c, sc, boosts, ps_.entries.p, ps_.qbeg.p, ps_.qtl.p, B, tot.n_entries, tot.max_qterms, tot.max_entries, multi,
-                 (size_t)tot.n_items, 0u, top_k, d_keys, d_scores, d_counts, st);
+                 (size_t)tot.n_items, 0u, top_k, d_keys, d_scores, d_counts, st, nullptr, nullptr, (size_t)tot.n_items_big);
   } else {
     // the batches K1d does not take: K1 k_score / K3 k_merge from the device-built plan, in the engine's
     // single set of per-batch buffers, once nothing else is in flight

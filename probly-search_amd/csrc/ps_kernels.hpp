@@ -169,6 +169,8 @@ struct KParams {
   const uint32_t* alive;        // one bit per doc id, cleared by a delta removal; null = every document alive
   uint32_t n_ditems, t_log2;
   uint32_t item_base;           // first item of this launch (the batch may be split into two launches)
+  const uint32_t* item_split_dev; // k_daat of a batch split between k_daat_small and k_daat (queries of <= 4 lists, one per query term /
+                                // the others): the first item of the second part as the preparation counted it (null: item_base)
   uint32_t* cand_cnt;           // [n_ditems] candidates an item left in its slot
   uint32_t* work_counter;    // next (query, run) item for the persistent waves of k_score
   unsigned long long* wstats;  // [WS_SLOTS][WS_WORDS] work counters (always on; see WorkStats)
@@ -1402,11 +1404,12 @@ __global__ __launch_bounds__(256) void k_build_bloom(const uint32_t* doc, const 
 }
 
 // ---- score planes --------------------------------------------------------------------------------
-// ((tfn * idf) * boost_x) of a (posting, field) depends on the list (idf), the scorer parameters and the
-// boosts, not on the query: k_list_bounds evaluates it ONCE per posting - the same f64 expression, left to
-// right (bm25.rs:78-86) - into a plane next to the postings, and K1d's per-visit work shrinks to
-// `sum_x plane_x * expansion_boost` (the last multiplication and the additions of the same expression, in
-// the same order: bit-identical).  item traces showed k_daat bound by VALU issue - ~800 wave instructions
+// (tfn * idf) of a (posting, field) depends on the list (idf) and the scorer parameters, not on the query and - since
+// round 5 - not on fields_boost either (src/query.rs:26: a per-call argument): k_list_bounds evaluates it ONCE per
+// posting - the first multiplication of the f64 expression, left to right (bm25.rs:78-86) - into a plane next to the
+// postings, and K1d's per-visit work shrinks to `sum_x (plane_x * boost_x) * expansion_boost` (the remaining
+// multiplications and the additions of the same expression, in the same order: bit-identical).  A new boost vector
+// therefore rewrites nothing and waits for nobody.  item traces showed k_daat bound by VALU issue - ~800 wave instructions
 // per 256 postings, most of them unpacking words and gathering the saturated-tf table - not by latency.
 template <int F_>
 __device__ __forceinline__ void plane_load(const KParams& p, const uint64_t pi, double (&t)[F_ ? F_ : MAX_F]) {
@@ -1431,7 +1434,7 @@ __device__ __forceinline__ void scores_from_plane(const KParams& p, const double
     double acc = 0.0;
 #pragma unroll
     for (int x = 0; x < FA; ++x)
-      if ((uint32_t)x < F) acc += t[u][x] * eb;  // ((tfn*idf)*boost)*expansion_boost; a field with tf == 0 adds +0.0
+      if ((uint32_t)x < F) acc += (t[u][x] * p.boost[x]) * eb;  // ((tfn*idf)*boost)*expansion_boost: the plane holds tfn*idf; a field with tf == 0 adds +0.0
     s[u] = on[u] ? acc : 0.0;
   }
 }
@@ -1615,14 +1618,16 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
   // persistent and pull items from the device-scope counter.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // (the grid is sized by the host's upper bound of the item count; the device-built count is exact)
-  const uint32_t n_ditems = p.n_ditems_dev ? min(p.n_ditems, *p.n_ditems_dev) : p.n_ditems;
+  const uint32_t item_base = p.item_split_dev ? *p.item_split_dev : p.item_base;
+  const uint32_t n_all = p.n_ditems_dev ? *p.n_ditems_dev : 0xFFFFFFFFu;
+  const uint32_t n_ditems = min(p.n_ditems, n_all > item_base ? n_all - item_base : 0u);
   const bool by_index = p.n_ditems <= gridDim.x * (uint32_t)DAAT_WGW;
   if (by_index) {
     // most waves of a launch only hold a chunk of a list that is already non-essential: they leave at once (every wave
     // for itself - the waves of a workgroup share nothing -, so none waits for its neighbour's two loads)
     const uint32_t id = blockIdx.x * (uint32_t)DAAT_WGW + (uint32_t)wave;
     if (id >= n_ditems) return;
-    const DItem it0 = p.ditems[p.item_base + id];
+    const DItem it0 = p.ditems[item_base + id];
     const double theta0 = __longlong_as_double((long long)__hip_atomic_load(&p.gthr[it0.q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (__builtin_amdgcn_readfirstlane((int)(it0.skip_thr < theta0))) {
       if (lane == 0) p.cand_cnt[it0.slot] = 0u;
@@ -1641,7 +1646,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
       id = __builtin_amdgcn_readfirstlane(id);
     }
     if (id >= n_ditems) break;
-    const DItem it = p.ditems[p.item_base + id];
+    const DItem it = p.ditems[item_base + id];
     const uint32_t e_own = __builtin_amdgcn_readfirstlane(it.entry);
     const ps_plan_entry& own = p.plan[e_own];
     const DEntry de = p.dentry[e_own];
@@ -2433,7 +2438,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
             double acc = 0.0;
 #pragma unroll
             for (int x = 0; x < FA; ++x)
-              if ((uint32_t)x < (F_ ? (uint32_t)F_ : p.F)) acc += t[x] * o_eb[k];
+              if ((uint32_t)x < (F_ ? (uint32_t)F_ : p.F)) acc += (t[x] * p.boost[x]) * o_eb[k];
             sk = found ? acc : 0.0;
           }
         }
@@ -2735,12 +2740,16 @@ struct PlanTotals {  // written by k_plan_scan
   uint32_t n_entries, max_entries, max_qterms, multi;
   unsigned long long postings;
   unsigned long long n_items;  // K1d work items of the batch under the chunking rule (chunk_min, split_div)
+  unsigned long long n_items_big;  // ... of them, the items of the queries k_daat_small does not take (PLAN_BIG)
 };
 
 // q_multi / PlanTotals::multi bits.  PLAN_Z_NOT_SIMPLE: the query is not "simple" in classify_zero_to_one's sense (a term with
 // several version layers, or several expansions of a query term AND a term reached by two query terms) - decided
 // conservatively (two query terms whose expansion ranges intersect count as sharing a term even if the shared terms are dead).
-constexpr uint32_t PLAN_MULTI = 1u, PLAN_Z_NOT_SIMPLE = 2u;
+// PLAN_BIG: the query has more than DAAT_SMALL_MAX lists or several lists under one query term - its items go to k_daat, the
+// others' to k_daat_small (a BM25 batch that holds both kinds is split between the two kernels: k_prep_query applies the same rule).
+constexpr uint32_t PLAN_MULTI = 1u, PLAN_Z_NOT_SIMPLE = 2u, PLAN_BIG = 4u;
+constexpr uint32_t PLAN_SMALL_MAX = 4u;  // (== DAAT_SMALL_MAX, defined with k_daat_small)
 
 __device__ __forceinline__ uint32_t utf8_next(const char* s, uint32_t& i, const uint32_t end) {
   const unsigned char c = (unsigned char)s[i++];
@@ -2884,6 +2893,7 @@ __device__ __noinline__ void plan_query_seq(const DevTrie& t, const char* s, con
     tb = i + 1;
   }
   if (!FILL) {
+    if (n_ent > PLAN_SMALL_MAX || (multi & PLAN_MULTI)) multi |= PLAN_BIG;
     q_cnt[q] = n_ent;
     q_terms_len[q] = n_tokens;
     q_nterms[q] = qord;
@@ -2978,6 +2988,7 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
       n_ent += __shfl_xor(n_ent, o); multi |= __shfl_xor(multi, o); it += __shfl_xor(it, o); po += __shfl_xor(po, o);
       minlen = min(minlen, (uint32_t)__shfl_xor((int)minlen, o));
     }
+    if (n_ent > PLAN_SMALL_MAX || (multi & PLAN_MULTI)) multi |= PLAN_BIG;
     if (lane == 0) {
       q_cnt[q] = n_ent;
       q_terms_len[q] = n_tokens;
@@ -3010,20 +3021,23 @@ __global__ __launch_bounds__(WAVE) void k_plan_scan(const uint32_t* q_cnt, const
   const uint32_t lane = threadIdx.x % WAVE, per = (B + WAVE - 1) / WAVE;
   const uint32_t b = min(B, lane * per), e = min(B, b + per);
   uint32_t sum = 0, me = 0, mt = 0, mm = 0;
-  unsigned long long ps = 0, it = 0;
-  for (uint32_t i = b; i < e; ++i) { sum += q_cnt[i]; me = max(me, q_cnt[i]); mt = max(mt, q_nterms[i]); mm |= q_multi[i]; ps += q_postings[i]; it += q_items[i]; }
+  unsigned long long ps = 0, it = 0, itb = 0;
+  for (uint32_t i = b; i < e; ++i) {
+    sum += q_cnt[i]; me = max(me, q_cnt[i]); mt = max(mt, q_nterms[i]); mm |= q_multi[i]; ps += q_postings[i]; it += q_items[i];
+    if (q_multi[i] & PLAN_BIG) itb += q_items[i];
+  }
   uint32_t inc = sum;
   for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
   for (int o = 32; o > 0; o >>= 1) {
     me = max(me, (uint32_t)__shfl_xor((int)me, o)); mt = max(mt, (uint32_t)__shfl_xor((int)mt, o)); mm |= (uint32_t)__shfl_xor((int)mm, o);
-    ps += __shfl_xor(ps, o); it += __shfl_xor(it, o);
+    ps += __shfl_xor(ps, o); it += __shfl_xor(it, o); itb += __shfl_xor(itb, o);
   }
   uint32_t run = inc - sum;  // exclusive prefix of this lane's first query
   for (uint32_t i = b; i < e; ++i) { qbeg[i] = run; run += q_cnt[i]; }
   if (lane == 0) {
     qbeg[B] = total;
-    tot->max_entries = me; tot->max_qterms = mt; tot->multi = mm; tot->postings = ps; tot->n_items = it;
+    tot->max_entries = me; tot->max_qterms = mt; tot->multi = mm; tot->postings = ps; tot->n_items = it; tot->n_items_big = itb;
     __threadfence_system();
     tot->n_entries = total;
   }

@@ -25,7 +25,10 @@ namespace ps {
 constexpr uint32_t PREP_CLASSES = 64;                 // length classes of the rank-0 and of the rank-1 lists (log2 with one fractional bit)
 constexpr uint32_t PREP_RANKS = 8;                    // ranks 2..7 get a bucket each, everything above shares the last
 constexpr uint32_t PREP_SAMPLE_BUCKETS = 4;           // K1d's sample phase: ranks 0, 1, 2, 3+ (in front of everything else)
-constexpr uint32_t PREP_BUCKETS = 2 * PREP_CLASSES + PREP_RANKS + 8 + PREP_SAMPLE_BUCKETS;  // (K1d: sample + 2 * PREP_CLASSES + PREP_RANKS; K1dz 4 per phase + the same)
+constexpr uint32_t PREP_SET_BUCKETS = PREP_SAMPLE_BUCKETS + 2 * PREP_CLASSES + PREP_RANKS;  // one set of K1d item buckets
+// K1d: two sets - the items of the queries k_daat_small takes, then those of the others (a batch that holds both kinds is scored by
+// two launches over the two parts of one item array; the boundary is bucket_start[PREP_SET_BUCKETS]); K1dz: 4 per phase + one set
+constexpr uint32_t PREP_BUCKETS = 2 * PREP_SET_BUCKETS;
 constexpr uint32_t PREP_MAX_ROWS = 64;                // dense-row candidates per snapshot
 constexpr uint32_t NO_CAND = 0xFFu;
 
@@ -59,11 +62,16 @@ struct PrepParams {
                              // the launch's first items, whatever their list's rank (a sample of the document space that publishes
                              // thresholds before the long lists start; K1dz's phase order, ps_z21_daat.hpp)
   const uint32_t* table;     // tile-offset tables (the sample phase finds a list's first posting at or above D0 there)
+  uint32_t sample_small;     // the sample phase also for the queries k_daat_small takes in a split batch (PS_DAAT_SAMPLE_ALL)
+  uint32_t split_kinds;      // the batch is split between k_daat_small and k_daat: the items of the PLAN_BIG queries take the second bucket set
   uint32_t split_first;      // most chunks of a query's shortest list (the first entry of that length in plan order)
   double boost[MAX_F];
   // per-list bounds (k_list_bounds)
   const double* bound_m;     // [n_layers][F]
-  const double* bound_j;     // [n_layers]
+  const double* bound_j;     // [n_layers] joint maximum under THESE boosts (F >= 3; null otherwise)
+  const double* bound_h;     // [n_layers][PREP_NDIR] support values of the list's (tfn_0, tfn_1) points (F == 2; null otherwise)
+  uint32_t h_lo;             // boosts = h_a * dir[h_lo] + h_b * dir[h_lo + 1], h_a, h_b >= 0 (host: boost_cone)
+  double h_a, h_b;
   // outputs
   DEntry* dentry;            // [ne]
   uint32_t* rorder;          // [ne]
@@ -87,15 +95,26 @@ struct PrepParams {
 // ---- per-list bounds --------------------------------------------------------------------------
 struct BoundUnit { uint32_t layer, begin, count; };  // a segment of one list
 
+// Two fields: the joint maximum J(b) = max over a list's postings of b_0 * tfn_0 + b_1 * tfn_1 is the support function of the
+// list's point set {(tfn_0, tfn_1)} in direction b.  Its values H_d in PREP_NDIR fixed directions w_d (angles 0 .. 90 degrees
+// in equal steps; the ends are the per-field maxima, the middle one is fields_boost = [1, 1]) are computed once per (k1, b,
+// averages); for any positive b = alpha * w_d + beta * w_(d+1) (the two directions around it, alpha, beta >= 0) every point
+// satisfies b . v = alpha * (w_d . v) + beta * (w_(d+1) . v) <= alpha * H_d + beta * H_(d+1): a bound for EVERY boost vector
+// without another pass over the postings - exact when b lies on a stored direction, at most a few percent loose between two
+// (a list whose postings hold the term in one field or the other has a kink there).
+constexpr int PREP_NDIR = 17;
+
 // One wave per unit (a list, or a 16 Ki-posting segment of a long one).  M[l][x] = max over the list's
-// postings of tfn_x, J[l] = max of sum_x boost_x * tfn_x; both through bm25_tfn, the expression the scoring
-// kernels evaluate, so they bound the COMPUTED values.  Positive doubles order like their bit patterns:
-// the segments of a list meet through 64-bit atomicMax.
-// The same pass writes the score plane the K1d kernels read (ps_kernels.hpp, "score planes"): per (posting,
-// field) the value (tfn * idf) * boost_x, the list's idf from `layer_idf` (the planner's own number).
+// postings of tfn_x; H[l][d] (two fields) = max of w_d . (tfn_0, tfn_1); J[l] (three fields and more, per boost vector) = max
+// of sum_x boost_x * tfn_x; all through bm25_tfn, the expression the scoring kernels evaluate, so they bound the COMPUTED
+// values.  Positive doubles order like their bit patterns: the segments of a list meet through 64-bit atomicMax.
+// The pass that computes M also writes the score plane the K1d kernels read (ps_kernels.hpp, "score planes"): per (posting,
+// field) the value tfn * idf, the list's idf from `layer_idf` (the planner's own number) - boost-free, so a new fields_boost
+// rewrites nothing.
 __global__ __launch_bounds__(256) void k_list_bounds(const KParams p, const BoundUnit* units, const uint32_t n_units,
                                                      const uint4* layer_a, unsigned long long* M, unsigned long long* J,
-                                                     const int with_m, double* plane, const double* layer_idf) {
+                                                     unsigned long long* H, const double2* dirs, const int with_m, double* plane,
+                                                     const double* layer_idf) {
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
   const int lane = threadIdx.x & (WAVE - 1);
   if (wave >= n_units) return;
@@ -103,32 +122,50 @@ __global__ __launch_bounds__(256) void k_list_bounds(const KParams p, const Boun
   const uint4 la = layer_a[u.layer];
   const uint64_t off = ((uint64_t)la.x | ((uint64_t)la.y << 32)) + u.begin;
   const double idf = layer_idf[u.layer];
-  double mj = 0.0, mm[MAX_F];
+  double mj = 0.0, mm[MAX_F], hh[PREP_NDIR];
   for (uint32_t x = 0; x < p.F; ++x) mm[x] = 0.0;
+#pragma unroll
+  for (int d = 0; d < PREP_NDIR; ++d) hh[d] = 0.0;
+  const bool with_h = H != nullptr && p.F == 2u;
   for (uint32_t i = lane; i < u.count; i += WAVE) {
     const uint64_t pi = off + i;
-    double sum = 0.0;
+    double sum = 0.0, t01[2] = {0.0, 0.0};
     for (uint32_t x = 0; x < p.F; ++x) {
       const uint32_t w = p.tfl[pi * p.F + x];
       uint32_t tfu = w >> 24, flu = w & TFL_FL_ESC;
-      if (tfu == 0) { plane[pi * p.F + x] = 0.0; continue; }
+      if (tfu == 0) { if (plane) plane[pi * p.F + x] = 0.0; continue; }
       tfl_exact(p, x, pi, tfu, flu);
       const double t = bm25_tfn(p, x, tfu, flu);
-      plane[pi * p.F + x] = (t * idf) * p.boost[x];  // bm25.rs:83-85, left to right; expansion_boost is the reader's
+      if (plane) plane[pi * p.F + x] = t * idf;  // bm25.rs:83-85, left to right; boost_x and expansion_boost are the reader's
       if (t > mm[x]) mm[x] = t;
+      if (x < 2u) t01[x] = t;
       sum += p.boost[x] * t;
     }
     if (sum > mj) mj = sum;
+    if (with_h) {
+#pragma unroll
+      for (int d = 0; d < PREP_NDIR; ++d) hh[d] = fmax(hh[d], dirs[d].x * t01[0] + dirs[d].y * t01[1]);
+    }
   }
   for (int o = 32; o > 0; o >>= 1) {
     mj = fmax(mj, __shfl_down(mj, o));
     for (uint32_t x = 0; x < p.F; ++x) mm[x] = fmax(mm[x], __shfl_down(mm[x], o));
   }
+  if (with_h) {
+#pragma unroll
+    for (int d = 0; d < PREP_NDIR; ++d)
+      for (int o = 32; o > 0; o >>= 1) hh[d] = fmax(hh[d], __shfl_down(hh[d], o));
+  }
   if (lane == 0) {
-    if (mj > 0.0) atomicMax(&J[u.layer], (unsigned long long)__double_as_longlong(mj));
+    if (J != nullptr && mj > 0.0) atomicMax(&J[u.layer], (unsigned long long)__double_as_longlong(mj));
     if (with_m)
       for (uint32_t x = 0; x < p.F; ++x)
         if (mm[x] > 0.0) atomicMax(&M[(size_t)u.layer * p.F + x], (unsigned long long)__double_as_longlong(mm[x]));
+    if (with_h) {
+#pragma unroll
+      for (int d = 0; d < PREP_NDIR; ++d)
+        if (hh[d] > 0.0) atomicMax(&H[(size_t)u.layer * PREP_NDIR + d], (unsigned long long)__double_as_longlong(hh[d]));
+    }
   }
 }
 
@@ -142,7 +179,15 @@ __device__ __forceinline__ double prep_entry_ub(const PrepParams& pp, const ps_p
     const double t = pp.bound_m[(size_t)e.node * pp.F + x];
     if (t > 0.0) ub_m += t * e.idf * pp.boost[x] * e.boost;
   }
-  const double ub_j = (e.idf * e.boost) * pp.bound_j[e.node] * (1.0 + 1e-12);
+  // the joint bound: the largest boosted sum of saturated term frequencies any posting of the list has (exactly for these
+  // boosts, F >= 3; from the direction supports, F == 2), times the list's weights
+  double jb;
+  if (pp.bound_j != nullptr) jb = pp.bound_j[e.node];
+  else if (pp.bound_h != nullptr) {
+    const double* h = pp.bound_h + (size_t)e.node * PREP_NDIR;
+    jb = pp.h_a * h[pp.h_lo] + pp.h_b * h[pp.h_lo + 1];
+  } else return ub_m;  // (one field: the per-field form is the maximum itself)
+  const double ub_j = (e.idf * e.boost) * jb * (1.0 + 1e-12);
   return fmin(ub_m, ub_j);
 }
 
@@ -165,7 +210,7 @@ __device__ __forceinline__ uint32_t prep_fine_entry(const PrepParams& pp, const 
     }
   return fine;
 }
-__device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint32_t len, const bool short_first = false) {
+__device__ __forceinline__ uint32_t prep_bucket_in_set(const uint32_t rank, const uint32_t len, const bool short_first) {
   if (rank <= 1) {  // 64 length classes, log2 with one fractional bit
     // First-ranked lists (every chunk runs): longest first.  Second-ranked lists: longest first as well for plans with one
     // list per query term (the ones that stay essential are what a launch ends on: the long ones must not start last),
@@ -179,6 +224,9 @@ __device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint3
     return PREP_SAMPLE_BUCKETS + (rank == 1u && short_first ? PREP_CLASSES + cls : rank * PREP_CLASSES + 63u - cls);
   }
   return PREP_SAMPLE_BUCKETS + 2 * PREP_CLASSES + (rank < PREP_RANKS ? rank : PREP_RANKS) - 1u;
+}
+__device__ __forceinline__ uint32_t prep_bucket(const uint32_t rank, const uint32_t len, const bool short_first = false, const bool big = false) {
+  return (big ? PREP_SET_BUCKETS : 0u) + prep_bucket_in_set(rank, len, short_first);
 }
 // Chunks [0, result) of a list cut into chunks of `c` postings lie entirely below the sample boundary (0: no sample phase, or
 // the list's table is too coarse to tell).  Scheduling only: any value in [0, chunks] is correct.
@@ -205,7 +253,8 @@ __device__ __forceinline__ bool prep_before(const double ua, const uint32_t la, 
 }
 
 template <int NMAX>
-__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, const uint32_t fine) {
+__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, const uint32_t fine,
+                                                     uint32_t& groups) {
   double ub[NMAX];
   uint32_t len[NMAX], grp[NMAX], rank[NMAX], qt[NMAX];
 #pragma unroll
@@ -224,6 +273,7 @@ __device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const
     if ((uint32_t)i < n && (i == 0 || qt[i] != qt[i > 0 ? i - 1 : 0])) ++n_groups;
     grp[i] = n_groups - 1;
   }
+  groups = n_groups;
 #pragma unroll
   for (int i = 0; i < NMAX; ++i) {
     uint32_t r = 0;
@@ -480,7 +530,10 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
   // (plans of <= 4 entries - one list per query term: C2, C4 - entirely in registers; wider ones walk their arrays in HBM.
   // An 8-entry register variant cost this kernel 145 VGPRs and 58 SGPR spills for every batch: 76 / 0 without it.)
   const uint32_t fine = prep_fine_entry(pp, b, n);
-  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n, fine) : prep_query_general(pp, q, b, n, fine);
+  uint32_t groups = 0;
+  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n, fine, groups) : prep_query_general(pp, q, b, n, fine);
+  // PLAN_BIG's rule (k_plan): more than 4 lists, or several lists under one query term -> k_daat's part of the batch
+  const bool big = pp.split_kinds && (n > 4u || groups != n);
   // candidate slots: query-major within the query; the wave's queries take one block of the batch's slots
   const uint32_t s0 = wave_add_by_key(&pp.ctl->total_slots, 0u, slots, have && n != 0);
   if (have) { pp.qslot[q] = n ? s0 : 0u; pp.qslot_n[q] = slots; }
@@ -494,12 +547,12 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
       const ps_plan_entry& en = pp.plan[b + i];
       const uint32_t c = prep_chunk(pp, en.len, i == fine);
       nc = (en.len + c - 1) / c;
-      ns = prep_sample_chunks(pp, en, c, nc);
-      pp.gen[b + i] = DItemGen{b + i, ns, c, sl};
+      ns = (big || !pp.split_kinds || pp.sample_small) ? prep_sample_chunks(pp, en, c, nc) : 0u;
+      pp.gen[b + i] = DItemGen{big ? 1u : 0u, ns, c, sl};  // (`entry`: gen is indexed by entry - the word carries the query's kind)
       sl += nc;
       const uint32_t rk = pp.dentry[b + i].rank;
-      bk = prep_bucket(rk, en.len, pp.multi != 0u);
-      bs = rk < PREP_SAMPLE_BUCKETS ? rk : PREP_SAMPLE_BUCKETS - 1u;
+      bk = prep_bucket(rk, en.len, pp.multi != 0u && (big || !pp.split_kinds), big);
+      bs = (big ? PREP_SET_BUCKETS : 0u) + (rk < PREP_SAMPLE_BUCKETS ? rk : PREP_SAMPLE_BUCKETS - 1u);
       if (pp.n_cand) cd = pp.cand_of_layer[en.node];
     }
     wave_add_by_key_noret(pp.ctl->bucket_total, bk, nc - ns, on && nc != ns);
@@ -534,10 +587,11 @@ __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
     len_i = len; chunk = c; first_slot = g.first_slot;
     nc = (len + c - 1) / c;
     ns = g.item_at;  // (k_prep_query: the list's chunks in the sample phase)
+    const bool big = g.entry != 0u;  // (... and its query's kind)
     const DEntry de_i = pp.dentry[i];
     skip_i = de_i.skip_thr; q_i = de_i.q;
-    bk = prep_bucket(de_i.rank, len, pp.multi != 0u);
-    bs = de_i.rank < PREP_SAMPLE_BUCKETS ? de_i.rank : PREP_SAMPLE_BUCKETS - 1u;
+    bk = prep_bucket(de_i.rank, len, pp.multi != 0u && (big || !pp.split_kinds), big);
+    bs = (big ? PREP_SET_BUCKETS : 0u) + (de_i.rank < PREP_SAMPLE_BUCKETS ? de_i.rank : PREP_SAMPLE_BUCKETS - 1u);
     if (pp.n_cand) {
       const uint32_t cd = pp.cand_of_layer[en.node];
       if (cd != NO_CAND) {

@@ -3,7 +3,7 @@
 //
 // Scope: top-k batches whose queries are all "simple" (ps_engine.hip, classification: one version layer, every
 // record of the query on its own (query term, trie node) pair; a node repeated under several query terms and
-// several expansions of one query term are both fine) with at most DAAT_SMALL_MAX lists.  Everything else stays
+// several expansions of one query term are both fine) with at most Z_MAX_LISTS (8) lists.  Everything else stays
 // on k_score<MODE_Z21S> / k_z21.
 //
 // What a document scores (zero_to_one.rs:84-126 for such queries): per field x the pool
@@ -49,6 +49,7 @@ namespace ps {
 #define PS_DAAT_ZPF 0  // 1: the next trip's own postings are requested before this trip's lookups (measured: no gain, 12-18 more VGPRs)
 #endif
 constexpr int Z_LEVELS = 3;
+constexpr int Z_MAX_LISTS = 8;                 // most records of a query K1dz takes (k_daat_z<F, WC, 8>; <= DAAT_SMALL_MAX: the narrow instantiation)
 constexpr uint32_t ZITEM_LEVEL_SHIFT = 30;     // DItem::count bits 30-31: levels l (the lowest ones) with every document of the chunk at or above D_l
 constexpr uint32_t ZITEM_COUNT = 0x3FFFFFFFu;
 constexpr uint32_t Z_NO_LEVEL = 0xFFFFFFFFu;   // KParams::z_dl of a level that does not exist (tiny corpora)
@@ -91,39 +92,40 @@ static_assert(4u * Z_LEVELS + 2u * PREP_CLASSES + 4u <= PREP_BUCKETS, "K1dz item
 // idf = the largest tf with min(score / tf, 1) * tf == score (the one-division arm's limit); ubnum = the largest
 // numerator over the term frequencies the list holds (z_numerator_bound); zub[e][x] = ubnum / max(shortest field x
 // holding the term, query_terms_len).
+template <int ZN>  // most records per query: ZN (4) or Z_MAX_LISTS (8)
 __global__ __launch_bounds__(64) void k_zplan_arrange(ps_plan_entry* __restrict__ entries, const uint32_t* __restrict__ qbeg,
                                                       const uint32_t* __restrict__ qtl, const uint32_t B, const uint32_t F,
                                                       const uint32_t* __restrict__ maxtf, const uint32_t* __restrict__ minfl,
                                                       double* __restrict__ ubnum, double* __restrict__ zub) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= B) return;
-  const uint32_t b = qbeg[q], n = min(qbeg[q + 1] - b, (uint32_t)DAAT_SMALL_MAX);
+  const uint32_t b = qbeg[q], n = min(qbeg[q + 1] - b, (uint32_t)ZN);
   const uint32_t ql = qtl[q];
-  ps_plan_entry en[DAAT_SMALL_MAX];
+  ps_plan_entry en[ZN];
 #pragma unroll
-  for (int i = 0; i < DAAT_SMALL_MAX; ++i)
+  for (int i = 0; i < ZN; ++i)
     if ((uint32_t)i < n) en[i] = entries[b + i];
   // stable insertion sort, score descending (a later record moves ahead of an earlier one only if its score is higher)
-  int ord[DAAT_SMALL_MAX];
+  int ord[ZN];
 #pragma unroll
-  for (int i = 0; i < DAAT_SMALL_MAX; ++i) ord[i] = i;
+  for (int i = 0; i < ZN; ++i) ord[i] = i;
 #pragma unroll
-  for (int i = 1; i < DAAT_SMALL_MAX; ++i)
+  for (int i = 1; i < ZN; ++i)
 #pragma unroll
     for (int j = i; j > 0; --j)
       if ((uint32_t)j < n && en[ord[j]].boost > en[ord[j - 1]].boost) { const int t = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t; }
-  uint32_t s_node[DAAT_SMALL_MAX], s_qterm[DAAT_SMALL_MAX], s_qt[DAAT_SMALL_MAX];
+  uint32_t s_node[ZN], s_qterm[ZN], s_qt[ZN];
 #pragma unroll
-  for (int i = 0; i < DAAT_SMALL_MAX; ++i) {
+  for (int i = 0; i < ZN; ++i) {
     if ((uint32_t)i >= n) break;
     ps_plan_entry e = en[0];
 #pragma unroll
-    for (int k = 1; k < DAAT_SMALL_MAX; ++k)
+    for (int k = 1; k < ZN; ++k)
       if (ord[i] == k) e = en[k];
     uint32_t need = 1, qt = 0, used = 0;
     bool seen = false;
 #pragma unroll
-    for (int j = 0; j < DAAT_SMALL_MAX; ++j) {
+    for (int j = 0; j < ZN; ++j) {
       if (j >= i) break;
       if (s_node[j] == e.node) ++need;
       if (s_qterm[j] == e.qterm) { qt = s_qt[j]; seen = true; }
@@ -162,8 +164,9 @@ __global__ __launch_bounds__(64) void k_zplan_arrange(ps_plan_entry* __restrict_
 
 // Thread per query: processing order (shortest list first: the long lists are the ones that become non-essential;
 // any order is exact), skip thresholds, chunking, candidate slots, bucket totals.
+template <int ZN>
 __global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {
-  constexpr int NMAX = DAAT_SMALL_MAX;
+  constexpr int NMAX = ZN;
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = q < pp.B;
   const uint32_t b = have ? pp.qbeg[q] : 0u, n = have ? min(pp.qbeg[q + 1] - b, (uint32_t)NMAX) : 0u;
@@ -337,12 +340,16 @@ __device__ __forceinline__ uint32_t z_level_of(const KParams& p, const uint32_t 
   return lv;
 }
 
-template <int F_, bool WC>  // WC: keep the work counters (ps_work_counters); the serving instantiation carries none
+// ZN: most lists per query of the batch - DAAT_SMALL_MAX (4: BASELINE config 3) or Z_MAX_LISTS (8: batches with queries of
+// five to eight records; the per-list state of a document - packed words, posting, found - is ZN registers wide and the
+// queues' per-list words ZN - 1 LDS planes, so the narrow instantiation stays what it was).
+template <int F_, bool WC, int ZN = DAAT_SMALL_MAX>  // WC: keep the work counters (ps_work_counters); the serving instantiation carries none
 __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   static_assert(F_ >= 1 && F_ <= 4, "k_daat_z is instantiated per field count");
+  static_assert(ZN == DAAT_SMALL_MAX || ZN == Z_MAX_LISTS, "k_daat_z is instantiated for 4 or 8 lists per query");
   auto cnt = [](const bool b) -> uint32_t { return WC ? (uint32_t)__popcll(__ballot(b)) : 0u; };  // wave-uniform count of lanes where b holds
   constexpr int U = PS_DAAT_ZU;
-  constexpr int NE = DAAT_SMALL_MAX;
+  constexpr int NE = ZN;
   constexpr int NO = NE - 1;  // other lists of a query, in sorted record order with the own one left out
   constexpr uint32_t QCAP = 128;
   constexpr uint32_t REL_NONE = 0xFFFFFFFFu, REL_MAYBE = 0xFFFFFFFEu;

@@ -22,7 +22,7 @@ CONFIGS = {
     "C2": dict(n_docs=1_000_000, fields=2, vocab=100_000, zipf_s=1.0, variants=1, batch=1024, q_terms=3,
                scorer="bm25", top_k=10, seed=0x5EED0002),
     "C3": dict(n_docs=1_000_000, fields=2, vocab=100_000, zipf_s=1.0, variants=1, batch=1024, q_terms=3,
-               scorer="zero_to_one", top_k=10, seed=0x5EED0003),
+               scorer="zero_to_one", top_k=10, seed=0x5EED0002),  # (C2's documents, the other scorer: one corpus serves both)
     "C4": dict(n_docs=5_000_000, fields=2, vocab=100_000, zipf_s=1.0, variants=1, batch=8192, q_terms=3,
                scorer="bm25", top_k=10, seed=0x5EED0004),
     "C5": dict(n_docs=1_000_000, fields=2, vocab=100_000, zipf_s=1.2, variants=4, batch=1024, q_terms=2,

@@ -10,6 +10,9 @@ template __global__ void k_daat<2, false>(const KParams);
 template __global__ void k_daat_z<2, true>(const KParams);
 template __global__ void k_daat_z<2, false>(const KParams);
 template __global__ void k_daat_z<1, false>(const KParams);
+template __global__ void k_daat_z<2, false, 8>(const KParams);
+template __global__ void k_zprep_query<4>(const ZPrepParams);
+template __global__ void k_zprep_query<8>(const ZPrepParams);
 template __global__ void k_score<MODE_BM25, 2, false, false, 8>(const KParams);
 template __global__ void k_score<MODE_BM25, 1, false, false, 8>(const KParams);
 template __global__ void k_score<MODE_BM25, 1, false, false, 4>(const KParams);

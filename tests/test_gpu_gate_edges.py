@@ -98,6 +98,103 @@ def test_all_ties_whole_batch_equals_the_streaming_kernel(corpus_pair):
         assert [[(r.key, bits(r.score)) for r in rs] for rs in a] == [[(r.key, bits(r.score)) for r in rs] for rs in b], K
 
 
+BOOST_VECTORS = [[1.0, 1.0], [2.0, 0.5], [0.25, 3.0], [1.0, 1e-3], [1e-3, 1.0], [7.0, 7.0], [1.0, 0.0985], [3.0, 2.9], [1e6, 1.0], [0.3, 0.3000001],
+                 [1.0, 1.0]]
+
+
+def test_fresh_fields_boost_every_batch(corpus_pair):
+    """fields_boost is a per-call argument (src/query.rs:26).  The score plane holds tfn * idf (boost-free) and the two-field
+    joint bound comes from direction supports, so a boost vector never seen before costs no pass over the postings
+    (`bounds_recomputed` stays 0 after the first batch) - and prunes exactly: every batch equals the streaming kernel, and
+    the oracle on a sample; vectors on a stored direction ([1, 1]), between two, and at the ends of the cone."""
+    corpus, p, o, snap = corpus_pair
+    queries = corpus.queries(192, 3, salt=21) + ["", "zzzz"]
+    sc, osc = product_scorer("bm25"), oracle_scorer("bm25")
+    L = psa.load()
+    snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=10)  # (whatever pass the scorer parameters need happens here)
+    for i, bs in enumerate(BOOST_VECTORS):
+        a = snap.query_batch(queries, sc, None, bs, top_k=10)
+        assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_daat"), bs
+        assert snap.last_stats()["bounds_recomputed"] == 0, (bs, "a new boost vector must not trigger a pass over the postings")
+        L.ps_set_option(b"PS_DAAT", 0)
+        try:
+            b = snap.query_batch(queries, sc, None, bs, top_k=10)
+            assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_score")
+        finally:
+            L.ps_set_option(b"PS_DAAT", 1)
+        assert [[(r.key, bits(r.score)) for r in rs] for rs in a] == [[(r.key, bits(r.score)) for r in rs] for rs in b], bs
+        for q, g in list(zip(queries, a))[:6]:
+            exp = o.query(q, osc, bs)[:10]
+            assert [(r.key, bits(r.score)) for r in g] == [(k, bits(s)) for k, s in exp], (q, bs)
+
+
+def test_fresh_fields_boost_three_fields():
+    """Three fields: the joint bound of a new boost vector is one pass over the packed words (no plane rewrite, nobody
+    drained); the three most recent vectors stay resident."""
+    cfg = dict(synth.CONFIGS["C2"], n_docs=20_000, vocab=1_500, fields=3)
+    corpus = synth.Corpus(**cfg)
+    p, o = synth.fill(psa.Index(3), corpus), synth.fill(orc.Index(3), corpus)
+    snap = p.snapshot(device=0)
+    queries = corpus.queries(64, 3, salt=5)
+    sc, osc = product_scorer("bm25"), oracle_scorer("bm25")
+    seen = []
+    for bs in ([1.0, 1.0, 1.0], [2.0, 0.5, 1.0], [0.1, 3.0, 9.0], [1.0, 1.0, 1.0], [5.0, 5.0, 0.01], [2.0, 0.5, 1.0]):
+        a = snap.query_batch(queries, sc, None, bs, top_k=10)
+        assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_daat"), bs
+        assert snap.last_stats()["bounds_recomputed"] == (0 if bs in seen[-3:] else 1), (bs, seen)
+        if bs in seen:
+            seen.remove(bs)
+        seen.append(bs)
+        for q, g in list(zip(queries, a))[:12]:
+            exp = o.query(q, osc, bs)[:10]
+            assert [(r.key, bits(r.score)) for r in g] == [(k, bits(s)) for k, s in exp], (q, bs)
+
+
+@pytest.mark.parametrize("device_plan", [False, True])
+def test_mixed_batch_is_split_between_k_daat_small_and_k_daat(corpus_pair, device_plan):
+    """src/query.rs:33-60 takes any number of terms and expansions.  k_daat_small takes queries of <= 4 lists, one per query term;
+    a batch that also holds other queries - five terms, a prefix with several expansions, a term repeated - is scored by both
+    kernels, each over its part of the item array (PS_DAAT_SPLIT).  Every query: == the unsplit batch (k_daat alone), == the
+    streaming kernel, == the oracle."""
+    from adapters import run_device_planned
+    corpus, p, o, snap = corpus_pair
+    base = corpus.queries(96, 3, salt=31)
+    stems = [q.split(" ")[0] for q in base]
+    odd = [" ".join(stems[i:i + 5]) for i in (0, 7)] + [stems[3][:3] + " " + stems[4], stems[5][:2], stems[6] + " " + stems[6], " ".join(stems[10:18])]
+    queries = base[:40] + odd[:3] + base[40:] + odd[3:] + ["", "zzzz"]
+    sc, osc = product_scorer("bm25"), oracle_scorer("bm25")
+    plans = [snap.plan(q, sc)[0] for q in queries]
+    assert max(len(e) for e in plans) > 4 and any(len(e) > len(q.split()) for e, q in zip(plans, queries) if q)
+    L = psa.load()
+
+    def run():
+        if device_plan:
+            return [[(k, bits(s_)) for k, s_ in rs] for rs in run_device_planned(snap, queries, [1.0, 1.0], 10)]
+        return [[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=10)]
+
+    L.ps_set_option(b"PS_DEVICE_PLAN", 1 if device_plan else 0)
+    try:
+        got = run()
+        name = snap.kernel_breakdown()["score_kernel"]
+        assert name.startswith("ps::k_daat_small") and " + ps::k_daat<" in name, name
+        for _ in range(2):
+            assert run() == got
+        L.ps_set_option(b"PS_DAAT_SPLIT", 0)
+        whole = run()
+        name = snap.kernel_breakdown()["score_kernel"]
+        assert name.startswith("ps::k_daat<"), name
+        assert whole == got
+        L.ps_set_option(b"PS_DAAT", 0)
+        assert run() == got
+    finally:
+        L.ps_set_option(b"PS_DAAT", 1)
+        L.ps_set_option(b"PS_DAAT_SPLIT", 1)
+        L.ps_set_option(b"PS_DEVICE_PLAN", 1)
+    for q, g in zip(queries, got):
+        exp = [(k, bits(s_)) for k, s_ in o.query(q, osc, [1.0, 1.0])[:10]]
+        assert g == exp, (q, g[:3], exp[:3])
+
+
 def test_corners_under_a_delta_with_removals(corpus_pair):
     """(last: it mutates the module's index)  Removed documents are tombstones until the next flatten; the tie order of
     the survivors must not change."""

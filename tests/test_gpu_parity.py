@@ -578,9 +578,10 @@ def test_zero_to_one_large_term_frequencies():
                 assert_same([tuple(r) for r in t5], exp[:5], (name, q, boosts, "top5"))
 
 
-def test_field_longer_than_the_packed_posting_word_holds():
-    """A field of 2^24 + 50 tokens: its length (and the term frequency) saturate the packed posting word
-    (8-bit tf, 24-bit field length) and every kernel has to fetch the exact values from the planes."""
+@pytest.fixture(scope="module")
+def huge_field_pair():
+    """(oracle index, snapshot) of four documents, one with a field of 2^24 + 50 tokens (tokenising 32 MB of text twice takes
+    ~15 s: built once for both kernel settings of this module)."""
     F = 2
     n = (1 << 24) + 50
     o, p = orc.Index(F), ProductIndex(F)
@@ -589,7 +590,13 @@ def test_field_longer_than_the_packed_posting_word_holds():
     for key, fields in docs:
         for ix in (o, p):
             ix.add_document(key, fields)
-    snap = p.idx.snapshot(device=0, tile_docs=256)
+    return o, p.idx.snapshot(device=0, tile_docs=256)
+
+
+def test_field_longer_than_the_packed_posting_word_holds(huge_field_pair):
+    """A field of 2^24 + 50 tokens: its length (and the term frequency) saturate the packed posting word
+    (8-bit tf, 24-bit field length) and every kernel has to fetch the exact values from the planes."""
+    o, snap = huge_field_pair
     queries = ["x", "rare", "x rare y", "y z", "ra"] * 2
     for name in ("bm25", "zero_to_one"):
         sc = product_scorer(name)

@@ -40,6 +40,58 @@ def _tuples(results):
     return [[(r.key, bits(r.score)) for r in rs] for rs in results]
 
 
+class _Both:
+    """The product index and the oracle index of one synthetic corpus: the text is generated ONCE (numpy: 30-40 s for 5 M
+    documents) and the oracle - the slower indexer by far (100 s for 5 M documents) - consumes the chunks on a thread of its
+    own (its C calls release the GIL) while the product index is built, flattened, uploaded and put through the
+    kernel-against-kernel checks; `oracle()` joins the thread."""
+
+    def __init__(self, cfg):
+        import queue
+        import threading
+        self.corpus = synth.Corpus(**cfg)
+        F = cfg["fields"]
+        self.product, self._o = psa.Index(F), orc.Index(F)
+        qq = queue.Queue()
+        self._err = []
+
+        def feed():
+            try:
+                while True:
+                    item = qq.get()
+                    if item is None:
+                        return
+                    self._o.add_documents_flat(*item)
+            except Exception as e:  # noqa: BLE001 (re-raised by oracle())
+                self._err.append(e)
+
+        self._t = threading.Thread(target=feed, daemon=True)
+        self._t.start()
+        for keys, text, offsets in self.corpus.chunks(100_000):
+            self.product.add_documents_flat(keys, text, offsets)
+            qq.put((keys, text, offsets))
+        qq.put(None)
+
+    def oracle(self):
+        self._t.join()
+        if self._err:
+            raise self._err[0]
+        return self._o
+
+
+_BOTH = {}
+
+
+def _both(cfg):
+    """One corpus per distinct (size, vocabulary, seed ...): C2 and C3 share theirs (same documents, another scorer), so the
+    second of the two tests neither generates nor indexes anything.  Only the most recent corpus is kept (C4's is 5 M documents)."""
+    key = tuple(cfg[k] for k in ("n_docs", "fields", "vocab", "zipf_s", "variants", "seed"))
+    if key not in _BOTH:
+        _BOTH.clear()
+        _BOTH[key] = _Both(cfg)
+    return _BOTH[key]
+
+
 def _full_size(config, n_full_lists, batch, n_oracle_topk=64):
     """One BASELINE config at its full size, pruning kernel (K1d k_daat) under test:
       * whole batch: K1d top-k == K1 k_score top-k (the streaming kernel that prunes nothing), every query;
@@ -49,13 +101,11 @@ def _full_size(config, n_full_lists, batch, n_oracle_topk=64):
       * fields_boost changed between consecutive batches of one snapshot (src/query.rs:26 takes it per call):
         each batch against K1 and, for the odd boosts, 8 queries against the oracle."""
     cfg = dict(synth.CONFIGS[config])
-    corpus = synth.Corpus(**cfg)
     F, K = cfg["fields"], cfg["top_k"]
     boosts = [1.0] * F
-    p = synth.fill(psa.Index(F), corpus)
-    snap = p.snapshot(device=0, tile_docs=512 if cfg["scorer"] == "zero_to_one" else 0)
-    del p
-    o = synth.fill(orc.Index(F), corpus)
+    both = _both(cfg)
+    corpus = both.corpus
+    snap = both.product.snapshot(device=0, tile_docs=512 if cfg["scorer"] == "zero_to_one" else 0)
     bm25 = cfg["scorer"] == "bm25"
     ps_sc = psa.bm25.new() if bm25 else psa.zero_to_one.new()
     or_sc = orc.bm25() if bm25 else orc.zero_to_one()
@@ -83,6 +133,7 @@ def _full_size(config, n_full_lists, batch, n_oracle_topk=64):
             b = snap.query_batch(queries[:512], ps_sc, None, bs, top_k=K)
             assert _tuples(a) == _tuples(b), (config, "boosts", bs)
             if bs != boosts:
+                o = both.oracle()
                 _, _, _, exp = o.bench_queries(queries[:8], or_sc, bs, threads=8, top_k=K)
                 for qi in range(8):
                     assert_same([tuple(r) for r in a[qi]], exp[qi], (config, qi, "boosts", bs))
@@ -105,6 +156,7 @@ def _full_size(config, n_full_lists, batch, n_oracle_topk=64):
         assert _tuples(top_stream) == _tuples(top), (config, "K1dz batch != streaming batch")
     # oracle top-k for many queries (one per host thread), whole lists for a few
     import os
+    o = both.oracle()
     nq = min(n_oracle_topk, batch)
     step = max(1, batch // nq)
     picks = list(range(0, batch, step))[:nq]
@@ -166,8 +218,9 @@ def test_c5_full_size_against_oracle():
 
 def test_c4_full_size_against_oracle():
     """BASELINE configs[3]: 5M documents, 2 fields, BM25, 1024-query shard of the 8192-query batch
-    (what one GPU of the 8 scores) + batch split invariance."""
-    snap, corpus, queries, top, o = _full_size("C4", 4, 1024)
+    (what one GPU of the 8 scores) + batch split invariance.  (The oracle answers a query over 5 M documents in ~4.5 s:
+    32 top-k queries on as many threads and 2 whole lists here, after the whole batch was compared kernel against kernel.)"""
+    snap, corpus, queries, top, o = _full_size("C4", 2, 1024, n_oracle_topk=32)
     sc = psa.bm25.new()
     halves = snap.query_batch(queries[:400], sc, None, [1.0, 1.0], top_k=10) + snap.query_batch(queries[400:], sc, None, [1.0, 1.0], top_k=10)
     assert halves == top

@@ -105,6 +105,46 @@ def test_field_count_gate_edge(fields, kernel):
         assert _topk(snap, queries, 10, boosts) == got
 
 
+@pytest.mark.parametrize("fields", [1, 2])
+@pytest.mark.parametrize("planner", [1, 0])
+def test_five_to_eight_lists_take_the_wide_instantiation(fields, planner):
+    """zero_to_one.rs:84-126 takes any number of records.  Queries of five to eight lists run on k_daat_z<F, WC, 8> (the same
+    kernel with eight lists of per-document state); a batch that mixes them with shorter queries takes that instantiation
+    whole.  Against the streaming kernels and the oracle, ties included; device- and host-planned."""
+    words, docs = _tie_corpus(30_000, fields, seed=70 + fields)
+    p, o = _build(docs, fields)
+    snap = p.snapshot(device=0, tile_docs=256)
+    rng = random.Random(fields)
+    queries = [" ".join(rng.sample(words[:12], rng.randint(5, 8))) for _ in range(24)]
+    queries += [" ".join(rng.choice(words[:8]) for _ in range(rng.randint(1, 4))) for _ in range(12)]
+    queries += ["w00 w01 w02 w03 w00 w01", "wa w00 w01 w02", "w00 w01 w02 w03 w04 w05 w06 w07", "zzz w00 w01 w02 w03 w04", ""]
+    plans = [snap.plan(q, psa.zero_to_one.new())[0] for q in queries]
+    assert 4 < max(len(e) for e in plans) <= 8
+    _opt(b"PS_DAAT_CHUNK", 256)
+    _opt(b"PS_DEVICE_PLAN", planner)
+    boosts = [1.0] * fields
+    try:
+        for K in (1, 10, 64):
+            got = _planned(snap, queries, K, boosts)
+            assert snap.last_stats()["device_planned"] == planner
+            name = snap.kernel_breakdown()["score_kernel"]
+            assert name.startswith("ps::k_daat_z<") and name.endswith(", 8>"), name
+            for _ in range(2):
+                assert _planned(snap, queries, K, boosts) == got
+            _opt(b"PS_DAAT_Z", 0)
+            ref = _planned(snap, queries, K, boosts)
+            assert snap.kernel_breakdown()["score_kernel"].startswith(("ps::k_score", "ps::k_z21"))
+            _opt(b"PS_DAAT_Z", 1)
+            for q, g, r in zip(queries, got, ref):
+                assert g == r, (q, K, g[:4], r[:4])
+            for q, g in zip(queries, got):
+                exp = [(k, bits(s)) for k, s in o.query(q, orc.zero_to_one(), boosts)[:K]]
+                assert g == exp, (q, K, g[:4], exp[:4])
+    finally:
+        _opt(b"PS_DEVICE_PLAN", 1)
+        _opt(b"PS_DAAT_Z", 1)
+
+
 def test_prefix_expansions_within_four_lists():
     """Several expansions of one query term (consumed_index, zero_to_one.rs:101-103) and the same node under
     two query terms (the pool rule, :104-113) - as long as a query has at most 4 lists it stays on K1dz."""

@@ -24,16 +24,20 @@ BUDGET = {
     # (36 bytes of frame are reserved for k_daat_z but its ISA holds no scratch instruction)
     # (its scan holds ~95 VGPRs since the first level moved behind the reach queue: 5 waves per SIMD for the serving
     # instantiation; the wave-uniform state - two sets of field-length limits, three tie levels - spills more SGPRs)
-    "ps::k_daat_z<2, true>": (104, 4, 36, 300),   # (the counting instantiation; 85 VGPRs)
-    "ps::k_daat_z<2, false>": (104, 5, 36, 200),
-    "ps::k_daat_z<1, false>": (96, 5, 36, 195),
+    "ps::k_daat_z<2, true, 4>": (104, 4, 36, 300),   # (the counting instantiation; 85 VGPRs)
+    "ps::k_daat_z<2, false, 4>": (104, 5, 36, 200),
+    "ps::k_daat_z<1, false, 4>": (96, 5, 36, 195),
+    # queries of five to eight records (round 5): twice the per-list state - 23 KB of LDS queues per two-wave workgroup (3 waves
+    # per SIMD) and the wave-uniform per-list words of 7 other lists in scalar registers (spilled to VGPR lanes); no scratch
+    "ps::k_daat_z<2, false, 8>": (128, 3, 0, 560),
     "ps::k_score<0, 2, false, false, 8>": (128, 4, 0, 115),
     "ps::k_score<1, 2, false, false, 8>": (128, 4, 0, 125),
     # known debt, frozen: the single-field latency kernel of C1
     "ps::k_score<0, 1, false, false, 8>": (130, 3, 0, 95),
     "ps::k_score<0, 1, false, false, 4>": (130, 3, 0, 95),
-    "ps::k_prep_query": (80, 6, 288, 0),  # (the 288 bytes are the frame of prep_query_general, out of line, for plans of > 4 entries)
-    "ps::k_zprep_query": (48, 8, 0, 0),
+    "ps::k_prep_query": (80, 6, 352, 0),  # (the 336 bytes are the frame of prep_query_general, out of line, for plans of > 4 entries)
+    "ps::k_zprep_query<4>": (48, 8, 0, 0),
+    "ps::k_zprep_query<8>": (64, 8, 0, 0),
     "ps::k_zprep_items": (48, 8, 0, 0),
     "ps::k_prep_items": (32, 8, 0, 0),
     "ps::k_merge_items": (40, 8, 0, 0),

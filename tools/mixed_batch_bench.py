@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""What a zero_to_one batch costs when a few of its queries are not for K1dz (five terms: more than 4 lists): split
-between K1dz and the streaming kernels (PS_DAAT_Z_SPLIT=1, default) against the whole batch on the streaming kernels (0).
-C3's corpus, 1024-query batches, `--other` of them five-term queries.  One JSON line per leg."""
+"""What a batch costs when some of its queries are wider than the narrow pruning kernels take (five terms: more than 4 lists).
+C3's corpus, 1024-query batches, `--other` of them five-term queries (1024: every query).  zero_to_one: K1dz's wide instantiation
+(k_daat_z<F, WC, 8>, PS_DAAT_Z=1) against the streaming kernels (PS_DAAT_Z=0); BM25 (`--scorer bm25`): the batch split between
+k_daat_small and k_daat (PS_DAAT_SPLIT=1) against the whole batch on k_daat (0).  One JSON line per leg."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import probly_search_amd as psa
@@ -11,13 +12,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--other", type=int, default=32)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--n-docs", type=int, default=0)
+ap.add_argument("--scorer", default="zero_to_one")
 args = ap.parse_args()
 cfg = dict(synth.CONFIGS["C3"])
 if args.n_docs:
     cfg["n_docs"] = args.n_docs
 corpus = synth.Corpus(**cfg)
 snap = synth.fill(psa.Index(2), corpus).snapshot(device=0)
-sc, K, B = psa.zero_to_one.new(), 10, 1024
+bm25 = args.scorer == "bm25"
+sc, K, B = (psa.bm25.new() if bm25 else psa.zero_to_one.new()), 10, 1024
+knob = b"PS_DAAT_SPLIT" if bm25 else b"PS_DAAT_Z"
 batches = []
 for s in range(4):
     qs = corpus.queries(B, 3, salt=s)
@@ -28,12 +32,12 @@ for s in range(4):
 buf = psd._DeviceBuffer(psd.block_bytes(B, K))
 L = psa.load()
 for leg in (1, 0, 1, 0):
-    L.ps_set_option(b"PS_DAAT_Z_SPLIT", leg)
+    L.ps_set_option(knob, leg)
     for w in range(3):
         snap.query_batch_allgather_flat(None, *batches[w % 4], sc, [1.0, 1.0], K, buf.ptr.value, buf.ptr.value, stream=None)
     t0 = time.perf_counter()
     for i in range(args.steps):
         snap.query_batch_allgather_flat(None, *batches[i % 4], sc, [1.0, 1.0], K, buf.ptr.value, buf.ptr.value, stream=None)
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
-    print(json.dumps({"PS_DAAT_Z_SPLIT": leg, "other_queries": args.other, "ms_per_1024_query_batch_synchronous": round(ms, 3),
+    print(json.dumps({knob.decode(): leg, "kernel": snap.kernel_breakdown()["score_kernel"], "other_queries": args.other, "ms_per_1024_query_batch_synchronous": round(ms, 3),
                       "queries_per_s": round(B / ms * 1e3)}))
