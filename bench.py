@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-queries", type=int, default=24, help="bounded CPU-baseline sample (queries, 1 thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scorer", default="", help="override: bm25 | zero_to_one")
+    ap.add_argument("--q-terms", type=int, default=0, help="override the config's terms per query (e.g. 5: queries of more than 4 lists)")
     ap.add_argument("--device-plan", action="store_true",
                     help="call the explicit device-planner entry (ps_snapshot_query_batch_device_planned_flat; N=1).  The default "
                          "entry already plans BM25 batches on the device (PS_DEVICE_PLAN=1)")
@@ -165,6 +166,8 @@ def main():
         cfg["n_docs"] = args.n_docs
     if args.scorer:
         cfg["scorer"] = args.scorer
+    if args.q_terms:
+        cfg["q_terms"] = args.q_terms
     # per-rank batch: the config's batch at N=1; C4's 8192-query batch is 1024 per GPU at 8 GPUs
     B = args.batch or min(cfg["batch"], 1024)
     K = cfg["top_k"]
@@ -712,7 +715,7 @@ def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layo
             from derive_roofline import kernel_source_hash
             fresh = d.get("kernel_sources_sha16") == kernel_source_hash(ROOT)
             same = (d.get("kernel") == kernel and d.get("config") == args.config and d.get("scorer") == cfg["scorer"]
-                    and bool(d.get("resident_rows")) == bool(args.resident_rows) and not args.n_docs and not args.batch)
+                    and bool(d.get("resident_rows")) == bool(args.resident_rows) and not args.n_docs and not args.batch and not args.q_terms)
             drv = d if (same and fresh) else None
             if not same:
                 out["derivation_skipped"] = "profiles/roofline_%s.json was made for kernel %r / another setup" % (

@@ -295,6 +295,7 @@ struct EngineImpl {
     hipEvent_t prepared = nullptr; // behind the batch's preparation (preparation stream)
     hipEvent_t counted = nullptr;  // behind the planner's count pass (planning stream)
     hipEvent_t scored = nullptr;   // behind the batch's k_daat (scoring stream)
+    hipEvent_t scored2 = nullptr;  // a split batch: behind the second part's kernel on the other scoring stream (the first stream waits for it)
     bool busy = false;
     PlanSet plan;                  // device-planned batches
     DevBuf<unsigned char> stage;   // host-planned batches: entries | qbeg | qterms_len as uploaded
@@ -486,7 +487,7 @@ Engine::~Engine() {
     c.cand_score.release(); c.rows.release(); c.gthr.release();
     for (void* p : {(void*)c.ctl, (void*)c.work, (void*)c.row_state, (void*)c.row_desc})
       if (p) (void)hipFree(p);
-    for (hipEvent_t e : {c.done, c.entry, c.prepared, c.counted, c.scored})
+    for (hipEvent_t e : {c.done, c.entry, c.prepared, c.counted, c.scored, c.scored2})
       if (e) (void)hipEventDestroy(e);
   }
   if (m.prep_stream) (void)hipStreamDestroy(m.prep_stream);
@@ -1247,6 +1248,7 @@ EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
     PS_HIP(hipEventCreateWithFlags(&c.prepared, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.counted, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.scored, hipEventDisableTiming));
+    PS_HIP(hipEventCreateWithFlags(&c.scored2, hipEventDisableTiming));
     PS_HIP(hipEventCreateWithFlags(&c.plan.h.done, hipEventDisableTiming));
     PS_HIP(hipMalloc((void**)&c.ctl, sizeof(PrepCtl)));
     PS_HIP(hipMalloc((void**)&c.work, 256));
@@ -2129,16 +2131,23 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     if (zb) launch_daat_z(m, kp, S, zb->zn);
     else if (split_kinds) {
       uint32_t* split_at = &c.ctl->bucket_start[PREP_SET_BUCKETS];  // first item of the second kind, as k_prep_query's last wave counted it
+      // the two parts are independent (disjoint queries): the second one goes to the OTHER scoring stream - a hardware queue of
+      // its own -, so its few long items start with the launch instead of behind the first part's tail (one stream, one after
+      // the other, 32 five-term queries among 1024: 0.91 ms per synchronous batch against 0.77 for the whole batch on k_daat)
+      hipStream_t S2 = S == m.score_stream ? m.score_stream_lo : m.score_stream;
+      PS_HIP(hipStreamWaitEvent(S2, c.prepared, 0));
+      KParams kb = kp;
+      kb.n_ditems = (uint32_t)n_items_big;
+      kb.item_split_dev = split_at;
+      launch_daat(m, kb, multi, false, m.n_cu, S2);
+      PS_HIP(hipEventRecord(c.scored2, S2));
+      const std::string big_name = m.score_kernel_name;
       KParams ks = kp;
       ks.n_ditems = (uint32_t)(n_items - n_items_big);
       ks.n_ditems_dev = split_at;
       launch_daat(m, ks, false, true, m.n_cu, S);
-      const std::string small_name = m.score_kernel_name;
-      KParams kb = kp;
-      kb.n_ditems = (uint32_t)n_items_big;
-      kb.item_split_dev = split_at;
-      launch_daat(m, kb, multi, false, m.n_cu, S);
-      m.score_kernel_name = small_name + " + " + m.score_kernel_name;
+      PS_HIP(hipStreamWaitEvent(S, c.scored2, 0));
+      m.score_kernel_name += " + " + big_name;
     } else launch_daat(m, kp, multi, max_entries <= (uint32_t)DAAT_SMALL_MAX, m.n_cu, S);
 #ifdef PS_ITEM_TRACE
     {  // profiling builds: the items' start / end times of this launch -> $PS_ITEM_TRACE_FILE (last batch wins)

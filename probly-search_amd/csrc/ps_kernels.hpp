@@ -407,6 +407,25 @@ __device__ __forceinline__ void dense_row_block(const KParams& p, double* rows, 
     }
     return;
   }
+  if (p.splane != nullptr) {
+    // K1d batches: tfn * idf of every (posting, field) already sits in the boost-free score plane (k_list_bounds, the list's own
+    // idf = rd.idf) - the row is the rest of the same expression, ((tfn * idf) * boost_x) * expansion_boost summed over the fields
+    // in order (a field with tf == 0 adds +0.0): the same bits without the two f64 divisions per field
+    for (uint32_t i = pb + threadIdx.x; i < pe; i += blockDim.x) {
+      const uint64_t pi = rd.post_off + i;
+      const uint32_t d = p.doc[pi];
+      double s = 0.0;
+      if (p.F == 2u) {
+        const double2 v = reinterpret_cast<const double2*>(p.splane)[pi];
+        s = (v.x * p.boost[0]) * rd.eb;
+        s += (v.y * p.boost[1]) * rd.eb;
+      } else {
+        for (uint32_t x = 0; x < p.F; ++x) s += (p.splane[pi * p.F + x] * p.boost[x]) * rd.eb;
+      }
+      row[d] = s;
+    }
+    return;
+  }
   for (uint32_t i = pb + threadIdx.x; i < pe; i += blockDim.x) {
     const uint64_t pi = rd.post_off + i;
     double s = 0.0;

@@ -416,6 +416,7 @@ def test_dense_rows_first_written_last_fused(fuse, fields, monkeypatch):
     monkeypatch.setenv("PS_DENSE_MIN_DENSITY_PCT", "30")  # only the head lists become rows: mixed plans
     monkeypatch.setenv("PS_DAAT_DENSE_MIN_DENSITY_PCT", "30")
     monkeypatch.setenv("PS_DENSE_FUSE", fuse)
+    psa.load().ps_set_option(b"PS_DAAT_Z", 0)  # (the zero_to_one half is here for the streaming kernels' rows: K1dz - which takes queries of up to 8 lists - reads none; reset by conftest)
     cfg = dict(synth.CONFIGS["C2" if fields == 2 else "C1"], n_docs=6_000, vocab=300)
     corpus = synth.Corpus(**cfg)
     p, o = synth.fill(psa.Index(fields), corpus), synth.fill(orc.Index(fields), corpus)

@@ -35,9 +35,11 @@ for leg in (1, 0, 1, 0):
     L.ps_set_option(knob, leg)
     for w in range(3):
         snap.query_batch_allgather_flat(None, *batches[w % 4], sc, [1.0, 1.0], K, buf.ptr.value, buf.ptr.value, stream=None)
+    snap.kernel_breakdown(reset=True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         snap.query_batch_allgather_flat(None, *batches[i % 4], sc, [1.0, 1.0], K, buf.ptr.value, buf.ptr.value, stream=None)
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
-    print(json.dumps({knob.decode(): leg, "kernel": snap.kernel_breakdown()["score_kernel"], "other_queries": args.other, "ms_per_1024_query_batch_synchronous": round(ms, 3),
-                      "queries_per_s": round(B / ms * 1e3)}))
+    kt = snap.kernel_breakdown(reset=True)
+    print(json.dumps({knob.decode(): leg, "kernel": kt["score_kernel"], "other_queries": args.other, "ms_per_1024_query_batch_synchronous": round(ms, 3),
+                      "scoring_kernels_ms_per_batch": round(kt["score_busy_ms"] / max(1, kt["launches"]), 4), "queries_per_s": round(B / ms * 1e3)}))
