@@ -61,6 +61,8 @@ def parse_args(argv=None):
                     help="skip the leg that alternates two fields_boost vectors between steps (reported as alternating_boosts)")
     ap.add_argument("--no-streaming-leg", action="store_true",
                     help="skip the untimed-for-headline K1 k_score leg (PS_DAAT=0) reported under roofline.streaming_kernel_leg")
+    ap.add_argument("--plan-ahead-depth", type=int, default=2,
+                    help="batches announced ahead of their query calls (ps_snapshot_plan_ahead_flat; the library takes up to PS_PLAN_AHEAD_DEPTH)")
     ap.add_argument("--no-plan-ahead", action="store_true",
                     help="do not announce the next batch to the library (ps_snapshot_plan_ahead_flat): every step then waits for its own "
                          "planner totals (~0.25 ms of host time per step, hidden only while three batches are in flight)")
@@ -273,13 +275,24 @@ def main():
             if hip.hipHostGetDevicePointer(ctypes.byref(dp), ctypes.c_void_p(hb.data_ptr()), 0) == 0 and dp.value:
                 host_dev_ptr[i] = dp.value
 
+    pending = []  # batches announced to the library and not asked for yet, oldest first (by identity)
+
     def step(batch, i, boosts=boosts, nxt=None):
-        """One step.  nxt: the batch of the NEXT step - announced to the library right after this one is enqueued
-        (ps_snapshot_plan_ahead_flat: a serving loop's double-buffered submission), so that its planner count pass runs
-        beside this step's scoring and the next call does not wait for the plan's totals."""
+        """One step.  nxt: the batches of the NEXT steps, in order - announced to the library right after this one is enqueued
+        (ps_snapshot_plan_ahead_flat: a serving loop's submission queue, `--plan-ahead-depth` batches deep), so that their
+        planner count passes run beside this step's scoring and the calls that follow do not wait for their plans' totals."""
+        if pending and pending[0] is batch:
+            pending.pop(0)
+        else:
+            del pending[:]  # (the library drops announcements that are not asked for in order)
         _step(batch, i, boosts)
         if nxt is not None and not args.no_plan_ahead:
-            snap.plan_ahead_flat(nxt[0], nxt[1], scorer, boosts)
+            for b in (nxt if isinstance(nxt, list) else [nxt]):
+                if any(b is p_ for p_ in pending):
+                    continue
+                if len(pending) >= args.plan_ahead_depth or not snap.plan_ahead_flat(b[0], b[1], scorer, boosts):
+                    break
+                pending.append(b)
 
     def _step(batch, i, boosts):
         text, offsets = batch
@@ -312,7 +325,7 @@ def main():
     L.ps_set_option(b"PS_WORK_COUNTERS", 0)
     L.ps_set_option(b"PS_KERNEL_TIMERS", 0)  # (no HIP timing events between the launches of the timed region either)
     for s in range(args.warmup):
-        step(packed[s], s, nxt=packed[s + 1] if s + 1 < n_total else None)
+        step(packed[s], s, nxt=packed[s + 1:s + 1 + args.plan_ahead_depth])
     fence()
     snap.kernel_breakdown(reset=True)
     snap.work_counters(reset=True)
@@ -327,7 +340,7 @@ def main():
     t_start = time.perf_counter()
     for s in range(args.warmup, n_total):
         ts = time.perf_counter()
-        step(packed[s], s, nxt=packed[s + 1] if s + 1 < n_total else None)
+        step(packed[s], s, nxt=packed[s + 1:s + 1 + args.plan_ahead_depth])
         st = snap.last_stats()
         postings += st["postings_visited"]
         layout_bytes += st["layout_bytes"]
@@ -347,7 +360,7 @@ def main():
     fence()
     t_dev0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + n_dev):
-        step(packed[s], s, nxt=packed[s + 1] if s + 1 < args.warmup + n_dev else None)
+        step(packed[s], s, nxt=packed[s + 1:min(s + 1 + args.plan_ahead_depth, args.warmup + n_dev)])
     fence()
     elapsed_dev = (time.perf_counter() - t_dev0) / n_dev
     if world > 1:
@@ -433,7 +446,7 @@ def main():
             "p50_single_query_ms": float(np.median(single) * 1e3) if single else None,
             "p50_batch_submit_ms": float(np.median(lat) * 1e3),
             "host_plan_ms_per_step": plan_ms / steps,
-            "host_plan_note": (("device-planned, every batch announced one step ahead (ps_snapshot_plan_ahead_flat): what is left of the host's "
+            "host_plan_note": (("device-planned, every batch announced %d steps ahead (ps_snapshot_plan_ahead_flat): what is left of the host's " % args.plan_ahead_depth +
                                 "wait for the planner's totals" if not args.no_plan_ahead else
                                 "device-planned: the host's wait for the planner's totals (one sync per batch)")
                                if dev_planned else "host planner: tokenise + expand + before_each on the host"),
@@ -463,12 +476,12 @@ def main():
 
             def boost_leg(vec_of):
                 for s_ in range(3):
-                    step(packed[s_], s_, vec_of(s_), nxt=packed[s_ + 1])
+                    step(packed[s_], s_, vec_of(s_), nxt=packed[s_ + 1:s_ + 1 + args.plan_ahead_depth])
                 fence()
                 rc_ = 0
                 t0_ = time.perf_counter()
                 for s_ in range(n):
-                    step(packed[-1 - s_], s_, vec_of(3 + s_), nxt=packed[-2 - s_] if s_ + 1 < n else None)
+                    step(packed[-1 - s_], s_, vec_of(3 + s_), nxt=[packed[-2 - s_ - j] for j in range(args.plan_ahead_depth) if s_ + 1 + j < n])
                     rc_ += snap.last_stats()["bounds_recomputed"]
                 fence()
                 return time.perf_counter() - t0_, rc_

@@ -309,7 +309,10 @@ ps_status ps_snapshot_query_batch(ps_snapshot* snap, const ps_scorer_desc* score
 /* Device-resident batched top-k for multi-GPU plumbing: results stay in HBM so the caller can
  * all-gather them over RCCL.  d_keys: u64[B*top_k], d_scores: f64[B*top_k], d_counts: u32[B]
  * (device pointers on the snapshot's device; unused slots are key=~0, score=0).  `hip_stream`
- * is a hipStream_t (NULL = the snapshot's own stream); the call returns after enqueueing when a
+ * is a hipStream_t (NULL = the snapshot's own stream - a NON-BLOCKING stream of the library: the call is then synchronous, and it is
+ * NOT ordered with work the caller enqueued on the legacy default stream (handle 0, which is what e.g.
+ * torch.cuda.current_stream().cuda_stream returns unless a stream was made current): zero-fills of the output block issued there must
+ * have completed - synchronise, or pass a real stream handle); the call returns after enqueueing when a
  * stream is given and all work is ordered on it.  Batches of one snapshot execute one after the
  * other even when they are enqueued on different streams (they share the snapshot's per-batch
  * device buffers; the library orders them with an event).  1 <= top_k <= PS_MAX_DEVICE_TOPK. */
@@ -322,8 +325,10 @@ ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc
 /* Pipelined submission (optional): announce the NEXT flat top-k batch (BM25, or zero_to_one) this snapshot will be asked to score.  The
  * library copies the text and starts the device planner's count pass at once, beside the batches still being scored;
  * the flat query call that follows with byte-identical (text, offsets) finds the plan's totals ready instead of waiting
- * ~0.25 ms for them.  One batch can be announced at a time; any other call in between simply drops it (nothing is
- * ever scored from an announced batch that was not asked for).  *accepted = 0 when the batch would not be planned on
+ * ~0.25 ms for them.  Up to PS_PLAN_AHEAD_DEPTH (3) batches may be announced, and they are asked for in the order they were
+ * announced (*accepted = 0 when the queue is full: nothing is dropped then); any other query call in between - another text, a
+ * host-planned or full-result batch, a knob changed through ps_set_option - simply drops them (nothing is ever scored from an
+ * announced batch that was not asked for).  *accepted = 0 when the batch would not be planned on
  * the device anyway (custom scorers, small batches).  src/query.rs:21-27 is still what the
  * query call mirrors; this is the async half of a server's double-buffered submission loop. */
 ps_status ps_snapshot_plan_ahead_flat(ps_snapshot* snap, const ps_scorer_desc* scorer, const char* text, const uint64_t* offsets,

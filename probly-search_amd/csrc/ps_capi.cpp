@@ -636,9 +636,13 @@ ps_status ps_snapshot_query_batch_device_planned_flat(ps_snapshot* snap, const p
     const double t0 = wall_ms();
     ps_batch_stats stats;
     if (!snap->engine->run_device_planned(*scorer, fields_boost, text, offsets, n_queries, top_k, d_keys, d_scores, d_counts,
-                                          hip_stream, stats))
-      return ps::run_device_flat(snap, scorer, text, offsets, n_queries, fields_boost, n_boost, nullptr, nullptr, top_k, d_keys, d_scores,
-                                 d_counts, hip_stream);  // (a zero_to_one batch K1dz does not take: the host planner)
+                                          hip_stream, stats)) {
+      // (a zero_to_one batch K1dz does not take whole: straight to the host planner - run_device_flat would ask the device
+      // planner a second time: another count pass and another host wait before the same answer)
+      std::vector<std::string_view> qs(n_queries);
+      for (size_t i = 0; i < n_queries; ++i) qs[i] = std::string_view(text + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
+      return run_device_views(snap, scorer, qs, fields_boost, n_boost, nullptr, nullptr, top_k, d_keys, d_scores, d_counts, hip_stream);
+    }
     stats.total_ms = wall_ms() - t0;
     set_stats(snap, stats);
     return PS_OK;

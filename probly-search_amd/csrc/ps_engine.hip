@@ -36,6 +36,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <deque>
 #include <map>
 #include <memory>
 #include <thread>
@@ -161,6 +162,7 @@ struct Tuning {
   uint32_t daat_split = 1;       // PS_DAAT_SPLIT: a BM25 K1d batch that holds queries k_daat_small takes AND others (more than 4 lists, several expansions of a term) is scored by both kernels, each over its part of the item array (0: one such query sends the whole batch to k_daat)
   uint32_t daat_sample_all = 0;  // PS_DAAT_SAMPLE_ALL: ... every K1d BM25 launch does (C2 / C4: slower)
   uint32_t dctx = 5;             // PS_DCTX: K1d batch contexts in the rotation (<= N_DCTX)
+  uint32_t plan_ahead_depth = 3; // PS_PLAN_AHEAD_DEPTH: batches that may be announced at a time (ps_snapshot_plan_ahead_flat)
   uint32_t score_alt = 1;        // PS_SCORE_ALT: consecutive K1d batches alternate between the scoring stream and a second one at the LOWEST stream priority (1) - a hardware queue of its own, whose kernel fills what the other's tail leaves free (two streams of one priority share a queue and serialise: 3); 0: one scoring stream; 2: everything on the low-priority stream; 4: three-way rotation normal / low / high.  Round 5, same box: C2 0.3025 -> 0.289 ms per step, C3 0.363 -> 0.312, C4 1.118 -> 0.940, C5 1.585 -> 1.213
   uint32_t device_plan = 1;      // PS_DEVICE_PLAN: flat BM25 top-k batches (built-in tokenizer) are planned by k_plan on the device
   void load();
@@ -330,7 +332,11 @@ struct EngineImpl {
   PlanTotals* d_totals_mapped = nullptr;
   // A batch announced ahead of its query call (Engine::plan_ahead): its text is in the context's pinned slot, its
   // count pass is in flight or done.  The next device-planned call with the same text picks it up.
-  struct Ahead { bool valid = false; int ctx = -1; size_t B = 0, n_bytes = 0; uint64_t tune_gen = 0; } ahead;  // tune_gen: the knobs its count pass chunked the lists with
+  // Several may be announced (oldest first; PS_PLAN_AHEAD_DEPTH): the host's loop - wait for a batch's totals, enqueue it, announce
+  // the next - is a chain of latencies (count pass under a running k_daat 30-160 us, the wake-up, ~100 us of enqueueing), and with one
+  // batch announced that chain, not the GPU, paced C2 (streams idle between kernels; kernel timeline, round 5).
+  struct Ahead { int ctx = -1; size_t B = 0, n_bytes = 0; uint64_t tune_gen = 0; };  // tune_gen: the knobs its count pass chunked the lists with
+  std::deque<Ahead> aheads;
   KTimer* last_kt_pending = nullptr;  // full-result path: the timer of the batch being enqueued
   uint64_t last_layout_bytes = 0;  // of the most recently staged batch
   uint32_t last_rows = 0, last_rows_built = 0;
@@ -547,7 +553,7 @@ void Engine::apply_delta(const DeltaRanges& r, std::vector<uint64_t>& removed_df
   std::lock_guard<std::mutex> lock(m.mu);
   PS_HIP(hipSetDevice(m.device));
   PS_HIP(hipDeviceSynchronize());  // no batch of this snapshot is in flight while its planes change
-  m.ahead.valid = false;           // (a batch announced ahead was counted against the old trie: its query call plans again)
+  m.aheads.clear();                // (batches announced ahead were counted against the old trie: their query calls plan again)
   uint64_t up = 0;
   auto put = [&](void* dst, const void* src, size_t bytes) {
     if (!bytes) return;
@@ -810,6 +816,7 @@ void Tuning::load() {
     work_counters = env_u32("PS_WORK_COUNTERS", work_counters);
     kernel_timers = env_u32("PS_KERNEL_TIMERS", kernel_timers);
     score_alt = env_u32("PS_SCORE_ALT", score_alt);
+    plan_ahead_depth = std::max(1u, env_u32("PS_PLAN_AHEAD_DEPTH", plan_ahead_depth));
     daat_sample_div = env_u32("PS_DAAT_SAMPLE_DIV", daat_sample_div);
     daat_sample_all = env_u32("PS_DAAT_SAMPLE_ALL", daat_sample_all);
     daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
@@ -1213,16 +1220,18 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
 // Drops a batch that was announced ahead (Engine::plan_ahead) and never asked for: its context goes back into the
 // rotation behind its count pass.
 void drop_ahead(EngineImpl& m) {
-  if (!m.ahead.valid) return;
-  m.ahead.valid = false;
-  EngineImpl::DaatCtx& c = m.dctx[m.ahead.ctx];
-  PS_HIP(hipEventRecord(c.done, m.plan_stream));  // (whoever gets the context next waits for the abandoned count pass)
-  c.busy = true;
+  for (const auto& a : m.aheads) {
+    EngineImpl::DaatCtx& c = m.dctx[a.ctx];
+    PS_HIP(hipEventRecord(c.done, m.plan_stream));  // (whoever gets the context next waits for the abandoned count pass)
+    c.busy = true;
+  }
+  m.aheads.clear();
 }
 
 // The next K1d batch context (they alternate); the two streams, its events and control blocks exist from first use.
 EngineImpl::DaatCtx& acquire_ctx(EngineImpl& m) {
-  if (m.ahead.valid && m.next_dctx == m.ahead.ctx) drop_ahead(m);  // (the rotation came round to an announced batch nobody asked for)
+  for (const auto& a : m.aheads)
+    if (a.ctx == m.next_dctx) { drop_ahead(m); break; }  // (the rotation came round to an announced batch nobody asked for)
   if (!m.prep_stream) {
     // the preparation stream at the highest priority: a queue of its own (queues are pooled per priority),
     // and its small kernels do not wait behind the tens of thousands of workgroups of a running k_daat
@@ -2494,7 +2503,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
       TT("k1dz batch");
       return;
     }
-    // A mixed batch: the queries K1dz takes (simple, <= 4 lists) go there, the others through the streaming kernels -
+    // A mixed batch: the queries K1dz takes (simple, <= 8 lists) go there, the others through the streaming kernels -
     // two sub-batches, each kernel's merge writing its queries' rows of the caller's block (KParams::out_row).  (Whole, the
     // batch would take the streaming kernels: 2.1 ms against 0.36 ms on C3's shape.)
     if (m.tune.daat && m.tune.daat_z && m.tune.daat_z_split && B >= m.tune.daat_min_batch && m.snap->F <= 4 && m.snap->n_ids > 0) {
@@ -2503,9 +2512,19 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
       if (rows_a.size() >= m.tune.daat_min_batch && !rows_b.empty()) {
         const Plan plan_a = sub_plan_of(plan, rows_a), plan_b = sub_plan_of(plan, rows_b);
         if (enqueue_daat_z_host(m, sc, boosts, plan_a, top_k, d_keys, d_scores, d_counts, st, &rows_a)) {
-          enqueue_topk(m, sc, boosts, plan_b, top_k, d_keys, d_scores, d_counts, st, sync_path, &rows_b);
-          TT("split batch");
-          return;
+          bool second_ok = true;
+          try {
+            enqueue_topk(m, sc, boosts, plan_b, top_k, d_keys, d_scores, d_counts, st, sync_path, &rows_b);
+          } catch (const std::exception&) {
+            // (staging the second half failed - an allocation, a length limit - with the first half already in flight: the
+            // caller's block must not stay half-written, so the WHOLE batch goes through the streaming kernels below; they
+            // wait for the K1dz context and write every row, the first half's with the same bits)
+            second_ok = false;
+          }
+          if (second_ok) {
+            TT("split batch");
+            return;
+          }
         }
       }
     }
@@ -2781,15 +2800,16 @@ PlanTotals device_plan(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
 // The context of a batch announced ahead, if this is that batch (same query count, same offsets, same text);
 // otherwise the announced batch is dropped (its context goes back into the rotation behind its count pass).
 EngineImpl::DaatCtx* take_ahead(EngineImpl& m, const char* text, const uint64_t* offsets, size_t B) {
-  if (!m.ahead.valid) return nullptr;
-  EngineImpl::DaatCtx& c = m.dctx[m.ahead.ctx];
-  if (offsets != nullptr && m.ahead.B == B) {
+  if (m.aheads.empty()) return nullptr;
+  const EngineImpl::Ahead ah = m.aheads.front();  // (announcements are taken in the order they were made)
+  EngineImpl::DaatCtx& c = m.dctx[ah.ctx];
+  if (offsets != nullptr && ah.B == B) {
     const size_t n_bytes = B ? (size_t)offsets[B] : 0, off_bytes = (B + 1) * 8, text_at = (off_bytes + 15) & ~(size_t)15;
     // (a knob changed since the announcement - ps_set_option; refresh_tuning ran just before this - means the count
     // pass's item total was computed under another chunking rule than the preparation kernels will apply: plan again)
-    if (m.ahead.tune_gen == m.tune_gen && m.ahead.n_bytes == n_bytes && memcmp(c.plan.h.p, offsets, off_bytes) == 0 &&
+    if (ah.tune_gen == m.tune_gen && ah.n_bytes == n_bytes && memcmp(c.plan.h.p, offsets, off_bytes) == 0 &&
         (n_bytes == 0 || memcmp(c.plan.h.p + text_at, text, n_bytes) == 0)) {
-      m.ahead.valid = false;
+      m.aheads.pop_front();
       // what acquire_ctx orders for a fresh context, for whatever was enqueued since the announcement: a k_score /
       // full-result batch still in flight shares the engine's per-batch buffers and tables
       if (m.tail_pending) {
@@ -2866,14 +2886,19 @@ bool Engine::plan_ahead(const ps_scorer_desc& sc, const char* text, const uint64
   refresh_tuning(m);
   if (!(m.tune.device_plan && m.tune.daat && B >= m.tune.daat_min_batch)) return false;
   if (z && !(m.tune.daat_z && m.snap->F <= 4 && m.snap->n_ids > 0)) return false;  // (the count pass is the same for both scorers)
-  (void)take_ahead(m, nullptr, nullptr, (size_t)-1);  // (at most one batch is announced at a time)
+  // (announced batches each hold a context: at most plan_ahead_depth of them, and never so many that the rotation comes round)
+  if (m.aheads.size() >= std::min<size_t>(m.tune.plan_ahead_depth, m.tune.dctx > 2 ? m.tune.dctx - 2 : 1)) return false;
+  static const bool trace_host = env_u32("PS_TRACE_HOST", 0) != 0;
+  const double t0 = now_ms();
   EngineImpl::DaatCtx& c = acquire_ctx(m);
   device_plan_begin(m, c, text, offsets, B);
-  m.ahead.valid = true;
-  m.ahead.ctx = (int)(&c - m.dctx);
-  m.ahead.B = B;
-  m.ahead.n_bytes = B ? (size_t)offsets[B] : 0;
-  m.ahead.tune_gen = m.tune_gen;
+  if (trace_host) fprintf(stderr, "[ps host] announce ctx %d: %.3f ms\n", (int)(&c - m.dctx), now_ms() - t0);
+  EngineImpl::Ahead a;
+  a.ctx = (int)(&c - m.dctx);
+  a.B = B;
+  a.n_bytes = B ? (size_t)offsets[B] : 0;
+  a.tune_gen = m.tune_gen;
+  m.aheads.push_back(a);
   return true;
 }
 
@@ -2907,10 +2932,16 @@ bool Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   // host planner (false), before or after the count pass has classified the queries
   if (z && !(m.tune.daat && m.tune.daat_z && m.tune.device_plan && B >= m.tune.daat_min_batch && s.F <= 4 && s.n_ids > 0)) return false;
   if (z) ensure_dev_z_bounds(m);
+  static const bool trace_host = env_u32("PS_TRACE_HOST", 0) != 0;  // (stderr: where the submitting thread's time goes, per call)
   EngineImpl::DaatCtx* announced = take_ahead(m, text, offsets, B);
+  const double ta = now_ms();
   EngineImpl::DaatCtx& c = announced ? *announced : acquire_ctx(m);
   if (!announced) device_plan_begin(m, c, text, offsets, B);
+  const double tb = now_ms();
+  const bool was_ready = hipEventQuery(c.counted) == hipSuccess;
   const PlanTotals tot = device_plan_totals(m, c);
+  if (trace_host) fprintf(stderr, "[ps host] ctx %d announced %d ready %d: take %.3f begin %.3f totals %.3f ms\n", (int)(&c - m.dctx), announced ? 1 : 0,
+                          was_ready ? 1 : 0, ta - t0, tb - ta, now_ms() - tb);
   if (z && !(tot.n_entries && tot.max_entries <= (uint32_t)Z_MAX_LISTS && !(tot.multi & PLAN_Z_NOT_SIMPLE) && tot.n_items &&
              tot.n_items < 0x3FFFFFF0ull)) {
     PS_HIP(hipEventRecord(c.done, m.plan_stream));  // (the context goes back into the rotation behind its count pass)
@@ -3016,6 +3047,7 @@ bool Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
   stats.postings_visited = tot.postings;
   stats.algorithmic_bytes = tot.postings * (4 + 8 * (uint64_t)s.F) + (uint64_t)B * top_k * 16;
   stats.plan_ms = t1 - t0;  // device planner incl. its one synchronisation (of the context's stream)
+  if (trace_host) fprintf(stderr, "[ps host] call %.3f ms (plan part %.3f, enqueue %.3f)\n", now_ms() - t0, t1 - t0, now_ms() - t1);
   stats.device_planned = 1;
   stats.bounds_recomputed = m.last_bounds_recomputed ? 1u : 0u;
   if (!stream) {
