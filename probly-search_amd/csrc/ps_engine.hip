@@ -2266,7 +2266,7 @@ void launch_daat_z(EngineImpl& m, KParams& kp, hipStream_t st, int zn) {
   const uint32_t n_wg = (kp.n_ditems + DAAT_WGW - 1) / DAAT_WGW;
   char nm[64];
   const bool wide = zn > DAAT_SMALL_MAX;
-  snprintf(nm, sizeof(nm), wide ? "ps::k_daat_z<%d, %s, 8>" : "ps::k_daat_z<%d, %s>", (int)std::min(kp.F, 4u), m.tune.work_counters ? "true" : "false");
+  snprintf(nm, sizeof(nm), wide ? "ps::k_daat_z<%d, %s, 8>" : "ps::k_daat_z<%d, %s, 4>", (int)std::min(kp.F, 4u), m.tune.work_counters ? "true" : "false");  // (the demangled symbols: what a profiler prints)
   m.score_kernel_name = nm;
 #define PS_Z(FV)                                                                                                  \
   do {                                                                                                            \
