@@ -196,7 +196,7 @@ def test_batches_announced_ahead():
     run(5, bufs[4])                                   # announced 4, asked for 5
     run(4, bufs[5])                                   # ... then 4 after all (planned afresh)
     snap.plan_ahead_flat(*packed[6], sc)
-    snap.plan_ahead_flat(*packed[7], sc)              # announced twice: the first is dropped
+    snap.plan_ahead_flat(*packed[7], sc)              # two announced, the SECOND asked for first: out of order - both are dropped
     run(7, bufs[6])
     snap.plan_ahead_flat(*packed[6], sc)
     run(0, bufs[7], scorer=z)                         # another scorer and another batch in between
@@ -216,6 +216,45 @@ def test_batches_announced_ahead():
         exp = want_z if is_z else want[i]
         assert [[(k, bits(s)) for k, s in rs] for rs in got] == exp, (i, is_z)
     hip.hipStreamDestroy(st)
+
+
+def test_several_batches_announced_in_a_row_and_scoring_stream_variants():
+    """The announcement queue (PS_PLAN_AHEAD_DEPTH, 3): three batches announced, then asked for in order - each finds its count
+    pass done; a fourth announcement is refused (accepted = 0) without dropping anything.  And every way of placing consecutive
+    batches on the scoring streams (PS_SCORE_ALT 0 / 1 / 2 / 3 / 4) returns the same bits."""
+    hip = psd._DeviceBuffer.hip()
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    cfg = dict(synth.CONFIGS["C2"], n_docs=60_000, vocab=3_000)
+    corpus = synth.Corpus(**cfg)
+    snap = synth.fill(psa.Index(2), corpus).snapshot(device=0)
+    sc, K, B = psa.bm25.new(), 10, 96
+    batches = [corpus.queries(B, 3, salt=170 + s) for s in range(6)]
+    packed = [synth.pack_queries(b) for b in batches]
+    want = [[[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(b, sc, None, [1.0, 1.0], top_k=K)] for b in batches]
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    L = psa.load()
+    try:
+        for alt in (1, 0, 2, 3, 4):
+            L.ps_set_option(b"PS_SCORE_ALT", alt)
+            bufs = [psd._DeviceBuffer(psd.block_bytes(B, K)) for _ in batches]
+            snap.query_batch(batches[0][:8], sc, None, [1.0, 1.0], top_k=K)  # (the knob is read at the next batch; drops stale announcements)
+            assert [snap.plan_ahead_flat(*packed[i], sc) for i in range(4)] == [True, True, True, False]
+            for i in range(6):
+                text, offsets = packed[i]
+                snap.query_batch_allgather_flat(None, text, offsets, sc, [1.0, 1.0], K, bufs[i].ptr.value, bufs[i].ptr.value, stream=st.value)
+                assert snap.last_stats()["device_planned"] == 1
+                if i + 3 < 6:
+                    assert snap.plan_ahead_flat(*packed[i + 3], sc) is True
+            assert hip.hipStreamSynchronize(st) == 0
+            for i, buf in enumerate(bufs):
+                got = psd.unpack_blocks(buf.to_host(), 1, B, K, [B])
+                assert [[(k, bits(s)) for k, s in rs] for rs in got] == want[i], (alt, i)
+    finally:
+        L.ps_set_option(b"PS_SCORE_ALT", 1)
+        hip.hipStreamDestroy(st)
 
 
 def test_work_counters_of_a_batch():
