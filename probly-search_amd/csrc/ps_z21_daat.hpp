@@ -357,7 +357,11 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   __shared__ uint32_t q_i[DAAT_WGW][QCAP];        // ... its posting within the own list
   __shared__ uint32_t q_w[F_][DAAT_WGW][QCAP];    // ... the own posting's packed {tf, field length} words
   __shared__ uint32_t q_rel[NO][DAAT_WGW][QCAP];  // ... per other list: posting within that list (bitmap hit), REL_MAYBE (filter), REL_NONE
-  __shared__ double btab[DAAT_WGW][NE][Z_FLN];    // B(m, fl), m = 1..NE
+  // B(m, fl), m = 1..NE - tabulated per item for the narrow instantiation; the wide one (whose per-list queue planes already take
+  // 15 KB per workgroup) recomputes the column of its lane whenever a threshold changes: the table's 8 KB are the difference
+  // between 3 and 4 waves per SIMD there
+  constexpr bool BTAB = ZN <= DAAT_SMALL_MAX;
+  __shared__ double btab[DAAT_WGW][BTAB ? NE : 1][BTAB ? Z_FLN : 1];
   // Reach queue (wave-private LDS ring): the postings that passed the scan's integer test - a few percent of the lanes
   // of a trip - wait here until 64 are together; the first level of the other lists (address arithmetic, filter
   // hashes, the loads, the tightening) then runs with every lane busy instead of four times per trip for a handful
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
     }
   }
   // ---- bound table of this item: B(m, fl) for m = 1..ne records and fl = lane ----
-  {
+  if constexpr (BTAB) {
     double env[NE];
 #pragma unroll
     for (int j = 0; j < NE; ++j) env[j] = (uint32_t)j < ne ? p.z_ubnum[e0 + j] : 0.0;
@@ -430,9 +434,26 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   auto set_flmax = [&](const double ts, const double tt) __attribute__((always_inline)) {
     flmax[0] = z_beats(0.0, ts, tt) ? Z_ALL : Z_NONE;
     flmax_s[0] = z_beats(0.0, ts, 0.0) ? Z_ALL : Z_NONE;
+    double col[NE];  // (wide instantiation) the lane's column of the table, by the table's own operations in the same order
+    if constexpr (!BTAB) {
+      double env[NE];
+#pragma unroll
+      for (int j = 0; j < NE; ++j) env[j] = (uint32_t)j < ne ? p.z_ubnum[e0 + j] : 0.0;
+#pragma unroll
+      for (int j = NE - 2; j >= 0; --j) env[j] = fmax(env[j], env[j + 1]);
+      const uint32_t den_u = (uint32_t)lane > qtl ? (uint32_t)lane : qtl;
+      const double den = (double)den_u;
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        if ((uint32_t)j < ne) acc += env[j] / den;
+        col[j] = acc;
+      }
+    }
 #pragma unroll
     for (int m = 1; m <= NE; ++m) {
-      const double bv = btab[wave][m - 1][lane];
+      double bv;
+      if constexpr (BTAB) bv = btab[wave][m - 1][lane]; else bv = col[m - 1];
       const int n_ok = (int)__popcll(__ballot(z_beats(bv, ts, tt)));  // B is non-increasing in fl: the lanes that pass are a prefix
       flmax[m] = n_ok == WAVE ? Z_ALL : n_ok - 1;
       const int n_s = (int)__popcll(__ballot(z_beats(bv, ts, 0.0)));
