@@ -48,6 +48,9 @@ namespace ps {
 #ifndef PS_DAAT_ZPF
 #define PS_DAAT_ZPF 0  // 1: the next trip's own postings are requested before this trip's lookups (measured: no gain, 12-18 more VGPRs)
 #endif
+#ifndef PS_DAAT_Z_BTAB
+#define PS_DAAT_Z_BTAB 1  // 0: the narrow instantiation recomputes its bound-table column too (A/B builds)
+#endif
 constexpr int Z_LEVELS = 3;
 constexpr int Z_MAX_LISTS = 8;                 // most records of a query K1dz takes (k_daat_z<F, WC, 8>; <= DAAT_SMALL_MAX: the narrow instantiation)
 constexpr uint32_t ZITEM_LEVEL_SHIFT = 30;     // DItem::count bits 30-31: levels l (the lowest ones) with every document of the chunk at or above D_l
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_z(const KParams p) {
   // B(m, fl), m = 1..NE - tabulated per item for the narrow instantiation; the wide one (whose per-list queue planes already take
   // 15 KB per workgroup) recomputes the column of its lane whenever a threshold changes: the table's 8 KB are the difference
   // between 3 and 4 waves per SIMD there
-  constexpr bool BTAB = ZN <= DAAT_SMALL_MAX;
+  constexpr bool BTAB = PS_DAAT_Z_BTAB && ZN <= DAAT_SMALL_MAX;
   __shared__ double btab[DAAT_WGW][BTAB ? NE : 1][BTAB ? Z_FLN : 1];
   // Reach queue (wave-private LDS ring): the postings that passed the scan's integer test - a few percent of the lanes
   // of a trip - wait here until 64 are together; the first level of the other lists (address arithmetic, filter
