@@ -21,8 +21,11 @@
 //                    tags; per tile harvest into a register-resident wave top-K with a per-query
 //                    threshold shared through one device-scope word.  No barriers after the LUT
 //                    load, no inter-wave atomics on scores: bit-reproducible.
-//   K1d k_daat       BM25 top-k batches: exact dynamic pruning (per-list upper bounds, essential lists,
-//                    document-at-a-time lookups), one wave per chunk of a list; K3d k_merge_items behind it
+//   K1d k_daat_small / k_daat   BM25 top-k batches: exact dynamic pruning (per-list upper bounds, essential lists,
+//                    document-at-a-time lookups), one wave per chunk of a list; K3d k_merge_items behind it.  A batch
+//                    that holds queries of both kinds is scored by both kernels; consecutive batches' kernels share
+//                    the chip on two scoring streams (normal / low priority); the score plane they read is boost-free
+//   K1dz k_daat_z    the same for zero_to_one (ps_z21_daat.hpp): queries of <= 4 lists, or <= 8 (wide instantiation)
 //   K2  k_z21        zero_to_one general case (same node under two query terms, version layers)
 //   K3  k_merge      per query: merge of the per-run top-K lists, doc id -> key
 //   K4  ps_sort.hip  full-result mode: canonical (score desc, key asc) order on the device
