@@ -49,6 +49,7 @@
 #include <string>
 
 #include "ps_engine.hpp"
+#include "ps_bounds.hpp"
 #include "ps_errors.hpp"
 #include "ps_kernels.hpp"
 #include "ps_prep_kernels.hpp"
@@ -957,43 +958,7 @@ void ensure_dev_trie(EngineImpl& m);  // (defined with the device planner below)
 // while the parameters stay what they were, and a boost vector seen recently finds its J array resident.
 struct BoundsRef { const double* M; const double* J; const double* plane; const double* H; uint32_t h_lo; double h_a, h_b; };
 
-// The PREP_NDIR directions of the two-field joint bound (ps_prep_kernels.hpp): angles 0 .. 90 degrees in equal steps.
-inline void bound_dir(int d, double& c, double& sn) {
-  if (d == 0) { c = 1.0; sn = 0.0; return; }
-  if (d == PREP_NDIR - 1) { c = 0.0; sn = 1.0; return; }
-  const double th = (3.14159265358979323846 / 2.0) * (double)d / (double)(PREP_NDIR - 1);
-  c = std::cos(th); sn = std::sin(th);
-}
-// boosts (two positive finite numbers) as a conic combination of the two directions around them: lo, a, b with
-// a * w_lo + b * w_(lo+1) >= boosts componentwise (verified below; inflated by what the solve may have rounded away), so that
-// a * H[lo] + b * H[lo+1] bounds boosts . v for every point v >= 0 of a list.
-inline void boost_cone(const double* boosts, uint32_t& lo, double& a, double& b) {
-  const double b0 = boosts[0], b1 = boosts[1];
-  const double th = std::atan2(b1, b0), step = (3.14159265358979323846 / 2.0) / (double)(PREP_NDIR - 1);
-  int d = (int)std::floor(th / step);
-  d = std::max(0, std::min(PREP_NDIR - 2, d));
-  for (int tries = 0; tries < 3; ++tries) {
-    double c0, s0, c1, s1;
-    bound_dir(d, c0, s0); bound_dir(d + 1, c1, s1);
-    const double det = c0 * s1 - s0 * c1;
-    double al = (b0 * s1 - b1 * c1) / det, be = (c0 * b1 - s0 * b0) / det;
-    if (al < 0.0 && d > 0 && tries < 2) { --d; continue; }                  // (rounding put the angle one sector off)
-    if (be < 0.0 && d < PREP_NDIR - 2 && tries < 2) { ++d; continue; }
-    al = std::max(al, 0.0); be = std::max(be, 0.0);
-    const double r0 = al * c0 + be * c1, r1 = al * s0 + be * s1;
-    double scale = 1.0;
-    if (!(r0 >= b0)) scale = std::max(scale, b0 / r0);
-    if (!(r1 >= b1)) scale = std::max(scale, b1 / r1);
-    if (!(scale >= 1.0) || !std::isfinite(scale)) break;
-    scale *= 1.0 + 1e-12;
-    lo = (uint32_t)d; a = al * scale; b = be * scale;
-    if (std::isfinite(a) && std::isfinite(b)) return;
-    break;
-  }
-  // (cannot happen for the boosts K1d admits - positive and finite; the per-field sum of maxima is always valid)
-  lo = 0; a = b0; b = b1 * 1e308;  // b * H[1] = +inf for any list with field-1 postings: min(ub_m, ub_j) keeps ub_m
-}
-
+static_assert(BOUND_NDIR == PREP_NDIR, "host and device agree on the directions of the two-field joint bound");
 BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const KParams& kp, hipStream_t st) {
   const Snapshot& s = *m.snap;
   EngineImpl::ListBounds& lb = m.bounds;

@@ -187,7 +187,9 @@ __device__ __forceinline__ double prep_entry_ub(const PrepParams& pp, const ps_p
     const double* h = pp.bound_h + (size_t)e.node * PREP_NDIR;
     jb = pp.h_a * h[pp.h_lo] + pp.h_b * h[pp.h_lo + 1];
   } else return ub_m;  // (one field: the per-field form is the maximum itself)
-  const double ub_j = (e.idf * e.boost) * jb * (1.0 + 1e-12);
+  // (the relative inflation covers the few roundings between the real-number bound and the computed scores; among SUBNORMAL
+  // products - boosts of 1e-320 are admitted - a rounding is an absolute 2^-1074 that no factor restores: 256 of them on top)
+  const double ub_j = (e.idf * e.boost) * jb * (1.0 + 1e-12) + 0x1p-1066;
   return fmin(ub_m, ub_j);
 }
 

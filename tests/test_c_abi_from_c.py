@@ -58,3 +58,13 @@ def test_c99_caller_of_the_key_table(tmp_path):
                     "-L", CSRC, "-lprobly_search_amd", "-Wl,-rpath," + CSRC], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_boost_cone_dominates_every_boost_vector(tmp_path):
+    """tests/c_abi/bounds_check.cpp: the host side of the two-field joint bound (csrc/ps_bounds.hpp) - for 200 000 boost vectors
+    from subnormal to 1e300 the two-direction combination dominates the vector componentwise, and the interpolated bound
+    dominates b . v on random point sets.  Plain C++, no device."""
+    exe = str(tmp_path / "bounds_check")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", os.path.join(ROOT, "tests", "c_abi", "bounds_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr

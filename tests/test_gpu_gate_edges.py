@@ -50,6 +50,8 @@ ADMITTED = [
     ({}, [5e-324, 1.0]),                  # subnormal boost: products underflow to 0 -> score() returns None for that field
     ({}, [1e300, 1e-300]),
     ({}, [1e300, 1e300]),
+    ({}, [3e-322, 2e-322]),               # both subnormal: every product is a subnormal or 0, a rounding is an absolute 2^-1074
+    ({}, [2.5e-308, 1e-310]),             # at the edge of the normal range
 ]
 REJECTED = [
     ({"k1": -0.5}, [1.0, 1.0]),           # negative k1: tfn no longer monotone
