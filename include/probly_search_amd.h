@@ -313,9 +313,12 @@ ps_status ps_snapshot_query_batch(ps_snapshot* snap, const ps_scorer_desc* score
  * NOT ordered with work the caller enqueued on the legacy default stream (handle 0, which is what e.g.
  * torch.cuda.current_stream().cuda_stream returns unless a stream was made current): zero-fills of the output block issued there must
  * have completed - synchronise, or pass a real stream handle); the call returns after enqueueing when a
- * stream is given and all work is ordered on it.  Batches of one snapshot execute one after the
- * other even when they are enqueued on different streams (they share the snapshot's per-batch
- * device buffers; the library orders them with an event).  1 <= top_k <= PS_MAX_DEVICE_TOPK. */
+ * stream is given and all work is ordered on it.  Top-k batches of the pruning kernels (>= 8 queries) run in the snapshot's batch
+ * contexts (5 in the rotation): several are in flight at once - the preparation of the next beside the scoring of the
+ * current ones, consecutive scoring kernels sharing the chip on two hardware queues - whatever streams they were
+ * enqueued on; what a caller can rely on is that a call's output block is complete once its stream has passed the
+ * point of the call.  The other batches (streaming kernels, full-result mode) execute one after the other (they share
+ * one set of per-batch device buffers; the library orders them with an event).  1 <= top_k <= PS_MAX_DEVICE_TOPK. */
 #define PS_MAX_DEVICE_TOPK 64
 ps_status ps_snapshot_query_batch_device(ps_snapshot* snap, const ps_scorer_desc* scorer, const ps_str* queries,
                                          size_t n_queries, const double* fields_boost, size_t n_boost,
