@@ -161,7 +161,6 @@ struct Tuning {
   uint32_t daat_z_levels = 3;    // PS_DAAT_Z_LEVELS: how many of them (1..3)
   uint32_t daat_z_split = 1;     // PS_DAAT_Z_SPLIT: a zero_to_one batch with queries K1dz does not take is split (those to the streaming kernels) instead of taking the streaming kernels whole
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
-  uint32_t daat_split_first = 0; // PS_DAAT_SPLIT_FIRST: a query's SHORTEST list (its first-ranked one: every chunk runs, and the longest of them are a launch's critical path) is cut into at most this many chunks (0: like the others, PS_DAAT_SPLIT_DIV)
   uint32_t daat_sample_div = 24; // PS_DAAT_SAMPLE_DIV: multi-expansion K1d launches (k_daat<F, true>: C5) start with the chunks below doc id ~ N / this, of every rank (0: plain rank-major order)
   uint32_t daat_split = 1;       // PS_DAAT_SPLIT: a BM25 K1d batch that holds queries k_daat_small takes AND others (more than 4 lists, several expansions of a term) is scored by both kernels, each over its part of the item array (0: one such query sends the whole batch to k_daat)
   uint32_t daat_sample_all = 0;  // PS_DAAT_SAMPLE_ALL: ... every K1d BM25 launch does (C2 / C4: slower)
@@ -780,8 +779,6 @@ bool result_block_release(void* p) {
   return true;
 }
 
-inline uint32_t split_first_of(const Tuning& t) { return t.daat_split_first ? std::max(t.daat_split_first, t.daat_split_div) : t.daat_split_div; }
-
 void Tuning::load() {
     dense_max_rows = env_u32("PS_DENSE_MAX_ROWS", dense_max_rows);
     row_cache_mb = env_u32("PS_ROW_CACHE_MB", row_cache_mb);
@@ -825,7 +822,6 @@ void Tuning::load() {
     daat_sample_all = env_u32("PS_DAAT_SAMPLE_ALL", daat_sample_all);
     daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
     dctx = std::max(2u, std::min((uint32_t)N_DCTX, env_u32("PS_DCTX", dctx)));
-    daat_split_first = env_u32("PS_DAAT_SPLIT_FIRST", daat_split_first);
     daat_z_d0_div = env_u32("PS_DAAT_Z_D0_DIV", daat_z_d0_div);
     daat_z_level_shift = env_u32("PS_DAAT_Z_LEVEL_SHIFT", daat_z_level_shift);
     daat_z_levels = env_u32("PS_DAAT_Z_LEVELS", daat_z_levels);
@@ -1148,7 +1144,7 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   memset(&pp, 0, sizeof(pp));
   pp.plan = d_plan; pp.qbeg = d_qbeg;
   pp.B = (uint32_t)B; pp.ne = (uint32_t)ne; pp.F = s.F; pp.multi = multi ? 1u : 0u;
-  pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div; pp.split_first = split_first_of(m.tune);
+  pp.chunk_min = m.tune.daat_chunk; pp.split_div = m.tune.daat_split_div;
   pp.table = m.d_table;
   pp.split_kinds = split_kinds ? 1u : 0u;
   pp.sample_small = m.tune.daat_sample_all;
@@ -1255,21 +1251,18 @@ size_t count_daat_items(const EngineImpl& m, const Plan& plan, uint32_t* max_slo
   size_t n = 0, nb = 0;
   uint32_t mx = 0;
   const size_t B = plan.qbeg.size() - 1;
-  const uint32_t sf = split_first_of(m.tune);
   auto chunks = [&](uint32_t len, uint32_t div) {
     const uint32_t c = std::max<uint32_t>(m.tune.daat_chunk, ((len + div - 1) / div + 255) & ~255u);
     return (len + c - 1) / c;
   };
   for (size_t q = 0; q < B; ++q) {
-    uint32_t sl = 0, mn = 0xFFFFFFFFu;
+    uint32_t sl = 0;
     bool big = plan.qbeg[q + 1] - plan.qbeg[q] > (uint32_t)DAAT_SMALL_MAX;  // PLAN_BIG's rule (k_plan, k_prep_query)
     for (uint32_t i = plan.qbeg[q]; i < plan.qbeg[q + 1]; ++i) {
       const uint32_t len = plan.entries[i].len;
       sl += chunks(len, m.tune.daat_split_div);
-      mn = std::min(mn, len);
       if (i > plan.qbeg[q] && plan.entries[i].qterm == plan.entries[i - 1].qterm) big = true;
     }
-    if (mn != 0xFFFFFFFFu && mn && sf != m.tune.daat_split_div) sl += chunks(mn, sf) - chunks(mn, m.tune.daat_split_div);  // (the query's shortest list: prep_fine_entry)
     n += sl;
     if (big) nb += sl;
     mx = std::max(mx, sl);
@@ -2717,7 +2710,7 @@ void device_plan_begin(EngineImpl& m, EngineImpl::DaatCtx& c, const char* text, 
   ps_.tok_node.ensure(B * (size_t)WAVE + 1);
   hipLaunchKernelGGL((k_plan<false>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, nullptr,
                      nullptr, ps_.cnt.p, ps_.qtl.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, nullptr, ps_.items.p, m.tune.daat_chunk,
-                     m.tune.daat_split_div, ps_.tok_node.p, 0u, split_first_of(m.tune));
+                     m.tune.daat_split_div, ps_.tok_node.p, 0u);
   // (the totals are written straight into pinned, device-mapped host memory: no copy-engine transfer to wait for)
   const int ci = (int)(&c - m.dctx);
   hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(WAVE), 0, st, ps_.cnt.p, ps_.nterms.p, ps_.multi.p, ps_.post.p, ps_.items.p, (uint32_t)B,
@@ -2750,7 +2743,7 @@ void device_plan_fill(EngineImpl& m, EngineImpl::DaatCtx& c, size_t B, const Pla
   const uint32_t blocks = (uint32_t)((B + PLAN_WAVES - 1) / PLAN_WAVES);
   hipLaunchKernelGGL((k_plan<true>), dim3(std::max(1u, blocks)), dim3(WAVE * PLAN_WAVES), 0, st, t, d_qtext, d_qoff, (uint32_t)B, ps_.qbeg.p,
                      ps_.entries.p, nullptr, nullptr, nullptr, nullptr, nullptr, ps_.qorder.p, nullptr, m.tune.daat_chunk,
-                     m.tune.daat_split_div, ps_.tok_node.p, zmode, m.tune.daat_split_div);
+                     m.tune.daat_split_div, ps_.tok_node.p, zmode);
   PS_HIP(hipGetLastError());
 }
 

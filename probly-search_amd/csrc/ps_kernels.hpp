@@ -2819,7 +2819,7 @@ template <bool FILL>
 __device__ __forceinline__ void plan_token(const DevTrie& t, const int64_t fn, const uint32_t tok_bytes, const uint32_t qord, const uint32_t qi,
                                            const uint32_t chunk_min, const uint32_t split_div, ps_plan_entry* entries, uint32_t w,
                                            uint32_t& here, unsigned long long& postings, uint32_t& items, const uint32_t zmode = 0u,
-                                           uint32_t* layered = nullptr, uint32_t* minlen = nullptr) {
+                                           uint32_t* layered = nullptr) {
   here = 0; postings = 0; items = 0;
   if (layered) *layered = 0u;
   if (fn < 0) return;
@@ -2860,7 +2860,6 @@ __device__ __forceinline__ void plan_token(const DevTrie& t, const int64_t fn, c
         uint32_t c = ((la.z + split_div - 1) / split_div + 255u) & ~255u;
         c = c > chunk_min ? c : chunk_min;
         items += (la.z + c - 1) / c;
-        if (minlen && la.z < *minlen) *minlen = la.z;
       }
       postings += la.z;
       ++here;
@@ -2874,24 +2873,13 @@ __device__ __forceinline__ void plan_token(const DevTrie& t, const int64_t fn, c
   }
 }
 
-// The query's SHORTEST list (its first-ranked one but for odd boosts; every chunk of it runs) may be cut into up to `split_first`
-// chunks instead of `split_div` (k_prep_query applies the same rule to the first entry of that length): the items that adds.
-__device__ __forceinline__ uint32_t plan_extra_items(const uint32_t minlen, const uint32_t chunk_min, const uint32_t split_div, const uint32_t split_first) {
-  if (minlen == 0xFFFFFFFFu || minlen == 0u || split_first == split_div) return 0u;
-  uint32_t c = ((minlen + split_div - 1) / split_div + 255u) & ~255u;
-  c = c > chunk_min ? c : chunk_min;
-  uint32_t f = ((minlen + split_first - 1) / split_first + 255u) & ~255u;
-  f = f > chunk_min ? f : chunk_min;
-  return (minlen + f - 1) / f - (minlen + c - 1) / c;
-}
-
 // A whole query by one thread (queries of more than 64 tokens; k_plan's wave hands them to its lane 0).
 template <bool FILL>
 __device__ __noinline__ void plan_query_seq(const DevTrie& t, const char* s, const uint32_t qb, const uint32_t qe, const uint32_t q,
                                             const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt, uint32_t* q_terms_len,
                                             uint32_t* q_nterms, uint32_t* q_multi, unsigned long long* q_postings, uint32_t* q_items,
-                                            const uint32_t chunk_min, const uint32_t split_div, const uint32_t zmode, const uint32_t split_first) {
-  uint32_t n_tokens = 0, qord = 0, n_ent = 0, multi = PLAN_Z_NOT_SIMPLE, items = 0, minlen = 0xFFFFFFFFu;  // (K1dz does not take these queries: not classified here)
+                                            const uint32_t chunk_min, const uint32_t split_div, const uint32_t zmode) {
+  uint32_t n_tokens = 0, qord = 0, n_ent = 0, multi = PLAN_Z_NOT_SIMPLE, items = 0;  // (K1dz does not take these queries: not classified here)
   unsigned long long postings = 0;
   uint32_t w = FILL ? qbeg[q] : 0u;
   // s.split(' ') (lib.rs:42-44): k separators -> k + 1 tokens; empty ones are skipped but counted (query.rs:32-35)
@@ -2903,7 +2891,7 @@ __device__ __noinline__ void plan_query_seq(const DevTrie& t, const char* s, con
     if (te > tb) {
       uint32_t here, it;
       unsigned long long po;
-      plan_token<FILL>(t, dev_find_node(t, s, tb, te), te - tb, qord, qi, chunk_min, split_div, entries, w, here, po, it, zmode, nullptr, &minlen);
+      plan_token<FILL>(t, dev_find_node(t, s, tb, te), te - tb, qord, qi, chunk_min, split_div, entries, w, here, po, it, zmode);
       w += here; postings += po; items += it;
       if (here > 1) multi |= PLAN_MULTI;
       n_ent += here;
@@ -2918,7 +2906,7 @@ __device__ __noinline__ void plan_query_seq(const DevTrie& t, const char* s, con
     q_nterms[q] = qord;
     q_multi[q] = multi;
     q_postings[q] = postings;
-    q_items[q] = items + plan_extra_items(minlen, chunk_min, split_div, split_first);
+    q_items[q] = items;
   }
 }
 
@@ -2932,8 +2920,7 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
                                           const uint32_t* qbeg, ps_plan_entry* entries, uint32_t* q_cnt,
                                           uint32_t* q_terms_len, uint32_t* q_nterms, uint32_t* q_multi,
                                           unsigned long long* q_postings, uint32_t* qorder, uint32_t* q_items,
-                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node, const uint32_t zmode,
-                                          const uint32_t split_first) {
+                                          const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node, const uint32_t zmode) {
   __shared__ uint32_t sh_tb[PLAN_WAVES][WAVE], sh_te[PLAN_WAVES][WAVE];
   const uint32_t wv = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const uint32_t q = blockIdx.x * PLAN_WAVES + wv;
@@ -2967,7 +2954,7 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
   ++n_tokens;  // the last token (k separators -> k + 1 tokens)
   if (overflow) {  // more than 64 tokens: one lane walks the query
     if (lane == 0) {
-      plan_query_seq<FILL>(t, s, qb, qe, q, qbeg, entries, q_cnt, q_terms_len, q_nterms, q_multi, q_postings, q_items, chunk_min, split_div, zmode, split_first);
+      plan_query_seq<FILL>(t, s, qb, qe, q, qbeg, entries, q_cnt, q_terms_len, q_nterms, q_multi, q_postings, q_items, chunk_min, split_div, zmode);
       if (FILL) qorder[q] = q;
     }
     return;
@@ -2986,8 +2973,8 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
   uint32_t here = 0, items = 0;
   unsigned long long postings = 0;
   if (!FILL) {
-    uint32_t layered = 0, minlen = 0xFFFFFFFFu;
-    if (nonempty) plan_token<false>(t, fn, te - tb, qord, lane, chunk_min, split_div, nullptr, 0u, here, postings, items, 0u, &layered, &minlen);
+    uint32_t layered = 0;
+    if (nonempty) plan_token<false>(t, fn, te - tb, qord, lane, chunk_min, split_div, nullptr, 0u, here, postings, items, 0u, &layered);
     // zero_to_one's K1dz takes "simple" queries only (PLAN_Z_NOT_SIMPLE): no term with several layers; and, if any query
     // term has several expansions, no term reached by two query terms - the expansions of a node are a contiguous range
     // of term ordinals, so two query terms can share a term only where their ranges intersect
@@ -3005,7 +2992,6 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
     unsigned long long po = postings;
     for (int o = 32; o > 0; o >>= 1) {
       n_ent += __shfl_xor(n_ent, o); multi |= __shfl_xor(multi, o); it += __shfl_xor(it, o); po += __shfl_xor(po, o);
-      minlen = min(minlen, (uint32_t)__shfl_xor((int)minlen, o));
     }
     if (n_ent > PLAN_SMALL_MAX || (multi & PLAN_MULTI)) multi |= PLAN_BIG;
     if (lane == 0) {
@@ -3014,7 +3000,7 @@ __device__ __forceinline__ void plan_wave(const DevTrie& t, const char* text, co
       q_nterms[q] = (uint32_t)__popcll(ne_mask);
       q_multi[q] = multi;
       q_postings[q] = po;
-      q_items[q] = it + plan_extra_items(minlen, chunk_min, split_div, split_first);
+      q_items[q] = it;
     }
   } else {
     // entries of token i go behind those of the tokens before it: the counts again (cheap: no trie walk),
@@ -3068,9 +3054,9 @@ __global__ __launch_bounds__(WAVE * PLAN_WAVES) void k_plan(const DevTrie t, con
                                                           uint32_t* q_terms_len, uint32_t* q_nterms, uint32_t* q_multi,
                                                           unsigned long long* q_postings, uint32_t* qorder, uint32_t* q_items,
                                                           const uint32_t chunk_min, const uint32_t split_div, int32_t* tok_node,
-                                                          const uint32_t zmode, const uint32_t split_first) {
+                                                          const uint32_t zmode) {
   plan_wave<FILL>(t, text, offsets, B, qbeg, entries, q_cnt, q_terms_len, q_nterms, q_multi, q_postings, qorder, q_items, chunk_min,
-                  split_div, tok_node, zmode, split_first);
+                  split_div, tok_node, zmode);
 }
 
 // Plan upload without the copy engine: the staged batch is read from the pinned, device-mapped

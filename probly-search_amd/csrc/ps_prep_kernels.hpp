@@ -64,7 +64,6 @@ struct PrepParams {
   const uint32_t* table;     // tile-offset tables (the sample phase finds a list's first posting at or above D0 there)
   uint32_t sample_small;     // the sample phase also for the queries k_daat_small takes in a split batch (PS_DAAT_SAMPLE_ALL)
   uint32_t split_kinds;      // the batch is split between k_daat_small and k_daat: the items of the PLAN_BIG queries take the second bucket set
-  uint32_t split_first;      // most chunks of a query's shortest list (the first entry of that length in plan order)
   double boost[MAX_F];
   // per-list bounds (k_list_bounds)
   const double* bound_m;     // [n_layers][F]
@@ -197,20 +196,8 @@ __device__ __forceinline__ uint32_t prep_chunk_of(const uint32_t split_div, cons
   const uint32_t c = ((len + split_div - 1) / split_div + 255u) & ~255u;
   return c > chunk_min ? c : chunk_min;
 }
-__device__ __forceinline__ uint32_t prep_chunk(const PrepParams& pp, const uint32_t len, const bool fine = false) {
-  return prep_chunk_of(fine ? pp.split_first : pp.split_div, pp.chunk_min, len);
-}
-// The entry of a query that gets the finer chunking: its shortest list (first in plan order among equals) - in practice the
-// first-ranked one, every chunk of which runs; a rule of the lengths alone, so the planner's count pass (plan_extra_items)
-// and the host (count_daat_items) size the launch exactly without knowing the bounds.
-__device__ __forceinline__ uint32_t prep_fine_entry(const PrepParams& pp, const uint32_t b, const uint32_t n) {
-  uint32_t fine = 0xFFFFFFFFu, mn = 0xFFFFFFFFu;
-  if (pp.split_first != pp.split_div)
-    for (uint32_t i = 0; i < n; ++i) {
-      const uint32_t len = pp.plan[b + i].len;
-      if (len < mn) { mn = len; fine = i; }
-    }
-  return fine;
+__device__ __forceinline__ uint32_t prep_chunk(const PrepParams& pp, const uint32_t len) {
+  return prep_chunk_of(pp.split_div, pp.chunk_min, len);
 }
 __device__ __forceinline__ uint32_t prep_bucket_in_set(const uint32_t rank, const uint32_t len, const bool short_first) {
   if (rank <= 1) {  // 64 length classes, log2 with one fractional bit
@@ -255,8 +242,7 @@ __device__ __forceinline__ bool prep_before(const double ua, const uint32_t la, 
 }
 
 template <int NMAX>
-__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, const uint32_t fine,
-                                                     uint32_t& groups) {
+__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, uint32_t& groups) {
   double ub[NMAX];
   uint32_t len[NMAX], grp[NMAX], rank[NMAX], qt[NMAX];
 #pragma unroll
@@ -340,14 +326,14 @@ __device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const
         dg._pad[0] = dg._pad[1] = dg._pad[2] = 0;
         pp.dgroup[b + i] = dg;
       }
-      const uint32_t c = prep_chunk(pp, len[i], (uint32_t)i == fine);
+      const uint32_t c = prep_chunk(pp, len[i]);
       slots += (len[i] + c - 1) / c;
     }
   }
   return slots;
 }
 
-__device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, const uint32_t fine) {
+__device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n) {
   // bounds; dense ordinal of every entry's query term (the entries of a term are adjacent in plan order)
   uint32_t n_groups = 0, cur = 0xFFFFFFFFu;
   for (uint32_t i = 0; i < n; ++i) {
@@ -424,7 +410,7 @@ __device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const 
   uint32_t slots = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t len = pp.plan[b + i].len;
-    const uint32_t c = prep_chunk(pp, len, i == fine);
+    const uint32_t c = prep_chunk(pp, len);
     slots += (len + c - 1) / c;
   }
   return slots;
@@ -531,9 +517,8 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
   uint32_t slots = 0;
   // (plans of <= 4 entries - one list per query term: C2, C4 - entirely in registers; wider ones walk their arrays in HBM.
   // An 8-entry register variant cost this kernel 145 VGPRs and 58 SGPR spills for every batch: 76 / 0 without it.)
-  const uint32_t fine = prep_fine_entry(pp, b, n);
   uint32_t groups = 0;
-  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n, fine, groups) : prep_query_general(pp, q, b, n, fine);
+  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n, groups) : prep_query_general(pp, q, b, n);
   // PLAN_BIG's rule (k_plan): more than 4 lists, or several lists under one query term -> k_daat's part of the batch
   const bool big = pp.split_kinds && (n > 4u || groups != n);
   // candidate slots: query-major within the query; the wave's queries take one block of the batch's slots
@@ -547,7 +532,7 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
     uint32_t bk = 0, bs = 0, nc = 0, ns = 0, cd = NO_CAND;
     if (on) {
       const ps_plan_entry& en = pp.plan[b + i];
-      const uint32_t c = prep_chunk(pp, en.len, i == fine);
+      const uint32_t c = prep_chunk(pp, en.len);
       nc = (en.len + c - 1) / c;
       ns = (big || !pp.split_kinds || pp.sample_small) ? prep_sample_chunks(pp, en, c, nc) : 0u;
       pp.gen[b + i] = DItemGen{big ? 1u : 0u, ns, c, sl};  // (`entry`: gen is indexed by entry - the word carries the query's kind)
