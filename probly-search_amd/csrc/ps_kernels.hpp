@@ -2271,9 +2271,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
 #ifndef PS_DAAT_US
 #define PS_DAAT_US 4   // postings per lane in flight
 #endif
-#ifndef PS_DAAT_STEP2
-#define PS_DAAT_STEP2 0  // 1: first level in two steps - the highest-bound lower-ranked list, then the rest for what it left alive (measured: row lookups 11.9 M -> 6.2 M per C2 launch, kernel 0.290 -> 0.327 ms: the extra dependency level costs more than the requests it saves)
-#endif
 #ifndef PS_EXP
 #define PS_EXP 0       // profiling builds only (wrong results): 1 = no top-K offers, 2 = no second level, 4 = no first-level loads
 #endif
@@ -2371,17 +2368,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   for (int k = 0; k < NO; ++k)
     if ((uint32_t)k + 1u < ne && o_rank[k] > own_rank) others += o_ub[k];
   others *= SLACK;
-  int k_first = -1;          // the highest-bound list ranked below the own one
-  double others_rest = 0.0;  // ... and what the remaining lower-ranked lists can add
-  {
-    double best = -1.0;
-#pragma unroll
-    for (int k = 0; k < NO; ++k)
-      if ((uint32_t)k + 1u < ne && o_rank[k] > own_rank && o_ub[k] > best) { best = o_ub[k]; k_first = k; }
-#pragma unroll
-    for (int k = 0; k < NO; ++k)
-      if ((uint32_t)k + 1u < ne && o_rank[k] > own_rank && k != k_first) others_rest += o_ub[k];
-  }
   TopK tk;
   tk.s = -1.0; tk.d = 0xFFFFFFFFu; tk.n = 0; tk.thr_s = 0.0; tk.thr_d = 0;
   double published = 0.0;
@@ -2526,10 +2512,9 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
       ws.reached += nr;
     }
     // ---- first level of the other lists for the documents that passed: dense-row value, {bits, rank} bitmap cell, or
-    // the sparse list's Bloom-filter word.  The launch is bound by the rate of scattered requests that miss L2
-    // (profiles/r04_fetch_size_calibration.txt: ~43 G/s, whatever their width), so the list that can add most - the
-    // highest-bound one ranked below the own list - is asked first, and only the documents it leaves alive ask the rest
-    // (PS_DAAT_STEP2; 0: every list at once, one dependency level less) ----
+    // the sparse list's Bloom-filter word - every list at once, all loads in flight together.  (Asking the highest-bound lower-ranked
+    // list first and the rest only for what it leaves alive halves the row lookups and was measured slower twice, rounds 4 and 5:
+    // the extra dependency level costs more than the requests it saves) ----
     uint2 fl[NO][U];
 #pragma unroll
     for (int k = 0; k < NO; ++k)
@@ -2565,31 +2550,8 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
         }
       }
     };
-    if (PS_DAAT_STEP2 && k_first >= 0) {
 #pragma unroll
-      for (int k = 0; k < NO; ++k)
-        if (k == k_first) first_level(k, rch);
-      bool rch2[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        double c1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < NO; ++k) {
-          if (k == k_first) {
-            if (o_shift[k] & DENSE_FLAG) c1 = __hiloint2double((int)fl[k][u].y, (int)fl[k][u].x);
-            else if (o_bm[k] != 0xFFFFFFFFu) c1 = ((fl[k][u].x >> (d[u] & 31u)) & 1u) ? o_ub[k] : 0.0;
-            else c1 = fl[k][u].x != 0u ? o_ub[k] : 0.0;
-          }
-        }
-        rch2[u] = rch[u] && ((s_own[u] + c1 + others_rest) * SLACK >= theta);
-      }
-#pragma unroll
-      for (int k = 0; k < NO; ++k)
-        if (k != k_first) first_level(k, rch2);
-    } else {
-#pragma unroll
-      for (int k = 0; k < NO; ++k) first_level(k, rch);
-    }
+    for (int k = 0; k < NO; ++k) first_level(k, rch);
     // ---- what the first level already tells: exact row values, bitmap membership, filter misses ----
 #pragma unroll
     for (int u = 0; u < U; ++u) {
