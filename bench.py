@@ -499,6 +499,25 @@ def main():
                                                  "what": "every step passes a fields_boost vector no earlier step used ([1 + 0.013 i, 1 / (1 + 0.007 i)]): "
                                                          "nothing is recomputed over the postings and no batch waits for another to leave "
                                                          "scoring (`bounds_recomputed` counts the steps that had to run k_list_bounds)"}
+            if not args.resident_rows:
+                # The library's DEFAULT keeps the dense score rows of hot lists resident across batches (they depend on the snapshot,
+                # the scorer parameters and the boosts - like the score plane - not on the queries); the headline switches that off
+                # and scores its rows inside every timed step.  The same batches with the default on, rows warm: what a caller of the
+                # C ABI gets in steady state with a fixed fields_boost.
+                L.ps_set_option(b"PS_ROW_CACHE_MB", 4096)
+                try:
+                    for rep in range(2):  # (every batch context meets the hot lists once)
+                        for s_ in range(min(len(packed), 12)):
+                            step(packed[s_], s_, boosts)
+                    fence()
+                    wall, _ = boost_leg(lambda i: boosts)
+                finally:
+                    L.ps_set_option(b"PS_ROW_CACHE_MB", 0)
+                result["resident_rows_library_default"] = {
+                    "queries_per_s": B * n / wall, "ms_per_step": wall / n * 1e3, "steps": n, "relative_to_headline": (B * n / wall) / qps,
+                    "what": "PS_ROW_CACHE_MB at its default (4096): dense score rows stay resident across batches; the headline (`value`) "
+                            "rebuilds the rows a batch reads inside every timed step (PS_ROW_CACHE_MB=0)"}
+                step(packed[0], 0, boosts)  # (the knob takes effect at the next batch)
             fence()
             L.ps_set_option(b"PS_WORK_COUNTERS", 1)
             L.ps_set_option(b"PS_KERNEL_TIMERS", 1)

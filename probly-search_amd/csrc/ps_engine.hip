@@ -162,6 +162,7 @@ struct Tuning {
   uint32_t daat_z_split = 1;     // PS_DAAT_Z_SPLIT: a zero_to_one batch with queries K1dz does not take is split (those to the streaming kernels) instead of taking the streaming kernels whole
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
   uint32_t daat_sample_div = 24; // PS_DAAT_SAMPLE_DIV: multi-expansion K1d launches (k_daat<F, true>: C5) start with the chunks below doc id ~ N / this, of every rank (0: plain rank-major order)
+  uint32_t daat_small_nl = 1;    // PS_DAAT_SMALL_NL: batches whose queries have <= 3 lists take k_daat_small<F, WC, 3> (0: always the four-list instantiation)
   uint32_t daat_split = 1;       // PS_DAAT_SPLIT: a BM25 K1d batch that holds queries k_daat_small takes AND others (more than 4 lists, several expansions of a term) is scored by both kernels, each over its part of the item array (0: one such query sends the whole batch to k_daat)
   uint32_t daat_sample_all = 0;  // PS_DAAT_SAMPLE_ALL: ... every K1d BM25 launch does (C2 / C4: slower)
   uint32_t dctx = 5;             // PS_DCTX: K1d batch contexts in the rotation (<= N_DCTX)
@@ -821,6 +822,7 @@ void Tuning::load() {
     daat_sample_div = env_u32("PS_DAAT_SAMPLE_DIV", daat_sample_div);
     daat_sample_all = env_u32("PS_DAAT_SAMPLE_ALL", daat_sample_all);
     daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
+    daat_small_nl = env_u32("PS_DAAT_SMALL_NL", daat_small_nl);
     dctx = std::max(2u, std::min((uint32_t)N_DCTX, env_u32("PS_DCTX", dctx)));
     daat_z_d0_div = env_u32("PS_DAAT_Z_D0_DIV", daat_z_d0_div);
     daat_z_level_shift = env_u32("PS_DAAT_Z_LEVEL_SHIFT", daat_z_level_shift);
@@ -1854,7 +1856,9 @@ void launch_k_score(EngineImpl& m, KParams& kp, bool tags, int n_cu, hipStream_t
 }
 
 // K1d: persistent 8-wave workgroups (the LUT is the only LDS), items from the device-scope counter
-void launch_daat(EngineImpl& m, KParams& kp, bool multi, bool small, int n_cu, hipStream_t st) {
+// `small_lists`: 0 = not for k_daat_small; else the most lists any query of the launch has (<= DAAT_SMALL_MAX)
+void launch_daat(EngineImpl& m, KParams& kp, bool multi, uint32_t small_lists, int n_cu, hipStream_t st) {
+  const bool small = small_lists != 0;
   // (PS_DAAT_PAD_LDS: extra dynamic LDS per workgroup - an occupancy cap for experiments; 24000 = 3 waves per SIMD)
   static const size_t pad_lds = env_u32("PS_DAAT_PAD_LDS", 0);
   const size_t lds = pad_lds;  // (K1d reads score planes: no table to stage)
@@ -1874,11 +1878,15 @@ void launch_daat(EngineImpl& m, KParams& kp, bool multi, bool small, int n_cu, h
     // plans of <= 4 lists, one per query term: the short-chain kernel
     const uint32_t n_wg = (kp.n_ditems + DAAT_WGW - 1) / DAAT_WGW;
     char nm[96];
-    snprintf(nm, sizeof(nm), "ps::k_daat_small<%d, %s>", kp.F <= 2 ? (int)kp.F : 0, m.tune.work_counters ? "true" : "false");
+    const bool three = small_lists <= 3 && m.tune.daat_small_nl;  // (queries of <= 3 lists: the instantiation with two other lists of state)
+    snprintf(nm, sizeof(nm), "ps::k_daat_small<%d, %s, %d>", kp.F <= 2 ? (int)kp.F : 0, m.tune.work_counters ? "true" : "false", three ? 3 : 4);
     m.score_kernel_name = nm;
 #define PS_SMALL(FV)                                                                                                    \
   do {                                                                                                                  \
-    if (m.tune.work_counters) hipLaunchKernelGGL((k_daat_small<FV, true>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp); \
+    if (three) {                                                                                                        \
+      if (m.tune.work_counters) hipLaunchKernelGGL((k_daat_small<FV, true, 3>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp); \
+      else hipLaunchKernelGGL((k_daat_small<FV, false, 3>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);             \
+    } else if (m.tune.work_counters) hipLaunchKernelGGL((k_daat_small<FV, true>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp); \
     else hipLaunchKernelGGL((k_daat_small<FV, false>), dim3(n_wg), dim3(WAVE * DAAT_WGW), lds, st, kp);                  \
   } while (0)
     if (kp.F == 1) PS_SMALL(1); else if (kp.F == 2) PS_SMALL(2); else PS_SMALL(0);
@@ -2109,16 +2117,16 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
       KParams kb = kp;
       kb.n_ditems = (uint32_t)n_items_big;
       kb.item_split_dev = split_at;
-      launch_daat(m, kb, multi, false, m.n_cu, S2);
+      launch_daat(m, kb, multi, 0u, m.n_cu, S2);
       PS_HIP(hipEventRecord(c.scored2, S2));
       const std::string big_name = m.score_kernel_name;
       KParams ks = kp;
       ks.n_ditems = (uint32_t)(n_items - n_items_big);
       ks.n_ditems_dev = split_at;
-      launch_daat(m, ks, false, true, m.n_cu, S);
+      launch_daat(m, ks, false, (uint32_t)DAAT_SMALL_MAX, m.n_cu, S);  // (the first part's longest plan is not known apart: the four-list instantiation)
       PS_HIP(hipStreamWaitEvent(S, c.scored2, 0));
       m.score_kernel_name += " + " + big_name;
-    } else launch_daat(m, kp, multi, max_entries <= (uint32_t)DAAT_SMALL_MAX, m.n_cu, S);
+    } else launch_daat(m, kp, multi, max_entries <= (uint32_t)DAAT_SMALL_MAX ? std::max(1u, max_entries) : 0u, m.n_cu, S);
 #ifdef PS_ITEM_TRACE
     {  // profiling builds: the items' start / end times of this launch -> $PS_ITEM_TRACE_FILE (last batch wins)
       PS_HIP(hipStreamSynchronize(S));

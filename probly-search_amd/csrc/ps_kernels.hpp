@@ -2284,11 +2284,19 @@ constexpr int DAAT_SMALL_MAX = 4;  // most lists per query
 // 145-165 SGPR spills instead of 123 / 114, and that code is slower: C2 0.273 -> 0.276 ms, C4 1.095 -> 1.212 (same box).
 #define PS_DAAT_SMALL_BARRIER 1
 #endif
-template <int F_, bool WC>
-__global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p) {
+// NL: most lists of a query of the launch (3 or DAAT_SMALL_MAX = 4).  The per-list words of the OTHER lists are wave-uniform state
+// (scalar registers, spilled to VGPR lanes beyond ~100) and every one of them unrolls another copy of the lookup code: the launch
+// of three-list queries (BASELINE configs 2 and 4) instantiated for three lists instead of four takes 0.288 -> 0.275 ms per step
+// on C2, its counting instantiation 0.268 -> 0.228 ms per launch (round 5, A/B/A/B on one box).
+#ifndef PS_DAAT_SMALL_WAVES3
+#define PS_DAAT_SMALL_WAVES3 4  // waves per SIMD the register allocation of the three-list instantiation aims at (102 VGPRs as is; 5 needs <= 96)
+#endif
+template <int F_, bool WC, int NL = DAAT_SMALL_MAX>
+__global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu(NL <= 3 ? PS_DAAT_SMALL_WAVES3 : 4))) void k_daat_small(const KParams p) {
+  static_assert(NL >= 2 && NL <= DAAT_SMALL_MAX, "k_daat_small is instantiated for 3 or 4 lists per query");
   auto cnt = [](const bool b) -> uint32_t { return WC ? (uint32_t)__popcll(__ballot(b)) : 0u; };  // wave-uniform count of lanes where b holds
   constexpr int U = PS_DAAT_US;
-  constexpr int NO = DAAT_SMALL_MAX - 1;  // other lists of a query
+  constexpr int NO = NL - 1;              // other lists of a query
   constexpr int FA = F_ ? F_ : MAX_F;
   constexpr uint32_t QCAP = 128;          // survivor queue entries per wave (a push adds <= 64 to < 64)
   constexpr double SLACK = 1.0 + 1e-9;    // bounds are summed in another order than the scores
@@ -2336,7 +2344,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) void k_daat_small(const KParams p)
   const ps_plan_entry& own = p.plan[e_own];
   const DEntry de = p.dentry[e_own];
   const uint32_t q = __builtin_amdgcn_readfirstlane(de.q);
-  const uint32_t e0 = p.qbeg[q], ne = p.qbeg[q + 1] - e0;  // ne <= DAAT_SMALL_MAX (host)
+  const uint32_t e0 = p.qbeg[q], ne = p.qbeg[q + 1] - e0;  // ne <= NL (host: the launch's instantiation covers its longest plan)
   const uint32_t own_pos = e_own - e0;
   const double own_eb = own.boost;
   const uint64_t own_off = own.post_off;

@@ -27,5 +27,5 @@ def _library_knobs_back_to_defaults():
     except Exception:  # noqa: BLE001 (library not built: nothing to reset)
         return
     for name, v in ((b"PS_DAAT", 1), (b"PS_DAAT_MULTI", 1), (b"PS_DAAT_Z", 1), (b"PS_DAAT_Z_SPLIT", 1), (b"PS_DEVICE_PLAN", 1), (b"PS_WORK_COUNTERS", 1),
-                    (b"PS_KERNEL_TIMERS", 1), (b"PS_DAAT_CHUNK", 4096), (b"PS_DAAT_SPLIT", 1), (b"PS_SCORE_ALT", 1)):
+                    (b"PS_KERNEL_TIMERS", 1), (b"PS_DAAT_CHUNK", 4096), (b"PS_DAAT_SPLIT", 1), (b"PS_SCORE_ALT", 1), (b"PS_DAAT_SMALL_NL", 1)):
         L.ps_set_option(name, v)

@@ -5,6 +5,8 @@ namespace ps {
 template __global__ void k_daat_small<2, true>(const KParams);
 template __global__ void k_daat_small<2, false>(const KParams);
 template __global__ void k_daat_small<1, false>(const KParams);
+template __global__ void k_daat_small<2, true, 3>(const KParams);
+template __global__ void k_daat_small<2, false, 3>(const KParams);
 template __global__ void k_daat<2, true>(const KParams);
 template __global__ void k_daat<2, false>(const KParams);
 template __global__ void k_daat_z<2, true>(const KParams);

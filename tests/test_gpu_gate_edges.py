@@ -100,6 +100,35 @@ def test_all_ties_whole_batch_equals_the_streaming_kernel(corpus_pair):
         assert [[(r.key, bits(r.score)) for r in rs] for rs in a] == [[(r.key, bits(r.score)) for r in rs] for rs in b], K
 
 
+def test_k_daat_small_is_instantiated_for_the_batchs_longest_plan(corpus_pair):
+    """Batches whose queries have at most three lists run k_daat_small<F, WC, 3> (two other lists of per-query state), one four-term
+    query moves the batch to <F, WC, 4>; PS_DAAT_SMALL_NL=0 always takes the four-list instantiation.  Same bits every way, and the
+    oracle's."""
+    corpus, p, o, snap = corpus_pair
+    three = corpus.queries(48, 3, salt=41) + corpus.queries(8, 2, salt=42) + corpus.queries(8, 1, salt=43) + ["", "zzzz"]
+    four = three[:40] + corpus.queries(4, 4, salt=44) + three[40:]
+    sc, osc = product_scorer("bm25"), oracle_scorer("bm25")
+    L = psa.load()
+
+    def run(queries):
+        return [[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=10)]
+
+    a = run(three)
+    assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_daat_small<2, ") and snap.kernel_breakdown()["score_kernel"].endswith(", 3>")
+    b = run(four)
+    assert snap.kernel_breakdown()["score_kernel"].endswith(", 4>")
+    L.ps_set_option(b"PS_DAAT_SMALL_NL", 0)
+    try:
+        assert run(three) == a
+        assert snap.kernel_breakdown()["score_kernel"].endswith(", 4>")
+    finally:
+        L.ps_set_option(b"PS_DAAT_SMALL_NL", 1)
+    for queries, got in ((three, a), (four, b)):
+        for q, g in zip(queries, got):
+            exp = [(k, bits(s_)) for k, s_ in o.query(q, osc, [1.0, 1.0])[:10]]
+            assert g == exp, (q, g[:3], exp[:3])
+
+
 BOOST_VECTORS = [[1.0, 1.0], [2.0, 0.5], [0.25, 3.0], [1.0, 1e-3], [1e-3, 1.0], [7.0, 7.0], [1.0, 0.0985], [3.0, 2.9], [1e6, 1.0], [0.3, 0.3000001],
                  [1.0, 1.0]]
 

@@ -16,9 +16,12 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 # kernel (demangled prefix) -> (max VGPRs, min waves per SIMD, max scratch bytes per lane, max SGPR spills)
 BUDGET = {
-    "ps::k_daat_small<2, true>": (128, 4, 0, 165),
-    "ps::k_daat_small<2, false>": (128, 4, 0, 125),
-    "ps::k_daat_small<1, false>": (128, 4, 0, 125),
+    "ps::k_daat_small<2, true, 4>": (128, 4, 0, 165),
+    "ps::k_daat_small<2, false, 4>": (128, 4, 0, 125),
+    "ps::k_daat_small<1, false, 4>": (128, 4, 0, 125),
+    # queries of <= 3 lists (BASELINE configs 2 and 4): two other lists of wave-uniform state instead of three
+    "ps::k_daat_small<2, true, 3>": (128, 4, 0, 165),
+    "ps::k_daat_small<2, false, 3>": (128, 4, 0, 125),
     "ps::k_daat<2, true>": (128, 4, 0, 105),
     "ps::k_daat<2, false>": (128, 4, 0, 105),
     # (36 bytes of frame are reserved for k_daat_z but its ISA holds no scratch instruction)

@@ -53,7 +53,7 @@ def run(tag):
     w = snap.work_counters(reset=True)
     n = max(1, int(kt["launches"]))
     keep = ("items", "items_run", "postings_scanned", "postings_reached_lookups", "lookups_row", "lookups_cell", "lookups_probe", "lookup_hits",
-            "offers", "bytes_touched")
+            "offers", "bytes_touched", "rows_built", "rows_used")
     return {"leg": tag, "kernel": kt["score_kernel"], "kernel_avg_ms": round(kt["score_ms"] / n, 4), "kernel_busy_ms": round(kt["score_busy_ms"] / n, 4), "step_ms": round(step_ms, 4),
             "rows_avg_ms": round(kt["rows_ms"] / n, 4), "per_launch": {k: round(w[k] / n) for k in keep}}
 
