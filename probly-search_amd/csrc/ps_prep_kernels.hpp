@@ -462,42 +462,68 @@ __device__ __forceinline__ void wave_add_by_key_noret(uint32_t* counters, const 
 // batch: a candidate used >= min_uses times is read as a row, scored with the (idf, expansion_boost) of its
 // FIRST user in plan order (deterministic); entries with other weights keep their bitmap lookups.  A resident
 // row with the same weights is not scored again.
+// Bucket starts from the bucket totals: an exclusive scan over PREP_BUCKETS counters by ONE wave - a lane takes a block of
+// consecutive buckets (its loads go out together), the blocks meet through a shuffle scan.  (One thread walking the 280 counters
+// with a dependent add per atomic load took ~150 us of every batch's preparation while a k_daat launch owned the chip - most of
+// k_prep_query, the kernel that paced the pipeline once the scoring kernels got faster; round 5.)
+__device__ __forceinline__ void prep_scan_buckets(PrepCtl& c) {
+  constexpr uint32_t PER = (PREP_BUCKETS + WAVE - 1) / WAVE;
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  uint32_t v[PER], sum = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < PER; ++j) {
+    const uint32_t k = lane * PER + j;
+    v[j] = k < PREP_BUCKETS ? __hip_atomic_load(&c.bucket_total[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < PER; ++j) sum += v[j];
+  uint32_t inc = sum;
+  for (int o = 1; o < WAVE; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
+  uint32_t at = inc - sum;
+#pragma unroll
+  for (uint32_t j = 0; j < PER; ++j) {
+    const uint32_t k = lane * PER + j;
+    if (k < PREP_BUCKETS) c.bucket_start[k] = at;
+    at += v[j];
+  }
+  if (lane == (uint32_t)WAVE - 1u) c.n_items = inc;
+}
+
 __device__ __forceinline__ void prep_finish(const PrepParams& pp) {
   PrepCtl& c = *pp.ctl;
-  if (threadIdx.x == 0) {
-    uint32_t at = 0;
-    for (uint32_t k = 0; k < PREP_BUCKETS; ++k) {
-      const uint32_t tot = __hip_atomic_load(&c.bucket_total[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      c.bucket_start[k] = at;
-      at += tot;
-    }
-    c.n_items = at;
-  }
-  if (threadIdx.x == 1) {
-    uint32_t n_build = 0, n_used = 0;
-    for (uint32_t cd = 0; cd < pp.n_cand; ++cd) {
-      RowState& rs = pp.row_state[cd];
-      rs.use_now = 0;
-      const uint32_t uses = __hip_atomic_load(&c.row_use[cd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long first = __hip_atomic_load(&c.row_first[cd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (uses < pp.min_uses || first == 0ull) continue;
+  prep_scan_buckets(c);
+  // dense rows: a lane per candidate (<= PREP_MAX_ROWS = 64); the rows to score are compacted in candidate order
+  const uint32_t cd = threadIdx.x & (WAVE - 1);
+  const bool have = cd < pp.n_cand;
+  bool use = false, build = false;
+  RowDesc rd;
+  rd.post_off = 0; rd.len = 0; rd._pad = 0; rd.idf = 0.0; rd.eb = 0.0; rd.slot = cd; rd.tbl_off = 0;
+  if (have) {
+    RowState& rs = pp.row_state[cd];
+    const uint32_t uses = __hip_atomic_load(&c.row_use[cd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long first = __hip_atomic_load(&c.row_first[cd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    use = uses >= pp.min_uses && first != 0ull;
+    rs.use_now = use ? 1u : 0u;
+    if (use) {
       const ps_plan_entry& en = pp.plan[~first];
       const unsigned long long ib = (unsigned long long)__double_as_longlong(en.idf), eb = (unsigned long long)__double_as_longlong(en.boost);
-      rs.use_now = 1;
-      ++n_used;
-      if (pp.rows_resident && rs.valid && rs.idf_bits == ib && rs.eb_bits == eb) continue;
-      rs.valid = 1; rs.idf_bits = ib; rs.eb_bits = eb;
-      const uint4 la = pp.layer_a[en.node];
-      RowDesc rd;
-      rd.post_off = (uint64_t)la.x | ((uint64_t)la.y << 32);
-      rd.len = la.z;
-      rd._pad = 0;
-      rd.idf = en.idf;
-      rd.eb = en.boost;
-      rd.slot = cd;
-      rd.tbl_off = la.w;  // candidates are lists with one table slot per tile (host: shift == 0)
-      pp.row_desc[n_build++] = rd;
+      build = !(pp.rows_resident && rs.valid && rs.idf_bits == ib && rs.eb_bits == eb);
+      if (build) {
+        rs.valid = 1; rs.idf_bits = ib; rs.eb_bits = eb;
+        const uint4 la = pp.layer_a[en.node];
+        rd.post_off = (uint64_t)la.x | ((uint64_t)la.y << 32);
+        rd.len = la.z;
+        rd.idf = en.idf;
+        rd.eb = en.boost;
+        rd.tbl_off = la.w;  // candidates are lists with one table slot per tile (host: shift == 0)
+      }
     }
+  }
+  const unsigned long long mb = __ballot(build), mu = __ballot(use);
+  const unsigned long long lt = cd ? (~0ull >> (64 - cd)) : 0ull;
+  if (build) pp.row_desc[__popcll(mb & lt)] = rd;
+  if (cd == 0) {
+    const uint32_t n_build = (uint32_t)__popcll(mb), n_used = (uint32_t)__popcll(mu);
     c.n_rows_build = n_build;
     c.n_rows_used = n_used;
     if (PS_WORK_COUNTERS && (n_build | n_used)) {

@@ -257,16 +257,7 @@ __global__ __launch_bounds__(WAVE) void k_zprep_query(const ZPrepParams pp) {
   t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
   if (t + 1u == gridDim.x) {  // the wave that finishes last closes the counters
     __threadfence();
-    if (threadIdx.x == 0) {
-      PrepCtl& c = *pp.ctl;
-      uint32_t at = 0;
-      for (uint32_t k = 0; k < PREP_BUCKETS; ++k) {
-        const uint32_t tot = __hip_atomic_load(&c.bucket_total[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.bucket_start[k] = at;
-        at += tot;
-      }
-      c.n_items = at;
-    }
+    prep_scan_buckets(*pp.ctl);  // (the whole wave: a lane per block of buckets)
   }
 }
 

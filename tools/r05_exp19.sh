@@ -1,0 +1,13 @@
+B="python bench.py --steps 100 --no-cpu-baseline --no-streaming-leg --no-bulk-index --no-alternating-boosts-leg --no-single-latency"
+mkdir -p gpurun_out/r05e19
+python -m pytest tests/test_gpu_gate_edges.py tests/test_device_planner.py tests/test_gpu_z21_daat.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -n 2
+for C in C2 C3 C5 C4; do
+  $B --config $C > gpurun_out/r05e19/${C}_a.json 2>/dev/null
+  $B --config $C > gpurun_out/r05e19/${C}_b.json 2>/dev/null
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r05e19/*.json')):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); r=d['roofline']
+    print(f.split('/')[-1], round(d['value']), round(d['ms_per_step'],4), 'busy', round(r['kernel_avg_ms'],4), 'submit', round(d['p50_batch_submit_ms'],3))
+PY
