@@ -13,6 +13,7 @@ _SO = os.path.join(_HERE, "_build", "libprobly_oracle.so")
 
 BM25 = 1
 ZERO_TO_ONE = 2
+NAN_PROBE = 3  # a test plugin (probly_oracle.cpp, NanProbe), not a reference scorer
 
 
 class _Str(C.Structure):
@@ -75,10 +76,14 @@ def lib():
                                       C.POINTER(C.c_double), C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
                                       C.POINTER(C.POINTER(_Res)), C.POINTER(C.c_size_t)]
         L.orc_results_free.argtypes = [C.POINTER(_Res)]
+        L.orc_index_query_flat.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p, C.c_size_t,
+                                           C.POINTER(C.c_double), C.c_size_t, C.c_int,
+                                           C.POINTER(C.POINTER(_Res)), C.POINTER(C.c_size_t)]
         L.orc_bench_queries.restype = C.c_double
         L.orc_bench_queries.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(_Str), C.c_size_t,
                                         C.POINTER(C.c_double), C.c_uint, C.POINTER(C.c_double),
-                                        C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(_Res)]
+                                        C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(_Res), C.c_int,
+                                        C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -96,6 +101,11 @@ def bm25(k1=1.2, b=0.75):
 def zero_to_one():
     """score::zero_to_one::new() (src/score/default/zero_to_one.rs:35-39)."""
     return Scorer(ZERO_TO_ONE)
+
+
+def nan_probe():
+    """The oracle's test plugin: a ScoreCalculator returning NaN for some (document, expansion) pairs."""
+    return Scorer(NAN_PROBE)
 
 
 def _wrap_tokenizer(py_tok):
@@ -229,8 +239,24 @@ class Index:
         self._L.orc_results_free(out)
         return res
 
-    def bench_queries(self, queries, scorer, fields_boost, threads=1, top_k=0):
-        """Time queries inside C++ (cpu_baseline leg).  Returns (wall_s, per_query_s, n_results, topk)."""
+    def query_flat(self, q, scorer, fields_boost, canonical=True):
+        """The same query through the second CPU-baseline leg (SwissTable-class containers): must equal query()."""
+        qb = q.encode("utf-8")
+        boosts = (C.c_double * len(fields_boost))(*fields_boost)
+        out, n = C.POINTER(_Res)(), C.c_size_t()
+        rc = self._L.orc_index_query_flat(self._h, scorer.kind, scorer.k1, scorer.b, qb, len(qb), boosts,
+                                          len(fields_boost), 1 if canonical else 0, C.byref(out), C.byref(n))
+        if rc == 1:
+            raise IndexError("fields_boost shorter than fields_num (reference: index out of bounds panic)")
+        if rc == 2:
+            raise ValueError("NaN score (reference: partial_cmp().unwrap() panic)")
+        res = [(out[i].key, out[i].score) for i in range(n.value)]
+        self._L.orc_results_free(out)
+        return res
+
+    def bench_queries(self, queries, scorer, fields_boost, threads=1, top_k=0, flat=False):
+        """Time queries inside C++ (cpu_baseline leg).  Returns (wall_s, per_query_s, n_results, topk); flat=True runs the
+        SwissTable-class leg (self.flat_build_s = seconds spent building its flat view, outside the clock)."""
         import numpy as np
         qb = [q.encode("utf-8") for q in queries]
         arr = (_Str * max(1, len(qb)))()
@@ -240,9 +266,12 @@ class Index:
         secs = np.zeros(len(qb), dtype=np.float64)
         nres = np.zeros(len(qb), dtype=np.uint64)
         topk = (_Res * max(1, len(qb) * top_k))() if top_k else None
+        fb = C.c_double(0.0)
         wall = self._L.orc_bench_queries(self._h, scorer.kind, scorer.k1, scorer.b, arr, len(qb), boosts, threads,
                                          secs.ctypes.data_as(C.POINTER(C.c_double)),
-                                         nres.ctypes.data_as(C.POINTER(C.c_uint64)), top_k, topk)
+                                         nres.ctypes.data_as(C.POINTER(C.c_uint64)), top_k, topk, 1 if flat else 0,
+                                         C.byref(fb))
+        self.flat_build_s = fb.value
         tk = None
         if top_k:
             tk = [[(topk[i * top_k + k].key, topk[i * top_k + k].score) for k in range(top_k)

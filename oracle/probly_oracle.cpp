@@ -30,11 +30,15 @@
 //     -ffp-contract=off; ln == glibc log (Rust f64::ln lowers to libm log).
 // ============================================================================
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <emmintrin.h>
+#include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -567,9 +571,222 @@ bool query(const Index& idx, const char* q, size_t qlen, ScoreCalculator& sc, or
   return true;
 }
 
+// A TEST PLUGIN, not a reference scorer: a ScoreCalculator whose `score` returns NaN for some (document, expansion)
+// pairs, to pin what max_score_merger does with NaN operands (f64::max returns the non-NaN one, query.rs:158; `+` poisons,
+// and a NaN that survives to the sort panics, query.rs:103).  tests/test_host_callbacks.py runs the same function as a
+// product plugin.  score(key, expanded) = NaN if (key + len(expanded)) % 3 == 0 else 0.25 * (key + 1) + len(expanded).
+struct NanProbe : ScoreCalculator {
+  bool score(const PreCalc*, const DocumentPointer&, const DocumentDetails& dd, int64_t, const double*,
+             const std::vector<FieldDetails>&, const TermData& td, double* out) override {
+    const size_t le = td.query_term_expanded->size();
+    *out = ((dd.key + le) % 3 == 0) ? std::nan("") : 0.25 * (double)(dd.key + 1) + (double)le;
+    return true;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// SECOND CPU-BASELINE LEG ("flat"): the same walk, the same five hash operations per pointer in the same order
+// (src/query.rs:63-88), but on hashbrown-class containers - the reference uses hashbrown 0.14 (src/query.rs:1,31,37,
+// src/index.rs:8), i.e. SwissTable: open addressing, 7-bit control bytes probed 16 at a time with SSE2, load factor 7/8,
+// triangular probing - and a per-thread bump arena behind the per-query tables, so that growing a table costs the
+// rehash and not malloc / mmap / page faults.  `std::unordered_*` (node-based, one allocation per insertion) is what the
+// literal leg above uses; it says so and is a pessimistic stand-in.  This leg is the stronger baseline.  Its results are
+// bit-identical to query() (tests/test_oracle_golden.py::test_flat_leg_matches_literal).
+// ---------------------------------------------------------------------------
+struct Arena {  // per thread; reset() keeps the memory
+  std::vector<std::pair<char*, size_t>> chunks;
+  size_t cur = 0, off = 0;
+  ~Arena() { for (auto& c : chunks) free(c.first); }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    while (cur < chunks.size() && off + bytes > chunks[cur].second) { ++cur; off = 0; }
+    if (cur == chunks.size()) {
+      const size_t sz = std::max<size_t>(bytes, (size_t)32 << 20);
+      chunks.emplace_back((char*)aligned_alloc(64, sz), sz);
+      off = 0;
+    }
+    void* r = chunks[cur].first + off;
+    off += bytes;
+    return r;
+  }
+  void reset() { cur = 0; off = 0; }
+};
+
+inline uint64_t swiss_hash(uint64_t k) {  // ahash's fallback: one folded 64 x 64 -> 128 multiply
+  const unsigned __int128 m = (unsigned __int128)(k ^ 0x243F6A8885A308D3ull) * 0x5851F42D4C957F2Dull;
+  return (uint64_t)m ^ (uint64_t)(m >> 64);
+}
+
+template <class V>
+struct Swiss {  // uint64_t -> V; insert and lookup only (the path never erases)
+  struct Slot { uint64_t key; V val; };
+  static constexpr uint8_t EMPTY = 0xFF;
+  uint8_t* ctrl = nullptr;
+  Slot* slots = nullptr;
+  size_t mask = 0, items = 0, growth_left = 0;
+  Arena* arena = nullptr;  // nullptr: malloc, released by the destructor
+  Swiss() {}
+  explicit Swiss(Arena* a) : arena(a) {}
+  Swiss(const Swiss&) = delete;
+  Swiss& operator=(const Swiss&) = delete;
+  ~Swiss() {
+    if (arena || !ctrl) return;
+    for (size_t i = 0; i <= mask; ++i)
+      if (ctrl[i] != EMPTY) slots[i].~Slot();
+    free(ctrl);
+    free(slots);
+  }
+  void* raw(size_t bytes) { return arena ? arena->alloc(bytes) : aligned_alloc(64, (bytes + 63) & ~(size_t)63); }
+  void set_ctrl(size_t i, uint8_t c) {
+    ctrl[i] = c;
+    if (i < 16) ctrl[mask + 1 + i] = c;  // the first group is mirrored behind the last one
+  }
+  const Slot* find(uint64_t k) const {
+    if (!ctrl) return nullptr;
+    const uint64_t h = swiss_hash(k);
+    const __m128i tag = _mm_set1_epi8((char)(h >> 57)), empty = _mm_set1_epi8((char)EMPTY);
+    size_t pos = h & mask, stride = 0;
+    for (;;) {
+      const __m128i g = _mm_loadu_si128((const __m128i*)(ctrl + pos));
+      unsigned bits = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(g, tag));
+      while (bits) {
+        const size_t i = (pos + (size_t)__builtin_ctz(bits)) & mask;
+        if (slots[i].key == k) return &slots[i];
+        bits &= bits - 1;
+      }
+      if (_mm_movemask_epi8(_mm_cmpeq_epi8(g, empty))) return nullptr;
+      stride += 16;
+      pos = (pos + stride) & mask;
+    }
+  }
+  Slot* place(uint64_t k) {  // a free slot for a key known to be absent
+    const uint64_t h = swiss_hash(k);
+    const __m128i empty = _mm_set1_epi8((char)EMPTY);
+    size_t pos = h & mask, stride = 0;
+    for (;;) {
+      const unsigned bits = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(ctrl + pos)), empty));
+      if (bits) {
+        const size_t i = (pos + (size_t)__builtin_ctz(bits)) & mask;
+        if (ctrl[i] == EMPTY) {  // (a bit of the mirrored tail can alias a full slot of the first group)
+          set_ctrl(i, (uint8_t)(h >> 57));
+          return &slots[i];
+        }
+      }
+      stride += 16;
+      pos = (pos + stride) & mask;
+    }
+  }
+  void grow() {
+    const size_t old_n = ctrl ? mask + 1 : 0, n = old_n ? old_n * 2 : 16;
+    uint8_t* oc = ctrl;
+    Slot* os = slots;
+    ctrl = (uint8_t*)raw(n + 16);
+    memset(ctrl, EMPTY, n + 16);
+    slots = (Slot*)raw(n * sizeof(Slot));
+    mask = n - 1;
+    growth_left = n / 8 * 7 - items;
+    for (size_t i = 0; i < old_n; ++i)
+      if (oc[i] != EMPTY) {
+        Slot* d = place(os[i].key);
+        new (d) Slot(std::move(os[i]));
+        os[i].~Slot();
+      }
+    if (!arena) { free(oc); free(os); }
+  }
+  // HashMap::insert / HashSet::insert: overwrite or add
+  void insert(uint64_t k, V v) {
+    if (Slot* s = const_cast<Slot*>(find(k))) { s->val = std::move(v); return; }
+    if (growth_left == 0) grow();
+    new (place(k)) Slot{k, std::move(v)};
+    ++items;
+    --growth_left;
+  }
+};
+
+struct FlatView {  // built once per index state by orc_index_build_flat; any mutation drops it
+  Swiss<DocumentDetails> docs;  // bucket = (key, DocumentDetails) inline, its Vec on the heap: hashbrown's layout
+  Swiss<char> removed;
+};
+
+// Index::count_documents (src/index.rs:282-297) on the flat `removed` set
+size_t count_documents_flat(const Index& idx, const FlatView& fv, int64_t node_index) {
+  int64_t p = idx.arena_index[(size_t)node_index].first_doc;
+  size_t df = 0;
+  while (p != NONE) {
+    const DocumentPointer& dp = idx.arena_doc[(size_t)p];
+    if (!idx.has_removed || fv.removed.find(dp.details_key) == nullptr) df += 1;
+    p = dp.next;
+  }
+  return df;
+}
+
+// query() above, line by line, on the flat containers
+bool query_flat(const Index& idx, const FlatView& fv, Arena& arena, const char* q, size_t qlen, ScoreCalculator& sc,
+                const double* fields_boost, bool canonical, std::vector<QueryResult>& result) {
+  arena.reset();
+  std::vector<std::string> query_terms = tokenize(q, qlen, nullptr, nullptr);
+  Swiss<double> scores(&arena);
+  size_t query_terms_len = query_terms.size();
+  for (size_t query_term_index = 0; query_term_index < query_terms.size(); ++query_term_index) {
+    const std::string& query_term = query_terms[query_term_index];
+    if (query_term.empty()) continue;
+    std::vector<std::string> expanded_terms = idx.expand_term(query_term);
+    Swiss<char> visited_documents_for_term(&arena);
+    for (const std::string& query_term_expanded : expanded_terms) {
+      int64_t term_node_index = idx.find_inverted_index_node(idx.root, query_term_expanded);
+      if (term_node_index == NONE) continue;
+      size_t document_frequency = count_documents_flat(idx, fv, term_node_index);
+      int64_t first_doc = idx.arena_index[(size_t)term_node_index].first_doc;
+      if (first_doc == NONE || document_frequency == 0) continue;
+      TermData td{query_term_index, &query_term, &query_term_expanded, query_terms_len};
+      PreCalc pre = sc.before_each(td, document_frequency, idx.docs);
+      int64_t pointer = first_doc;
+      while (pointer != NONE) {
+        const DocumentPointer& pb = idx.arena_doc[(size_t)pointer];
+        uint64_t key = pb.details_key;
+        if (!idx.has_removed || fv.removed.find(key) == nullptr) {
+          double s;
+          bool some = sc.score(pre.some ? &pre : nullptr, pb, fv.docs.find(key)->val, term_node_index, fields_boost,
+                               idx.fields, td, &s);  // docs.get(key).unwrap()
+          if (some) {
+            const Swiss<double>::Slot* prev = scores.find(key);                          // scores.get(key)
+            const bool visited = visited_documents_for_term.find(key) != nullptr;          // visited.contains(key)
+            scores.insert(key, max_score_merger(s, prev ? &prev->val : nullptr, visited));  // scores.insert(..)
+          }
+        }
+        visited_documents_for_term.insert(key, 0);  // visited.insert(key)
+        pointer = pb.next;
+      }
+    }
+  }
+  result.clear();
+  result.reserve(scores.items);
+  if (scores.ctrl)
+    for (size_t i = 0; i <= scores.mask; ++i)
+      if (scores.ctrl[i] != Swiss<double>::EMPTY) result.push_back(QueryResult{scores.slots[i].key, scores.slots[i].val});
+  sc.finalize(result);
+  for (const QueryResult& r : result)
+    if (std::isnan(r.score)) return false;
+  std::stable_sort(result.begin(), result.end(),
+                   [](const QueryResult& a, const QueryResult& b) { return b.score < a.score; });
+  if (canonical) {
+    std::sort(result.begin(), result.end(), [](const QueryResult& a, const QueryResult& b) {
+      if (a.score != b.score) return a.score > b.score;
+      return a.key < b.key;
+    });
+  }
+  return true;
+}
+
+void build_flat(const Index& idx, FlatView& fv) {
+  for (const auto& kv : idx.docs) fv.docs.insert(kv.first, kv.second);
+  for (const uint64_t k : idx.removed) fv.removed.insert(k, 0);
+}
+
 ScoreCalculator* make_scorer(int kind, double k1, double b) {
   if (kind == 1) { BM25* s = new BM25(); s->bm25k1 = k1; s->bm25b = b; return s; }
   if (kind == 2) return new ZeroToOne();
+  if (kind == 3) return new NanProbe();  // test plugin
   return nullptr;
 }
 
@@ -712,6 +929,25 @@ int orc_index_query(void* h, int scorer_kind, double k1, double b, const char* q
   for (size_t i = 0; i < res.size(); ++i) { (*out)[i].key = res[i].key; (*out)[i].score = res[i].score; }
   return 0;
 }
+// The same query through the flat leg (default tokenizer); builds the flat view for this call.
+int orc_index_query_flat(void* h, int scorer_kind, double k1, double b, const char* q, size_t qlen,
+                         const double* fields_boost, size_t n_boost, int canonical, orc_result** out, size_t* out_len) {
+  Index* idx = (Index*)h;
+  if (n_boost < idx->fields.size()) return 1;
+  ScoreCalculator* sc = make_scorer(scorer_kind, k1, b);
+  if (!sc) return 1;
+  FlatView fv;
+  build_flat(*idx, fv);
+  Arena arena;
+  std::vector<QueryResult> res;
+  bool ok = query_flat(*idx, fv, arena, q, qlen, *sc, fields_boost, canonical != 0, res);
+  delete sc;
+  if (!ok) return 2;
+  *out_len = res.size();
+  *out = (orc_result*)malloc(sizeof(orc_result) * (res.size() ? res.size() : 1));
+  for (size_t i = 0; i < res.size(); ++i) { (*out)[i].key = res[i].key; (*out)[i].score = res[i].score; }
+  return 0;
+}
 void orc_results_free(orc_result* p) { free(p); }
 
 // CPU-baseline timing leg: runs `n` queries (default tokenizer) with `threads` worker threads, one
@@ -719,18 +955,31 @@ void orc_results_free(orc_result* p) { free(p); }
 // threads == 1 is the reference's own execution model).  seconds[i] = wall time of query i;
 // n_results[i] = result count; returns total wall seconds.  If top_k > 0 the first top_k canonical
 // results per query are written to out_topk[i*top_k ..] (key=~0 padding) for cross-checks.
+// flavor 0 = the literal leg (std::unordered_*), 1 = the flat leg (SwissTable-class containers + a per-thread arena; its
+// flat view of `docs` / `removed` is built before the clock starts, *flat_build_s says how long that took).
 double orc_bench_queries(void* h, int scorer_kind, double k1, double b, const orc_str* queries, size_t n,
                          const double* fields_boost, unsigned threads, double* seconds, uint64_t* n_results,
-                         size_t top_k, orc_result* out_topk) {
+                         size_t top_k, orc_result* out_topk, int flavor, double* flat_build_s) {
   Index* idx = (Index*)h;
   if (threads == 0) threads = 1;
+  std::unique_ptr<FlatView> fv;
+  if (flavor == 1) {
+    auto b0 = std::chrono::steady_clock::now();
+    fv.reset(new FlatView());
+    build_flat(*idx, *fv);
+    if (flat_build_s) *flat_build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
+  }
+  std::atomic<size_t> next{0};
   auto t0 = std::chrono::steady_clock::now();
   auto worker = [&](unsigned tid) {
-    for (size_t i = tid; i < n; i += threads) {
+    Arena arena;
+    (void)tid;
+    for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) {  // a shared queue: a thread that drew a cheap query takes another
       ScoreCalculator* sc = make_scorer(scorer_kind, k1, b);
       std::vector<QueryResult> res;
       auto a = std::chrono::steady_clock::now();
-      query(*idx, queries[i].ptr, queries[i].len, *sc, nullptr, nullptr, fields_boost, true, res);
+      if (flavor == 1) query_flat(*idx, *fv, arena, queries[i].ptr, queries[i].len, *sc, fields_boost, true, res);
+      else query(*idx, queries[i].ptr, queries[i].len, *sc, nullptr, nullptr, fields_boost, true, res);
       auto z = std::chrono::steady_clock::now();
       seconds[i] = std::chrono::duration<double>(z - a).count();
       n_results[i] = res.size();

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 
@@ -444,7 +445,7 @@ void Index::query_callbacks(const ps_score_callbacks& cb, std::string_view query
             if (cb.score(cb.user, some ? memory : nullptr, &dp, &det, (uint64_t)node, &field_data, &td, &s) != 0) {
               auto it = scores.find(key);  // max_score_merger, query.rs:150-164
               if (it == scores.end()) scores.emplace(key, s);
-              else it->second = visited.count(key) ? std::max(it->second, s) : it->second + s;
+              else it->second = visited.count(key) ? std::fmax(it->second, s) : it->second + s;  // f64::max (query.rs:158): a NaN operand loses
             }
           }
           visited.insert(key);  // query.rs:87

@@ -210,6 +210,19 @@ struct WorkStats {  // K1d, per item
 __device__ __forceinline__ uint32_t lanes_on(const bool b) {  // wave-uniform count of lanes where b holds
   return PS_WORK_COUNTERS ? (uint32_t)__popcll(__ballot(b)) : 0u;
 }
+#ifndef PS_REQ_TRACE
+#define PS_REQ_TRACE 0   // profiling builds only (tools/build_variant.sh): k_daat_small's counters count distinct 128-byte LINES per wave-level
+#endif                   // first-level load instead of lookups: probe = row lines at 8 B / doc, hit = at 2 B / doc, offer = bitmap-cell lines, reached = filter words
+// Distinct lines among the lanes where `on` holds; the lanes of a trip hold ascending doc ids, so equal lines are neighbours.
+__device__ __forceinline__ uint32_t distinct_lines(const bool on, const uint32_t line, const int lane) {
+  const uint32_t prev = (uint32_t)__shfl_up((int)line, 1);
+  const unsigned long long S = __ballot(lane == 0 || line != prev);  // run starts
+  const unsigned long long A = __ballot(on);
+  const unsigned long long upto = S & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  const int start = 63 - __clzll((long long)upto);
+  const unsigned long long before = ((1ull << lane) - 1ull) & ~((1ull << start) - 1ull);
+  return (uint32_t)__popcll(__ballot(on && !(A & before)));
+}
 
 // ------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -2274,6 +2287,13 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
 #ifndef PS_EXP
 #define PS_EXP 0       // profiling builds only (wrong results): 1 = no top-K offers, 2 = no second level, 4 = no first-level loads
 #endif
+#ifndef PS_DAAT_DEFER_HIGHER
+// 1: the lists ranked ABOVE the own one are asked by the survivors only.  A document evaluated here sits in none of them, so
+// their first level cannot tighten its bound - it can only cancel the few documents that do sit in one (then evaluated by that
+// list's items).  Asking them for every document that passes the first bound test was 3.7 M filter words + ~2 M bitmap cells of a
+// C2 launch's 23 M first-level lookups (profiles/r06_request_lines.txt).  0: round 5's all-lists-at-once first level.
+#define PS_DAAT_DEFER_HIGHER 1
+#endif
 constexpr int DAAT_SMALL_MAX = 4;  // most lists per query
 
 // WC: keep the work counters (ps_work_counters).  The serving instantiation (PS_WORK_COUNTERS=0 at run time) carries none
@@ -2389,6 +2409,44 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
   uint32_t n_trips = 0;
 #endif
 
+  // First level of other list k for one document per lane: the dense-row value, the {bits, postings before} bitmap cell, or the
+  // sparse list's filter word (x = 1: maybe) - and what it says: where the posting is / the row value (`loc`), whether the list
+  // holds the document (`hit`; for a filter: maybe).
+  auto first_level_load = [&](const int k, const uint32_t dd, const bool on) -> uint2 {
+    uint2 r = make_uint2(0u, 0u);
+    if (PS_EXP & 4) return r;
+    if (o_shift[k] & DENSE_FLAG) {
+      if (on) r = *reinterpret_cast<const uint2*>(p.rows + (uint64_t)o_row[k] * p.row_stride + dd);
+      ws.row += cnt(on);
+    } else if (o_bm[k] != 0xFFFFFFFFu) {
+      if (on) r = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(dd >> 5));
+      ws.cell += cnt(on);
+    } else if (o_bloom[k] != NO_BLOOM) {
+      uint64_t wi;
+      unsigned long long mk;
+      bloom_probe(dd, o_bloom[k], wi, mk);
+      const unsigned long long w = on ? p.bloom[wi] : 0ull;
+      r.x = (on && (w & mk) == mk) ? 1u : 0u;  // maybe
+      ws.cell += cnt(on);
+    } else {
+      r.x = on ? 1u : 0u;  // no filter: ask the table
+    }
+    return r;
+  };
+  auto first_level_loc = [&](const int k, const uint2 f, const uint32_t dd, bool& hit) -> unsigned long long {
+    if (o_shift[k] & DENSE_FLAG) {
+      hit = __hiloint2double((int)f.y, (int)f.x) > 0.0;
+      return (unsigned long long)f.x | ((unsigned long long)f.y << 32);
+    }
+    if (o_bm[k] != 0xFFFFFFFFu) {
+      const uint32_t bit = dd & 31u;
+      hit = (f.x >> bit) & 1u;
+      return hit ? o_off[k] + f.y + (uint32_t)__popc(f.x & ((1u << bit) - 1u)) : ~0ull;
+    }
+    hit = f.x != 0u;  // the filter (or its absence) says maybe
+    return hit ? 0ull : ~0ull;
+  };
+
   // Second level + the sum in PLAN order (query.rs:33-89; one list per query term: always the `+` / assign
   // arm) + the top-K offer for the first `count` (<= 64) queued documents, one per lane.
   auto process = [&](const uint32_t count, const double theta) {
@@ -2396,12 +2454,31 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
     bool ok = (uint32_t)lane < count;
     const uint32_t d = ok ? q_d[wave][at] : 0u;
     const double s_own = ok ? q_s[wave][at] : 0.0;
+    // the lists ranked above the own one: their first level now, for these <= 64 documents only (every list's load in flight together)
+    unsigned long long dloc[NO];
+    if (PS_DAAT_DEFER_HIGHER) {
+      uint2 dfl[NO];
+#pragma unroll
+      for (int k = 0; k < NO; ++k) {
+        dfl[k] = make_uint2(0u, 0u);
+        if ((uint32_t)k + 1u < ne && o_rank[k] < own_rank) dfl[k] = first_level_load(k, d, ok);
+      }
+#pragma unroll
+      for (int k = 0; k < NO; ++k) {
+        dloc[k] = ~0ull;
+        if ((uint32_t)k + 1u < ne && o_rank[k] < own_rank) {
+          bool hit;
+          dloc[k] = first_level_loc(k, dfl[k], d, hit);
+        }
+      }
+    }
     double P = 0.0;
 #pragma unroll
     for (int k = 0; k <= NO; ++k) {
       if ((uint32_t)k == own_pos && ok && s_own > 0.0) P += s_own;
       if (k < NO && (uint32_t)k + 1u < ne && !(PS_EXP & 2)) {
-        const unsigned long long loc = ok ? q_loc[k < NO ? k : 0][wave][at] : ~0ull;
+        unsigned long long loc = ok ? q_loc[k < NO ? k : 0][wave][at] : ~0ull;
+        if (PS_DAAT_DEFER_HIGHER && o_rank[k] < own_rank) loc = ok ? dloc[k < NO ? k : 0] : ~0ull;
         double sk = 0.0;
         if (o_shift[k] & DENSE_FLAG) {
           sk = ok ? __longlong_as_double((long long)loc) : 0.0;
@@ -2422,7 +2499,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
               lo = p.table[o_tbl[k] + slot];
               hi = p.table[o_tbl[k] + slot + 1];
             }
-            ws.probe += 2u * cnt(open);
+            if (!PS_REQ_TRACE) ws.probe += 2u * cnt(open);
             open = open && lo < hi;
             while (__any(open)) {
               uint32_t v[4];
@@ -2430,7 +2507,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
               for (int t = 0; t < 4; ++t) {
                 const bool rd = open && lo + t < hi;
                 v[t] = rd ? docs[lo + t] : 0xFFFFFFFFu;
-                ws.probe += cnt(rd);
+                if (!PS_REQ_TRACE) ws.probe += cnt(rd);
               }
               if (open) {
 #pragma unroll
@@ -2442,7 +2519,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
               }
             }
           }
-          ws.hit += cnt(found);
+          if (!PS_REQ_TRACE) ws.hit += cnt(found);
           if (__any(found)) {
             double t[FA];
 #pragma unroll
@@ -2462,7 +2539,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
       }
     }
     const bool offer = ok && P >= theta;
-    ws.offer += cnt(offer);
+    if (!PS_REQ_TRACE) ws.offer += cnt(offer);
     if (!(PS_EXP & 1) && __any(offer)) topk_offer(tk, p.K, lane, ok, P, d, theta);
     q_head = (q_head + count) & (QCAP - 1u);
     q_n -= count;
@@ -2497,7 +2574,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
     essential = !(skip_thr < theta);  // false: the whole list has become non-essential
     const uint32_t n_in = min(end - i0, (uint32_t)(WAVE * U));
     if (!essential) {  // (its doc ids and plane values were requested with the threshold: booked, then out)
-      if (WC) ws.probe += n_in * (1u + 2u * (F_ ? (uint32_t)F_ : p.F));
+      if (WC && !PS_REQ_TRACE) ws.probe += n_in * (1u + 2u * (F_ ? (uint32_t)F_ : p.F));
       break;
     }
     // ---- own scores; first bound test: everything the other entries could add, at most - below theta the
@@ -2517,7 +2594,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
     for (int u = 0; u < U; ++u) {
       rch[u] = inr[u] && (s_own[u] + others >= theta);
       const uint32_t nr = cnt(rch[u]);  // every document that passed asks every other list's first level
-      ws.reached += nr;
+      if (!PS_REQ_TRACE) ws.reached += nr;
     }
     // ---- first level of the other lists for the documents that passed: dense-row value, {bits, rank} bitmap cell, or
     // the sparse list's Bloom-filter word - every list at once, all loads in flight together.  (Asking the highest-bound lower-ranked
@@ -2529,18 +2606,20 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int u = 0; u < U; ++u) fl[k][u] = make_uint2(0u, 0u);
     auto first_level = [&](const int k, const bool (&on)[U]) {
-      if ((uint32_t)k + 1u < ne && !(PS_EXP & 4)) {
+      if ((uint32_t)k + 1u < ne && !(PS_EXP & 4) && !(PS_DAAT_DEFER_HIGHER && o_rank[k] < own_rank)) {
         if (o_shift[k] & DENSE_FLAG) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             if (on[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.rows + (uint64_t)o_row[k] * p.row_stride + d[u]);
             ws.row += cnt(on[u]);
+            if (PS_REQ_TRACE) { ws.probe += distinct_lines(on[u], d[u] >> 4, lane); ws.hit += distinct_lines(on[u], d[u] >> 6, lane); }
           }
         } else if (o_bm[k] != 0xFFFFFFFFu) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             if (on[u]) fl[k][u] = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(d[u] >> 5));
             ws.cell += cnt(on[u]);
+            if (PS_REQ_TRACE) ws.offer += distinct_lines(on[u], d[u] >> 9, lane);
           }
         } else if (o_bloom[k] != NO_BLOOM) {
 #pragma unroll
@@ -2551,6 +2630,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
             const unsigned long long w = on[u] ? p.bloom[wi] : 0ull;
             fl[k][u].x = (on[u] && (w & mk) == mk) ? 1u : 0u;  // maybe
             ws.cell += cnt(on[u]);
+            if (PS_REQ_TRACE) ws.reached += cnt(on[u]);
           }
         } else {
 #pragma unroll
@@ -2569,7 +2649,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int k = 0; k < NO; ++k) {
         loc[k] = ~0ull;
-        if ((uint32_t)k + 1u < ne) {
+        if ((uint32_t)k + 1u < ne && !(PS_DAAT_DEFER_HIGHER && o_rank[k] < own_rank)) {
           const bool dense = (o_shift[k] & DENSE_FLAG) != 0, bitmap = !dense && o_bm[k] != 0xFFFFFFFFu;
           double c;
           bool hit;

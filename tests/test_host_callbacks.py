@@ -134,6 +134,49 @@ def test_plugin_exception_propagates_and_snapshot_refuses():
         idx.snapshot(device=-1).query("a", Boom(), None, [1.0])
 
 
+class PluginNanProbe(psa.ScoreCalculator):
+    """The oracle's NanProbe test plugin (oracle/probly_oracle.cpp) written against the product's plugin trait."""
+
+    def score(self, before_output, dp, dd, index_node, fd, te):
+        le = len(te.query_term_expanded.encode())
+        return float("nan") if (dp.details_key + le) % 3 == 0 else 0.25 * (dp.details_key + 1) + le
+
+
+def test_nan_returning_plugin_follows_f64_max():
+    """max_score_merger uses f64::max (src/query.rs:150-164): with one NaN operand it returns the OTHER one, so a NaN
+    a plugin returned for one expansion of a query term is repaired by a later expansion of the same term (and a later
+    NaN does not overwrite a number); `+` across query terms poisons, and a NaN that reaches the sort panics
+    (query.rs:103).  std::max would keep / introduce the NaN depending on operand order (VERDICT r05 item 7)."""
+    p, o = psa.Index(1), orc.Index(1)
+    # every document holds all three expansions of "ab"; exactly one of them scores NaN for any key:
+    # first in the expansion order for keys 1, 4 (the NaN is STORED, then repaired), in the middle for 0, 3, last for 2, 5
+    for k in range(6):
+        text = " ".join(["ab", "abc", "abcd"][(k + i) % 3] for i in range(3))
+        p.add_field_values(k, [text])
+        o.add_document(k, [text])
+    assert o.expand_term("ab") == ["ab", "abc", "abcd"]
+    for q in ("ab", "ab ab", "abc", "abcd ab"):
+        try:
+            exp = o.query(q, orc.nan_probe(), [1.0])
+        except ValueError:
+            exp = None
+        if exp is None:
+            with pytest.raises(Exception, match="NaN"):  # the reference panics (query.rs:103); the product reports it
+                p.query(q, PluginNanProbe(), None, [1.0])
+        else:
+            assert [(r.key, r.score) for r in p.query(q, PluginNanProbe(), None, [1.0])] == exp, q
+    exp = o.query("ab", orc.nan_probe(), [1.0])
+    by_hand = [(k, 0.25 * (k + 1) + (4 if (k + 4) % 3 else 3)) for k in range(6)]  # the best non-NaN expansion
+    assert exp == sorted(by_hand, key=lambda r: (-r[1], r[0])), exp
+    # a document whose only expansion scores NaN: nothing repairs it, the sort refuses it - on both sides
+    p.add_field_values(7, ["ab"])
+    o.add_document(7, ["ab"])
+    with pytest.raises(ValueError):
+        o.query("ab", orc.nan_probe(), [1.0])
+    with pytest.raises(Exception, match="NaN"):
+        p.query("ab", PluginNanProbe(), None, [1.0])
+
+
 def _build_c(tmp_path):
     exe = str(tmp_path / "callbacks_bm25")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
