@@ -364,6 +364,11 @@ int ps_comm_world_size(const ps_comm* comm);
  * if none could be loaded.  The string lives until the next call. */
 const char* ps_comm_rccl_path(void);
 int ps_comm_rank(const ps_comm* comm);
+/* The communicator's one collective, for the caller's own small exchanges (a barrier, the max of a timing over the ranks): every
+ * rank contributes `bytes` from d_send, d_recv receives world_size x bytes in rank order.  Device pointers; ordered on
+ * `hip_stream` (NULL: blocking).  ncclAllGather over xGMI (or the debugging transport); one rank: a copy.  With it a host
+ * program needs no second communicator (e.g. a torch.distributed "nccl" group) beside the library's. */
+ps_status ps_comm_all_gather(ps_comm* comm, const void* d_send, void* d_recv, size_t bytes, void* hip_stream);
 /* A rank's top-k block: [n_queries*top_k u64 keys | n_queries*top_k f64 scores | n_queries u32
  * counts, padded to a multiple of 16 bytes]; unused slots key = ~0, score = 0. */
 size_t ps_topk_block_bytes(size_t n_queries, size_t top_k);

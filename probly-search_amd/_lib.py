@@ -185,6 +185,7 @@ SYMBOLS = {
     "ps_comm_world_size": (C.c_int, [_P]),
     "ps_comm_rccl_path": (C.c_char_p, []),
     "ps_comm_rank": (C.c_int, [_P]),
+    "ps_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "ps_topk_block_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t]),
     "ps_snapshot_query_batch_allgather_flat": (C.c_int, [_P, _P, C.POINTER(ScorerDesc), _P, _P, C.c_size_t,
                                                          C.POINTER(C.c_double), C.c_size_t, _P, _P, C.c_size_t, _P,

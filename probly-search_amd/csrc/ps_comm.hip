@@ -289,6 +289,41 @@ void ps_comm_free(ps_comm* c) {
 int ps_comm_world_size(const ps_comm* c) { return c ? c->world : 1; }
 int ps_comm_rank(const ps_comm* c) { return c ? c->rank : 0; }
 
+ps_status ps_comm_all_gather(ps_comm* comm, const void* d_send, void* d_recv, size_t bytes, void* hip_stream) {
+  if (!d_send || !d_recv) return ps::set_error(PS_EINVAL, "null buffer");
+  return comm_guard([&]() -> ps_status {
+    const int world = comm ? comm->world : 1;
+    const int rank = comm ? comm->rank : 0;
+    hipStream_t s = (hipStream_t)hip_stream;
+    static const bool force = getenv("PS_COMM_FORCE_COLLECTIVE") && *getenv("PS_COMM_FORCE_COLLECTIVE") == '1';  // tests
+    if (world == 1 && !(force && comm && comm->nccl)) {  // one rank: no exchange at all
+      if (d_recv != d_send) {
+        if (s) hip_check(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+        else hip_check(hipMemcpy(d_recv, d_send, bytes, hipMemcpyDeviceToDevice), "hipMemcpy");
+      }
+      return PS_OK;
+    }
+    if (comm->shm) {  // debugging transport (blocking)
+      if (bytes > SHM_SLOT) return ps::set_error(PS_EUNSUPPORTED, "hostshm transport: block larger than 16 MiB");
+      if (s) hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+      ShmHeader* h = reinterpret_cast<ShmHeader*>(comm->shm_base);
+      unsigned char* data = comm->shm_base + SHM_HEADER;
+      hip_check(hipMemcpy(data + (size_t)rank * SHM_SLOT, d_send, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+      shm_barrier(h, world);
+      for (int r = 0; r < world; ++r)
+        hip_check(hipMemcpy((unsigned char*)d_recv + (size_t)r * bytes, data + (size_t)r * SHM_SLOT, bytes,
+                            hipMemcpyHostToDevice), "hipMemcpy H2D");
+      shm_barrier(h, world);  // the slots may be rewritten
+      return PS_OK;
+    }
+    // a NULL stream: the caller's data is complete (its producing call was synchronous); gather on our own stream and wait
+    hipStream_t gs = s ? s : comm->own_stream;
+    rccl_check(rccl().AllGather(d_send, d_recv, bytes, ncclInt8, comm->nccl, gs), "ncclAllGather");
+    if (!s) hip_check(hipStreamSynchronize(gs), "hipStreamSynchronize");
+    return PS_OK;
+  });
+}
+
 ps_status ps_snapshot_query_batch_allgather_flat(ps_snapshot* snap, ps_comm* comm, const ps_scorer_desc* scorer,
                                                  const char* text, const uint64_t* offsets, size_t n_queries,
                                                  const double* fields_boost, size_t n_boost, ps_tokenizer_fn tokenizer,
@@ -301,38 +336,7 @@ ps_status ps_snapshot_query_batch_allgather_flat(ps_snapshot* snap, ps_comm* com
   ps_status st = ps::run_device_flat(snap, scorer, text, offsets, n_queries, fields_boost, n_boost, tokenizer, user, top_k,
                                      blk, blk + nk * 8, blk + nk * 16, hip_stream);
   if (st != PS_OK) return st;
-  return comm_guard([&]() -> ps_status {
-    const size_t bytes = ps_topk_block_bytes(n_queries, top_k);
-    const int world = comm ? comm->world : 1;
-    const int rank = comm ? comm->rank : 0;
-    hipStream_t s = (hipStream_t)hip_stream;
-    static const bool force = getenv("PS_COMM_FORCE_COLLECTIVE") && *getenv("PS_COMM_FORCE_COLLECTIVE") == '1';  // tests
-    if (world == 1 && !(force && comm && comm->nccl)) {  // batch fits one GPU: no exchange at all
-      if (d_all_blocks != d_local_block) {
-        if (s) hip_check(hipMemcpyAsync(d_all_blocks, d_local_block, bytes, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
-        else hip_check(hipMemcpy(d_all_blocks, d_local_block, bytes, hipMemcpyDeviceToDevice), "hipMemcpy");
-      }
-      return PS_OK;
-    }
-    if (comm->shm) {  // debugging transport (blocking)
-      if (bytes > SHM_SLOT) return ps::set_error(PS_EUNSUPPORTED, "hostshm transport: block larger than 16 MiB");
-      if (s) hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
-      ShmHeader* h = reinterpret_cast<ShmHeader*>(comm->shm_base);
-      unsigned char* data = comm->shm_base + SHM_HEADER;
-      hip_check(hipMemcpy(data + (size_t)rank * SHM_SLOT, d_local_block, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H");
-      shm_barrier(h, world);
-      for (int r = 0; r < world; ++r)
-        hip_check(hipMemcpy((unsigned char*)d_all_blocks + (size_t)r * bytes, data + (size_t)r * SHM_SLOT, bytes,
-                            hipMemcpyHostToDevice), "hipMemcpy H2D");
-      shm_barrier(h, world);  // the slots may be rewritten
-      return PS_OK;
-    }
-    // a NULL stream made the scoring call synchronous: the block is complete, gather on our own stream
-    hipStream_t gs = s ? s : comm->own_stream;
-    rccl_check(rccl().AllGather(d_local_block, d_all_blocks, bytes, ncclInt8, comm->nccl, gs), "ncclAllGather");
-    if (!s) hip_check(hipStreamSynchronize(gs), "hipStreamSynchronize");
-    return PS_OK;
-  });
+  return ps_comm_all_gather(comm, d_local_block, d_all_blocks, ps_topk_block_bytes(n_queries, top_k), hip_stream);
 }
 
 }  // extern "C"

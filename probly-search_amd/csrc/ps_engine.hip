@@ -161,6 +161,7 @@ struct Tuning {
   uint32_t daat_z_levels = 3;    // PS_DAAT_Z_LEVELS: how many of them (1..3)
   uint32_t daat_z_split = 1;     // PS_DAAT_Z_SPLIT: a zero_to_one batch with queries K1dz does not take is split (those to the streaming kernels) instead of taking the streaming kernels whole
   uint32_t daat_z = 1;           // PS_DAAT_Z: zero_to_one top-k batches of simple queries with <= 4 lists take K1dz k_daat_z (ps_z21_daat.hpp)
+  uint32_t daat_prime = 1;       // PS_DAAT_PRIME: threshold priming - a query's threshold starts at the K-th best posting score of its best single list (k_list_kth), lists that are non-essential under it get no work items (0: thresholds start at 0)
   uint32_t daat_sample_div = 24; // PS_DAAT_SAMPLE_DIV: multi-expansion K1d launches (k_daat<F, true>: C5) start with the chunks below doc id ~ N / this, of every rank (0: plain rank-major order)
   uint32_t daat_small_nl = 1;    // PS_DAAT_SMALL_NL: batches whose queries have <= 3 lists take k_daat_small<F, WC, 3> (0: always the four-list instantiation)
   uint32_t daat_split = 1;       // PS_DAAT_SPLIT: a BM25 K1d batch that holds queries k_daat_small takes AND others (more than 4 lists, several expansions of a term) is scored by both kernels, each over its part of the item array (0: one such query sends the whole batch to k_daat)
@@ -193,6 +194,8 @@ struct EngineImpl {
   double* d_lut = nullptr;
   uint32_t* d_work = nullptr;
   unsigned long long* d_wstats = nullptr;  // work counters the scoring kernels add to (ps_work_counters)
+  uint32_t* h_fault = nullptr;             // [4] pinned, device-mapped: a preparation kernel that finds the device's and the host's item counts at odds says so here
+  uint32_t* d_fault = nullptr;
   uint64_t wc_launches = 0, wc_items = 0, wc_results = 0, wc_cand_slots = 0, wc_k = 0;  // host-side part of the same accounting
   int n_cu = 256;
   Tuning tune;
@@ -224,6 +227,7 @@ struct EngineImpl {
     JSet j[3];
     DevBuf<double> plane;          // tfn * idf per (posting, field): boost-free, one per (k1, b, averages)
     DevBuf<unsigned long long> H;  // [n_layers][PREP_NDIR] (F == 2)
+    DevBuf<unsigned long long> kth;  // [n_layers][F + 1][KTH_RANKS] r-th best plane values per list (F <= 2; threshold priming)
     DevBuf<double2> dirs;          // the PREP_NDIR directions
     uint64_t epoch = 0;
     DevBuf<BoundUnit> units;
@@ -403,6 +407,16 @@ struct EngineImpl {
     if (hipEventElapsedTime(&ms0, t.a, t.split ? t.r : t.m) == hipSuccess) kt_rows_ms += ms0;
     t.pending = false;
   }
+  // hipEventElapsedTime is a float: ten seconds behind the reference an offset still resolves a microsecond, an hour behind it a
+  // quarter of a millisecond - and the union of intervals would be noise.  Before a timer is taken for a new launch:
+  // once the offsets pass 10 s, everything outstanding is harvested (oldest first) and the reference re-recorded.  The accumulated
+  // sums carry over; only the running interval end starts again (nothing timed is in flight at that moment).
+  void rebase_timers_if_stale(hipStream_t st) {
+    if (kt_cur_end < 10000.0 || !kt_ref) return;
+    for (int i = 0; i < N_KTIMER; ++i) harvest(kt[(next_kt + i) % N_KTIMER], true);
+    if (hipEventRecord(kt_ref, st) == hipSuccess) (void)hipEventSynchronize(kt_ref);
+    kt_cur_end = -1.0;
+  }
 };
 
 namespace { void forget_rows(EngineImpl& m); }
@@ -438,6 +452,9 @@ Engine::Engine(const Snapshot& snap, int device) : impl_(new EngineImpl()) {
     for (auto& js : m.bounds.j) PS_HIP(hipEventCreateWithFlags(&js.ready, hipEventDisableTiming));
     PS_HIP(hipMalloc((void**)&m.d_wstats, (size_t)WS_SLOTS * WS_WORDS * 8));
     PS_HIP(hipMemset(m.d_wstats, 0, (size_t)WS_SLOTS * WS_WORDS * 8));
+    PS_HIP(hipHostMalloc((void**)&m.h_fault, 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(m.h_fault, 0, 4 * sizeof(uint32_t));
+    PS_HIP(hipHostGetDevicePointer((void**)&m.d_fault, m.h_fault, 0));
     PS_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     for (auto& ev : m.ev) PS_HIP(hipEventCreate(&ev));
     for (auto& sg : m.stage) PS_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
@@ -513,6 +530,7 @@ Engine::~Engine() {
   m.d_fnodes.release(); m.d_layer_a.release(); m.d_layer_b.release(); m.d_fbits.release(); m.d_fchar.release(); m.d_fchild.release();
   m.d_term_meta.release(); m.d_term_delta.release(); m.d_term_df.release(); m.d_term_idf.release(); m.d_eb_table.release(); m.d_layer_idf.release(); m.d_bloom.release(); m.d_layer_bloom.release();
   if (m.h_totals) (void)hipHostFree(m.h_totals);
+  if (m.h_fault) (void)hipHostFree(m.h_fault);
   m.d_sort_doc.release(); m.d_seg.release(); m.d_sort_score.release(); m.d_pack_off.release();
   m.d_sort_tmp.release(); m.d_pack.release(); m.d_gs_u32.release(); m.d_gs_u64.release();
   for (auto& sg : m.stage) {
@@ -820,6 +838,7 @@ void Tuning::load() {
     score_alt = env_u32("PS_SCORE_ALT", score_alt);
     plan_ahead_depth = std::max(1u, env_u32("PS_PLAN_AHEAD_DEPTH", plan_ahead_depth));
     daat_sample_div = env_u32("PS_DAAT_SAMPLE_DIV", daat_sample_div);
+    daat_prime = env_u32("PS_DAAT_PRIME", daat_prime);
     daat_sample_all = env_u32("PS_DAAT_SAMPLE_ALL", daat_sample_all);
     daat_split = env_u32("PS_DAAT_SPLIT", daat_split);
     daat_small_nl = env_u32("PS_DAAT_SMALL_NL", daat_small_nl);
@@ -954,7 +973,7 @@ void ensure_dev_trie(EngineImpl& m);  // (defined with the device planner below)
 // Per-list score bounds on the device (k_list_bounds) for the current (k1, b, avg) and boosts; see
 // EngineImpl::ListBounds.  Enqueued on `st` in front of the batch that needs them; nothing is recomputed
 // while the parameters stay what they were, and a boost vector seen recently finds its J array resident.
-struct BoundsRef { const double* M; const double* J; const double* plane; const double* H; uint32_t h_lo; double h_a, h_b; };
+struct BoundsRef { const double* M; const double* J; const double* plane; const double* H; uint32_t h_lo; double h_a, h_b; const double* kth; };
 
 static_assert(BOUND_NDIR == PREP_NDIR, "host and device agree on the directions of the two-field joint bound");
 BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const KParams& kp, hipStream_t st) {
@@ -972,13 +991,14 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
   if (need_j)
     for (auto& js : lb.j)
       if (js.valid && js.boosts == bv) tgt = &js;
-  BoundsRef ref{nullptr, nullptr, nullptr, nullptr, 0u, 0.0, 0.0};
+  BoundsRef ref{nullptr, nullptr, nullptr, nullptr, 0u, 0.0, 0.0, nullptr};
   if (F == 2) boost_cone(boosts, ref.h_lo, ref.h_a, ref.h_b);
   auto fill = [&]() {
     ref.M = reinterpret_cast<const double*>(lb.M.p);
     ref.J = need_j ? reinterpret_cast<const double*>(tgt->J.p) : nullptr;
     ref.plane = lb.plane.p;
     ref.H = F == 2 ? reinterpret_cast<const double*>(lb.H.p) : nullptr;
+    ref.kth = F <= 2 ? reinterpret_cast<const double*>(lb.kth.p) : nullptr;
     return ref;
   };
   if (m_ok && (!need_j || tgt)) {
@@ -1034,6 +1054,16 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
                        m_ok ? nullptr : lb.plane.p, m.d_layer_idf.p);
     PS_HIP(hipGetLastError());
   }
+  if (!m_ok && F <= 2) {  // threshold priming tables from the plane just written (same stream, in order)
+    const size_t nk = nl * (F == 1 ? 1 : 3) * KTH_RANKS + 1;
+    lb.kth.ensure(nk);
+    PS_HIP(hipMemsetAsync(lb.kth.p, 0, nk * 8, st));
+    if (lb.n_units) {
+      if (F == 1) hipLaunchKernelGGL(k_list_kth<1>, dim3((lb.n_units + 3) / 4), dim3(256), 0, st, lb.units.p, lb.n_units, m.d_layer_a.p, lb.plane.p, lb.kth.p);
+      else hipLaunchKernelGGL(k_list_kth<2>, dim3((lb.n_units + 3) / 4), dim3(256), 0, st, lb.units.p, lb.n_units, m.d_layer_a.p, lb.plane.p, lb.kth.p);
+      PS_HIP(hipGetLastError());
+    }
+  }
   if (!m_ok) PS_HIP(hipEventRecord(lb.m_ready, st)); else PS_HIP(hipStreamWaitEvent(st, lb.m_ready, 0));
   if (tgt) {
     PS_HIP(hipEventRecord(tgt->ready, st));
@@ -1055,13 +1085,17 @@ void ensure_bloom(EngineImpl& m, hipStream_t st) {
   const size_t nl = s.layers.size();
   std::vector<unsigned long long> desc(std::max<size_t>(nl, 1), NO_BLOOM);
   uint64_t words = 0;
+  uint32_t id_bits = 0;  // bits of the largest doc id a delta can still append
+  while (id_bits < 32 && ((uint64_t)s.tiles_cap * s.T - 1) >> id_bits) ++id_bits;
   for (size_t l = 0; l < nl; ++l) {
     const LayerInfo& L = s.layers[l];
     if (L.bm_off != NO_BITMAP || L.len == 0) continue;
     uint64_t nw = 1;
     uint32_t lg = 0;
     while (nw * 64 < (uint64_t)L.len * BLOOM_BITS_PER_KEY) { nw <<= 1; ++lg; }
-    desc[l] = words | ((unsigned long long)lg << 58);
+    // doc-ordered layout: word = doc id >> shift, every id of the snapshot's id space (headroom included) below nw
+    const uint32_t shift = id_bits > lg ? id_bits - lg : 0u;
+    desc[l] = words | ((unsigned long long)shift << 40) | ((unsigned long long)lg << 58);
     words += nw;
   }
   if (words >= (1ull << 40)) throw std::length_error("Bloom filters: more than 2^40 words");
@@ -1111,12 +1145,26 @@ void ensure_row_candidates(EngineImpl& m, hipStream_t st) {
   rc.valid = true;
 }
 
+// A preparation kernel found the device's item counts above the ones the host sized a scoring launch from (the "which kernel takes
+// this query" rule lives in the planner's count pass, in k_plan and in k_prep_query): some batch since the last check may have
+// skipped items.  Reported at the next submission / result fetch as an internal error instead of a silently wrong top-k.
+void check_device_fault(EngineImpl& m) {
+  if (!m.h_fault) return;
+  const volatile uint32_t* f = m.h_fault;
+  if (f[0] == 0u) return;
+  const uint32_t code = f[0], n = f[1], split = f[2], host = f[3];
+  m.h_fault[0] = 0u;
+  throw std::logic_error("internal: K1d preparation and host disagree on a batch's work items (code " + std::to_string(code) + ": device " +
+                         std::to_string(n) + " items, split at " + std::to_string(split) + ", host " + std::to_string(host) +
+                         "); an earlier batch's results may be incomplete");
+}
+
 // The device-side preparation of a K1d batch (ps_prep_kernels.hpp) over a plan that already lives in
 // HBM - uploaded by the host planner or written by the device planner: bounds -> descriptors / order /
 // candidate slots -> items and dense-row flags.  `items_bound` >= the batch's item count (exact when the
 // host knows the list lengths).  Fills the K1d members of `kp`.
 void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc, const double* boosts, KParams& kp, ps_plan_entry* d_plan,
-                 const uint32_t* d_qbeg, size_t B, size_t ne, bool multi, size_t items_bound, bool split_kinds) {
+                 const uint32_t* d_qbeg, size_t B, size_t ne, bool multi, size_t items_bound, bool split_kinds, size_t items_big = 0) {
   const Snapshot& s = *m.snap;
   hipStream_t st = m.prep_stream;
   const uint64_t rc0 = m.bounds.recomputed;
@@ -1167,6 +1215,18 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   pp.cand_of_layer = m.cands.of_layer.p; pp.n_cand = m.cands.n; pp.min_uses = std::max(1u, m.tune.dense_min_uses);
   pp.rows_resident = m.tune.row_cache_mb != 0;
   pp.layer_a = m.d_layer_a.p; pp.row_state = c.row_state; pp.row_desc = c.row_desc; pp.wstats = m.d_wstats;
+  pp.host_items = (uint32_t)items_bound; pp.host_items_big = (uint32_t)items_big; pp.fault = m.d_fault;
+  // threshold priming: off while the snapshot carries tombstones (a removed document may be one of a list's K best), for K beyond
+  // the stored ranks, and for three fields and more (no tables)
+  pp.gthr = kp.gthr;
+  pp.kth = nullptr;
+  if (m.tune.daat_prime && br.kth != nullptr && kp.alive == nullptr && kp.K >= 1 && kp.K <= 64) {
+    static const uint32_t ranks[KTH_RANKS] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40, 50, 64};
+    uint32_t j = 0;
+    while (ranks[j] < kp.K) ++j;
+    pp.kth = br.kth;
+    pp.kth_rank = j;
+  }
   if (B) {
     hipLaunchKernelGGL(k_prep_query, dim3((uint32_t)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, pp);
     if (ne) hipLaunchKernelGGL(k_prep_items, dim3((uint32_t)((ne + 2 * WAVE - 1) / (2 * WAVE))), dim3(2 * WAVE), 0, st, pp);
@@ -2031,6 +2091,7 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
                   size_t n_items, uint32_t max_slots, size_t top_k, void* d_keys, void* d_scores, void* d_counts, hipStream_t caller,
                   const ZBatch* zb = nullptr, const uint32_t* d_out_row = nullptr, size_t n_items_big = 0) {
   const Snapshot& s = *m.snap;
+  check_device_fault(m);
   hipStream_t P = m.prep_stream, S = m.score_stream;
   if (m.tune.score_alt == 4) {  // three-way rotation: normal, low, high
     const uint32_t r = m.score_flip++ % 3u;
@@ -2064,9 +2125,9 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     // a BM25 batch with both kinds of queries - those k_daat_small takes (<= 4 lists, one per query term) and others - is scored
     // by both kernels, each over its part of one item array (the preparation puts the second kind's items behind the first's)
     const bool split_kinds = !zb && m.tune.daat_split && m.tune.daat_small && !m.tune.daat_persistent && n_items_big > 0 && n_items_big < n_items;
+    kp.K = (uint32_t)top_k;  // (the preparation primes the thresholds for this K)
     if (zb) launch_prep_z(m, c, *zb, kp, d_plan, d_qbeg, B, ne, n_items);
-    else launch_prep(m, c, sc, boosts, kp, d_plan, d_qbeg, B, ne, multi, n_items, split_kinds);
-    kp.K = (uint32_t)top_k;
+    else launch_prep(m, c, sc, boosts, kp, d_plan, d_qbeg, B, ne, multi, n_items, split_kinds, split_kinds ? n_items_big : 0);
     const size_t n_cand = n_items * top_k;
     c.cand_score.ensure(n_cand + 1);
     c.cand_doc.ensure(n_cand + 1);
@@ -2078,6 +2139,7 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     // consecutive scoring kernels; ps_snapshot_kernel_breakdown then has nothing to report for these batches)
     const bool timers = m.tune.kernel_timers != 0;
     if (timers) {
+      m.rebase_timers_if_stale(m.stream);
       kt = &m.kt[m.next_kt];
       m.next_kt = (m.next_kt + 1) % N_KTIMER;
       m.harvest(*kt, true);
@@ -2529,6 +2591,7 @@ void enqueue_topk(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts,
   kp.out_counts = (uint32_t*)d_counts;
   m.last_kt = nullptr;
   if (timed) {
+    m.rebase_timers_if_stale(m.stream);
     kt = &m.kt[m.next_kt];
     m.next_kt = (m.next_kt + 1) % N_KTIMER;
     m.harvest(*kt, true);
@@ -2983,6 +3046,7 @@ bool Engine::run_device_planned(const ps_scorer_desc& sc, const double* boosts, 
       kp.cand_score = m.d_cand_score.p;
       kp.cand_doc = m.d_cand_doc.p;
       kp.out_keys = (uint64_t*)d_keys; kp.out_scores = (double*)d_scores; kp.out_counts = (uint32_t*)d_counts;
+      m.rebase_timers_if_stale(m.stream);
       EngineImpl::KTimer* kt = &m.kt[m.next_kt];
       m.next_kt = (m.next_kt + 1) % N_KTIMER;
       m.harvest(*kt, true);
@@ -3154,6 +3218,7 @@ void Engine::run_host(const ps_scorer_desc& sc, const double* boosts, const Plan
   memcpy(h_off, cap.data(), (B + 1) * 8);
   PS_HIP(hipMemcpyAsync(m.d_full_off.p, h_off, (B + 1) * 8, hipMemcpyHostToDevice, st));
   PS_HIP(hipMemsetAsync(m.d_full_cnt.p, 0, (B + 1) * 4, st));
+  m.rebase_timers_if_stale(m.stream);
   EngineImpl::KTimer& kt = m.kt[m.next_kt];
   m.last_kt_pending = &kt;
   m.next_kt = (m.next_kt + 1) % N_KTIMER;

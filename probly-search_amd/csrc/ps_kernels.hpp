@@ -1411,11 +1411,26 @@ __global__ __launch_bounds__(WAVE * MERGE_WAVES) void k_merge(const KParams p) {
 // ---- Bloom filters of the sparse lists --------------------------------------------------------------
 constexpr unsigned long long NO_BLOOM = ~0ull;
 constexpr uint32_t BLOOM_BITS_PER_KEY = 16;
-__device__ __forceinline__ void bloom_probe(const uint32_t d, const unsigned long long desc, uint64_t& word, unsigned long long& mask) {
+#ifndef PS_BLOOM_DOC_ORDER
+// 1: the filter word of a document is chosen by its DOC ID (d >> shift: the filter is laid out in document order, like the list
+// itself), only the three bits inside the word by a hash.  The documents a wave asks about are consecutive postings of its own
+// doc-sorted list, i.e. a narrow range of the document space: their filter words then share a handful of 128-byte lines
+// instead of 64 lines scattered over the whole filter (C2: 3.65 M filter words per launch = a quarter of all line requests of
+// k_daat_small, profiles/r06_request_lines.txt).  A list whose documents cluster in id space loads some words more than others
+// - more "maybe" answers there, never a wrong one.  0: round 5's hashed word.
+#define PS_BLOOM_DOC_ORDER 1
+#endif
+// filter descriptor: bits 0-39 first word, 40-45 shift (doc-ordered layout), 58-63 log2(words)
+__device__ __host__ __forceinline__ void bloom_probe(const uint32_t d, const unsigned long long desc, uint64_t& word, unsigned long long& mask) {
   const unsigned long long h = (unsigned long long)d * 0x9E3779B97F4A7C15ull;
+#if PS_BLOOM_DOC_ORDER
+  word = (desc & ((1ull << 40) - 1ull)) + (uint64_t)(d >> (uint32_t)((desc >> 40) & 63u));
+  mask = (1ull << (h >> 58)) | (1ull << ((h >> 52) & 63u)) | (1ull << ((h >> 46) & 63u));  // (the product's high bits are the mixed ones)
+#else
   const uint32_t lg = (uint32_t)(desc >> 58);
   word = (desc & ((1ull << 40) - 1ull)) + ((h >> 36) & ((1ull << lg) - 1ull));
   mask = (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u)) | (1ull << ((h >> 12) & 63u));
+#endif
 }
 // one wave per sparse list: every posting sets its three bits (blocked filter: all three in one 64-bit word)
 __global__ __launch_bounds__(256) void k_build_bloom(const uint32_t* doc, const uint4* layer_a, const unsigned long long* layer_bloom,
@@ -2287,13 +2302,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
 #ifndef PS_EXP
 #define PS_EXP 0       // profiling builds only (wrong results): 1 = no top-K offers, 2 = no second level, 4 = no first-level loads
 #endif
-#ifndef PS_DAAT_DEFER_HIGHER
-// 1: the lists ranked ABOVE the own one are asked by the survivors only.  A document evaluated here sits in none of them, so
-// their first level cannot tighten its bound - it can only cancel the few documents that do sit in one (then evaluated by that
-// list's items).  Asking them for every document that passes the first bound test was 3.7 M filter words + ~2 M bitmap cells of a
-// C2 launch's 23 M first-level lookups (profiles/r06_request_lines.txt).  0: round 5's all-lists-at-once first level.
-#define PS_DAAT_DEFER_HIGHER 1
-#endif
 constexpr int DAAT_SMALL_MAX = 4;  // most lists per query
 
 // WC: keep the work counters (ps_work_counters).  The serving instantiation (PS_WORK_COUNTERS=0 at run time) carries none
@@ -2409,44 +2417,6 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
   uint32_t n_trips = 0;
 #endif
 
-  // First level of other list k for one document per lane: the dense-row value, the {bits, postings before} bitmap cell, or the
-  // sparse list's filter word (x = 1: maybe) - and what it says: where the posting is / the row value (`loc`), whether the list
-  // holds the document (`hit`; for a filter: maybe).
-  auto first_level_load = [&](const int k, const uint32_t dd, const bool on) -> uint2 {
-    uint2 r = make_uint2(0u, 0u);
-    if (PS_EXP & 4) return r;
-    if (o_shift[k] & DENSE_FLAG) {
-      if (on) r = *reinterpret_cast<const uint2*>(p.rows + (uint64_t)o_row[k] * p.row_stride + dd);
-      ws.row += cnt(on);
-    } else if (o_bm[k] != 0xFFFFFFFFu) {
-      if (on) r = *reinterpret_cast<const uint2*>(p.bits + (uint64_t)o_bm[k] + 2 * (uint64_t)(dd >> 5));
-      ws.cell += cnt(on);
-    } else if (o_bloom[k] != NO_BLOOM) {
-      uint64_t wi;
-      unsigned long long mk;
-      bloom_probe(dd, o_bloom[k], wi, mk);
-      const unsigned long long w = on ? p.bloom[wi] : 0ull;
-      r.x = (on && (w & mk) == mk) ? 1u : 0u;  // maybe
-      ws.cell += cnt(on);
-    } else {
-      r.x = on ? 1u : 0u;  // no filter: ask the table
-    }
-    return r;
-  };
-  auto first_level_loc = [&](const int k, const uint2 f, const uint32_t dd, bool& hit) -> unsigned long long {
-    if (o_shift[k] & DENSE_FLAG) {
-      hit = __hiloint2double((int)f.y, (int)f.x) > 0.0;
-      return (unsigned long long)f.x | ((unsigned long long)f.y << 32);
-    }
-    if (o_bm[k] != 0xFFFFFFFFu) {
-      const uint32_t bit = dd & 31u;
-      hit = (f.x >> bit) & 1u;
-      return hit ? o_off[k] + f.y + (uint32_t)__popc(f.x & ((1u << bit) - 1u)) : ~0ull;
-    }
-    hit = f.x != 0u;  // the filter (or its absence) says maybe
-    return hit ? 0ull : ~0ull;
-  };
-
   // Second level + the sum in PLAN order (query.rs:33-89; one list per query term: always the `+` / assign
   // arm) + the top-K offer for the first `count` (<= 64) queued documents, one per lane.
   auto process = [&](const uint32_t count, const double theta) {
@@ -2454,31 +2424,12 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
     bool ok = (uint32_t)lane < count;
     const uint32_t d = ok ? q_d[wave][at] : 0u;
     const double s_own = ok ? q_s[wave][at] : 0.0;
-    // the lists ranked above the own one: their first level now, for these <= 64 documents only (every list's load in flight together)
-    unsigned long long dloc[NO];
-    if (PS_DAAT_DEFER_HIGHER) {
-      uint2 dfl[NO];
-#pragma unroll
-      for (int k = 0; k < NO; ++k) {
-        dfl[k] = make_uint2(0u, 0u);
-        if ((uint32_t)k + 1u < ne && o_rank[k] < own_rank) dfl[k] = first_level_load(k, d, ok);
-      }
-#pragma unroll
-      for (int k = 0; k < NO; ++k) {
-        dloc[k] = ~0ull;
-        if ((uint32_t)k + 1u < ne && o_rank[k] < own_rank) {
-          bool hit;
-          dloc[k] = first_level_loc(k, dfl[k], d, hit);
-        }
-      }
-    }
     double P = 0.0;
 #pragma unroll
     for (int k = 0; k <= NO; ++k) {
       if ((uint32_t)k == own_pos && ok && s_own > 0.0) P += s_own;
       if (k < NO && (uint32_t)k + 1u < ne && !(PS_EXP & 2)) {
-        unsigned long long loc = ok ? q_loc[k < NO ? k : 0][wave][at] : ~0ull;
-        if (PS_DAAT_DEFER_HIGHER && o_rank[k] < own_rank) loc = ok ? dloc[k < NO ? k : 0] : ~0ull;
+        const unsigned long long loc = ok ? q_loc[k < NO ? k : 0][wave][at] : ~0ull;
         double sk = 0.0;
         if (o_shift[k] & DENSE_FLAG) {
           sk = ok ? __longlong_as_double((long long)loc) : 0.0;
@@ -2606,7 +2557,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int u = 0; u < U; ++u) fl[k][u] = make_uint2(0u, 0u);
     auto first_level = [&](const int k, const bool (&on)[U]) {
-      if ((uint32_t)k + 1u < ne && !(PS_EXP & 4) && !(PS_DAAT_DEFER_HIGHER && o_rank[k] < own_rank)) {
+      if ((uint32_t)k + 1u < ne && !(PS_EXP & 4)) {
         if (o_shift[k] & DENSE_FLAG) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
@@ -2649,7 +2600,7 @@ __global__ __launch_bounds__(WAVE * DAAT_WGW) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
       for (int k = 0; k < NO; ++k) {
         loc[k] = ~0ull;
-        if ((uint32_t)k + 1u < ne && !(PS_DAAT_DEFER_HIGHER && o_rank[k] < own_rank)) {
+        if ((uint32_t)k + 1u < ne) {
           const bool dense = (o_shift[k] & DENSE_FLAG) != 0, bitmap = !dense && o_bm[k] != 0xFFFFFFFFu;
           double c;
           bool hit;

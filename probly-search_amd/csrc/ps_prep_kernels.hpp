@@ -89,7 +89,15 @@ struct PrepParams {
   RowState* row_state;           // [PREP_MAX_ROWS]
   RowDesc* row_desc;             // [PREP_MAX_ROWS] rows to score this batch
   unsigned long long* wstats;    // work counters (rows built / used)
+  // threshold priming (k_list_kth): a query's final K-th best score is at least the K-th best posting score of any ONE of its lists
+  const double* kth;             // [n_layers][F + 1][KTH_RANKS] (plane units; null: off)
+  uint32_t kth_rank;             // index of the smallest stored rank >= K
+  unsigned long long* gthr;      // [B] the batch's threshold words: start at theta0 instead of 0
+  // consistency of the three copies of the "which kernel takes this query" rule (planner count pass / host, k_plan, k_prep_query):
+  uint32_t host_items, host_items_big;  // what the launch grids are sized from
+  uint32_t* fault;                      // engine-wide, host-mapped: {code, device items, device split, host items}; 0 = fine
 };
+constexpr uint32_t FAULT_ITEM_COUNTS = 1;  // the device counted more items (of one kind) than the host sized the launch for: items would be skipped
 
 // ---- per-list bounds --------------------------------------------------------------------------
 struct BoundUnit { uint32_t layer, begin, count; };  // a segment of one list
@@ -168,6 +176,87 @@ __global__ __launch_bounds__(256) void k_list_bounds(const KParams p, const Boun
   }
 }
 
+// ---- threshold priming ---------------------------------------------------------------------------
+// Every contribution to a document's score is >= 0 (K1d's gates: positive boosts, k1 >= 0, 0 <= b <= 1) and contributions meet
+// through `+` and `max` (query.rs:150-164), so a document scores at least what ANY one of its postings gives it.  Hence the
+// query's final K-th best score theta_K >= the K-th best posting score of any single list of the query - a number that does
+// not depend on the query and is known before the launch ("threshold priming" of MaxScore / WAND: the rank-safe top-K needs
+// no document strictly below it).  Stored per list: the r-th largest value of each score plane x (plane_x = tfn_x * idf) and of
+// plane_0 + plane_1, for 16 ranks r up to 64.  With it (k_prep_query): gthr[q] starts at theta0 = max over the query's lists,
+// and a list whose skip threshold is already below theta0 gets NO work items at all - round 5 dispatched ~60 k workgroups per
+// C2 launch (of 66 k) only to have them read the threshold and leave.  A long list is scanned in segments whose tables meet
+// through atomicMax: the r-th best of a segment is a lower bound of the list's r-th best.
+constexpr int KTH_RANKS = 16;
+__device__ __forceinline__ uint32_t kth_rank_of(const int j) {
+  constexpr uint32_t R[KTH_RANKS] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40, 50, 64};
+  return R[j];
+}
+// `top` = the wave's 64 largest values so far, sorted descending over the lanes; merges 64 new values (one per lane) into it
+__device__ __forceinline__ void top64_merge(double& top, double v, const int lane) {
+  for (int k = 2; k <= WAVE; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {  // bitonic sort of v, descending
+      const double o = __shfl_xor(v, j);
+      v = (((lane & j) == 0) == ((lane & k) == 0)) ? fmax(v, o) : fmin(v, o);
+    }
+  double w = fmax(top, __shfl(v, WAVE - 1 - lane));  // descending against ascending: a bitonic sequence holding the 64 largest of both
+  for (int j = WAVE / 2; j > 0; j >>= 1) {
+    const double o = __shfl_xor(w, j);
+    w = ((lane & j) == 0) ? fmax(w, o) : fmin(w, o);
+  }
+  top = w;
+}
+template <int F_>
+__global__ __launch_bounds__(256) void k_list_kth(const BoundUnit* units, const uint32_t n_units, const uint4* layer_a, const double* plane,
+                                                  unsigned long long* kth) {
+  static_assert(F_ == 1 || F_ == 2, "threshold priming tables exist for one and two fields");
+  constexpr int D = F_ == 1 ? 1 : 3;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1);
+  if (wave >= n_units) return;
+  const BoundUnit u = units[wave];
+  const uint4 la = layer_a[u.layer];
+  const uint64_t off = ((uint64_t)la.x | ((uint64_t)la.y << 32)) + u.begin;
+  double top[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) top[d] = 0.0;
+  for (uint32_t i0 = 0; i0 < u.count; i0 += WAVE) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    double v[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) v[d] = 0.0;
+    if (i < u.count) {
+      if (F_ == 1) v[0] = plane[off + i];
+      else {
+        const double2 t = reinterpret_cast<const double2*>(plane)[off + i];
+        v[0] = t.x; v[1] = t.y; v[D - 1] = t.x + t.y;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (__any(v[d] > readlane_f64(top[d], WAVE - 1))) top64_merge(top[d], v[d], lane);
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    for (int j = 0; j < KTH_RANKS; ++j)
+      if ((uint32_t)lane + 1u == kth_rank_of(j) && top[d] > 0.0)
+        atomicMax(&kth[((size_t)u.layer * D + d) * KTH_RANKS + j], (unsigned long long)__double_as_longlong(top[d]));
+}
+// theta0 of plan entry e: at least K of its postings score at least this much - through the readers' own expression
+// ((plane_x * boost_x) * expansion_boost, monotone in plane_x; the other field adds >= 0), or, for two fields, through the
+// K-th best plane sum with the smaller boost (a real-number inequality, deflated past the few roundings between the two).
+__device__ __forceinline__ double prep_entry_theta0(const PrepParams& pp, const ps_plan_entry& e) {
+  if (pp.kth == nullptr) return 0.0;
+  const uint32_t D = pp.F == 1u ? 1u : 3u;
+  const double* k = pp.kth + ((size_t)e.node * D) * KTH_RANKS + pp.kth_rank;
+  double th = 0.0;
+  for (uint32_t x = 0; x < pp.F; ++x) th = fmax(th, (k[x * KTH_RANKS] * pp.boost[x]) * e.boost);
+  if (pp.F == 2u) {
+    const double sdir = k[2 * KTH_RANKS] * fmin(pp.boost[0], pp.boost[1]) * e.boost * (1.0 - 1e-12);
+    if (sdir > 1e-290) th = fmax(th, sdir);  // (not among subnormal products: a rounding there is absolute)
+  }
+  return th;
+}
+
 // Upper bound of any posting score of plan entry `e`, rounding included: the per-field form pushes the
 // maxima through the kernels' own expression (every operation is monotone: ((tfn * idf) * boost) * eb,
 // summed over the fields in order), the joint form bounds the real-number value and is inflated past the
@@ -242,8 +331,9 @@ __device__ __forceinline__ bool prep_before(const double ua, const uint32_t la, 
 }
 
 template <int NMAX>
-__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, uint32_t& groups) {
-  double ub[NMAX];
+__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, uint32_t& groups, double& th0) {
+  double ub[NMAX], t0[NMAX];
+  th0 = 0.0;
   uint32_t len[NMAX], grp[NMAX], rank[NMAX], qt[NMAX];
 #pragma unroll
   for (int i = 0; i < NMAX; ++i) {
@@ -251,8 +341,10 @@ __device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const
     if ((uint32_t)i < n) {
       const ps_plan_entry& en = pp.plan[b + i];
       ub[i] = prep_entry_ub(pp, en);
+      t0[i] = prep_entry_theta0(pp, en);
       len[i] = en.len;
       qt[i] = en.qterm;
+      th0 = fmax(th0, t0[i]);
     }
   }
   uint32_t n_groups = 0;
@@ -327,19 +419,21 @@ __device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const
         pp.dgroup[b + i] = dg;
       }
       const uint32_t c = prep_chunk(pp, len[i]);
-      slots += (len[i] + c - 1) / c;
+      if (!(d.skip_thr < th0)) slots += (len[i] + c - 1) / c;  // (a list that is non-essential from the start gets no items)
     }
   }
   return slots;
 }
 
-__device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n) {
+__device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, double& th0) {
   // bounds; dense ordinal of every entry's query term (the entries of a term are adjacent in plan order)
   uint32_t n_groups = 0, cur = 0xFFFFFFFFu;
+  th0 = 0.0;
   for (uint32_t i = 0; i < n; ++i) {
     const ps_plan_entry& en = pp.plan[b + i];
     DEntry& d = pp.dentry[b + i];
     d.ub = prep_entry_ub(pp, en);
+    th0 = fmax(th0, prep_entry_theta0(pp, en));
     d.q = q;
     if (en.qterm != cur) { cur = en.qterm; ++n_groups; }
     pp.gord[b + i] = (uint8_t)(n_groups - 1);
@@ -411,7 +505,7 @@ __device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const 
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t len = pp.plan[b + i].len;
     const uint32_t c = prep_chunk(pp, len);
-    slots += (len + c - 1) / c;
+    if (!(pp.dentry[b + i].skip_thr < th0)) slots += (len + c - 1) / c;
   }
   return slots;
 }
@@ -544,7 +638,9 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
   // (plans of <= 4 entries - one list per query term: C2, C4 - entirely in registers; wider ones walk their arrays in HBM.
   // An 8-entry register variant cost this kernel 145 VGPRs and 58 SGPR spills for every batch: 76 / 0 without it.)
   uint32_t groups = 0;
-  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n, groups) : prep_query_general(pp, q, b, n);
+  double th0 = 0.0;  // the query's primed threshold
+  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n, groups, th0) : prep_query_general(pp, q, b, n, th0);
+  if (have && pp.gthr != nullptr) pp.gthr[q] = (unsigned long long)__double_as_longlong(th0);
   // PLAN_BIG's rule (k_plan): more than 4 lists, or several lists under one query term -> k_daat's part of the batch
   const bool big = pp.split_kinds && (n > 4u || groups != n);
   // candidate slots: query-major within the query; the wave's queries take one block of the batch's slots
@@ -559,8 +655,9 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
     if (on) {
       const ps_plan_entry& en = pp.plan[b + i];
       const uint32_t c = prep_chunk(pp, en.len);
-      nc = (en.len + c - 1) / c;
-      ns = (big || !pp.split_kinds || pp.sample_small) ? prep_sample_chunks(pp, en, c, nc) : 0u;
+      const bool dead = pp.dentry[b + i].skip_thr < th0;  // non-essential before the launch: no items, no candidate slots
+      nc = dead ? 0u : (en.len + c - 1) / c;
+      ns = dead ? 0u : (big || !pp.split_kinds || pp.sample_small) ? prep_sample_chunks(pp, en, c, nc) : 0u;
       pp.gen[b + i] = DItemGen{big ? 1u : 0u, ns, c, sl};  // (`entry`: gen is indexed by entry - the word carries the query's kind)
       sl += nc;
       const uint32_t rk = pp.dentry[b + i].rank;
@@ -583,6 +680,17 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
   if (t + 1u == gridDim.x) {
     __threadfence();
     prep_finish(pp);
+    if (pp.fault != nullptr) {
+      // the scoring launches are sized from the host's item counts and clamp to the device's: a device count ABOVE the host's
+      // would silently skip items (a wrong top-k, no error) - make it loud instead
+      __threadfence();
+      if ((threadIdx.x & (WAVE - 1)) == 0u) {
+        const uint32_t n = __hip_atomic_load(&pp.ctl->n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t split = pp.split_kinds ? __hip_atomic_load(&pp.ctl->bucket_start[PREP_SET_BUCKETS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n;
+        const bool bad = n > pp.host_items || (pp.split_kinds && (split > pp.host_items - pp.host_items_big || n - split > pp.host_items_big));
+        if (bad && atomicCAS(&pp.fault[0], 0u, FAULT_ITEM_COUNTS) == 0u) { pp.fault[1] = n; pp.fault[2] = split; pp.fault[3] = pp.host_items; }
+      }
+    }
   }
 }
 
@@ -598,10 +706,12 @@ __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
     const DItemGen g = pp.gen[i];
     const uint32_t len = en.len, c = g.chunk;
     len_i = len; chunk = c; first_slot = g.first_slot;
-    nc = (len + c - 1) / c;
+    const DEntry de_i = pp.dentry[i];
+    // (k_prep_query's rule: a list whose skip threshold is below the query's primed threshold has no items)
+    const bool dead = pp.gthr != nullptr && de_i.skip_thr < __longlong_as_double((long long)pp.gthr[de_i.q]);
+    nc = dead ? 0u : (len + c - 1) / c;
     ns = g.item_at;  // (k_prep_query: the list's chunks in the sample phase)
     const bool big = g.entry != 0u;  // (... and its query's kind)
-    const DEntry de_i = pp.dentry[i];
     skip_i = de_i.skip_thr; q_i = de_i.q;
     bk = prep_bucket(de_i.rank, len, pp.multi != 0u && (big || !pp.split_kinds), big);
     bs = (big ? PREP_SET_BUCKETS : 0u) + (de_i.rank < PREP_SAMPLE_BUCKETS ? de_i.rank : PREP_SAMPLE_BUCKETS - 1u);

@@ -1,6 +1,7 @@
 """Multi-GPU plumbing for the query path: replicated corpus, query batch sharded across ranks,
-per-rank top-k blocks all-gathered with torch.distributed (backend "nccl" == RCCL over xGMI on
-ROCm; "gloo" in the CPU tests).
+per-rank top-k blocks all-gathered by the library's own RCCL communicator (ps_comm_*: ncclAllGather over xGMI).
+`all_gather_topk` is the same exchange written against torch.distributed for hosts that already own a process group
+("gloo" in the CPU tests).
 
 The reference has no distributed mode at all; what makes this sharding natural is that queries
 are independent — each `Index::query` call owns its `scores` / `visited` maps and the index is
@@ -118,6 +119,65 @@ class Comm:
         dist.broadcast_object_list(box, src=0, group=group)
         return cls.init_rank(box[0], world, rank, device)
 
+    @classmethod
+    def from_env_store(cls, device, world=None, rank=None, timeout_s=300):
+        """The launch contract of `python -m torch.distributed.run` (WORLD_SIZE / RANK / MASTER_ADDR / MASTER_PORT) WITHOUT a
+        torch.distributed process group: the 128-byte id travels through the launcher's key-value store (a TCPStore client
+        of the agent's store under torchrun, TORCHELASTIC_USE_AGENT_STORE; otherwise rank 0 hosts one on MASTER_PORT), and
+        everything else the ranks exchange - barriers, the max of a timing - goes through the library's own communicator
+        (`all_gather_bytes`).  One RCCL communicator per process: the library's; no "nccl" group beside it, no gloo either."""
+        import os
+        world = int(os.environ["WORLD_SIZE"]) if world is None else world
+        rank = int(os.environ["RANK"]) if rank is None else rank
+        uid, store = cls.exchange_id_via_store(world, rank, timeout_s)
+        comm = cls.init_rank(uid, world, rank, device)
+        comm._store = store  # rank 0's server must outlive the slowest reader
+        comm.barrier()
+        return comm
+
+    @classmethod
+    def exchange_id_via_store(cls, world, rank, timeout_s=300):
+        """Rank 0 makes the id and publishes it in the launcher's store; every rank returns (id, store).  No device involved."""
+        import datetime
+        import os
+        from torch.distributed import TCPStore
+        addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() in ("1", "true")
+        store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=timeout_s),
+                         wait_for_workers=False)
+        # (a key per launch attempt: a restarted group must not read the id of the one before it)
+        key = "ps_comm_id/%s/%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+        if rank == 0:
+            store.set(key, cls.unique_id())
+        return bytes(store.get(key)), store  # (get blocks until rank 0 has set the key)
+
+    def all_gather_bytes(self, payload):
+        """Every rank contributes the same number of bytes; returns the `world` payloads in rank order (host bytes).  Through the
+        library's communicator (ncclAllGather / the debugging transport), blocking."""
+        n = len(payload)
+        send, recv = _DeviceBuffer(max(16, n)), _DeviceBuffer(max(16, n) * self.world)
+        send.from_host(payload)
+        _lib.check(self._L.ps_comm_all_gather(self._h, send.ptr, recv.ptr, max(16, n), None))
+        raw = recv.to_host()
+        return [raw[r * max(16, n): r * max(16, n) + n] for r in range(self.world)]
+
+    def barrier(self):
+        self.all_gather_bytes(b"\0" * 8)
+
+    def max_f64(self, x):
+        import struct
+        return max(struct.unpack("<d", b)[0] for b in self.all_gather_bytes(struct.pack("<d", float(x))))
+
+    def min_i64(self, x):
+        import struct
+        return min(struct.unpack("<q", b)[0] for b in self.all_gather_bytes(struct.pack("<q", int(x))))
+
+    def broadcast_bytes(self, payload, src=0, size=None):
+        """`payload` of rank `src` on every rank (all ranks pass a payload of the same length, or `size`)."""
+        n = len(payload) if size is None else size
+        mine = payload if self.rank == src else b"\0" * n
+        return self.all_gather_bytes(mine.ljust(n, b"\0"))[src]
+
     def free(self):
         if self._h:
             self._L.ps_comm_free(self._h)
@@ -205,6 +265,10 @@ class _DeviceBuffer:
         if self.hip().hipMalloc(C.byref(p), max(nbytes, 16)) != 0:
             raise MemoryError("hipMalloc(%d) failed" % nbytes)
         self.ptr = p
+
+    def from_host(self, payload):
+        if self.hip().hipMemcpy(self.ptr, C.c_char_p(bytes(payload)), len(payload), 1) != 0:  # hipMemcpyHostToDevice
+            raise RuntimeError("hipMemcpy H2D failed")
 
     def to_host(self):
         buf = C.create_string_buffer(self.nbytes)

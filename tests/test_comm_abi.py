@@ -29,6 +29,36 @@ def test_block_layout_and_argument_checks():
     assert L.ps_comm_init_rank(b"\0" * 128, 2, 5, 0, C.byref(h)) == _lib.PS_EINVAL
 
 
+def test_id_exchange_through_the_launcher_store_needs_no_process_group(tmp_path):
+    """bench.py --gpus N (dist.Comm.from_env_store): the 128-byte communicator id goes from rank 0 to the others through the
+    launcher's TCP store - here rank 0 hosts it, as without torchrun's agent store - and no torch.distributed process group
+    (no second RCCL communicator, no gloo) is ever initialised.  Two processes, no GPU."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from probly_search_amd import dist as psd\n"
+            "import torch.distributed as td\n"
+            "uid, store = psd.Comm.exchange_id_via_store(2, int(sys.argv[1]))\n"
+            "store.add('seen', 1)\n"
+            "import time\n"
+            "while int(store.add('seen', 0)) < 2: time.sleep(0.01)\n"
+            "print('UID=' + uid.hex() + ' PG=' + str(td.is_initialized()))\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PS_COMM_TRANSPORT="hostshm")
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in (0, 1)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines = [[l for l in o.splitlines() if l.startswith("UID=")][-1] for o, _ in outs]
+    assert lines[0] == lines[1] and lines[0].endswith("PG=False") and len(lines[0]) > 4 + 2 * 128 - 1, lines
+    import ctypes as C
+    assert _lib.load().ps_comm_all_gather(None, None, None, 8, None) == _lib.PS_EINVAL
+
+
 def _corpus_file(tmp_path, n_docs=300, n_queries=7):
     cfg = dict(synth.CONFIGS["C2"], n_docs=n_docs, vocab=120)
     corpus = synth.Corpus(**cfg)
@@ -98,6 +128,10 @@ def test_world_of_one_goes_through_rccl(monkeypatch):
     got = psd.query_batch_sharded(snap, queries, psa.bm25.new(), [1.0, 1.0], 10, comm)
     exp = [o.query(q, orc.bm25(), [1.0, 1.0])[:10] for q in queries]
     assert got == exp
+    # the caller's own small exchanges go through the same communicator (bench.py's barrier / max over ranks)
+    assert comm.all_gather_bytes(b"abcdefgh-123") == [b"abcdefgh-123"]
+    comm.barrier()
+    assert comm.max_f64(2.5) == 2.5 and comm.min_i64(-7) == -7 and comm.broadcast_bytes(b"xyz", size=16) == b"xyz".ljust(16, b"\0")
     comm.free()
     assert psd.query_batch_sharded(snap, queries, psa.bm25.new(), [1.0, 1.0], 10, None) == exp
 
@@ -116,8 +150,8 @@ def _rccl_path_in_subprocess(preload_torch):
 
 
 def test_one_rccl_per_process():
-    """bench.py --gpus N runs torch's nccl backend (torch/lib/librccl.so) and the library's own communicator in one
-    process: the library must pick up the instance that is already mapped instead of loading /opt/rocm's beside it;
+    """A host application may run torch's nccl backend (torch/lib/librccl.so) beside the library's own communicator in one
+    process (bench.py itself no longer does): the library must pick up the instance that is already mapped instead of loading /opt/rocm's beside it;
     a process without torch gets the system library.  No GPU needed: only the loader is exercised."""
     import os
     with_torch = _rccl_path_in_subprocess(True)

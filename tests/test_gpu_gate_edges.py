@@ -192,6 +192,11 @@ def test_mixed_batch_is_split_between_k_daat_small_and_k_daat(corpus_pair, devic
     base = corpus.queries(96, 3, salt=31)
     stems = [q.split(" ")[0] for q in base]
     odd = [" ".join(stems[i:i + 5]) for i in (0, 7)] + [stems[3][:3] + " " + stems[4], stems[5][:2], stems[6] + " " + stems[6], " ".join(stems[10:18])]
+    # duplicate tokens and dead tokens (no such term: no entry) inside both kinds of queries - the "which kernel takes this query"
+    # rule is applied by the planner's count pass, by k_plan and by k_prep_query, and the launch grids are sized from the first
+    # (if they ever disagree the preparation now raises the engine's fault word and the next call fails loudly)
+    odd += [" ".join(stems[20:24] + [stems[20]]), stems[25] + " qqqq " + stems[26], "qqqq " + " ".join(stems[27:32]),
+            stems[33] + " " + stems[33] + " " + stems[34], " ".join(stems[35:39]) + " qqqq"]
     queries = base[:40] + odd[:3] + base[40:] + odd[3:] + ["", "zzzz"]
     sc, osc = product_scorer("bm25"), oracle_scorer("bm25")
     plans = [snap.plan(q, sc)[0] for q in queries]
@@ -224,6 +229,47 @@ def test_mixed_batch_is_split_between_k_daat_small_and_k_daat(corpus_pair, devic
     for q, g in zip(queries, got):
         exp = [(k, bits(s_)) for k, s_ in o.query(q, osc, [1.0, 1.0])[:10]]
         assert g == exp, (q, g[:3], exp[:3])
+
+
+@pytest.mark.parametrize("K", [1, 3, 10, 17, 64])
+def test_threshold_priming_changes_work_not_results(corpus_pair, K):
+    """PS_DAAT_PRIME: a query's threshold starts at the K-th best posting score of its best single list and lists that are
+    non-essential under it get no work items (k_list_kth / k_prep_query).  Rank-safe: the batch with priming == without ==
+    the streaming kernel == the oracle, for K at, between and at the end of the stored ranks, other boosts (the plane-sum
+    direction), lists shorter than K, and one- to six-term queries; and priming must actually drop work items."""
+    corpus, p, o, snap = corpus_pair
+    base = corpus.queries(160, 3, salt=77)
+    stems = [q.split(" ")[0] for q in base]
+    queries = base + stems[:24] + [" ".join(stems[i:i + 2]) for i in range(24, 48, 2)] + [" ".join(stems[i:i + 6]) for i in (50, 60)] + [stems[70][:3]]
+    sc, osc = product_scorer("bm25"), oracle_scorer("bm25")
+    L = psa.load()
+
+    def run(boosts):
+        snap.work_counters(reset=True)
+        got = [[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(queries, sc, None, boosts, top_k=K)]
+        return got, snap.work_counters(reset=True)
+
+    try:
+        for boosts in ([1.0, 1.0], [0.5, 3.0], [2.0, 0.25]):
+            L.ps_set_option(b"PS_DAAT_PRIME", 1)
+            primed, w1 = run(boosts)
+            assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_daat")
+            L.ps_set_option(b"PS_DAAT_PRIME", 0)
+            plain, w0 = run(boosts)
+            assert primed == plain, (K, boosts)
+            assert w1["items_run"] <= w0["items_run"] and w1["postings_scanned"] <= w0["postings_scanned"], (K, w1, w0)
+            if K <= 10 and boosts == [1.0, 1.0]:
+                assert w1["postings_scanned"] < w0["postings_scanned"], (K, w1["postings_scanned"], w0["postings_scanned"])
+            L.ps_set_option(b"PS_DAAT", 0)
+            streamed, _ = run(boosts)
+            L.ps_set_option(b"PS_DAAT", 1)
+            assert streamed == primed, (K, boosts)
+            for q, g in list(zip(queries, primed))[::9]:
+                exp = [(k, bits(s_)) for k, s_ in o.query(q, osc, boosts)[:K]]
+                assert g == exp, (K, boosts, q, g[:3], exp[:3])
+    finally:
+        L.ps_set_option(b"PS_DAAT", 1)
+        L.ps_set_option(b"PS_DAAT_PRIME", 1)
 
 
 def test_corners_under_a_delta_with_removals(corpus_pair):

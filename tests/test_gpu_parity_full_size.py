@@ -92,11 +92,11 @@ def _both(cfg):
     return _BOTH[key]
 
 
-def _full_size(config, n_full_lists, batch, n_oracle_topk=64):
+def _full_size(config, n_full_lists, batch, n_oracle_topk=256):
     """One BASELINE config at its full size, pruning kernel (K1d k_daat) under test:
       * whole batch: K1d top-k == K1 k_score top-k (the streaming kernel that prunes nothing), every query;
       * the same batch five times: bit-identical (K1d's thresholds race between waves; results must not);
-      * `n_oracle_topk` queries of the batch against the ORACLE's top-k (threads: one query each), and
+      * `n_oracle_topk` queries of the batch (every fourth by default) against the ORACLE's top-k (all host cores, shared queue), and
         `n_full_lists` whole-list oracle comparisons (every match, every score bit);
       * fields_boost changed between consecutive batches of one snapshot (src/query.rs:26 takes it per call):
         each batch against K1 and, for the odd boosts, 8 queries against the oracle."""
@@ -154,7 +154,7 @@ def _full_size(config, n_full_lists, batch, n_oracle_topk=64):
         finally:
             _set("PS_DAAT_Z", 1)
         assert _tuples(top_stream) == _tuples(top), (config, "K1dz batch != streaming batch")
-    # oracle top-k for many queries (one per host thread), whole lists for a few
+    # oracle top-k for many queries (all host cores: the oracle's timed entry point takes queries from a shared queue), whole lists for a few
     import os
     o = both.oracle()
     nq = min(n_oracle_topk, batch)
@@ -219,8 +219,8 @@ def test_c5_full_size_against_oracle():
 def test_c4_full_size_against_oracle():
     """BASELINE configs[3]: 5M documents, 2 fields, BM25, 1024-query shard of the 8192-query batch
     (what one GPU of the 8 scores) + batch split invariance.  (The oracle answers a query over 5 M documents in ~4.5 s:
-    32 top-k queries on as many threads and 2 whole lists here, after the whole batch was compared kernel against kernel.)"""
-    snap, corpus, queries, top, o = _full_size("C4", 2, 1024, n_oracle_topk=32)
+    128 top-k queries on all host cores and 2 whole lists here, after the whole batch was compared kernel against kernel.)"""
+    snap, corpus, queries, top, o = _full_size("C4", 2, 1024, n_oracle_topk=128)
     sc = psa.bm25.new()
     halves = snap.query_batch(queries[:400], sc, None, [1.0, 1.0], top_k=10) + snap.query_batch(queries[400:], sc, None, [1.0, 1.0], top_k=10)
     assert halves == top

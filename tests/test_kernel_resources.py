@@ -28,7 +28,7 @@ BUDGET = {
     # (its scan holds ~95 VGPRs since the first level moved behind the reach queue: 5 waves per SIMD for the serving
     # instantiation; the wave-uniform state - two sets of field-length limits, three tie levels - spills more SGPRs)
     "ps::k_daat_z<2, true, 4>": (104, 4, 36, 300),   # (the counting instantiation; 85 VGPRs)
-    "ps::k_daat_z<2, false, 4>": (104, 5, 36, 200),
+    "ps::k_daat_z<2, false, 4>": (104, 5, 36, 210),  # (+6 spills in round 6: the doc-ordered filter word carries a shift beside its base)
     "ps::k_daat_z<1, false, 4>": (96, 5, 36, 195),
     # queries of five to eight records (round 5): twice the per-list state - 15 KB of LDS queues per two-wave workgroup (its bound
     # table is recomputed per threshold change instead of tabulated: 4 waves per SIMD) and the wave-uniform per-list words of 7
@@ -41,7 +41,8 @@ BUDGET = {
     "ps::k_score<0, 1, false, false, 4>": (130, 3, 0, 95),
     # (a thread per query, 16 one-wave workgroups per batch: occupancy is not what bounds it; the 320 bytes are the frame of
     # prep_query_general, out of line, for plans of > 4 entries)
-    "ps::k_prep_query": (88, 5, 352, 0),
+    # (round 6: + the primed threshold per entry - k_list_kth table reads, a fourth array of per-entry doubles in the register arm)
+    "ps::k_prep_query": (92, 5, 384, 0),
     "ps::k_zprep_query<4>": (48, 8, 0, 0),
     "ps::k_zprep_query<8>": (64, 8, 0, 0),
     "ps::k_zprep_items": (48, 8, 0, 0),

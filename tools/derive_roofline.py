@@ -147,8 +147,27 @@ def main():
                 "kernel_avg_ms_live": rl.get("kernel_avg_ms")}
     except Exception:  # noqa: BLE001
         pass
+    # the roofline from the traces alone: bytes the kernel counted itself (the traced run's bench line) / the trace's average
+    # duration - overlapped pass (two scoring queues: individual durations overlap, the fraction understates the chip) and
+    # serialised pass (PS_SCORE_ALT=0: duration = cost)
+    from_trace = {}
+    for name in ("kt", "kt_serial"):
+        try:
+            ktx, _ = parse(os.path.join(d, name + ".txt"))
+            line = [l for l in open(os.path.join(d, name + ".bench.json")) if l.startswith("{")][-1]
+            rlx = json.loads(line)["roofline"]
+            sym = [k for k in ktx if demangle(k) == rlx["kernel"]]
+            if sym:
+                avg = ktx[sym[0]]["avg_us"]
+                from_trace[name] = {"kernel": rlx["kernel"], "calls": ktx[sym[0]]["calls"], "avg_us_in_trace": avg,
+                                    "bytes_touched_per_launch": rlx["bytes_touched"],
+                                    "frac_of_8TBps": rlx["bytes_touched"] / (avg * 1e-6) / HBM_PEAK,
+                                    "bench_line": {k: rlx.get(k) for k in ("frac", "frac_overlapped", "frac_serial", "kernel_avg_ms",
+                                                                           "kernel_busy_avg_ms", "kernel_serial_avg_ms")}}
+        except Exception as e:  # noqa: BLE001
+            from_trace[name] = {"error": str(e)}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = {"config": cfg, "scorer": scorer, "head": head, "kernel_sources_sha16": kernel_source_hash(root), "kernel": demangle(dom), "kernel_symbol": dom, "work_counters": work,
+    out = {"config": cfg, "roofline_from_traces": from_trace, "scorer": scorer, "head": head, "kernel_sources_sha16": kernel_source_hash(root), "kernel": demangle(dom), "kernel_symbol": dom, "work_counters": work,
            "resident_rows": "--resident-rows" in args, "bench_args": args,
            "kernel_avg_us_in_trace": score[dom]["avg_us"], "registers": {k: score[dom][k] for k in ("vgpr", "sgpr", "lds")},
            "measured_clock_GHz": clock / 1e9, "counters_per_launch": ctr,
@@ -159,7 +178,7 @@ def main():
                       "wave-cycles are stalled on s_waitcnt, the kernel is bound by dependent memory latency, not by a "
                       "throughput peak - then `binding` still names the busiest unit and `wave_cycles` says why it is idle"}
     json.dump(out, open(os.path.join(d, "roofline_%s.json" % cfg), "w"), indent=1)
-    print(json.dumps({k: out[k] for k in ("kernel", "kernel_avg_us_in_trace", "measured_clock_GHz", "fractions_in_profiled_run",
+    print(json.dumps({k: out[k] for k in ("kernel", "roofline_from_traces", "kernel_avg_us_in_trace", "measured_clock_GHz", "fractions_in_profiled_run",
                                            "wave_cycles", "binding", "hbm_bytes_per_launch")}, indent=1))
     print("all kernels in the trace:")
     for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_us"]):

@@ -22,6 +22,9 @@ run() {  # name, rocprof args...
   rm -rf $OUT/$name
 }
 run kt --kernel-trace --stats
+# the same kernel trace with scoring serialised (one scoring queue): a kernel's duration in THIS trace is what it costs the chip,
+# so bytes touched / avg_us here is a roofline fraction a reader can recompute from the summary alone (derive.log, frac_serial_from_trace)
+PS_SCORE_ALT=0 run kt_serial --kernel-trace --stats
 run pmc_fetch --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE
 run pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
