@@ -69,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-config4-leg", action="store_true",
                     help="N > 1 only: skip the untimed-for-headline leg on BASELINE config 4 (5M docs, ONE 8192-query batch split "
                          "over the ranks, all-gather of the top-k blocks), reported as config4")
+    ap.add_argument("--no-update-leg", action="store_true", help="skip the live-index leg (ps_snapshot_update between batches; reported as live_index_updates)")
     ap.add_argument("--no-bulk-index", action="store_true",
                     help="skip timing the GPU bulk indexer on the same corpus (reported beside index_build_s; N=1, <= 2M docs)")
     return ap.parse_args(argv)
@@ -543,9 +544,19 @@ def main():
             # the streaming kernel the north star describes (K1 k_score: every posting of every list through
             # the LDS tiles), on the same batches, outside the timed region of the headline
             result["roofline"]["streaming_kernel_leg"] = streaming_leg(args, cfg, snap, step, fence, packed, F, B, K)
+        sample = [q for b in batches[args.warmup:] for q in b]
         if world == 1 and not args.no_cpu_baseline:
-            sample = [q for b in batches[args.warmup:] for q in b]
             result["cpu_baseline"] = cpu_baseline(args, cfg, corpus, sample, boosts, snap, scorer, K, B)
+        if world == 1 and not args.no_bulk_index:
+            try:
+                result["add_100k_docs"] = add100k_leg(dev)
+            except Exception as e:  # noqa: BLE001
+                result["add_100k_docs"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_update_leg and cfg["scorer"] == "bm25" and B > 1 and not args.n_docs:
+            try:
+                result["live_index_updates"] = update_leg(args, cfg, corpus, index, dev, tile_docs, scorer, boosts, K, B, sample)
+            except Exception as e:  # noqa: BLE001
+                result["live_index_updates"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
     fence()
     if world > 1:
         rp = psa.load().ps_comm_rccl_path() if not debug_1gpu else b"(debug transport: hostshm)"
@@ -825,6 +836,140 @@ def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layo
     return out
 
 
+_ORACLE = [None]
+
+
+def add100k_leg(dev):
+    """The reference's OWN benchmark workload (benches/test_benchmark.rs:16-63, `add_100k_docs`, the only thing it times): 99 999
+    documents, one field, title = two random 5-letter tokens over its 24-letter alphabet, added one by one into
+    Index::new_with_capacity(1, 100000, 100000).  Timed here: the host indexer of the library (ps_index_add_documents_flat: the
+    per-document add_document loop behind the C ABI), the GPU bulk indexer (ps_index_add_documents_flat_gpu, N4) and the
+    reference-faithful restatement (oracle: one heap pointer per occurrence, linked trie) on one host thread; the three
+    indexes must agree (node count, live pointers, field sums) and answer a query identically."""
+    import numpy as np
+    import probly_search_amd as psa
+    from oracle import oracle as orc
+    n = 99_999
+    rng = np.random.default_rng(0xADD100)
+    alpha = np.frombuffer(b"abcdefghilkjapqrstuvwxyz", dtype=np.uint8)
+    letters = alpha[rng.integers(0, len(alpha), size=(n, 10))]
+    text = np.full((n, 12), ord(" "), dtype=np.uint8)   # "xxxxx yyyyy " (every field value ends with one space, as synth.chunks writes them)
+    text[:, 0:5] = letters[:, 0:5]
+    text[:, 6:11] = letters[:, 5:10]
+    text = text.reshape(-1)
+    keys = np.arange(n, dtype=np.uint64)
+    offsets = np.arange(0, 12 * (n + 1), 12, dtype=np.uint64)
+    out = {"workload": "benches/test_benchmark.rs add_100k_docs: %d documents, 1 field, two random 5-letter tokens each" % n}
+    t0 = time.perf_counter()
+    host = psa.Index.new_with_capacity(1, 100000, 100000)
+    host.add_documents_flat(keys, text, offsets)
+    out["host_indexer_docs_per_s"] = n / (time.perf_counter() - t0)
+    gpu = psa.Index.new_with_capacity(1, 100000, 100000)
+    gpu.add_documents_flat_gpu(keys[:8], text[:96], offsets[:9], device=dev)  # (first touch of the bulk indexer's kernels / buffers)
+    gpu = psa.Index.new_with_capacity(1, 100000, 100000)
+    t0 = time.perf_counter()
+    used = gpu.add_documents_flat_gpu(keys, text, offsets, device=dev)
+    out["gpu_bulk_indexer_docs_per_s"] = n / (time.perf_counter() - t0)
+    out["gpu_path_ran"] = bool(used)
+    t0 = time.perf_counter()
+    o = orc.Index(1)
+    o.add_documents_flat(keys, text, offsets)
+    out["reference_restatement_docs_per_s_1_thread"] = n / (time.perf_counter() - t0)
+    same = (host.count_nodes() == gpu.count_nodes() == o.count_nodes() and host.live_pointers() == gpu.live_pointers() == o.arena_doc_live()
+            and host.fields == gpu.fields and (host.fields[0].sum, host.fields[0].avg) == o.field_details(0))
+    q = bytes(text[:5]).decode() + " " + bytes(text[18:21]).decode()
+    exp = o.query(q, orc.bm25(), [1.0])
+    got = [[(r.key, r.score) for r in ix.query(q, psa.bm25.new(), None, [1.0])] for ix in (host, gpu)]
+    out["indexes_agree"] = bool(same and got[0] == exp and got[1] == exp)
+    return out
+
+
+
+def update_leg(args, cfg, corpus, index, dev, tile_docs, scorer, boosts, K, B, sample):
+    """What a LIVE index costs (src/index.rs:77-191: every add / remove changes N and the field averages, i.e. every idf and every
+    saturated term frequency): pipelined 1024-query batches with a ps_snapshot_update of ~0.1 % removed + ~0.1 % added documents
+    between every 10 batches, against the same loop without updates on the same snapshot (built with headroom so that additions
+    are a delta and not a re-flatten).  Parity: after every update a few queries against the oracle, mutated the same way
+    (outside the clock).  Honest pricing of the work that sits outside the headline's timed region: the per-snapshot-state
+    kernels (bounds + score plane, threshold-priming tables, filters, device trie) run again after every update."""
+    import numpy as np
+    import torch
+    import probly_search_amd as psa
+    from probly_search_amd import dist as psd, synth
+    from oracle import oracle as orc
+    F = cfg["fields"]
+    o = _ORACLE[0]
+    t0 = time.time()
+    snap = index.snapshot(device=dev, tile_docs=tile_docs, headroom_pct=5)
+    t_snap = time.time() - t0
+    n_b, per_cycle, cycles = 30, 10, 4
+    packed = [synth.pack_queries(corpus.queries(B, cfg["q_terms"], salt=500 + i)) for i in range(n_b)]
+    buf = torch.zeros(psd.block_bytes(B, K) // 8, dtype=torch.int64, device="cuda")
+    base = buf.data_ptr()
+    st = torch.cuda.Stream()
+
+    def run(lo, hi):
+        t = time.perf_counter()
+        for i in range(lo, hi):
+            text, offs = packed[i % n_b]
+            snap.query_batch_device_flat(text, offs, scorer, boosts, K, base, base + 8 * B * K, base + 16 * B * K, stream=st.cuda_stream)
+        st.synchronize()
+        return time.perf_counter() - t
+
+    t_first = run(0, 1)           # the first batch of a fresh snapshot pays the per-state preparation
+    run(1, 6)
+    t_sync = min(run(6, 7), run(7, 8))
+    t_static = run(0, n_b) / n_b
+    k_static = snap.kernel_breakdown(reset=True)["score_kernel"]
+    n_upd = max(1, cfg["n_docs"] // 1000)
+    fresh = synth.Corpus(**dict(cfg, n_docs=n_upd * cycles, seed=cfg["seed"] ^ 0xABCDEF))
+    new_chunks = list(fresh.chunks(n_upd))
+    rng = np.random.default_rng(7)
+    victims = rng.choice(cfg["n_docs"], size=n_upd * cycles, replace=False)
+    osc = (orc.bm25() if cfg["scorer"] == "bm25" else orc.zero_to_one()) if o is not None else None
+    timed, upd, mism, checked, kernels = 0.0, [], 0, 0, set()
+    for c in range(cycles):
+        ta = time.perf_counter()
+        keys, text, offsets = new_chunks[c]
+        keys = keys + np.uint64(cfg["n_docs"] + c * n_upd)
+        for k in victims[c * n_upd:(c + 1) * n_upd]:
+            index.remove_document(int(k))
+        index.add_documents_flat(keys, text, offsets)
+        t_host_index = time.perf_counter() - ta
+        tb = time.perf_counter()
+        us = snap.update()
+        t_update = time.perf_counter() - tb
+        t_first_after = run(c * per_cycle, c * per_cycle + 1)
+        t_rest = run(c * per_cycle + 1, (c + 1) * per_cycle)
+        timed += t_update + t_first_after + t_rest   # (the host index's own add / remove is the reference's work, not counted)
+        kernels.add(snap.kernel_breakdown(reset=True)["score_kernel"])
+        upd.append({"mode": "delta" if us["mode"] == 1 else "reflatten" if us["mode"] == 2 else str(us["mode"]), "update_call_ms": t_update * 1e3,
+                    "library_host_ms": us["host_ms"], "library_device_ms": us["device_ms"], "bytes_uploaded": int(us["bytes_uploaded"]),
+                    "first_batch_after_ms": t_first_after * 1e3, "host_index_mutation_ms": t_host_index * 1e3})
+        if o is not None:
+            for k in victims[c * n_upd:(c + 1) * n_upd]:
+                o.remove_document(int(k))
+            o.add_documents_flat(keys, text, offsets)
+            qs = sample[4 * c:4 * c + 4]
+            got = snap.query_batch(qs + qs, scorer, None, boosts, top_k=K)[:len(qs)]  # (>= 8 queries: the pruning kernels' batch gate)
+            _, _, _, exp = o.bench_queries(qs, osc, boosts, threads=min(4, len(qs)), top_k=K)
+            mism += sum(1 for g, e in zip(got, exp) if [(r.key, r.score) for r in g] != e)
+            checked += len(qs)
+    rate_static = B / t_static
+    rate_upd = cycles * per_cycle * B / timed
+    return {"what": "%d cycles of {ps_snapshot_update of %d removed + %d added documents (0.1 %% each), then %d pipelined %d-query batches}; "
+                    "clock = update calls + batches (the host index's own add / remove excluded)" % (cycles, n_upd, n_upd, per_cycle, B),
+            "queries_per_s_static_same_snapshot": rate_static, "queries_per_s_with_updates": rate_upd, "ratio": rate_upd / rate_static,
+            "snapshot_with_headroom_s": t_snap,
+            "snapshot_prepare": {"first_batch_ms": t_first * 1e3, "steady_synchronous_batch_ms": t_sync * 1e3,
+                                 "prepare_ms": (t_first - t_sync) * 1e3,
+                                 "what": "per-snapshot-state kernels outside any timed region: per-list bounds + score plane (k_list_bounds), "
+                                         "threshold-priming tables (k_list_kth), filters (k_build_bloom), packed words, device trie; their "
+                                         "per-kernel times are in profiles/r06_*_rocprof_summary.txt"},
+            "kernel_static": k_static, "kernels_after_updates": sorted(kernels), "updates": upd,
+            "topk_mismatches_vs_oracle_after_updates": mism if o is not None else None, "queries_checked": checked}
+
+
 def cpu_baseline(args, cfg, corpus, pool, boosts, snap, scorer, K, B):
     """Times the oracle (reference-faithful C++ restatement: same linked posting lists, one pointer
     per occurrence, two passes, five hash operations per pointer) on queries of the timed batches:
@@ -838,6 +983,7 @@ def cpu_baseline(args, cfg, corpus, pool, boosts, snap, scorer, K, B):
     t0 = time.time()
     o = synth.fill(orc.Index(cfg["fields"]), corpus)
     t_build = time.time() - t0
+    _ORACLE[0] = o  # (the update leg mutates it alongside the product index)
     osc = orc.bm25() if cfg["scorer"] == "bm25" else orc.zero_to_one()
     sample = pool[:args.cpu_queries if B > 1 else 1000]
     wall1, secs1, nres, top = o.bench_queries(sample, osc, boosts, threads=1, top_k=K)

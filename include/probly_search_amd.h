@@ -142,10 +142,23 @@ void ps_free(void* p);
 void ps_results_split(const ps_result* results, size_t n, uint64_t* keys, double* scores);
 /* Number of visible HIP devices (0 if none / HIP unusable). */
 int ps_device_count(void);
-/* Tuning knobs by name - the PS_* names listed in DESIGN.md section 11 (e.g. "PS_DAAT", "PS_ROW_CACHE_MB",
- * "PS_DENSE_MIN_USES").  A value set here wins over the environment variable of the same name; knobs are
- * read when a snapshot's engine is created (ps_index_snapshot*, ps_snapshot_load), so set them before.
- * ps_get_option returns 1 and the effective override / environment value, 0 if the knob is at its default. */
+/* The version of THIS header's struct layouts and entry points.  The output structs (ps_kernel_times, ps_work_counters,
+ * ps_update_stats, ps_query_stats ...) are written whole by the library - memset + fill, sizeof as the library was built - and grow
+ * at the end between versions: a caller compiled against an older header would be written past its struct.  Compare
+ * ps_abi_version() with PS_ABI_VERSION once after loading and refuse a mismatch (the Python binding does).
+ * 6: ps_kernel_times.score_busy_ms (round 5), ps_comm_all_gather (round 6). */
+#define PS_ABI_VERSION 6u
+uint32_t ps_abi_version(void);
+/* Run-time options by name.  A value set here wins over the environment variable of the same name; engines read their options when
+ * they are created and again at the next batch after any ps_set_option.  The list (PS_EINVAL for any other name):
+ *   PS_DAAT (1)  PS_DAAT_MIN_BATCH (8)  PS_DAAT_MULTI (1)  PS_DAAT_SMALL (1)  PS_DAAT_SMALL_NL (1)  PS_DAAT_SPLIT (1)  PS_DAAT_Z (1)
+ *   PS_DAAT_Z_SPLIT (1)  PS_DAAT_PRIME (1)  PS_DAAT_CHUNK (4096): which exact-pruning kernels take which batches, threshold priming;
+ *   PS_DEVICE_PLAN (1): the device-side planner;  PS_ROW_CACHE_MB (4096): resident dense rows;  PS_DENSE_MIN_USES (4), PS_DENSE_MAX_ROWS (64);
+ *   PS_WORK_COUNTERS (1), PS_KERNEL_TIMERS (1): ps_snapshot_work_counters / ps_snapshot_kernel_breakdown instrumentation;
+ *   PS_SCORE_ALT (1), PS_DCTX (5), PS_PLAN_AHEAD_DEPTH (3): scoring queues, batch contexts, announced batches;
+ *   PS_RESULT_PINNED_MIN_KB (4096), PS_FULL_PARTS_MIN_KB (32768): full-result mode;  PS_PLAN_THREADS, PS_FLATTEN_THREADS: host pools.
+ * The engine's experiment knobs are environment variables; this call takes them only under
+ * PS_EXPERIMENT_KNOBS=1.  ps_get_option returns 1 and the effective override / environment value, 0 if the option is at its default. */
 ps_status ps_set_option(const char* name, uint32_t value);
 int ps_get_option(const char* name, uint32_t* value);
 

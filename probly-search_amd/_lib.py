@@ -18,6 +18,7 @@ class PsError(RuntimeError):
 
 PS_OK, PS_EINVAL, PS_ENOMEM, PS_EHIP, PS_EUNSUPPORTED, PS_ENODEVICE, PS_ERCCL = range(7)
 PS_COMM_ID_BYTES = 128
+PS_ABI_VERSION = 6  # include/probly_search_amd.h
 
 
 class Str(C.Structure):
@@ -125,6 +126,7 @@ SYMBOLS = {
     "ps_free": (None, [_P]),
     "ps_results_split": (None, [_P, C.c_size_t, _P, _P]),
     "ps_device_count": (C.c_int, []),
+    "ps_abi_version": (C.c_uint32, []),
     "ps_set_option": (C.c_int, [C.c_char_p, C.c_uint32]),
     "ps_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32)]),
     "ps_index_new": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
@@ -243,6 +245,9 @@ def load():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if L.ps_abi_version() != PS_ABI_VERSION:  # the ctypes structs above mirror ONE header version
+            raise LibraryNotBuilt("%s was built for ABI version %d, this binding mirrors version %d: rebuild (make -C csrc)" % (
+                _SO, L.ps_abi_version(), PS_ABI_VERSION))
         _lib = L
     return _lib
 

@@ -214,8 +214,25 @@ void ps_results_split(const ps_result* r, size_t n, uint64_t* keys, double* scor
   for (auto& x : th) x.join();
 }
 int ps_device_count(void) { return ps::device_count(); }
+uint32_t ps_abi_version(void) { return PS_ABI_VERSION; }
 ps_status ps_set_option(const char* name, uint32_t value) {
   if (!name || strncmp(name, "PS_", 3) != 0) return fail(PS_EINVAL, "option names are the PS_* knob names");
+  // The run-time options of the ABI (include/probly_search_amd.h): what a serving process may reasonably
+  // switch.  Everything else the engine reads - several dozen experiment knobs whose A/B is settled - stays reachable through the
+  // environment variable of its name, and through this call only when PS_EXPERIMENT_KNOBS=1 (tools/knob_sweep.py).
+  static const char* const kRuntime[] = {
+      "PS_DAAT", "PS_DAAT_MIN_BATCH", "PS_DAAT_MULTI", "PS_DAAT_SMALL", "PS_DAAT_SMALL_NL", "PS_DAAT_SPLIT", "PS_DAAT_Z", "PS_DAAT_Z_SPLIT",
+      "PS_DAAT_PRIME", "PS_DAAT_CHUNK", "PS_DEVICE_PLAN", "PS_ROW_CACHE_MB", "PS_WORK_COUNTERS", "PS_KERNEL_TIMERS", "PS_SCORE_ALT", "PS_DCTX",
+      "PS_PLAN_AHEAD_DEPTH", "PS_RESULT_PINNED_MIN_KB", "PS_FULL_PARTS_MIN_KB", "PS_DENSE_MIN_USES", "PS_DENSE_MAX_ROWS", "PS_PLAN_THREADS",
+      "PS_FLATTEN_THREADS"};
+  bool known = false;
+  for (const char* k : kRuntime) known = known || strcmp(k, name) == 0;
+  if (!known) {
+    const char* e = getenv("PS_EXPERIMENT_KNOBS");
+    if (!(e && *e == '1'))
+      return fail(PS_EINVAL, (std::string(name) + " is not a run-time option (see ps_set_option in probly_search_amd.h); experiment knobs are "
+                              "environment variables, or set PS_EXPERIMENT_KNOBS=1").c_str());
+  }
   ps::set_option(name, value);
   return PS_OK;
 }

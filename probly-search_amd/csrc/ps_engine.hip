@@ -1226,6 +1226,7 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
     while (ranks[j] < kp.K) ++j;
     pp.kth = br.kth;
     pp.kth_rank = j;
+    pp.prime_keep_items = m.tune.daat_prime == 2 ? 1u : 0u;
   }
   if (B) {
     hipLaunchKernelGGL(k_prep_query, dim3((uint32_t)((B + WAVE - 1) / WAVE)), dim3(WAVE), 0, st, pp);

@@ -93,6 +93,7 @@ struct PrepParams {
   const double* kth;             // [n_layers][F + 1][KTH_RANKS] (plane units; null: off)
   uint32_t kth_rank;             // index of the smallest stored rank >= K
   unsigned long long* gthr;      // [B] the batch's threshold words: start at theta0 instead of 0
+  uint32_t prime_keep_items;     // debugging (PS_DAAT_PRIME=2): thresholds are primed but every list keeps its work items
   // consistency of the three copies of the "which kernel takes this query" rule (planner count pass / host, k_plan, k_prep_query):
   uint32_t host_items, host_items_big;  // what the launch grids are sized from
   uint32_t* fault;                      // engine-wide, host-mapped: {code, device items, device split, host items}; 0 = fine
@@ -419,7 +420,7 @@ __device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const
         pp.dgroup[b + i] = dg;
       }
       const uint32_t c = prep_chunk(pp, len[i]);
-      if (!(d.skip_thr < th0)) slots += (len[i] + c - 1) / c;  // (a list that is non-essential from the start gets no items)
+      if (pp.prime_keep_items || !(d.skip_thr < th0)) slots += (len[i] + c - 1) / c;  // (a list that is non-essential from the start gets no items)
     }
   }
   return slots;
@@ -505,7 +506,7 @@ __device__ __noinline__ uint32_t prep_query_general(const PrepParams& pp, const 
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t len = pp.plan[b + i].len;
     const uint32_t c = prep_chunk(pp, len);
-    if (!(pp.dentry[b + i].skip_thr < th0)) slots += (len + c - 1) / c;
+    if (pp.prime_keep_items || !(pp.dentry[b + i].skip_thr < th0)) slots += (len + c - 1) / c;
   }
   return slots;
 }
@@ -655,10 +656,10 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
     if (on) {
       const ps_plan_entry& en = pp.plan[b + i];
       const uint32_t c = prep_chunk(pp, en.len);
-      const bool dead = pp.dentry[b + i].skip_thr < th0;  // non-essential before the launch: no items, no candidate slots
+      const bool dead = !pp.prime_keep_items && pp.dentry[b + i].skip_thr < th0;  // non-essential before the launch: no items, no candidate slots
       nc = dead ? 0u : (en.len + c - 1) / c;
       ns = dead ? 0u : (big || !pp.split_kinds || pp.sample_small) ? prep_sample_chunks(pp, en, c, nc) : 0u;
-      pp.gen[b + i] = DItemGen{big ? 1u : 0u, ns, c, sl};  // (`entry`: gen is indexed by entry - the word carries the query's kind)
+      pp.gen[b + i] = DItemGen{(big ? 1u : 0u) | (dead ? 2u : 0u), ns, c, sl};  // (`entry`: gen is indexed by entry - the word carries the query's kind and "no items")
       sl += nc;
       const uint32_t rk = pp.dentry[b + i].rank;
       bk = prep_bucket(rk, en.len, pp.multi != 0u && (big || !pp.split_kinds), big);
@@ -707,11 +708,10 @@ __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
     const uint32_t len = en.len, c = g.chunk;
     len_i = len; chunk = c; first_slot = g.first_slot;
     const DEntry de_i = pp.dentry[i];
-    // (k_prep_query's rule: a list whose skip threshold is below the query's primed threshold has no items)
-    const bool dead = pp.gthr != nullptr && de_i.skip_thr < __longlong_as_double((long long)pp.gthr[de_i.q]);
+    const bool dead = (g.entry & 2u) != 0u;  // (k_prep_query: the list is non-essential under the query's primed threshold - no items)
     nc = dead ? 0u : (len + c - 1) / c;
     ns = g.item_at;  // (k_prep_query: the list's chunks in the sample phase)
-    const bool big = g.entry != 0u;  // (... and its query's kind)
+    const bool big = (g.entry & 1u) != 0u;  // (... and its query's kind)
     skip_i = de_i.skip_thr; q_i = de_i.q;
     bk = prep_bucket(de_i.rank, len, pp.multi != 0u && (big || !pp.split_kinds), big);
     bs = (big ? PREP_SET_BUCKETS : 0u) + (de_i.rank < PREP_SAMPLE_BUCKETS ? de_i.rank : PREP_SAMPLE_BUCKETS - 1u);

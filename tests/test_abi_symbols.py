@@ -57,3 +57,22 @@ def test_queries_fail_loudly_without_device_snapshot():
         assert e.status == _lib.PS_ENODEVICE
     else:
         raise AssertionError("host-only snapshot must refuse to score (no CPU fallback)")
+
+
+def test_set_option_takes_the_documented_runtime_options_only(monkeypatch):
+    """ps_set_option: the short list of run-time options in the header; the engine's several dozen experiment knobs stay
+    environment variables (and go through this call only under PS_EXPERIMENT_KNOBS=1, which the A/B tools set)."""
+    import probly_search_amd as psa
+    from probly_search_amd import _lib
+    L = psa.load()
+    monkeypatch.delenv("PS_EXPERIMENT_KNOBS", raising=False)
+    header = open(os.path.join(ROOT, "include", "probly_search_amd.h")).read()
+    for name in (b"PS_DAAT", b"PS_DAAT_PRIME", b"PS_DEVICE_PLAN", b"PS_ROW_CACHE_MB", b"PS_WORK_COUNTERS", b"PS_SCORE_ALT", b"PS_DCTX"):
+        assert name.decode() in header
+        assert L.ps_get_option(name, None) in (0, 1)
+    assert L.ps_set_option(b"PS_DAAT_PRIME", 1) == _lib.PS_OK
+    assert L.ps_set_option(b"PS_DAAT_UMQ", 3) == _lib.PS_EINVAL and b"not a run-time option" in L.ps_last_error()
+    assert L.ps_set_option(b"NOT_A_KNOB", 1) == _lib.PS_EINVAL
+    monkeypatch.setenv("PS_EXPERIMENT_KNOBS", "1")
+    assert L.ps_set_option(b"PS_DAAT_SAMPLE_DIV", 24) == _lib.PS_OK
+    assert L.ps_abi_version() == _lib.PS_ABI_VERSION

@@ -32,7 +32,7 @@ import sys
 N_CU, N_SIMD, N_XCD, CLOCK_HZ = 256, 1024, 8, 2.4e9
 HBM_PEAK, L2_PEAK, LDS_BPC = 8.0e12, 34.5e12, 256
 FABRIC_REQ_PEAK = 43.0e9  # scattered L2-missing loads per second this chip sustained (profiles/r04_fetch_size_calibration.txt)
-KERNEL_SOURCES = ("ps_kernels.hpp", "ps_prep_kernels.hpp", "ps_z21_daat.hpp")
+KERNEL_SOURCES = ("ps_kernels_common.hpp", "ps_kernels_score.hpp", "ps_kernels_daat.hpp", "ps_kernels_plan.hpp", "ps_prep_kernels.hpp", "ps_z21_daat.hpp")
 
 
 def kernel_source_hash(root):

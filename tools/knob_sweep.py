@@ -8,6 +8,8 @@ import itertools
 import json
 import os
 import sys
+
+os.environ.setdefault("PS_EXPERIMENT_KNOBS", "1")  # (ps_set_option takes the engine's experiment knobs too)
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
