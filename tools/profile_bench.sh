@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
-BENCH="python bench.py --no-cpu-baseline --no-single-latency --no-bulk-index --no-streaming-leg --no-alternating-boosts-leg $*"
+BENCH="python bench.py --no-cpu-baseline --no-single-latency --no-bulk-index --no-streaming-leg --no-alternating-boosts-leg --no-update-leg $*"
 echo "rocprofv3 <pass> -- $BENCH --steps 6 --warmup 2" > $OUT/command.txt
 run() {  # name, rocprof args...
   local name=$1; shift
