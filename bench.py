@@ -839,6 +839,38 @@ def roofline(args, cfg, kernel, k_avg_ms, rows_avg_ms, launches, alg_bytes, layo
 _ORACLE = [None]
 
 
+def effective_cpus():
+    """Host CPUs this process can really use: the visible ones (os.cpu_count), its affinity mask, and the container's CPU
+    quota (cgroup v2 cpu.max / v1 cfs quota).  The GPU boxes show 256 hardware threads and grant 16 CPUs' worth of time (cpu.max 1600000 100000):
+    a leg that starts 256 threads there measures the throttle, not the host (round 6: throughput flat from 32 threads up,
+    per-query time growing linearly with the thread count - profiles/r06_cpu_baseline_scaling.txt)."""
+    n = os.cpu_count() or 1
+    src = "os.cpu_count"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, src = a, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, src = max(1, int(quota + 0.5)), "cgroup cpu quota %.2f" % quota
+    return n, src
+
+
+
 def add100k_leg(dev):
     """The reference's OWN benchmark workload (benches/test_benchmark.rs:16-63, `add_100k_docs`, the only thing it times): 99 999
     documents, one field, title = two random 5-letter tokens over its 24-letter alphabet, added one by one into
@@ -992,16 +1024,18 @@ def cpu_baseline(args, cfg, corpus, pool, boosts, snap, scorer, K, B):
     flat_build_s = o.flat_build_s
     flat_mism = sum(1 for a, b in zip(top, topF) if a != b)
     cores = os.cpu_count() or 1
-    # all cores: the WHOLE batch (B queries) through a shared queue - a thread that drew a cheap query takes another.  (Round 5
-    # gave every thread exactly one query: the wall clock was the most expensive query's, "8 x from 256 cores".)
-    many = pool[:max(len(sample), B if B > 1 else min(cores, 512))]
-    threads = min(cores, len(many))
+    usable, usable_src = effective_cpus()
+    # all cores: 256 queries of the batch through a shared queue - a thread that drew a cheap query takes another - on as many threads
+    # as the process really has CPUs for.  (Round 5 gave each of 256 threads exactly one query: the wall clock was the most
+    # expensive query's, under a container quota of 16 CPUs - "8 x from 256 cores".)
+    many = pool[:max(len(sample), min(B, 256) if B > 1 else min(cores, 512))]
+    threads = max(1, min(usable, len(many)))
     wallN, secsN, _, topN = o.bench_queries(many, osc, boosts, threads=threads, top_k=K)
     wallNF, secsNF, _, _ = o.bench_queries(many, osc, boosts, threads=threads, top_k=0, flat=True)
 
     def all_cores(wall, secs, alone_mean):
         busy = float(secs.sum())
-        return {"value": len(many) / wall, "cores": threads, "host_cores": cores,
+        return {"value": len(many) / wall, "cores": threads, "host_cores": cores, "usable_cpus": usable, "usable_cpus_from": usable_src,
                 "speedup_vs_1_thread": (len(many) / wall) / (1.0 / alone_mean),
                 "thread_seconds_per_wall_second": busy / wall,
                 "per_query_slowdown_under_load": (busy / len(many)) / alone_mean,
@@ -1032,7 +1066,7 @@ def cpu_baseline(args, cfg, corpus, pool, boosts, snap, scorer, K, B):
                              "containers (open addressing, 16 control bytes probed per step with SSE2, load 7/8, folded-multiply hash: "
                              "what hashbrown 0.14 is) with a per-thread bump arena behind the per-query tables: the STRONGER baseline"},
             "all_cores": dict(all_cores(wallN, secsN, float(np.mean(secs1))),
-                              sample="%d queries (the whole batch), shared queue over %d threads, shared read-only index" % (len(many), threads),
+                              sample="%d queries of the timed batches, shared queue over %d threads (= the CPUs the process can use: %s), shared read-only index" % (len(many), threads, usable_src),
                               flat=all_cores(wallNF, secsNF, float(np.mean(secsF)))),
             "gpu_like_for_like": {"value": len(sample) / t_lib, "unit": "queries/s",
                                   "what": "ps_snapshot_query_batch(top_k=0): every match of the same %d queries, sorted "

@@ -232,6 +232,7 @@ struct EngineImpl {
     uint64_t epoch = 0;
     DevBuf<BoundUnit> units;
     uint32_t n_units = 0;
+    uint64_t units_sig = 0;        // what the work list was built for (layer count and lengths)
     double last_ms = 0.0;  // host wall time of the most recent (re)computation's enqueue
     uint64_t recomputed = 0;
   } bounds;
@@ -419,7 +420,7 @@ struct EngineImpl {
   }
 };
 
-namespace { void forget_rows(EngineImpl& m); }
+namespace { void forget_rows(EngineImpl& m); void ensure_bound_units(EngineImpl& m); }
 
 int device_count() {
   int n = 0;
@@ -553,20 +554,26 @@ Engine::~Engine() {
 
 // Per layer: sum of tf over the postings whose document a delta removed (Index::count_documents skips
 // removed documents, index.rs:287-293).  One workgroup-strided pass over the doc / tf planes.
+// One wave per unit (a list, or a 16 Ki-posting segment of a long one - the units of k_list_bounds): a block per LIST left the
+// million-posting lists to 256 threads each (4.7 ms for C2's planes); segments keep every compute unit busy.
 __global__ __launch_bounds__(256) void k_removed_df(const uint32_t* doc, const uint32_t* tf, const uint32_t* alive, uint64_t P,
-                                                     uint32_t F, const uint64_t* lay_off, const uint32_t* lay_len, uint32_t n_layers,
+                                                     uint32_t F, const BoundUnit* units, uint32_t n_units, const uint4* layer_a,
                                                      unsigned long long* out) {
-  for (uint32_t l = blockIdx.x; l < n_layers; l += gridDim.x) {
-    unsigned long long acc = 0;
-    for (uint32_t i = threadIdx.x; i < lay_len[l]; i += blockDim.x) {
-      const uint64_t pi = lay_off[l] + i;
-      const uint32_t d = doc[pi];
-      if (!((alive[d >> 5] >> (d & 31u)) & 1u))
-        for (uint32_t x = 0; x < F; ++x) acc += tf[(uint64_t)x * P + pi];
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&out[l], acc);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+  const uint32_t lane = threadIdx.x & (WAVE - 1);
+  if (wave >= n_units) return;
+  const BoundUnit u = units[wave];
+  const uint4 la = layer_a[u.layer];
+  const uint64_t off = ((uint64_t)la.x | ((uint64_t)la.y << 32)) + u.begin;
+  unsigned long long acc = 0;
+  for (uint32_t i = lane; i < u.count; i += WAVE) {
+    const uint64_t pi = off + i;
+    const uint32_t d = doc[pi];
+    if (!((alive[d >> 5] >> (d & 31u)) & 1u))
+      for (uint32_t x = 0; x < F; ++x) acc += tf[(uint64_t)x * P + pi];
   }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane == 0 && acc) atomicAdd(&out[u.layer], acc);
 }
 
 void Engine::apply_delta(const DeltaRanges& r, std::vector<uint64_t>& removed_df, uint64_t* bytes_uploaded) {
@@ -597,30 +604,35 @@ void Engine::apply_delta(const DeltaRanges& r, std::vector<uint64_t>& removed_df
   }
   if (r.table_end > r.table_begin) put(m.d_table + r.table_begin, s.table.data() + r.table_begin, (r.table_end - r.table_begin) * 4);
   if (r.key_end > r.key_begin) put(m.d_keys + r.key_begin, s.keys.data() + r.key_begin, (r.key_end - r.key_begin) * 8);
-  if (r.alive_words.size() * 8 > s.alive.size()) {
+  if (r.alive_words.size() > 16) {  // (one blocking 4-byte copy per word cost ~10 us each: 1000 removals = 10 ms; the whole bitmap of a million documents is 125 KB)
     put(m.d_alive, s.alive.data(), s.alive.size() * 4);
   } else {
     for (uint32_t w : r.alive_words) put(m.d_alive + w, s.alive.data() + w, 4);
   }
   // what depended on the old state: resident dense rows (doc range, avg), the saturated-tf LUT (avg),
   // the device copy of the trie / term tables
+  const bool filters_still_good = m.bloom_valid && r.plane_end == r.plane_begin;  // removals only: every list holds the documents it held (tombstones answer "maybe", which is right)
   forget_rows(m);
+  m.bloom_valid = filters_still_good;
   m.dev_trie_valid = false;
   removed_df.assign(s.layers.size(), 0);
   if (s.any_dead && !s.layers.empty()) {
     const size_t nl = s.layers.size();
-    std::vector<uint64_t> off(nl);
-    std::vector<uint32_t> len(nl);
-    for (size_t l = 0; l < nl; ++l) { off[l] = s.layers[l].post_off; len[l] = s.layers[l].len; }
-    m.d_removed_df.ensure(nl * 3 + 8);
+    // the per-layer {post_off, len} table of the new state.  (NOT ensure_dev_trie: its idf tables need the document frequencies this
+    // very pass is about to correct - they are rebuilt at the next batch, dev_trie_valid stays false)
+    {
+      std::vector<uint4> la(nl);
+      for (size_t l = 0; l < nl; ++l) la[l] = make_uint4((uint32_t)s.layers[l].post_off, (uint32_t)(s.layers[l].post_off >> 32), s.layers[l].len, s.layers[l].tbl_off);
+      m.d_layer_a.ensure(nl + 1);
+      PS_HIP(hipMemcpy(m.d_layer_a.p, la.data(), nl * sizeof(uint4), hipMemcpyHostToDevice));
+    }
+    ensure_bound_units(m);
+    m.d_removed_df.ensure(nl + 8);
     unsigned long long* d_out = m.d_removed_df.p;
-    uint64_t* d_off = reinterpret_cast<uint64_t*>(m.d_removed_df.p + nl);
-    uint32_t* d_len = reinterpret_cast<uint32_t*>(m.d_removed_df.p + 2 * nl);
     PS_HIP(hipMemset(d_out, 0, nl * 8));
-    PS_HIP(hipMemcpy(d_off, off.data(), nl * 8, hipMemcpyHostToDevice));
-    PS_HIP(hipMemcpy(d_len, len.data(), nl * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_removed_df, dim3((uint32_t)std::min<size_t>(nl, 65535)), dim3(256), 0, m.stream, m.d_doc, m.d_tf, m.d_alive,
-                       (uint64_t)P, (uint32_t)F, d_off, d_len, (uint32_t)nl, d_out);
+    if (m.bounds.n_units)
+      hipLaunchKernelGGL(k_removed_df, dim3((m.bounds.n_units + 3) / 4), dim3(256), 0, m.stream, m.d_doc, m.d_tf, m.d_alive, (uint64_t)P,
+                         (uint32_t)F, m.bounds.units.p, m.bounds.n_units, m.d_layer_a.p, d_out);
     PS_HIP(hipGetLastError());
     PS_HIP(hipStreamSynchronize(m.stream));
     PS_HIP(hipMemcpy(removed_df.data(), d_out, nl * 8, hipMemcpyDeviceToHost));
@@ -975,6 +987,28 @@ void ensure_dev_trie(EngineImpl& m);  // (defined with the device planner below)
 // while the parameters stay what they were, and a boost vector seen recently finds its J array resident.
 struct BoundsRef { const double* M; const double* J; const double* plane; const double* H; uint32_t h_lo; double h_a, h_b; const double* kth; };
 
+// The work list of the per-list passes (k_list_bounds, k_list_kth, k_removed_df): one wave per list, long lists in 16 Ki-posting
+// segments; rebuilt when the snapshot's layers change (a delta appended some).
+void ensure_bound_units(EngineImpl& m) {
+  const Snapshot& s = *m.snap;
+  EngineImpl::ListBounds& lb = m.bounds;
+  const size_t nl = s.layers.size();
+  uint64_t sig = nl;
+  for (size_t l = 0; l < nl; ++l) sig = sig * 0x9E3779B97F4A7C15ull + s.layers[l].len;  // (a delta may also lengthen nothing but append layers: both change it)
+  if (lb.n_units != 0 && lb.units_sig == sig) return;
+  std::vector<BoundUnit> units;
+  units.reserve(nl + s.n_postings / 16384 + 1);
+  for (size_t l = 0; l < nl; ++l)
+    for (uint32_t b0 = 0; b0 < s.layers[l].len; b0 += 16384u)
+      units.push_back(BoundUnit{(uint32_t)l, b0, std::min<uint32_t>(16384u, s.layers[l].len - b0)});
+  // longest segments first, so a launch ends on its cheapest waves
+  std::stable_sort(units.begin(), units.end(), [](const BoundUnit& a, const BoundUnit& b) { return a.count > b.count; });
+  lb.units.ensure(units.size() + 1);
+  if (!units.empty()) PS_HIP(hipMemcpy(lb.units.p, units.data(), units.size() * sizeof(BoundUnit), hipMemcpyHostToDevice));
+  lb.n_units = (uint32_t)units.size();
+  lb.units_sig = sig;
+}
+
 static_assert(BOUND_NDIR == PREP_NDIR, "host and device agree on the directions of the two-field joint bound");
 BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const double* boosts, const KParams& kp, hipStream_t st) {
   const Snapshot& s = *m.snap;
@@ -1016,18 +1050,7 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
     for (auto& c : m.dctx)
       if (c.busy && c.scored) PS_HIP(hipStreamWaitEvent(st, c.scored, 0));
   const double t0 = now_ms();
-  if (lb.n_layers != nl || lb.n_units == 0) {  // the work list: one wave per list, long lists in 16 Ki-posting segments
-    std::vector<BoundUnit> units;
-    units.reserve(nl + s.n_postings / 16384 + 1);
-    for (size_t l = 0; l < nl; ++l)
-      for (uint32_t b0 = 0; b0 < s.layers[l].len; b0 += 16384u)
-        units.push_back(BoundUnit{(uint32_t)l, b0, std::min<uint32_t>(16384u, s.layers[l].len - b0)});
-    // longest segments first, so the launch ends on its cheapest waves
-    std::stable_sort(units.begin(), units.end(), [](const BoundUnit& a, const BoundUnit& b) { return a.count > b.count; });
-    lb.units.ensure(units.size() + 1);
-    if (!units.empty()) PS_HIP(hipMemcpy(lb.units.p, units.data(), units.size() * sizeof(BoundUnit), hipMemcpyHostToDevice));
-    lb.n_units = (uint32_t)units.size();
-  }
+  ensure_bound_units(m);
   if (need_j && !tgt) {  // an invalid slot, else the least recently used one
     for (auto& js : lb.j)
       if (!tgt || (!js.valid && tgt->valid) || (js.valid == tgt->valid && js.last_use < tgt->last_use)) tgt = &js;
@@ -1059,8 +1082,8 @@ BoundsRef ensure_list_bounds(EngineImpl& m, const ps_scorer_desc& sc, const doub
     lb.kth.ensure(nk);
     PS_HIP(hipMemsetAsync(lb.kth.p, 0, nk * 8, st));
     if (lb.n_units) {
-      if (F == 1) hipLaunchKernelGGL(k_list_kth<1>, dim3((lb.n_units + 3) / 4), dim3(256), 0, st, lb.units.p, lb.n_units, m.d_layer_a.p, lb.plane.p, lb.kth.p);
-      else hipLaunchKernelGGL(k_list_kth<2>, dim3((lb.n_units + 3) / 4), dim3(256), 0, st, lb.units.p, lb.n_units, m.d_layer_a.p, lb.plane.p, lb.kth.p);
+      if (F == 1) hipLaunchKernelGGL(k_list_kth<1>, dim3((lb.n_units + 3) / 4), dim3(256), 0, st, lb.units.p, lb.n_units, m.d_layer_a.p, lb.plane.p, m.d_doc, kp.alive, lb.kth.p);
+      else hipLaunchKernelGGL(k_list_kth<2>, dim3((lb.n_units + 3) / 4), dim3(256), 0, st, lb.units.p, lb.n_units, m.d_layer_a.p, lb.plane.p, m.d_doc, kp.alive, lb.kth.p);
       PS_HIP(hipGetLastError());
     }
   }
@@ -1216,11 +1239,11 @@ void launch_prep(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& sc
   pp.rows_resident = m.tune.row_cache_mb != 0;
   pp.layer_a = m.d_layer_a.p; pp.row_state = c.row_state; pp.row_desc = c.row_desc; pp.wstats = m.d_wstats;
   pp.host_items = (uint32_t)items_bound; pp.host_items_big = (uint32_t)items_big; pp.fault = m.d_fault;
-  // threshold priming: off while the snapshot carries tombstones (a removed document may be one of a list's K best), for K beyond
-  // the stored ranks, and for three fields and more (no tables)
+  // threshold priming: off for K beyond the stored ranks and for three fields and more (no tables).  Tombstones: the tables skip
+  // removed documents (k_list_kth reads the alive bitmap; every delta recomputes them with the bounds)
   pp.gthr = kp.gthr;
   pp.kth = nullptr;
-  if (m.tune.daat_prime && br.kth != nullptr && kp.alive == nullptr && kp.K >= 1 && kp.K <= 64) {
+  if (m.tune.daat_prime && br.kth != nullptr && kp.K >= 1 && kp.K <= 64) {
     static const uint32_t ranks[KTH_RANKS] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40, 50, 64};
     uint32_t j = 0;
     while (ranks[j] < kp.K) ++j;

@@ -208,7 +208,7 @@ __device__ __forceinline__ void top64_merge(double& top, double v, const int lan
 }
 template <int F_>
 __global__ __launch_bounds__(256) void k_list_kth(const BoundUnit* units, const uint32_t n_units, const uint4* layer_a, const double* plane,
-                                                  unsigned long long* kth) {
+                                                  const uint32_t* doc, const uint32_t* alive, unsigned long long* kth) {
   static_assert(F_ == 1 || F_ == 2, "threshold priming tables exist for one and two fields");
   constexpr int D = F_ == 1 ? 1 : 3;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void k_list_kth(const BoundUnit* units, const 
     double v[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) v[d] = 0.0;
-    if (i < u.count) {
+    // (documents a delta removed keep their postings until the next flatten: they are not among a list's K best - `alive` is null
+    // while the snapshot carries no tombstones, and every delta recomputes these tables)
+    if (i < u.count && (alive == nullptr || ((alive[doc[off + i] >> 5] >> (doc[off + i] & 31u)) & 1u))) {
       if (F_ == 1) v[0] = plane[off + i];
       else {
         const double2 t = reinterpret_cast<const double2*>(plane)[off + i];

@@ -287,3 +287,34 @@ def test_corners_under_a_delta_with_removals(corpus_pair):
         for K in (1, 10, 64):
             _run(snap, o, queries, kw, boosts, K, "ps::k_daat")
     _run(snap, o, queries, {"k1": -0.5}, [1.0, 1.0], 10, "ps::k_score")
+    # threshold priming stays on under tombstones: the per-list tables skip removed documents (k_list_kth reads the alive bitmap) -
+    # primed == unprimed == oracle for every query, and priming still drops work.  The best documents of a few lists are removed
+    # on purpose: exactly the postings a stale table would still count on.
+    sc, osc = product_scorer("bm25"), oracle_scorer("bm25")
+    qs = corpus.queries(96, 3, salt=41)
+    victims = set()
+    for q in qs[:24]:
+        for r in o.query(q, osc, [1.0, 1.0])[:10]:
+            victims.add(r[0])
+    for k in sorted(victims):
+        p.remove_document(k)
+        o.remove_document(k)
+    st = snap.update()
+    assert st["mode"] in (1, 2) and st["docs_removed"] == len(victims), st
+    L = psa.load()
+    try:
+        out = {}
+        for prime in (1, 0):
+            L.ps_set_option(b"PS_DAAT_PRIME", prime)
+            snap.work_counters(reset=True)
+            out[prime] = ([[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(qs, sc, None, [1.0, 1.0], top_k=10)],
+                          snap.work_counters(reset=True))
+            assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_daat")
+        assert out[1][0] == out[0][0]
+        assert out[1][1]["items_run"] < out[0][1]["items_run"], (out[1][1]["items_run"], out[0][1]["items_run"])
+        for q, g in zip(qs, out[1][0]):
+            exp = [(k, bits(s_)) for k, s_ in o.query(q, osc, [1.0, 1.0])[:10]]
+            assert g == exp, (q, g[:3], exp[:3])
+            assert not ({k for k, _ in g} & victims)
+    finally:
+        L.ps_set_option(b"PS_DAAT_PRIME", 1)
