@@ -14,9 +14,15 @@ under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU); u
 saved as a snapshot file and mmap-loaded by the other ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
-dominant kernel (timed alone with HIP events inside the library, on the launch stream) and
-`cpu_baseline` (the reference-faithful C++ restatement in oracle/, timed on this box's host
-cores on a bounded sample of the same batch; N=1 only).
+dominant kernel (timed alone with HIP events inside the library, on the launch stream: mean
+individual duration, busy time per launch under the two scoring queues, and the duration with
+scoring serialised - `frac`, `frac_overlapped`, `frac_serial`) and `cpu_baseline` (the
+reference-faithful C++ restatement in oracle/ - literal leg and SwissTable-class `flat` leg -
+timed on this box's host cores on a bounded sample of the same batch; N=1 only).  Further legs
+at N=1, outside the headline's timed region: `live_index_updates` (ps_snapshot_update between
+batches + what the per-snapshot-state kernels cost), `add_100k_docs` (the reference's own
+benchmark workload through the host and the GPU bulk indexer), `alternating_boosts` /
+`fresh_boosts_every_step`, `streaming_kernel_leg`, `gpu_bulk_index`.
 """
 import argparse
 import json

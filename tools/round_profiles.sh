@@ -11,7 +11,7 @@ for C in C2 C3 C5 C4; do
 done
 PS_DAAT=0 bash tools/profile_bench.sh C2stream $HEAD --config C2 > gpurun_out/prof_C2stream.log 2>&1
 mkdir -p gpurun_out/${TAG}final
-python bench.py > gpurun_out/${TAG}final/bench_C2_driver_style.json 2> gpurun_out/${TAG}final/bench_C2_driver_style.err
+python bench.py --gpus 1 --steps 25 --warmup 5 > gpurun_out/${TAG}final/bench_C2_driver_style.json 2> gpurun_out/${TAG}final/bench_C2_driver_style.err
 for C in C2 C3 C5 C1 C4; do
   python bench.py --config $C --steps 100 --warmup 10 > gpurun_out/${TAG}final/bench_$C.json 2> gpurun_out/${TAG}final/bench_$C.err
 done
