@@ -89,6 +89,18 @@ struct DevBuf {
     if (zero) PS_HIP(hipMemset(p, 0, want * sizeof(T)));
     return true;
   }
+  // grows the buffer keeping its first `keep` elements
+  void ensure_keep(size_t n, size_t keep) {
+    if (n <= cap) return;
+    T* old = p;
+    const size_t want = n + n / 4 + 64;
+    T* np = nullptr;
+    PS_HIP(hipMalloc((void**)&np, want * sizeof(T)));
+    if (old && keep) PS_HIP(hipMemcpy(np, old, keep * sizeof(T), hipMemcpyDeviceToDevice));
+    if (old) (void)hipFree(old);
+    p = np;
+    cap = want;
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -232,7 +244,9 @@ struct EngineImpl {
     uint64_t epoch = 0;
     DevBuf<BoundUnit> units;
     uint32_t n_units = 0;
-    uint64_t units_sig = 0;        // what the work list was built for (layer count and lengths)
+    uint64_t units_sig = 0;        // what the work list was built for (lengths of its first units_layers layers)
+    size_t units_layers = 0;
+    uint32_t units_n = 0;          // units in the buffer (n_units is reset by forget_rows: the buffer outlives it)
     double last_ms = 0.0;  // host wall time of the most recent (re)computation's enqueue
     uint64_t recomputed = 0;
   } bounds;
@@ -269,6 +283,7 @@ struct EngineImpl {
   // N2 device-side planner: the frozen trie + per-term / per-layer tables in HBM (uploaded on first
   // use, again after a delta changed them), per-batch scratch
   bool dev_trie_valid = false;
+  bool dev_trie_struct_valid = false;  // the frozen trie itself (nodes, child characters): survives deltas that add no term
   DevBuf<uint4> d_fnodes, d_layer_a, d_layer_b, d_fbits;
   DevBuf<uint32_t> d_fchar, d_fchild, d_term_meta, d_term_delta;
   DevBuf<uint64_t> d_term_df;
@@ -615,6 +630,7 @@ void Engine::apply_delta(const DeltaRanges& r, std::vector<uint64_t>& removed_df
   forget_rows(m);
   m.bloom_valid = filters_still_good;
   m.dev_trie_valid = false;
+  if (r.trie_refrozen) m.dev_trie_struct_valid = false;
   removed_df.assign(s.layers.size(), 0);
   if (s.any_dead && !s.layers.empty()) {
     const size_t nl = s.layers.size();
@@ -993,20 +1009,36 @@ void ensure_bound_units(EngineImpl& m) {
   const Snapshot& s = *m.snap;
   EngineImpl::ListBounds& lb = m.bounds;
   const size_t nl = s.layers.size();
-  uint64_t sig = nl;
-  for (size_t l = 0; l < nl; ++l) sig = sig * 0x9E3779B97F4A7C15ull + s.layers[l].len;  // (a delta may also lengthen nothing but append layers: both change it)
-  if (lb.n_units != 0 && lb.units_sig == sig) return;
-  std::vector<BoundUnit> units;
-  units.reserve(nl + s.n_postings / 16384 + 1);
-  for (size_t l = 0; l < nl; ++l)
+  auto sig_of = [&](size_t n) {
+    uint64_t sig = n;
+    for (size_t l = 0; l < n; ++l) sig = sig * 0x9E3779B97F4A7C15ull + s.layers[l].len;
+    return sig;
+  };
+  auto add_layer = [&](std::vector<BoundUnit>& units, size_t l) {
     for (uint32_t b0 = 0; b0 < s.layers[l].len; b0 += 16384u)
       units.push_back(BoundUnit{(uint32_t)l, b0, std::min<uint32_t>(16384u, s.layers[l].len - b0)});
-  // longest segments first, so a launch ends on its cheapest waves
-  std::stable_sort(units.begin(), units.end(), [](const BoundUnit& a, const BoundUnit& b) { return a.count > b.count; });
-  lb.units.ensure(units.size() + 1);
-  if (!units.empty()) PS_HIP(hipMemcpy(lb.units.p, units.data(), units.size() * sizeof(BoundUnit), hipMemcpyHostToDevice));
-  lb.n_units = (uint32_t)units.size();
-  lb.units_sig = sig;
+  };
+  if (lb.units_n != 0 && lb.units_layers <= nl && sig_of(lb.units_layers) == lb.units_sig) {
+    if (lb.units_layers == nl) { lb.n_units = lb.units_n; return; }
+    // a delta appended layers (the lists it touched): their units go behind the existing ones - no re-sort, no re-upload of the rest
+    std::vector<BoundUnit> extra;
+    for (size_t l = lb.units_layers; l < nl; ++l) add_layer(extra, l);
+    lb.units.ensure_keep(lb.units_n + extra.size() + 1, lb.units_n);
+    if (!extra.empty()) PS_HIP(hipMemcpy(lb.units.p + lb.units_n, extra.data(), extra.size() * sizeof(BoundUnit), hipMemcpyHostToDevice));
+    lb.units_n += (uint32_t)extra.size();
+  } else {
+    std::vector<BoundUnit> units;
+    units.reserve(nl + s.n_postings / 16384 + 1);
+    for (size_t l = 0; l < nl; ++l) add_layer(units, l);
+    // longest segments first, so a launch ends on its cheapest waves
+    std::stable_sort(units.begin(), units.end(), [](const BoundUnit& a, const BoundUnit& b) { return a.count > b.count; });
+    lb.units.ensure(units.size() + 1);
+    if (!units.empty()) PS_HIP(hipMemcpy(lb.units.p, units.data(), units.size() * sizeof(BoundUnit), hipMemcpyHostToDevice));
+    lb.units_n = (uint32_t)units.size();
+  }
+  lb.n_units = lb.units_n;
+  lb.units_layers = nl;
+  lb.units_sig = sig_of(nl);
 }
 
 static_assert(BOUND_NDIR == PREP_NDIR, "host and device agree on the directions of the two-field joint bound");
@@ -2709,8 +2741,10 @@ void ensure_dev_trie(EngineImpl& m) {
   if (m.dev_trie_valid) return;
   const Snapshot& s = *m.snap;
   const size_t nn = s.fnodes.size(), nt = s.terms.size(), nl = s.layers.size();
-  std::vector<uint4> fn(nn), la(std::max<size_t>(nl, 1)), lb(std::max<size_t>(nl, 1));
-  for (size_t i = 0; i < nn; ++i) fn[i] = make_uint4(s.fnodes[i].child_begin, s.fnodes[i].child_count, s.fnodes[i].term_begin, s.fnodes[i].term_end);
+  // (a delta that brought no new term leaves the frozen trie as it was: only the per-term / per-layer tables follow the new state)
+  const bool structure = !m.dev_trie_struct_valid;
+  std::vector<uint4> fn(structure ? nn : 0), la(std::max<size_t>(nl, 1)), lb(std::max<size_t>(nl, 1));
+  for (size_t i = 0; i < fn.size(); ++i) fn[i] = make_uint4(s.fnodes[i].child_begin, s.fnodes[i].child_count, s.fnodes[i].term_begin, s.fnodes[i].term_end);
   for (size_t l = 0; l < nl; ++l) {
     const LayerInfo& L = s.layers[l];
     la[l] = make_uint4((uint32_t)L.post_off, (uint32_t)(L.post_off >> 32), L.len, L.tbl_off);
@@ -2738,7 +2772,8 @@ void ensure_dev_trie(EngineImpl& m) {
     buf.ensure(v.size() + 1);
     PS_HIP(hipMemcpy(buf.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
   };
-  up(m.d_fnodes, fn); up(m.d_layer_a, la); up(m.d_layer_b, lb); up(m.d_term_meta, meta); up(m.d_term_delta, delta);
+  if (structure) up(m.d_fnodes, fn);
+  up(m.d_layer_a, la); up(m.d_layer_b, lb); up(m.d_term_meta, meta); up(m.d_term_delta, delta);
   up(m.d_term_df, df); up(m.d_term_idf, idf); up(m.d_eb_table, eb);
   {  // per list (layer) the idf of its term: what the score planes are built with
     std::vector<double> lidf(std::max<size_t>(nl, 1), 0.0);
@@ -2749,6 +2784,7 @@ void ensure_dev_trie(EngineImpl& m) {
     }
     up(m.d_layer_idf, lidf);
   }
+  if (structure) {
   std::vector<uint32_t> fc(s.fchar.begin(), s.fchar.end()), fd(s.fchild.begin(), s.fchild.end());
   if (fc.empty()) { fc.push_back(0); fd.push_back(0); }
   up(m.d_fchar, fc); up(m.d_fchild, fd);
@@ -2764,6 +2800,8 @@ void ensure_dev_trie(EngineImpl& m) {
       fb[2 * i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
     up(m.d_fbits, fb);
+  }
+  m.dev_trie_struct_valid = true;
   }
   if (!m.h_totals) {
     PS_HIP(hipHostMalloc((void**)&m.h_totals, N_DCTX * sizeof(PlanTotals), hipHostMallocMapped | hipHostMallocCoherent));

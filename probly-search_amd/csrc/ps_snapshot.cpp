@@ -59,6 +59,7 @@ struct SnapshotStorage {
   // removed documents are subtracted
   std::vector<int32_t> term_node;
   std::vector<uint64_t> df_total;
+  std::unordered_map<int32_t, uint32_t> ord_of;  // source trie node -> term ordinal: built by the first delta with additions, redone when the trie is re-frozen
   // doc ids for which the flattener folded a duplicate record (a key re-added without removal whose
   // term frequencies did not change): df_raw counts that record (index.rs:282-297 counts every
   // pointer), but no posting stands for it, so the per-posting re-count of a delta removal would
@@ -732,9 +733,13 @@ bool Snapshot::apply_delta(const Index& idx, DeltaRanges& out) {
       return false;
     }
     // terms: does every touched node already have a term ordinal?
-    std::unordered_map<int32_t, uint32_t> ord_of;
-    ord_of.reserve(st.term_node.size() * 2);
-    for (size_t o = 0; o < st.term_node.size(); ++o) ord_of.emplace(st.term_node[o], (uint32_t)o);
+    // (100 k insertions: 3-5 ms if redone for every delta - it only changes when the trie is re-frozen)
+    std::unordered_map<int32_t, uint32_t>& ord_of = st.ord_of;
+    if (ord_of.size() != st.term_node.size()) {
+      ord_of.clear();
+      ord_of.reserve(st.term_node.size() * 2);
+      for (size_t o = 0; o < st.term_node.size(); ++o) ord_of.emplace(st.term_node[o], (uint32_t)o);
+    }
     bool new_terms = false;
     for (auto& kv : by_node)
       if (!ord_of.count(kv.first)) { new_terms = true; break; }
