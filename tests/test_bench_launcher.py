@@ -60,3 +60,27 @@ def test_eight_ranks_debug_one_gpu_end_to_end():
     d = json.loads(line)
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8192 and d["value"] > 0 and d["scaling"] == "weak"
     assert "DEBUG" in d["data"]
+
+
+def test_effective_cpus_reads_the_containers_quota(tmp_path, monkeypatch):
+    """bench.py sizes the oracle's all-cores legs from the CPUs the process can really use: the GPU boxes show 256 hardware threads
+    under a cgroup quota of 16 (profiles/r06_cpu_baseline_scaling.txt)."""
+    import builtins
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    n, src = b.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    real_open = builtins.open
+
+    def fake_open(path, *a, **kw):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("200000 100000\n")
+            return real_open(str(f), *a, **kw)
+        return real_open(path, *a, **kw)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    if (os.cpu_count() or 1) > 2:
+        assert b.effective_cpus() == (2, "cgroup cpu quota 2.00")

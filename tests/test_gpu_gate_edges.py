@@ -318,3 +318,42 @@ def test_corners_under_a_delta_with_removals(corpus_pair):
             assert not ({k for k, _ in g} & victims)
     finally:
         L.ps_set_option(b"PS_DAAT_PRIME", 1)
+
+
+def test_doc_ordered_filters_with_clustered_lists():
+    """The Bloom filters of sparse lists are laid out in document order (word = doc id >> shift, bits by hash): a list whose
+    documents sit in one narrow id range loads a few filter words with all of its keys - more "maybe" answers there, never a
+    wrong one.  Rare terms confined to 200-document windows, a common term everywhere, queries that pair them: the pruning
+    kernels (lookups through filters -> table slots) == the streaming kernel == the oracle."""
+    rng = random.Random(5)
+    n = 40_000
+    p, o = psa.Index(2), orc.Index(2)
+    rare = ["rare%02d" % i for i in range(24)]
+    window = {t: rng.randrange(0, n - 200) for t in rare}
+    for k in range(n):
+        f0 = ["common"] if k % 3 else ["common", "other"]
+        f1 = ["filler%d" % (k % 7), "common" if k % 5 == 0 else "pad"]
+        for t in rare:
+            if window[t] <= k < window[t] + 200 and rng.random() < 0.8:
+                (f0 if rng.random() < 0.5 else f1).append(t)
+        if k % 97 == 0:
+            f1.append(rng.choice(rare))  # a few stragglers outside the windows
+        vals = [" ".join(f0), " ".join(f1)]
+        p.add_field_values(k, vals)
+        o.add_document(k, vals)
+    snap = p.snapshot(device=0)
+    queries = [a + " " + b for a in rare[:12] for b in rare[12:16]] + [t + " common" for t in rare] + [t + " other filler3" for t in rare[:8]]
+    sc, osc = product_scorer("bm25"), oracle_scorer("bm25")
+    L = psa.load()
+    for K in (1, 10):
+        a = [[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=K)]
+        assert snap.kernel_breakdown()["score_kernel"].startswith("ps::k_daat")
+        L.ps_set_option(b"PS_DAAT", 0)
+        try:
+            b = [[(r.key, bits(r.score)) for r in rs] for rs in snap.query_batch(queries, sc, None, [1.0, 1.0], top_k=K)]
+        finally:
+            L.ps_set_option(b"PS_DAAT", 1)
+        assert a == b, K
+        for q, g in list(zip(queries, a))[::3]:
+            exp = [(k, bits(s_)) for k, s_ in o.query(q, osc, [1.0, 1.0])[:K]]
+            assert g == exp, (K, q, g[:3], exp[:3])
