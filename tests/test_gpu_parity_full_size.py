@@ -182,7 +182,8 @@ def test_c2_full_size_against_oracle():
 
 
 def test_c3_full_size_against_oracle():
-    _full_size("C3", 4, 1024)
+    # (128 oracle queries: a zero_to_one query over 1 M documents costs the oracle ~5 s, and the GPU boxes grant 16 CPUs of time)
+    _full_size("C3", 4, 1024, n_oracle_topk=128)
 
 
 def test_c5_full_size_against_oracle():
