@@ -244,6 +244,29 @@ __global__ __launch_bounds__(256) void k_list_kth(const BoundUnit* units, const 
       if ((uint32_t)lane + 1u == kth_rank_of(j) && top[d] > 0.0)
         atomicMax(&kth[((size_t)u.layer * D + d) * KTH_RANKS + j], (unsigned long long)__double_as_longlong(top[d]));
 }
+// The same two numbers from values that are already in registers (one or two fields): k_prep_query requests the tables of all
+// of a query's entries together - a thread per query is a chain of dependent loads, and under a running k_daat every level of it
+// costs 3-5 us - and evaluates afterwards.  Same operations in the same order as prep_entry_ub / prep_entry_theta0.
+__device__ __forceinline__ double prep_ub_from(const PrepParams& pp, const double idf, const double eb, const double m0, const double m1,
+                                               const double ha, const double hb) {
+  double ub_m = 0.0;
+  if (m0 > 0.0) ub_m += m0 * idf * pp.boost[0] * eb;
+  if (pp.F == 2u && m1 > 0.0) ub_m += m1 * idf * pp.boost[1] * eb;
+  if (pp.F != 2u || pp.bound_h == nullptr) return ub_m;
+  const double jb = pp.h_a * ha + pp.h_b * hb;
+  const double ub_j = (idf * eb) * jb * (1.0 + 1e-12) + 0x1p-1066;
+  return fmin(ub_m, ub_j);
+}
+__device__ __forceinline__ double prep_theta0_from(const PrepParams& pp, const double eb, const double k0, const double k1, const double ks) {
+  double th = fmax(0.0, (k0 * pp.boost[0]) * eb);
+  if (pp.F == 2u) {
+    th = fmax(th, (k1 * pp.boost[1]) * eb);
+    const double sdir = ks * fmin(pp.boost[0], pp.boost[1]) * eb * (1.0 - 1e-12);
+    if (sdir > 1e-290) th = fmax(th, sdir);
+  }
+  return th;
+}
+
 // theta0 of plan entry e: at least K of its postings score at least this much - through the readers' own expression
 // ((plane_x * boost_x) * expansion_boost, monotone in plane_x; the other field adds >= 0), or, for two fields, through the
 // K-th best plane sum with the smaller boost (a real-number inequality, deflated past the few roundings between the two).
@@ -333,21 +356,66 @@ __device__ __forceinline__ bool prep_before(const double ua, const uint32_t la, 
   return ua > ub || (ua == ub && (la < lb || (la == lb && ia < ib)));
 }
 
+// (what the entry loop of k_prep_query needs of a small query's entries, kept in registers: no second round of loads)
 template <int NMAX>
-__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, uint32_t& groups, double& th0) {
+struct PrepSmall { uint32_t len[NMAX], node[NMAX], rank[NMAX], cand[NMAX], dead; };
+
+template <int NMAX>
+__device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const uint32_t q, const uint32_t b, const uint32_t n, uint32_t& groups, double& th0,
+                                                     PrepSmall<NMAX>& ps) {
   double ub[NMAX], t0[NMAX];
   th0 = 0.0;
+  ps.dead = 0u;
   uint32_t len[NMAX], grp[NMAX], rank[NMAX], qt[NMAX];
+  if (pp.F <= 2u) {
+    // level 1: the entries' own words (an entry past the plan's end re-reads the last one: no branch between the loads);
+    // level 2: everything that hangs on the list ordinal - per-field maxima, two direction supports, priming ranks, row candidate
+    uint32_t node[NMAX];
+    double idf[NMAX], eb[NMAX];
 #pragma unroll
-  for (int i = 0; i < NMAX; ++i) {
-    ub[i] = 0.0; len[i] = 0; qt[i] = 0xFFFFFFFFu;
-    if ((uint32_t)i < n) {
-      const ps_plan_entry& en = pp.plan[b + i];
-      ub[i] = prep_entry_ub(pp, en);
-      t0[i] = prep_entry_theta0(pp, en);
-      len[i] = en.len;
-      qt[i] = en.qterm;
+    for (int i = 0; i < NMAX; ++i) {
+      const ps_plan_entry& en = pp.plan[b + ((uint32_t)i < n ? (uint32_t)i : n - 1u)];
+      len[i] = en.len; qt[i] = en.qterm; node[i] = en.node; idf[i] = en.idf; eb[i] = en.boost;
+    }
+    double m0[NMAX], m1[NMAX], ha[NMAX], hb[NMAX], k0[NMAX], k1[NMAX], ks[NMAX];
+    const bool two = pp.F == 2u, with_h = two && pp.bound_h != nullptr, with_k = pp.kth != nullptr;
+    const uint32_t D = two ? 3u : 1u;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+      const size_t l = node[i];
+      m0[i] = pp.bound_m[l * pp.F];
+      m1[i] = two ? pp.bound_m[l * 2 + 1] : 0.0;
+      ha[i] = with_h ? pp.bound_h[l * PREP_NDIR + pp.h_lo] : 0.0;
+      hb[i] = with_h ? pp.bound_h[l * PREP_NDIR + pp.h_lo + 1] : 0.0;
+      const double* k = pp.kth + (l * D) * KTH_RANKS + pp.kth_rank;
+      k0[i] = with_k ? k[0] : 0.0;
+      k1[i] = with_k && two ? k[KTH_RANKS] : 0.0;
+      ks[i] = with_k && two ? k[2 * KTH_RANKS] : 0.0;
+      ps.cand[i] = pp.n_cand ? (uint32_t)pp.cand_of_layer[l] : NO_CAND;
+      ps.node[i] = node[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+      const bool on = (uint32_t)i < n;
+      ub[i] = on ? prep_ub_from(pp, idf[i], eb[i], m0[i], m1[i], ha[i], hb[i]) : 0.0;
+      t0[i] = on && with_k ? prep_theta0_from(pp, eb[i], k0[i], k1[i], ks[i]) : 0.0;
+      if (!on) { len[i] = 0; qt[i] = 0xFFFFFFFFu; }
       th0 = fmax(th0, t0[i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+      ub[i] = 0.0; len[i] = 0; qt[i] = 0xFFFFFFFFu; ps.node[i] = 0; ps.cand[i] = NO_CAND;
+      if ((uint32_t)i < n) {
+        const ps_plan_entry& en = pp.plan[b + i];
+        ub[i] = prep_entry_ub(pp, en);
+        t0[i] = prep_entry_theta0(pp, en);
+        len[i] = en.len;
+        qt[i] = en.qterm;
+        ps.node[i] = en.node;
+        ps.cand[i] = pp.n_cand ? (uint32_t)pp.cand_of_layer[en.node] : NO_CAND;
+        th0 = fmax(th0, t0[i]);
+      }
     }
   }
   uint32_t n_groups = 0;
@@ -422,8 +490,12 @@ __device__ __forceinline__ uint32_t prep_query_small(const PrepParams& pp, const
         pp.dgroup[b + i] = dg;
       }
       const uint32_t c = prep_chunk(pp, len[i]);
-      if (pp.prime_keep_items || !(d.skip_thr < th0)) slots += (len[i] + c - 1) / c;  // (a list that is non-essential from the start gets no items)
+      const bool dead = !pp.prime_keep_items && d.skip_thr < th0;  // (a list that is non-essential from the start gets no items)
+      if (!dead) slots += (len[i] + c - 1) / c;
+      ps.dead |= dead ? 1u << i : 0u;
     }
+    ps.len[i] = len[i];
+    ps.rank[i] = rank[i];
   }
   return slots;
 }
@@ -634,6 +706,14 @@ __device__ __forceinline__ void prep_finish(const PrepParams& pp) {
 // gets the wave slots two finishing k_daat waves leave behind - a 1024-thread workgroup can wait 200 us for
 // a compute unit to have room): descriptors, candidate slots, item-bucket totals, dense-row uses.
 __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
+  // The workgroup's (= the wave's) contributions to the item-bucket totals and the dense-row uses are summed in LDS and flushed
+  // once, every non-empty bin by its own lane and all at once.  (Round 5 aggregated per distinct key with shuffles - one pass and
+  // one atomic per key and entry position, 20-50 us of a wave's time while a scoring kernel keeps the memory system busy.)
+  __shared__ uint32_t h_bucket[PREP_BUCKETS];
+  __shared__ uint32_t h_row[PREP_MAX_ROWS];
+  for (uint32_t k = threadIdx.x; k < PREP_BUCKETS; k += WAVE) h_bucket[k] = 0u;
+  h_row[threadIdx.x & (PREP_MAX_ROWS - 1u)] = 0u;
+  __syncthreads();
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = q < pp.B;
   const uint32_t b = have ? pp.qbeg[q] : 0u, n = have ? pp.qbeg[q + 1] - b : 0u;
@@ -642,7 +722,8 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
   // An 8-entry register variant cost this kernel 145 VGPRs and 58 SGPR spills for every batch: 76 / 0 without it.)
   uint32_t groups = 0;
   double th0 = 0.0;  // the query's primed threshold
-  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n, groups, th0) : prep_query_general(pp, q, b, n, th0);
+  PrepSmall<4> ps;
+  if (n) slots = n <= 4 ? prep_query_small<4>(pp, q, b, n, groups, th0, ps) : prep_query_general(pp, q, b, n, th0);
   if (have && pp.gthr != nullptr) pp.gthr[q] = (unsigned long long)__double_as_longlong(th0);
   // PLAN_BIG's rule (k_plan): more than 4 lists, or several lists under one query term -> k_daat's part of the batch
   const bool big = pp.split_kinds && (n > 4u || groups != n);
@@ -656,24 +737,45 @@ __global__ __launch_bounds__(WAVE) void k_prep_query(const PrepParams pp) {
     const bool on = i < n;
     uint32_t bk = 0, bs = 0, nc = 0, ns = 0, cd = NO_CAND;
     if (on) {
-      const ps_plan_entry& en = pp.plan[b + i];
-      const uint32_t c = prep_chunk(pp, en.len);
-      const bool dead = !pp.prime_keep_items && pp.dentry[b + i].skip_thr < th0;  // non-essential before the launch: no items, no candidate slots
-      nc = dead ? 0u : (en.len + c - 1) / c;
-      ns = dead ? 0u : (big || !pp.split_kinds || pp.sample_small) ? prep_sample_chunks(pp, en, c, nc) : 0u;
+      // a small query's entries are in registers (prep_query_small); a wide one's are read back from its arrays
+      uint32_t len_i, rk;
+      bool dead;
+      if (n <= 4u) {
+        const uint32_t k = i & 3u;
+        len_i = k == 0u ? ps.len[0] : k == 1u ? ps.len[1] : k == 2u ? ps.len[2] : ps.len[3];
+        rk = k == 0u ? ps.rank[0] : k == 1u ? ps.rank[1] : k == 2u ? ps.rank[2] : ps.rank[3];
+        cd = k == 0u ? ps.cand[0] : k == 1u ? ps.cand[1] : k == 2u ? ps.cand[2] : ps.cand[3];
+        dead = ((ps.dead >> k) & 1u) != 0u;
+      } else {
+        const ps_plan_entry& en = pp.plan[b + i];
+        len_i = en.len;
+        rk = pp.dentry[b + i].rank;
+        dead = !pp.prime_keep_items && pp.dentry[b + i].skip_thr < th0;  // non-essential before the launch: no items, no candidate slots
+        if (pp.n_cand) cd = pp.cand_of_layer[en.node];
+      }
+      const uint32_t c = prep_chunk(pp, len_i);
+      nc = dead ? 0u : (len_i + c - 1) / c;
+      ns = dead ? 0u : (big || !pp.split_kinds || pp.sample_small) ? prep_sample_chunks(pp, pp.plan[b + i], c, nc) : 0u;
       pp.gen[b + i] = DItemGen{(big ? 1u : 0u) | (dead ? 2u : 0u), ns, c, sl};  // (`entry`: gen is indexed by entry - the word carries the query's kind and "no items")
       sl += nc;
-      const uint32_t rk = pp.dentry[b + i].rank;
-      bk = prep_bucket(rk, en.len, pp.multi != 0u && (big || !pp.split_kinds), big);
+      bk = prep_bucket(rk, len_i, pp.multi != 0u && (big || !pp.split_kinds), big);
       bs = (big ? PREP_SET_BUCKETS : 0u) + (rk < PREP_SAMPLE_BUCKETS ? rk : PREP_SAMPLE_BUCKETS - 1u);
-      if (pp.n_cand) cd = pp.cand_of_layer[en.node];
     }
-    wave_add_by_key_noret(pp.ctl->bucket_total, bk, nc - ns, on && nc != ns);
-    if (pp.sample_tile) wave_add_by_key_noret(pp.ctl->bucket_total, bs, ns, on && ns != 0);
-    if (pp.n_cand) {
-      wave_add_by_key_noret(pp.ctl->row_use, cd == NO_CAND ? 0u : cd, 1u, on && cd != NO_CAND);
-      if (on && cd != NO_CAND) atomicMax(&pp.ctl->row_first[cd], ~(unsigned long long)(b + i));
+    if (on && nc != ns) atomicAdd(&h_bucket[bk], nc - ns);
+    if (pp.sample_tile && on && ns != 0) atomicAdd(&h_bucket[bs], ns);
+    if (pp.n_cand && on && cd != NO_CAND) {
+      atomicAdd(&h_row[cd], 1u);
+      atomicMax(&pp.ctl->row_first[cd], ~(unsigned long long)(b + i));
     }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < PREP_BUCKETS; k += WAVE) {
+    const uint32_t v = h_bucket[k];
+    if (v) atomicAdd(&pp.ctl->bucket_total[k], v);
+  }
+  if (pp.n_cand) {
+    const uint32_t v = h_row[threadIdx.x & (PREP_MAX_ROWS - 1u)];
+    if (v) atomicAdd(&pp.ctl->row_use[threadIdx.x & (PREP_MAX_ROWS - 1u)], v);
   }
   // the wave that finishes last closes the batch's counters (k_prep_finish's work, without its launch)
   __threadfence();
@@ -729,13 +831,23 @@ __global__ __launch_bounds__(2 * WAVE) void k_prep_items(const PrepParams pp) {
       }
     }
   }
-  const uint32_t off = wave_add_by_key(pp.ctl->bucket_fill, bk, nc - ns, have && nc != ns);
-  const uint32_t at = have && nc != ns ? pp.ctl->bucket_start[bk] + off : 0u;
-  uint32_t at_s = 0;
-  if (pp.sample_tile) {
-    const uint32_t off_s = wave_add_by_key(pp.ctl->bucket_fill, bs, ns, have && ns != 0);
-    at_s = have && ns ? pp.ctl->bucket_start[bs] + off_s : 0u;
+  // the lists' places in their buckets: offsets within the workgroup from LDS atomics, then ONE round trip to the buckets' fill
+  // counters for all of the workgroup's buckets together (a lane per bucket), instead of one round trip per distinct bucket
+  __shared__ uint32_t h_cnt[PREP_BUCKETS];
+  __shared__ uint32_t h_base[PREP_BUCKETS];
+  for (uint32_t k = threadIdx.x; k < PREP_BUCKETS; k += 2 * WAVE) h_cnt[k] = 0u;
+  __syncthreads();
+  uint32_t local = 0, local_s = 0;
+  if (have && nc != ns) local = atomicAdd(&h_cnt[bk], nc - ns);
+  if (pp.sample_tile && have && ns != 0) local_s = atomicAdd(&h_cnt[bs], ns);
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < PREP_BUCKETS; k += 2 * WAVE) {
+    const uint32_t v = h_cnt[k];
+    h_base[k] = v ? pp.ctl->bucket_start[k] + atomicAdd(&pp.ctl->bucket_fill[k], v) : 0u;
   }
+  __syncthreads();
+  const uint32_t at = have && nc != ns ? h_base[bk] + local : 0u;
+  const uint32_t at_s = pp.sample_tile && have && ns ? h_base[bs] + local_s : 0u;
   if (have) {
     // the list's items (~20 on average): stores nobody waits for; chunks [0, ns) are in the sample phase
     for (uint32_t j = 0; j < nc; ++j) {
