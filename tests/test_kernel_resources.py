@@ -42,7 +42,9 @@ BUDGET = {
     # (a thread per query, 16 one-wave workgroups per batch: occupancy is not what bounds it; the 320 bytes are the frame of
     # prep_query_general, out of line, for plans of > 4 entries)
     # (round 6: + the primed threshold per entry - k_list_kth table reads, a fourth array of per-entry doubles in the register arm)
-    "ps::k_prep_query": (96, 5, 384, 0),
+    # (round 6, second half: a small query requests the tables of all its entries together - 7 doubles x 4 entries in flight -
+    # and keeps its entries' facts in registers for the entry loop: 102 VGPRs; 16 one-wave workgroups per batch, occupancy is moot)
+    "ps::k_prep_query": (104, 4, 384, 0),
     "ps::k_zprep_query<4>": (48, 8, 0, 0),
     "ps::k_zprep_query<8>": (64, 8, 0, 0),
     "ps::k_zprep_items": (48, 8, 0, 0),
