@@ -2180,7 +2180,10 @@ void enqueue_daat(EngineImpl& m, EngineImpl::DaatCtx& c, const ps_scorer_desc& s
     kp.S = 1; kp.n_super = s.n_tiles; kp.slice_bytes = 0;
     // a BM25 batch with both kinds of queries - those k_daat_small takes (<= 4 lists, one per query term) and others - is scored
     // by both kernels, each over its part of one item array (the preparation puts the second kind's items behind the first's)
-    const bool split_kinds = !zb && m.tune.daat_split && m.tune.daat_small && !m.tune.daat_persistent && n_items_big > 0 && n_items_big < n_items;
+    // (... unless most of the batch is of the second kind: after a delta with additions nearly every query has a delta layer under some
+    // term, and two launches - a near-empty k_daat_small beside k_daat - measured 1.64 ms per batch against 1.01 for k_daat alone)
+    const bool split_kinds = !zb && m.tune.daat_split && m.tune.daat_small && !m.tune.daat_persistent && n_items_big > 0 && n_items_big < n_items &&
+                             n_items_big * 2 < n_items;
     kp.K = (uint32_t)top_k;  // (the preparation primes the thresholds for this K)
     if (zb) launch_prep_z(m, c, *zb, kp, d_plan, d_qbeg, B, ne, n_items);
     else launch_prep(m, c, sc, boosts, kp, d_plan, d_qbeg, B, ne, multi, n_items, split_kinds, split_kinds ? n_items_big : 0);
